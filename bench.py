@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""bench.py -- Llama-3-8B W4A16 (g128, bf16 activations) WQLinear hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+
+  step      = one decode pass of the hot path: the 160 WQLinear GEMV calls (32 layers x
+              {qkv 4096->6144, o 4096->4096, gate 4096->14336, up 4096->14336, down 14336->4096})
+              of one Llama-3-8B token, M = 1, every layer with its OWN packed weights (3.7 GB total,
+              >> the 256 MB Infinity Cache, so every byte comes from HBM), captured in one hipGraph.
+              Attention / norms / lm_head are off-path and excluded.
+  value     = decode tokens/s over the whole job (N GPUs = K-sharded tensor parallel, strong scaling).
+  roofline  = the dominant kernel (decode GEMV): algorithmic bytes per launch / average launch
+              duration (HIP events over the timed region, on the launch stream) vs 8 TB/s.
+  prefill   = extra object: the same 160 calls at M = 2048 (GEMM), tok/s and fraction of the 2.5 PFLOP/s
+              dense bf16 MFMA peak.
+  cpu_baseline = the reference's pure-PyTorch pseudo-quant Linear (awq/quantize/quantizer.py:106-122,
+              restated in oracle/awq_oracle.py) timed with F.linear on the host cores, rank 0, N = 1 only,
+              on a bounded sample (one decoder block's five linears, M = 1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA
+LAYERS = 32
+SHAPES = [("qkv", 4096, 6144), ("o", 4096, 4096), ("gate", 4096, 14336), ("up", 4096, 14336), ("down", 14336, 4096)]
+
+
+def algo_bytes(M, K, N, esz=2, group=128):
+    """packed int4 + scales + scaled_zeros + x + out."""
+    return N * K // 2 + 2 * (K // group) * N * esz + M * K * esz + M * N * esz
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--prefill-m", type=int, default=2048)
+    ap.add_argument("--prefill-iters", type=int, default=3)
+    ap.add_argument("--no-prefill", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--layers", type=int, default=LAYERS)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import llm_awq_amd
+    from llm_awq_amd import synth
+    eng = llm_awq_amd.load_engine()
+    dtype = torch.bfloat16
+
+    if world > 1:
+        from llm_awq_amd.parallel import run_tp_bench
+        out = run_tp_bench(args, eng, dist, rank, world, dev, SHAPES, algo_bytes)
+        if rank == 0:
+            print(json.dumps(out))
+        dist.destroy_process_group()
+        return
+
+    # ---------------- weights: every layer distinct (HBM-resident, 3.7 GB) ----------------
+    L = args.layers
+    weights = []
+    for li in range(L):
+        for si, (name, K, N) in enumerate(SHAPES):
+            w = synth.random_wq(K, N, dtype=dtype, device=dev, seed=li * 16 + si, keep_q=False)
+            weights.append((K, N, w["qweight"], w["scales"], w["scaled_zeros"]))
+    torch.cuda.synchronize()
+
+    def run_pass(xs):
+        outs = []
+        for (K, N, qw, s, sz) in weights:
+            x = xs[K]
+            m = x.numel() // K
+            if m < 8:
+                outs.append(eng.gemv_forward_cuda_new(x, qw, s, sz, m, N, K, 128))
+            else:
+                outs.append(eng.gemm_forward_cuda_new(x, qw, s, sz))
+        return outs
+
+    g = torch.Generator(device=dev).manual_seed(1)
+    def make_x(M):
+        return {K: torch.randn(M, K, device=dev, generator=g).to(dtype) for K in (4096, 14336)}
+
+    # ---------------- decode leg: K timed steps ----------------
+    xs1 = make_x(1)
+    side = torch.cuda.Stream(device=dev)
+    graph = None
+    with torch.cuda.stream(side):
+        run_pass(xs1)  # lazy init outside capture
+        torch.cuda.synchronize()
+        if not args.no_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                keep = run_pass(xs1)
+        step = (lambda: graph.replay()) if graph is not None else (lambda: run_pass(xs1))
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(side)
+        for _ in range(args.steps):
+            step()
+        e1.record(side)
+        torch.cuda.synchronize()
+        wall_ms = (time.perf_counter() - t0) * 1e3
+        ev_ms = e0.elapsed_time(e1)
+    ms_per_step = wall_ms / args.steps
+    launches = len(weights)
+    bytes_step = sum(algo_bytes(1, K, N) for (K, N, *_r) in weights)
+    avg_launch_us = ev_ms * 1e3 / (args.steps * launches)
+    gbs = bytes_step * args.steps / (ev_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "gemv_w4a16_kernel<BF16>", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_us": round(avg_launch_us, 3), "algorithmic_bytes_per_launch": bytes_step // launches,
+                "launches_per_step": launches, "timing": "hip events on the launch stream over the timed region"}
+    tok_s = 1e3 / ms_per_step * (L / LAYERS)  # tokens/s of a full 32-layer model
+
+    out = {"metric": "W4A16 decode+prefill tok/s, Llama-3-8B; achieved %HBM (GEMV) / %MFMA (GEMM)",
+           "value": round(tok_s, 2),
+           "unit": "decode tok/s (160 WQLinear calls per token; attention/norm/lm_head off-path)",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": "Llama-3-8B W4A16 g128 bf16 activations on 1xMI355X (decode GEMV + prefill GEMM)",
+                      "layers": L, "decode_m": 1, "prefill_m": args.prefill_m, "graph": graph is not None,
+                      "parallelism": "tp1"},
+           "roofline": roofline, "device": torch.cuda.get_device_name(dev)}
+
+    # ---------------- prefill leg ----------------
+    if not args.no_prefill:
+        M = args.prefill_m
+        xsm = make_x(M)
+        with torch.cuda.stream(side):
+            run_pass(xsm)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(side)
+            for _ in range(args.prefill_iters):
+                run_pass(xsm)
+            e1.record(side)
+            torch.cuda.synchronize()
+            pms = e0.elapsed_time(e1) / args.prefill_iters
+        flops = sum(2.0 * M * K * N for (K, N, *_r) in weights)
+        tfl = flops / (pms * 1e-3) / 1e12
+        out["prefill"] = {"m": M, "ms_per_pass": round(pms, 3), "tok_s": round(M / (pms * 1e-3) * (LAYERS / L), 1),
+                          "roofline": {"bound": "mfma", "kernel": "gemm_w4a16<BF16>", "achieved": round(tfl, 1),
+                                       "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / MFMA_PEAK_TFLOPS, 4),
+                                       "traffic": None}}
+
+    # ---------------- CPU baseline (reference's pseudo-quant Linear on the host cores) ----------------
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out))
+
+
+def cpu_baseline(budget_s: float = 12.0):
+    import torch.nn.functional as F
+    from oracle import awq_oracle as O
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    lins = []
+    gen = torch.Generator().manual_seed(0)
+    for (_n, K, N) in SHAPES:
+        w = torch.randn(N, K, generator=gen) * 0.02
+        lins.append(O.pseudo_quant_linear(w, 4, 128, torch.bfloat16))
+    xs = {4096: torch.randn(1, 4096).bfloat16(), 14336: torch.randn(1, 14336).bfloat16()}
+    def one_block():
+        for lin in lins:
+            F.linear(xs[lin.in_features], lin.weight)
+    with torch.no_grad():
+        for _ in range(2):
+            one_block()
+        ts = []
+        t_end = time.perf_counter() + budget_s
+        while time.perf_counter() < t_end and len(ts) < 200:
+            t0 = time.perf_counter()
+            one_block()
+            ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {"value": round(1.0 / (med * LAYERS), 3), "unit": "decode tok/s (32 x one block's five pseudo-quant Linears, M=1)",
+            "cores": cores, "kind": "port", "dtype": "bf16 F.linear",
+            "sample": f"one Llama-3-8B decoder block (5 linears, M=1), median of {len(ts)} runs, x32 layers",
+            "ms_per_block": round(med * 1e3, 3)}
+
+
+if __name__ == "__main__":
+    main()

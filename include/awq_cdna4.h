@@ -1,0 +1,94 @@
+/*
+ * awq_cdna4.h -- C ABI of the MI355X-native (gfx950 / CDNA4) W4A16 fused dequant+matmul path.
+ *
+ * This is the drop-in boundary for the ONE hot path of mit-han-lab/llm-awq that this repository
+ * accelerates: the two extension entry points behind `awq.quantize.qmodule.WQLinear.forward`
+ *     awq_inference_engine.gemv_forward_cuda_new   (awq/kernels/csrc/quantization_new/gemv/gemv_cuda.h:4-12,
+ *                                                   gemv_cuda.cu:245-338, bound at awq/kernels/csrc/pybind.cpp:23)
+ *     awq_inference_engine.gemm_forward_cuda_new   (awq/kernels/csrc/quantization_new/gemm/gemm_cuda.h:3,
+ *                                                   gemm_cuda.cu:1126-1236, bound at awq/kernels/csrc/pybind.cpp:22)
+ * plus the data-format helpers either side of it (tinychat/offline-weight-repacker.py).
+ *
+ * Plain pointers and sizes only -- no torch types.  All pointers are DEVICE pointers unless
+ * stated; `stream` is a hipStream_t passed as void* (NULL = the null stream).  Every function
+ * returns AWQ_OK (0) or a negative AWQ_ERR_* code and never throws; kernels are enqueued
+ * asynchronously on `stream`.  Tensors follow the reference's v2 contract:
+ *     qweight       int16 [N/4, K]      (awq/quantize/qmodule.py:26-65, 98-108)
+ *     scales        T     [Gpad, N]     (qmodule.py:109-119), Gpad = 8*ceil(K/G/8) rows, only K/G used
+ *     scaled_zeros  T     [Gpad, N]     (qmodule.py:120-130), = -(scales * zeros)
+ *     x             T     [M, K] row-major contiguous,  out  T [M, N]
+ * with T = fp16 or bf16 (`dtype`), G = group_size = 128.
+ *
+ * Numerics: each weight is materialised as round_T(q*s + sz) exactly as the
+ * reference's __hfma2 does, products are accumulated in fp32 (MFMA), the result is rounded once to T.
+ */
+#ifndef AWQ_CDNA4_H_
+#define AWQ_CDNA4_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AWQ_ABI_VERSION 1
+
+/* status codes */
+#define AWQ_OK 0
+#define AWQ_ERR_BATCH (-1)      /* gemv: m outside [1,16] ("Unsupported batch size for gemv kernel", gemv_cuda.cu:328-329) */
+#define AWQ_ERR_GROUP (-2)      /* group_size != 128 ("Unsupported group size for gemv kernel", gemv_cuda.cu:332-335) */
+#define AWQ_ERR_DTYPE (-3)      /* dtype is neither AWQ_F16 nor AWQ_BF16 (dispatch_utils.cuh:7-18) */
+#define AWQ_ERR_SHAPE (-4)      /* n % 8 != 0, k % 128 != 0, non-positive sizes */
+#define AWQ_ERR_ALIGN (-5)      /* a pointer is not 16-byte aligned */
+#define AWQ_ERR_NULL (-6)       /* NULL pointer */
+#define AWQ_ERR_WORKSPACE (-7)  /* workspace too small */
+#define AWQ_ERR_LAUNCH (-8)     /* hipLaunch / runtime error (hipGetLastError text via awq_last_hip_error) */
+#define AWQ_ERR_BITS (-9)       /* unsupported w_bit */
+
+/* activation / scale element type */
+#define AWQ_F16 0
+#define AWQ_BF16 1
+
+int awq_abi_version(void);
+const char* awq_status_string(int status);
+const char* awq_last_hip_error(void);
+
+/* Replaces gemv_forward_cuda_new (gemv_cuda.cu:245-338): out[m,n] = x[m,k] . Wdeq[n,k]^T for
+ * 1 <= m <= 16 (the reference accepts 1..7; the Python binding keeps that limit). */
+int awq_w4a16_gemv(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
+                   void* out, int m, int n, int k, int group_size, int dtype, void* stream);
+
+/* Replaces gemm_forward_cuda_new (gemm_cuda.cu:1126-1236) for any m >= 1.  `workspace` may be
+ * NULL when awq_w4a16_gemm_workspace_bytes(m,n,k) == 0. It is zero-initialised by the callee when
+ * used (the reference's uninitialised semaphore tensor, gemm_cuda.cu:28, is not reproduced). */
+size_t awq_w4a16_gemm_workspace_bytes(int m, int n, int k);
+int awq_w4a16_gemm(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
+                   void* out, int m, int n, int k, int group_size, int dtype,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* WQLinear.forward's dispatch (qmodule.py:201-224): m < 8 -> gemv, else gemm; optional bias[n]
+ * (may be NULL) added in T after the matmul result was rounded to T, like `out + self.bias`. */
+int awq_w4a16_forward(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
+                      const void* bias, void* out, int m, int n, int k, int group_size, int dtype,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* Parity / format helpers running the SAME device unpack + dequant code as the matmul kernels. */
+/* out_u8[n, k] = logical 4-bit integer Q[n,k]  (inverse of pack_intweight, qmodule.py:26-65) */
+int awq_unpack_v2(const void* qweight, void* out_u8, int n, int k, void* stream);
+/* out[n, k] = round_T(Q[n,k] * scales[k/G, n] + scaled_zeros[k/G, n])  (gemv_cuda.cu:159-166) */
+int awq_dequant_v2(const void* qweight, const void* scales, const void* scaled_zeros, void* out,
+                   int n, int k, int group_size, int dtype, void* stream);
+/* qweight_v2[n/4, k] from logical Q u8 [n, k]  (pack_intweight / packing_v2_from_unpacked) */
+int awq_pack_v2(const void* q_u8, void* qweight, int n, int k, void* stream);
+/* v1 checkpoint tensors -> v2 (tinychat/offline-weight-repacker.py:111-152):
+ *   qweight_v1 int32 [n, k/8] -> qweight_v2 int16 [n/4, k]
+ *   scales_v1 T [n, gpad], qzeros_v1 int32 [n, gpad/8] -> scales_v2 T [gpad, n], scaled_zeros_v2 T [gpad, n] */
+int awq_repack_v1_to_v2(const void* qweight_v1, const void* scales_v1, const void* qzeros_v1,
+                        void* qweight_v2, void* scales_v2, void* scaled_zeros_v2,
+                        int n, int k, int gpad, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AWQ_CDNA4_H_ */

@@ -1,0 +1,60 @@
+"""ctypes view of the C ABI (include/awq_cdna4.h) -- used by the host-side format tools, by
+`llm_awq_amd.ops` and by the parity tests (which must call through the C ABI).
+
+There is NO fallback: if libawq_cdna4.so is missing this module raises at first use.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libawq_cdna4.so")
+
+AWQ_F16, AWQ_BF16 = 0, 1
+_lib = None
+
+_vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+SIGNATURES = {
+    "awq_abi_version": (_i, []),
+    "awq_status_string": (ctypes.c_char_p, [_i]),
+    "awq_last_hip_error": (ctypes.c_char_p, []),
+    "awq_w4a16_gemv": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "awq_w4a16_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
+    "awq_w4a16_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "awq_w4a16_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "awq_unpack_v2": (_i, [_vp, _vp, _i, _i, _vp]),
+    "awq_dequant_v2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "awq_pack_v2": (_i, [_vp, _vp, _i, _i, _vp]),
+    "awq_repack_v1_to_v2": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+}
+
+
+class AwqNativeError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AwqNativeError(
+                f"{LIB_PATH} is missing: the MI355X HIP library has not been built "
+                "(run `python -m llm_awq_amd.build`). There is no CPU/PyTorch fallback for the hot path.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        if L.awq_abi_version() != 1:
+            raise AwqNativeError("libawq_cdna4.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(status: int) -> None:
+    if status != 0:
+        L = lib()
+        msg = L.awq_status_string(status).decode()
+        if status == -8:
+            msg += " " + L.awq_last_hip_error().decode()
+        raise AwqNativeError(f"awq_cdna4 error {status}: {msg}")

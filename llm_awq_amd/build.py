@@ -1,0 +1,90 @@
+"""In-tree build of the native pieces (gfx950 only):
+
+  llm_awq_amd/lib/libawq_cdna4.so          hipcc  --offload-arch=gfx950   kernels + the C ABI (include/awq_cdna4.h)
+  llm_awq_amd/ext/awq_inference_engine*.so g++    pybind/torch shim over the C ABI (no device code, no hipify)
+
+Both are git-ignored but travel to the GPU box with the repo snapshot.  `python -m llm_awq_amd.build`
+rebuilds whatever is older than its sources; hipcc cross-compiles without a GPU.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+import sysconfig
+import time
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB_DIR = os.path.join(PKG, "lib")
+EXT_DIR = os.path.join(PKG, "ext")
+LIB_PATH = os.path.join(LIB_DIR, "libawq_cdna4.so")
+EXT_SUFFIX = sysconfig.get_config_var("EXT_SUFFIX") or ".so"
+EXT_PATH = os.path.join(EXT_DIR, "awq_inference_engine" + EXT_SUFFIX)
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+HIP_SOURCES = ["awq_gemv.hip", "awq_gemm.hip", "awq_util.hip", "awq_capi.hip"]
+HIP_DEPS = ["awq_device.hpp", "awq_kernels.hpp", os.path.join(ROOT, "include", "awq_cdna4.h")]
+
+
+def _newer(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd, what):
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout[-4000:] + "\n" + r.stderr[-8000:] + "\n")
+        raise RuntimeError(f"building {what} failed (exit {r.returncode}): {' '.join(cmd[:6])} ...")
+    return time.time() - t0
+
+
+def build_lib(force: bool = False, verbose: bool = True) -> str:
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    deps = srcs + [d if os.path.isabs(d) else os.path.join(CSRC, d) for d in HIP_DEPS]
+    if force or _newer(LIB_PATH, deps):
+        os.makedirs(LIB_DIR, exist_ok=True)
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+               "-Wno-unused-function", *srcs, "-o", LIB_PATH]
+        dt = _run(cmd, "libawq_cdna4.so")
+        if verbose:
+            print(f"[llm_awq_amd.build] libawq_cdna4.so built in {dt:.1f}s")
+    return LIB_PATH
+
+
+def build_ext(force: bool = False, verbose: bool = True) -> str:
+    import torch
+    from torch.utils import cpp_extension as cpp
+
+    src = os.path.join(CSRC, "torch_binding.cpp")
+    deps = [src, os.path.join(ROOT, "include", "awq_cdna4.h")]
+    if force or _newer(EXT_PATH, deps):
+        build_lib(verbose=verbose)
+        os.makedirs(EXT_DIR, exist_ok=True)
+        tlib = cpp.library_paths()[0]
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+               "-DHIPBLAS_V2", "-DTORCH_EXTENSION_NAME=awq_inference_engine", "-DTORCH_API_INCLUDE_EXTENSION_H",
+               f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-Wno-deprecated-declarations"]
+        for inc in cpp.include_paths() + ["/opt/rocm/include", sysconfig.get_paths()["include"]]:
+            cmd += ["-isystem", inc]
+        cmd += [src, "-o", EXT_PATH, "-L" + tlib, "-L" + LIB_DIR, "-lawq_cdna4", "-lc10", "-lc10_hip", "-ltorch_cpu",
+                "-ltorch_hip", "-ltorch", "-ltorch_python", "-L/opt/rocm/lib", "-lamdhip64",
+                "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath," + tlib]
+        dt = _run(cmd, "awq_inference_engine extension")
+        if verbose:
+            print(f"[llm_awq_amd.build] awq_inference_engine extension built in {dt:.1f}s")
+    return EXT_PATH
+
+
+def build_all(force: bool = False, verbose: bool = True):
+    return build_lib(force, verbose), build_ext(force, verbose)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

@@ -1,0 +1,130 @@
+// extern "C" entry points declared in include/awq_cdna4.h: argument validation + dispatch.
+// No torch types; errors are returned as codes (the Python/pybind layer turns them into
+// RuntimeError with the reference's messages).
+#include "../../include/awq_cdna4.h"
+
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include "awq_kernels.hpp"
+
+namespace {
+thread_local char g_last_hip_error[256] = "";
+
+int finish_launch() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    strncpy(g_last_hip_error, hipGetErrorString(e), sizeof(g_last_hip_error) - 1);
+    return AWQ_ERR_LAUNCH;
+  }
+  return AWQ_OK;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int check_common(const void* x, const void* qweight, const void* scales, const void* zeros, const void* out, int m, int n,
+                 int k, int group_size, int dtype) {
+  if (!x || !qweight || !scales || !zeros || !out) return AWQ_ERR_NULL;
+  if (dtype != AWQ_F16 && dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
+  if (group_size != 128) return AWQ_ERR_GROUP;
+  if (m < 1 || n < 8 || k < 128 || (n % 8) != 0 || (k % 128) != 0) return AWQ_ERR_SHAPE;
+  if (!aligned16(x) || !aligned16(qweight) || !aligned16(out) || (reinterpret_cast<uintptr_t>(scales) & 1u) ||
+      (reinterpret_cast<uintptr_t>(zeros) & 1u))
+    return AWQ_ERR_ALIGN;
+  return AWQ_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int awq_abi_version(void) { return AWQ_ABI_VERSION; }
+
+const char* awq_last_hip_error(void) { return g_last_hip_error; }
+
+const char* awq_status_string(int status) {
+  switch (status) {
+    case AWQ_OK: return "ok";
+    case AWQ_ERR_BATCH: return "Unsupported batch size for gemv kernel.";
+    case AWQ_ERR_GROUP: return "Unsupported group size for gemv kernel.";
+    case AWQ_ERR_DTYPE: return "Unsupported dtype: expected float16 or bfloat16.";
+    case AWQ_ERR_SHAPE: return "Unsupported shape: need n % 8 == 0, k % 128 == 0, m >= 1.";
+    case AWQ_ERR_ALIGN: return "Pointer is not 16-byte aligned (tensors must be contiguous).";
+    case AWQ_ERR_NULL: return "NULL pointer argument.";
+    case AWQ_ERR_WORKSPACE: return "Workspace too small.";
+    case AWQ_ERR_LAUNCH: return "HIP launch failed.";
+    case AWQ_ERR_BITS: return "Only 4-bit (and the repo's 3-bit extension) are supported.";
+    default: return "unknown status";
+  }
+}
+
+int awq_w4a16_gemv(const void* x, const void* qweight, const void* scales, const void* scaled_zeros, void* out, int m,
+                   int n, int k, int group_size, int dtype, void* stream) {
+  if (group_size != 128) return AWQ_ERR_GROUP;
+  if (m < 1 || m > 16) return AWQ_ERR_BATCH;
+  int st = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
+  if (st != AWQ_OK) return st;
+  awq::launch_gemv(x, qweight, scales, scaled_zeros, out, m, n, k, dtype, (hipStream_t)stream);
+  return finish_launch();
+}
+
+size_t awq_w4a16_gemm_workspace_bytes(int m, int n, int k) { return awq::gemm_workspace_bytes(m, n, k); }
+
+int awq_w4a16_gemm(const void* x, const void* qweight, const void* scales, const void* scaled_zeros, void* out, int m,
+                   int n, int k, int group_size, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  int st = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
+  if (st != AWQ_OK) return st;
+  const size_t need = awq::gemm_workspace_bytes(m, n, k);
+  if (need > 0 && (!workspace || workspace_bytes < need)) return AWQ_ERR_WORKSPACE;
+  awq::launch_gemm(x, qweight, scales, scaled_zeros, out, m, n, k, dtype, workspace, workspace_bytes, (hipStream_t)stream);
+  return finish_launch();
+}
+
+int awq_w4a16_forward(const void* x, const void* qweight, const void* scales, const void* scaled_zeros, const void* bias,
+                      void* out, int m, int n, int k, int group_size, int dtype, void* workspace, size_t workspace_bytes,
+                      void* stream) {
+  int st;
+  if (m < 8)
+    st = awq_w4a16_gemv(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype, stream);
+  else
+    st = awq_w4a16_gemm(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype, workspace, workspace_bytes,
+                        stream);
+  if (st != AWQ_OK || !bias) return st;
+  awq::launch_bias_add(out, bias, m, n, dtype, (hipStream_t)stream);
+  return finish_launch();
+}
+
+int awq_unpack_v2(const void* qweight, void* out_u8, int n, int k, void* stream) {
+  if (!qweight || !out_u8) return AWQ_ERR_NULL;
+  if (n < 4 || (n % 4) != 0 || k < 64 || (k % 64) != 0) return AWQ_ERR_SHAPE;
+  awq::launch_unpack_v2(qweight, out_u8, n, k, (hipStream_t)stream);
+  return finish_launch();
+}
+
+int awq_dequant_v2(const void* qweight, const void* scales, const void* scaled_zeros, void* out, int n, int k,
+                   int group_size, int dtype, void* stream) {
+  if (!qweight || !scales || !scaled_zeros || !out) return AWQ_ERR_NULL;
+  if (dtype != AWQ_F16 && dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
+  if (group_size != 128) return AWQ_ERR_GROUP;
+  if (n < 4 || (n % 4) != 0 || k < 128 || (k % 128) != 0) return AWQ_ERR_SHAPE;
+  awq::launch_dequant_v2(qweight, scales, scaled_zeros, out, n, k, dtype, (hipStream_t)stream);
+  return finish_launch();
+}
+
+int awq_pack_v2(const void* q_u8, void* qweight, int n, int k, void* stream) {
+  if (!q_u8 || !qweight) return AWQ_ERR_NULL;
+  if (n < 4 || (n % 4) != 0 || k < 64 || (k % 64) != 0) return AWQ_ERR_SHAPE;
+  awq::launch_pack_v2(q_u8, qweight, n, k, (hipStream_t)stream);
+  return finish_launch();
+}
+
+int awq_repack_v1_to_v2(const void* qweight_v1, const void* scales_v1, const void* qzeros_v1, void* qweight_v2,
+                        void* scales_v2, void* scaled_zeros_v2, int n, int k, int gpad, int dtype, void* stream) {
+  if (!qweight_v1 || !scales_v1 || !qzeros_v1 || !qweight_v2 || !scales_v2 || !scaled_zeros_v2) return AWQ_ERR_NULL;
+  if (dtype != AWQ_F16 && dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
+  if (n < 4 || (n % 4) != 0 || k < 64 || (k % 64) != 0 || gpad < 8 || (gpad % 8) != 0) return AWQ_ERR_SHAPE;
+  awq::launch_repack_v1_to_v2(qweight_v1, scales_v1, qzeros_v1, qweight_v2, scales_v2, scaled_zeros_v2, n, k, gpad, dtype,
+                              (hipStream_t)stream);
+  return finish_launch();
+}
+
+}  // extern "C"

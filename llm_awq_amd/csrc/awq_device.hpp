@@ -1,0 +1,149 @@
+// Device-side building blocks shared by every kernel of the W4A16 hot path (gfx950 only).
+//
+//  * v2 int4 interleave addressing (reference: awq/quantize/qmodule.py:26-65, closed form in
+//    SURVEY.md 8(a) a2): a lane's 16-byte load = one output row n x one 32-k chunk.
+//  * word -> four "pair registers": extraction i of word w yields the two adjacent weights
+//    k = 8*i + 2*w + {0,1} of the chunk, so the four words of a chunk give, for every i, eight
+//    consecutive k -- exactly one MFMA 16x16x32 operand (4 VGPRs).
+//  * dequantisation with the reference's numerics (dequantize.cuh:18-123 + the hfma2 at
+//    gemv_cuda.cu:159-166 / gemm_cuda.cu:304-307): W = round_T(q * s + sz), q unsigned 0..15.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace awq {
+
+using u32 = uint32_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kGroup = 128;  // the only group size the reference kernels implement (gemv_cuda.cu:332-335)
+
+// ---------------------------------------------------------------------------------------------
+// v2 layout addressing.  qweight is int16 [N/4, K] viewed as u32 words: a packed row has K/2 words;
+// every 32-word block holds 64 k of 4 rows: words [8*rr + 4*c, +4) = row 4r+rr, 32-k chunk c.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ size_t v2_chunk_word(int n, int chunk /* = k/32 */, int K) {
+  return (size_t)(n >> 2) * (size_t)(K >> 1) + (size_t)(chunk >> 1) * 32 + (n & 3) * 8 + (chunk & 1) * 4;
+}
+
+// logical k (inside the 32-k chunk) of nibble `nib` of word `w` (0..3) of a chunk
+__device__ __forceinline__ int v2_nibble_k(int w, int nib) { return 8 * (nib & 3) + 2 * w + (nib >> 2); }
+
+// ---------------------------------------------------------------------------------------------
+// dtype traits
+// ---------------------------------------------------------------------------------------------
+struct F16 {
+  using elem = _Float16;
+  using vec8 = f16x8;
+  static constexpr int id = 0;
+  // per-(n, group) dequant constants, prepared once per 16-byte chunk
+  struct SZ {
+    f16x2 s, z;
+  };
+  static __device__ __forceinline__ SZ make_sz(uint16_t s_bits, uint16_t z_bits) {
+    SZ r;
+    r.s = __builtin_bit_cast(f16x2, (u32)s_bits * 0x00010001u);
+    r.z = __builtin_bit_cast(f16x2, (u32)z_bits * 0x00010001u);
+    return r;
+  }
+  // word -> 4 packed pairs (pair i = weights k=8i+2w, 8i+2w+1), already dequantised & rounded to fp16.
+  // Exact int->fp16 via the 0x6400 magic (1024+q) and, for the high nibbles, (1024+16q)/16-64;
+  // then ONE packed fma per pair == the reference's __hfma2(q, s, sz).
+  static __device__ __forceinline__ void dequant_word(u32 w, const SZ& c, u32 (&out)[4]) {
+    const f16x2 k1024 = {(_Float16)1024.f, (_Float16)1024.f};
+    const f16x2 k16th = {(_Float16)0.0625f, (_Float16)0.0625f};
+    const f16x2 kneg64 = {(_Float16)-64.f, (_Float16)-64.f};
+    const u32 w8 = w >> 8;
+    f16x2 q0 = __builtin_bit_cast(f16x2, (w & 0x000F000Fu) | 0x64006400u) - k1024;
+    f16x2 q1 = __builtin_elementwise_fma(__builtin_bit_cast(f16x2, (w & 0x00F000F0u) | 0x64006400u), k16th, kneg64);
+    f16x2 q2 = __builtin_bit_cast(f16x2, (w8 & 0x000F000Fu) | 0x64006400u) - k1024;
+    f16x2 q3 = __builtin_elementwise_fma(__builtin_bit_cast(f16x2, (w8 & 0x00F000F0u) | 0x64006400u), k16th, kneg64);
+    out[0] = __builtin_bit_cast(u32, __builtin_elementwise_fma(q0, c.s, c.z));
+    out[1] = __builtin_bit_cast(u32, __builtin_elementwise_fma(q1, c.s, c.z));
+    out[2] = __builtin_bit_cast(u32, __builtin_elementwise_fma(q2, c.s, c.z));
+    out[3] = __builtin_bit_cast(u32, __builtin_elementwise_fma(q3, c.s, c.z));
+  }
+  static __device__ __forceinline__ f32x4 mfma(const vec8& a, const vec8& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ uint16_t from_float(float f) {
+    return __builtin_bit_cast(uint16_t, (_Float16)f);
+  }
+};
+
+struct BF16 {
+  using elem = __bf16;
+  using vec8 = bf16x8;
+  static constexpr int id = 1;
+  struct SZ {
+    float s, z;
+  };
+  static __device__ __forceinline__ SZ make_sz(uint16_t s_bits, uint16_t z_bits) {
+    SZ r;
+    r.s = __builtin_bit_cast(float, (u32)s_bits << 16);
+    r.z = __builtin_bit_cast(float, (u32)z_bits << 16);
+    return r;
+  }
+  // gfx950 has no packed bf16 fma.  q*s (4 x 8 significant bits) + sz is exactly representable in
+  // fp32 (|sz| = s*z, z <= 15 keeps the exponent gap <= 5 bits), so fmaf() is exact and the single
+  // RNE rounding of v_cvt_pk_bf16_f32 reproduces the reference's bf16 __hfma2 bit for bit.
+  static __device__ __forceinline__ u32 pair(u32 qlo, u32 qhi, const SZ& c) {
+    float a = __builtin_fmaf((float)qlo, c.s, c.z);
+    float b = __builtin_fmaf((float)qhi, c.s, c.z);
+    bf16x2 r = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(u32, r);
+  }
+  static __device__ __forceinline__ void dequant_word(u32 w, const SZ& c, u32 (&out)[4]) {
+    u32 e = w & 0x0F0F0F0Fu;         // nibbles 0,2,4,6 -> bytes 0..3
+    u32 o = (w >> 4) & 0x0F0F0F0Fu;  // nibbles 1,3,5,7 -> bytes 0..3
+    // keep the byte-lane form so the conversions lower to v_cvt_f32_ubyte{0..3}
+    asm volatile("" : "+v"(e), "+v"(o));
+    out[0] = pair(e & 0xFFu, (e >> 16) & 0xFFu, c);  // nibbles (0,4)
+    out[1] = pair(o & 0xFFu, (o >> 16) & 0xFFu, c);  // nibbles (1,5)
+    out[2] = pair((e >> 8) & 0xFFu, e >> 24, c);     // nibbles (2,6)
+    out[3] = pair((o >> 8) & 0xFFu, o >> 24, c);     // nibbles (3,7)
+  }
+  static __device__ __forceinline__ f32x4 mfma(const vec8& a, const vec8& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ uint16_t from_float(float f) {
+    return __builtin_bit_cast(uint16_t, (__bf16)f);
+  }
+};
+
+// Dequantise one 16-byte chunk (4 words = 32 k of one row) into four MFMA operands:
+// op[j] = weights k0+8j .. k0+8j+7 in natural order.
+template <typename DT>
+__device__ __forceinline__ void dequant_chunk(const u32x4& w, const typename DT::SZ& c, typename DT::vec8 (&op)[4]) {
+  u32 p0[4], p1[4], p2[4], p3[4];
+  DT::dequant_word(w.x, c, p0);
+  DT::dequant_word(w.y, c, p1);
+  DT::dequant_word(w.z, c, p2);
+  DT::dequant_word(w.w, c, p3);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    u32x4 v = {p0[j], p1[j], p2[j], p3[j]};
+    op[j] = __builtin_bit_cast(typename DT::vec8, v);
+  }
+}
+
+// raw (un-dequantised) nibble extraction in the same pair order: used by the unpack-index check.
+__device__ __forceinline__ void unpack_word_pairs(u32 w, u32 (&lo)[4], u32 (&hi)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    lo[i] = (w >> (4 * i)) & 0xFu;
+    hi[i] = (w >> (4 * i + 16)) & 0xFu;
+  }
+}
+
+__device__ __forceinline__ u32x4 ldg_nt_u32x4(const u32* p) {
+  return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+}
+
+}  // namespace awq

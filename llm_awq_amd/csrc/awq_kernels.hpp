@@ -1,0 +1,19 @@
+// Internal launcher declarations (host side).  The public surface is include/awq_cdna4.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace awq {
+int launch_gemv(const void* x, const void* qw, const void* s, const void* z, void* out, int m, int n, int k, int dtype,
+                hipStream_t st);
+int launch_gemm(const void* x, const void* qw, const void* s, const void* z, void* out, int m, int n, int k, int dtype,
+                void* ws, size_t ws_bytes, hipStream_t st);
+size_t gemm_workspace_bytes(int m, int n, int k);
+int launch_bias_add(void* out, const void* bias, int m, int n, int dtype, hipStream_t st);
+int launch_unpack_v2(const void* qw, void* out_u8, int n, int k, hipStream_t st);
+int launch_dequant_v2(const void* qw, const void* s, const void* z, void* out, int n, int k, int dtype, hipStream_t st);
+int launch_pack_v2(const void* q_u8, void* qw, int n, int k, hipStream_t st);
+int launch_repack_v1_to_v2(const void* qw1, const void* s1, const void* qz1, void* qw2, void* s2, void* sz2, int n, int k,
+                           int gpad, int dtype, hipStream_t st);
+}  // namespace awq

@@ -1,0 +1,178 @@
+// Format / parity helper kernels.  They run the SAME device unpack + dequant routines as the
+// GEMV / GEMM kernels (awq_device.hpp), so a bit-exact match of their outputs with the oracle
+// pins the index arithmetic and the dequant numerics of the hot path.
+//
+// Reference behaviour restated: awq/quantize/qmodule.py:26-65 (pack), dequantize.cuh:18-123 +
+// gemv_cuda.cu:150-174 (unpack order), gemv_cuda.cu:159-166 (dequant),
+// tinychat/offline-weight-repacker.py:8-19,64-73,111-152 (v1 -> v2).
+#include "awq_device.hpp"
+#include "awq_kernels.hpp"
+
+namespace awq {
+
+// one thread per 16-byte chunk (row n, 32 k)
+__global__ void unpack_v2_kernel(const u32* __restrict__ qw, uint8_t* __restrict__ out, int N, int K) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int chunks = K / 32;
+  if (t >= (size_t)N * chunks) return;
+  const int n = (int)(t / chunks), c = (int)(t % chunks);
+  const u32x4 w = *reinterpret_cast<const u32x4*>(qw + v2_chunk_word(n, c, K));
+  const u32 ws[4] = {w.x, w.y, w.z, w.w};
+  uint8_t* o = out + (size_t)n * K + (size_t)c * 32;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    u32 lo[4], hi[4];
+    unpack_word_pairs(ws[a], lo, hi);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o[8 * i + 2 * a] = (uint8_t)lo[i];
+      o[8 * i + 2 * a + 1] = (uint8_t)hi[i];
+    }
+  }
+}
+
+template <typename DT>
+__global__ void dequant_v2_kernel(const u32* __restrict__ qw, const uint16_t* __restrict__ scales,
+                                  const uint16_t* __restrict__ zeros, uint16_t* __restrict__ out, int N, int K) {
+  using vec8 = typename DT::vec8;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int chunks = K / 32;
+  if (t >= (size_t)N * chunks) return;
+  const int n = (int)(t / chunks), c = (int)(t % chunks);
+  const u32x4 w = *reinterpret_cast<const u32x4*>(qw + v2_chunk_word(n, c, K));
+  const int grp = (c * 32) / kGroup;
+  vec8 op[4];
+  dequant_chunk<DT>(w, DT::make_sz(scales[(size_t)grp * N + n], zeros[(size_t)grp * N + n]), op);
+  vec8* o = reinterpret_cast<vec8*>(out + (size_t)n * K + (size_t)c * 32);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = op[j];
+}
+
+// logical u8 [N,K] -> v2.  One thread per output u32 word.
+__global__ void pack_v2_kernel(const uint8_t* __restrict__ q, u32* __restrict__ qw, int N, int K) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t words = (size_t)N * K / 8;
+  if (t >= words) return;
+  // invert v2_chunk_word: word index -> (n, chunk, a)
+  const size_t row_words = (size_t)K / 2;
+  const int r = (int)(t / row_words);
+  const int wi = (int)(t % row_words);
+  const int kb = wi / 32, in = wi % 32;
+  const int rr = in / 8, cc = (in % 8) / 4, a = in % 4;
+  const int n = r * 4 + rr, k0 = kb * 64 + cc * 32;
+  const uint8_t* src = q + (size_t)n * K + k0;
+  u32 w = 0;
+#pragma unroll
+  for (int nib = 0; nib < 8; ++nib) w |= (u32)(src[v2_nibble_k(a, nib)] & 0xF) << (4 * nib);
+  qw[t] = w;
+}
+
+// v1 qweight int32 [N, K/8] (nibble kk%8 of word kk/8) -> v2.  One thread per v2 word.
+__global__ void repack_qweight_v1_to_v2_kernel(const u32* __restrict__ qw1, u32* __restrict__ qw2, int N, int K) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t words = (size_t)N * K / 8;
+  if (t >= words) return;
+  const size_t row_words = (size_t)K / 2;
+  const int r = (int)(t / row_words);
+  const int wi = (int)(t % row_words);
+  const int kb = wi / 32, in = wi % 32;
+  const int rr = in / 8, cc = (in % 8) / 4, a = in % 4;
+  const int n = r * 4 + rr, k0 = kb * 64 + cc * 32;
+  const u32* src = qw1 + (size_t)n * (K / 8) + k0 / 8;  // 4 v1 words = this 32-k chunk
+  u32 w = 0;
+#pragma unroll
+  for (int nib = 0; nib < 8; ++nib) {
+    const int kl = v2_nibble_k(a, nib);
+    w |= ((src[kl >> 3] >> (4 * (kl & 7))) & 0xFu) << (4 * nib);
+  }
+  qw2[t] = w;
+}
+
+// scales_v1 T [N, gpad] -> scales_v2 T [gpad, N];  scaled_zeros_v2 = -(scales * zero) in T
+// (multiply_scale_qzero_negative with zp_shift = 0, repacker :64-73,:142: product rounded to T, then negated)
+template <typename DT>
+__global__ void repack_scales_v1_to_v2_kernel(const uint16_t* __restrict__ s1, const u32* __restrict__ qz1,
+                                              uint16_t* __restrict__ s2, uint16_t* __restrict__ sz2, int N, int gpad) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)N * gpad) return;
+  const int n = (int)(t % N), gi = (int)(t / N);  // write-coalesced over n
+  const uint16_t sb = s1[(size_t)n * gpad + gi];
+  const u32 zq = (qz1[(size_t)n * (gpad / 8) + gi / 8] >> (4 * (gi % 8))) & 0xFu;
+  float s;
+  if (DT::id == 0)
+    s = (float)__builtin_bit_cast(_Float16, sb);
+  else
+    s = __builtin_bit_cast(float, (u32)sb << 16);
+  const uint16_t prod = DT::from_float(s * (float)zq);  // exact product, one rounding to T
+  s2[(size_t)gi * N + n] = sb;
+  // -(x + 0*s): x + (+0) keeps x, unary minus flips the sign bit (also of zero: -(+0) = -0)
+  sz2[(size_t)gi * N + n] = prod ^ 0x8000u;
+}
+
+template <typename DT>
+__global__ void bias_add_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict__ bias, size_t total, int N) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  float a, b;
+  if (DT::id == 0) {
+    a = (float)__builtin_bit_cast(_Float16, out[t]);
+    b = (float)__builtin_bit_cast(_Float16, bias[t % N]);
+  } else {
+    a = __builtin_bit_cast(float, (u32)out[t] << 16);
+    b = __builtin_bit_cast(float, (u32)bias[t % N] << 16);
+  }
+  out[t] = DT::from_float(a + b);  // == T-precision add (sum of two T values rounded once)
+}
+
+static inline unsigned nblk(size_t n, unsigned b) { return (unsigned)((n + b - 1) / b); }
+
+int launch_unpack_v2(const void* qw, void* out_u8, int n, int k, hipStream_t st) {
+  const size_t items = (size_t)n * (k / 32);
+  hipLaunchKernelGGL(unpack_v2_kernel, dim3(nblk(items, 256)), dim3(256), 0, st, (const u32*)qw, (uint8_t*)out_u8, n, k);
+  return 0;
+}
+
+int launch_dequant_v2(const void* qw, const void* s, const void* z, void* out, int n, int k, int dtype, hipStream_t st) {
+  const size_t items = (size_t)n * (k / 32);
+  if (dtype == 0)
+    hipLaunchKernelGGL((dequant_v2_kernel<F16>), dim3(nblk(items, 256)), dim3(256), 0, st, (const u32*)qw,
+                       (const uint16_t*)s, (const uint16_t*)z, (uint16_t*)out, n, k);
+  else
+    hipLaunchKernelGGL((dequant_v2_kernel<BF16>), dim3(nblk(items, 256)), dim3(256), 0, st, (const u32*)qw,
+                       (const uint16_t*)s, (const uint16_t*)z, (uint16_t*)out, n, k);
+  return 0;
+}
+
+int launch_pack_v2(const void* q_u8, void* qw, int n, int k, hipStream_t st) {
+  const size_t words = (size_t)n * k / 8;
+  hipLaunchKernelGGL(pack_v2_kernel, dim3(nblk(words, 256)), dim3(256), 0, st, (const uint8_t*)q_u8, (u32*)qw, n, k);
+  return 0;
+}
+
+int launch_repack_v1_to_v2(const void* qw1, const void* s1, const void* qz1, void* qw2, void* s2, void* sz2, int n, int k,
+                           int gpad, int dtype, hipStream_t st) {
+  const size_t words = (size_t)n * k / 8;
+  hipLaunchKernelGGL(repack_qweight_v1_to_v2_kernel, dim3(nblk(words, 256)), dim3(256), 0, st, (const u32*)qw1,
+                     (u32*)qw2, n, k);
+  const size_t items = (size_t)n * gpad;
+  if (dtype == 0)
+    hipLaunchKernelGGL((repack_scales_v1_to_v2_kernel<F16>), dim3(nblk(items, 256)), dim3(256), 0, st,
+                       (const uint16_t*)s1, (const u32*)qz1, (uint16_t*)s2, (uint16_t*)sz2, n, gpad);
+  else
+    hipLaunchKernelGGL((repack_scales_v1_to_v2_kernel<BF16>), dim3(nblk(items, 256)), dim3(256), 0, st,
+                       (const uint16_t*)s1, (const u32*)qz1, (uint16_t*)s2, (uint16_t*)sz2, n, gpad);
+  return 0;
+}
+
+int launch_bias_add(void* out, const void* bias, int m, int n, int dtype, hipStream_t st) {
+  const size_t total = (size_t)m * n;
+  if (dtype == 0)
+    hipLaunchKernelGGL((bias_add_kernel<F16>), dim3(nblk(total, 256)), dim3(256), 0, st, (uint16_t*)out,
+                       (const uint16_t*)bias, total, n);
+  else
+    hipLaunchKernelGGL((bias_add_kernel<BF16>), dim3(nblk(total, 256)), dim3(256), 0, st, (uint16_t*)out,
+                       (const uint16_t*)bias, total, n);
+  return 0;
+}
+
+}  // namespace awq

@@ -1,0 +1,123 @@
+"""Torch-tensor conveniences over the C ABI (device memory + current stream are the only things
+torch provides here).  Every function requires GPU tensors and the built HIP library."""
+from __future__ import annotations
+
+import torch
+
+from . import _capi
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float16:
+        return _capi.AWQ_F16
+    if t.dtype == torch.bfloat16:
+        return _capi.AWQ_BF16
+    raise TypeError(f"expected float16/bfloat16, got {t.dtype}")
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _capi.AwqNativeError("llm_awq_amd ops run on the GPU only (no CPU fallback)")
+        if t is not None and not t.is_contiguous():
+            raise ValueError("tensors must be contiguous")
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def gemv(x, qweight, scales, scaled_zeros, group_size: int = 128):
+    """C-ABI awq_w4a16_gemv: x [..., K] with 1 <= M <= 16 rows."""
+    _need_gpu(x, qweight, scales, scaled_zeros)
+    k = x.shape[-1]
+    m = x.numel() // k
+    n = qweight.shape[0] * 4
+    out = torch.empty(*x.shape[:-1], n, dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _capi.check(_capi.lib().awq_w4a16_gemv(x.data_ptr(), qweight.data_ptr(), scales.data_ptr(),
+                                                scaled_zeros.data_ptr(), out.data_ptr(), m, n, k, group_size, _dt(x),
+                                                _stream(x)))
+    return out
+
+
+def gemm(x, qweight, scales, scaled_zeros, group_size: int = 128):
+    """C-ABI awq_w4a16_gemm: any M >= 1."""
+    _need_gpu(x, qweight, scales, scaled_zeros)
+    k = x.shape[-1]
+    m = x.numel() // k
+    n = qweight.shape[0] * 4
+    out = torch.empty(*x.shape[:-1], n, dtype=x.dtype, device=x.device)
+    L = _capi.lib()
+    wsb = L.awq_w4a16_gemm_workspace_bytes(m, n, k)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
+    with torch.cuda.device(x.device):
+        _capi.check(L.awq_w4a16_gemm(x.data_ptr(), qweight.data_ptr(), scales.data_ptr(), scaled_zeros.data_ptr(),
+                                     out.data_ptr(), m, n, k, group_size, _dt(x), ws.data_ptr() if wsb else None, wsb,
+                                     _stream(x)))
+    return out
+
+
+def forward(x, qweight, scales, scaled_zeros, bias=None, group_size: int = 128):
+    """C-ABI awq_w4a16_forward: WQLinear.forward's dispatch + optional bias."""
+    _need_gpu(x, qweight, scales, scaled_zeros, bias)
+    k = x.shape[-1]
+    m = x.numel() // k
+    n = qweight.shape[0] * 4
+    out = torch.empty(*x.shape[:-1], n, dtype=x.dtype, device=x.device)
+    L = _capi.lib()
+    wsb = L.awq_w4a16_gemm_workspace_bytes(m, n, k)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
+    with torch.cuda.device(x.device):
+        _capi.check(L.awq_w4a16_forward(x.data_ptr(), qweight.data_ptr(), scales.data_ptr(), scaled_zeros.data_ptr(),
+                                        bias.data_ptr() if bias is not None else None, out.data_ptr(), m, n, k,
+                                        group_size, _dt(x), ws.data_ptr() if wsb else None, wsb, _stream(x)))
+    return out
+
+
+def unpack_v2(qweight):
+    """int16 [N/4, K] -> uint8 [N, K] logical 4-bit integers (GPU kernel, same unpack code as the matmuls)."""
+    _need_gpu(qweight)
+    n, k = qweight.shape[0] * 4, qweight.shape[1]
+    out = torch.empty(n, k, dtype=torch.uint8, device=qweight.device)
+    with torch.cuda.device(qweight.device):
+        _capi.check(_capi.lib().awq_unpack_v2(qweight.data_ptr(), out.data_ptr(), n, k, _stream(qweight)))
+    return out
+
+
+def dequant_v2(qweight, scales, scaled_zeros, group_size: int = 128):
+    """-> T [N, K] = round_T(q*s + sz) (GPU kernel, same dequant code as the matmuls)."""
+    _need_gpu(qweight, scales, scaled_zeros)
+    n, k = qweight.shape[0] * 4, qweight.shape[1]
+    out = torch.empty(n, k, dtype=scales.dtype, device=qweight.device)
+    with torch.cuda.device(qweight.device):
+        _capi.check(_capi.lib().awq_dequant_v2(qweight.data_ptr(), scales.data_ptr(), scaled_zeros.data_ptr(),
+                                                out.data_ptr(), n, k, group_size, _dt(scales), _stream(qweight)))
+    return out
+
+
+def pack_v2(q_u8):
+    """uint8 [N, K] -> int16 [N/4, K] (GPU pack_intweight)."""
+    _need_gpu(q_u8)
+    assert q_u8.dtype == torch.uint8
+    n, k = q_u8.shape
+    out = torch.empty(n // 4, k, dtype=torch.int16, device=q_u8.device)
+    with torch.cuda.device(q_u8.device):
+        _capi.check(_capi.lib().awq_pack_v2(q_u8.data_ptr(), out.data_ptr(), n, k, _stream(q_u8)))
+    return out
+
+
+def repack_v1_to_v2(qweight_v1, scales_v1, qzeros_v1):
+    """v1 (qweight int32 [N,K/8], scales T [N,Gpad], qzeros int32 [N,Gpad/8]) -> v2 triple."""
+    _need_gpu(qweight_v1, scales_v1, qzeros_v1)
+    n, k = qweight_v1.shape[0], qweight_v1.shape[1] * 8
+    gpad = scales_v1.shape[1]
+    dev = qweight_v1.device
+    qw2 = torch.empty(n // 4, k, dtype=torch.int16, device=dev)
+    s2 = torch.empty(gpad, n, dtype=scales_v1.dtype, device=dev)
+    sz2 = torch.empty(gpad, n, dtype=scales_v1.dtype, device=dev)
+    with torch.cuda.device(dev):
+        _capi.check(_capi.lib().awq_repack_v1_to_v2(qweight_v1.data_ptr(), scales_v1.data_ptr(), qzeros_v1.data_ptr(),
+                                                     qw2.data_ptr(), s2.data_ptr(), sz2.data_ptr(), n, k, gpad,
+                                                     _dt(scales_v1), _stream(qweight_v1)))
+    return qw2, s2, sz2

@@ -1,0 +1,156 @@
+"""`WQLinear` for MI355X: same Python API and packed-buffer contract as the reference's
+awq/quantize/qmodule.py:78-235, with forward() running the hand-written gfx950 kernels.
+
+Mirrored surface: ctor signature, attributes (in_features, out_features, w_bit,
+group_size, split_k_iters, interleave), registered buffers `qweight int16 [N/4, K]`,
+`scales T [Gpad, N]`, `scaled_zeros T [Gpad, N]`, `bias T [N]`, `from_linear`, `forward`,
+`extra_repr`; module-level `pack_intweight`, `calculate_zeros_width`, `make_divisible`,
+`ScaledActivation`.  Importing this module needs no GPU; forward() does (no CPU fallback).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import load_engine
+
+
+def make_divisible(c: int, divisor: int) -> int:
+    """qmodule.py:7-8 -- a ceiling division (the reference's name is kept for drop-in imports)."""
+    return -(-c // divisor)
+
+
+def calculate_zeros_width(in_features: int, group_size: int = 128, pack_num: int = 8) -> int:
+    """qmodule.py:11-23: int32 zero-point words per row in v1; the v2 scale buffers have 8x this many rows."""
+    if group_size >= 128:
+        mult = 1
+    elif group_size in (64, 32):
+        mult = 128 // group_size
+    else:
+        raise NotImplementedError
+    return make_divisible(make_divisible(in_features // group_size, pack_num), mult) * mult
+
+
+def _v2_nibble_source(K: int, device) -> torch.Tensor:
+    """For one packed row-quad of the v2 layout: index table src[c, j] -> (rr * K + k) of the logical
+    weight stored in nibble j of int16 column c.  Closed form of the three permutations of
+    qmodule.py:31-57 (see include/awq_cdna4.h / DESIGN.md 'v2 interleave')."""
+    c = torch.arange(K, device=device).view(K, 1)
+    j = torch.arange(4, device=device).view(1, 4)
+    p = (c % 64) * 4 + j  # nibble position inside the 256-nibble block
+    rr, t = p // 64, p % 32
+    chunk = (p % 64) // 32
+    a, u = t // 8, t % 8
+    k = (c // 64) * 64 + chunk * 32 + 8 * (u % 4) + 2 * a + u // 4
+    return rr * K + k  # [K, 4]
+
+
+def pack_intweight(unpacked_qweight: torch.Tensor, interleave: int = 4, kstride: int = 64) -> torch.Tensor:
+    """int [N, K] (values 0..15) -> v2 `int16 [N/4, K]`, bit-identical to qmodule.py:26-65.
+    Pure index arithmetic in torch (runs where the tensor lives; the reference round-trips via numpy)."""
+    if interleave != 4 or kstride != 64:
+        raise NotImplementedError("the v2 format is defined for interleave=4, kstride=64 only")
+    N, K = unpacked_qweight.shape
+    assert N % 4 == 0 and K % 64 == 0
+    q = unpacked_qweight.to(torch.int32).reshape(N // 4, 4 * K)
+    src = _v2_nibble_source(K, q.device)  # [K, 4]
+    nib = q[:, src.reshape(-1)].reshape(N // 4, K, 4) & 0xF
+    word = nib[..., 0] | (nib[..., 1] << 4) | (nib[..., 2] << 8) | (nib[..., 3] << 12)
+    # two's-complement wrap to int16 exactly like numpy's astype("int16") in the reference
+    return ((word + 0x8000) % 0x10000 - 0x8000).to(torch.int16).contiguous()
+
+
+def unpack_intweight(qweight: torch.Tensor) -> torch.Tensor:
+    """Inverse of :func:`pack_intweight` -> int32 [N, K] (host-side format tool)."""
+    R, K = qweight.shape
+    src = _v2_nibble_source(K, qweight.device)  # [K, 4]
+    w = qweight.to(torch.int32) & 0xFFFF
+    nib = torch.stack([(w >> (4 * j)) & 0xF for j in range(4)], dim=-1).reshape(R, K * 4)
+    out = torch.empty(R, 4 * K, dtype=torch.int32, device=qweight.device)
+    out[:, src.reshape(-1)] = nib
+    return out.reshape(R * 4, K)
+
+
+class ScaledActivation(nn.Module):
+    """qmodule.py:68-75 (imported by awq/quantize/quantizer.py:5 and auto_scale.py:11)."""
+
+    def __init__(self, module, scales):
+        super().__init__()
+        self.act = module
+        self.scales = nn.Parameter(scales.data)
+
+    def forward(self, x):
+        return self.act(x) / self.scales.view(1, 1, -1).to(x.device)
+
+
+class WQLinear(nn.Module):
+    def __init__(self, w_bit, group_size, in_features, out_features, bias, dev, dtype=torch.float16):
+        super().__init__()
+        if w_bit not in [4]:
+            raise NotImplementedError("Only 4-bit are supported for now.")  # qmodule.py:82-83
+        self.in_features = in_features
+        self.out_features = out_features
+        self.w_bit = w_bit
+        self.group_size = group_size if group_size != -1 else in_features
+        self.split_k_iters = 8  # kept writable for tinychat/utils/tune.py:51-65; unused by the HIP kernels
+        self.interleave = 4
+        assert self.in_features % self.group_size == 0
+        assert out_features % (32 // self.w_bit) == 0
+        assert out_features % self.interleave == 0
+        gpad = calculate_zeros_width(in_features, self.group_size) * (32 // self.w_bit)
+        self.register_buffer(
+            "qweight",
+            torch.zeros((out_features // self.interleave, in_features // (16 // self.w_bit) * self.interleave),
+                        dtype=torch.int16, device=dev))
+        self.register_buffer("scales", torch.zeros((gpad, out_features), dtype=dtype, device=dev))
+        self.register_buffer("scaled_zeros", torch.zeros((gpad, out_features), dtype=dtype, device=dev))
+        if bias:
+            self.register_buffer("bias", torch.zeros((out_features), dtype=dtype, device=dev))
+        else:
+            self.bias = None
+
+    @classmethod
+    def from_linear(cls, linear, w_bit, group_size, init_only=False, scales=None, zeros=None):
+        """qmodule.py:139-199.  `linear.weight` must already be fake-quantised (on the grid)."""
+        q = cls(w_bit, group_size, linear.in_features, linear.out_features, linear.bias is not None,
+                linear.weight.device, dtype=linear.weight.data.dtype)
+        if init_only:
+            return q
+        assert scales is not None and zeros is not None
+        G = q.group_size
+        dtype = scales.dtype
+        gpad = calculate_zeros_width(linear.in_features, group_size) * (32 // q.w_bit)
+        qscales = torch.zeros((scales.shape[0], gpad), dtype=dtype, device=scales.device)
+        qscales[:, : scales.shape[1]] = scales
+        q.scales = qscales.transpose(1, 0).contiguous()
+        if linear.bias is not None:
+            q.bias = linear.bias.clone().to(dtype)
+        # integer recovery, same arithmetic (in the tensors' dtype, no clamp) as the reference's
+        # per-column loop at qmodule.py:176-184, vectorised over columns
+        gi = torch.arange(q.in_features, device=scales.device) // G
+        scale_zeros = zeros * scales
+        intweight = torch.round((linear.weight.data + scale_zeros[:, gi]) / qscales[:, gi]).to(torch.int32)
+        q.qweight = pack_intweight(intweight.contiguous(), interleave=4, kstride=64)
+        zi = zeros.to(dtype=torch.int32)
+        sz = torch.zeros_like(qscales)
+        sz[:, : scales.shape[1]] = -(qscales[:, : scales.shape[1]] * zi.to(torch.float32)).to(dtype)
+        q.scaled_zeros = sz.transpose(1, 0).contiguous()
+        return q
+
+    @torch.no_grad()
+    def forward(self, x):
+        """qmodule.py:201-224: fewer than 8 rows -> decode GEMV, else prefill GEMM; bias added after."""
+        eng = load_engine()
+        if not x.is_contiguous():
+            x = x.contiguous()
+        rows = x.numel() // x.shape[-1]
+        if rows < 8:
+            out = eng.gemv_forward_cuda_new(x, self.qweight, self.scales, self.scaled_zeros, rows,
+                                            self.out_features, self.in_features, self.group_size)
+        else:
+            out = eng.gemm_forward_cuda_new(x, self.qweight, self.scales, self.scaled_zeros)
+        return out + self.bias if self.bias is not None else out
+
+    def extra_repr(self) -> str:
+        return "in_features={}, out_features={}, bias={}, w_bit={}, group_size={}".format(
+            self.in_features, self.out_features, self.bias is not None, self.w_bit, self.group_size)

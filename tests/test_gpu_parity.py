@@ -1,0 +1,130 @@
+"""-m gpu: the HIP path against the CPU oracle, called THROUGH THE C ABI (llm_awq_amd.ops -> ctypes
+-> libawq_cdna4.so).  Integer / index work must be bit exact; matmul within the bounds in
+tests/helpers.py (half an ulp of T around the exact contraction + fp32 accumulation slack, and
+<= 1e-3 norm-wise as BASELINE.json states)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import awq_oracle as O
+from tests.helpers import check_forward, make_case
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float16, torch.bfloat16]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from llm_awq_amd import ops as _ops
+    _ops._capi.lib()  # fail loudly if the HIP library is missing
+    return _ops
+
+
+@pytest.mark.parametrize("N,K", [(4, 64), (16, 128), (64, 256), (128, 768), (768, 3072), (1024, 4096)])
+def test_unpack_and_pack_bit_exact(ops, N, K):
+    rng = np.random.default_rng(N * 7 + K)
+    q = rng.integers(0, 16, size=(N, K)).astype(np.uint8)
+    packed = O.pack_v2(q)
+    got = ops.unpack_v2(torch.from_numpy(packed).cuda()).cpu().numpy()
+    assert (got == q).all()
+    got_p = ops.pack_v2(torch.from_numpy(q).cuda()).cpu().numpy()
+    assert (got_p == packed).all()
+
+
+def test_unpack_golden(ops, golden):
+    g = golden("pack_v2.npz")
+    for key in ["0", "1", "2", "3", "4", "_struct"]:
+        q, p = g["q" + key], g["p" + key]
+        assert (ops.unpack_v2(torch.from_numpy(p).cuda()).cpu().numpy() == q).all()
+        assert (ops.pack_v2(torch.from_numpy(q).cuda()).cpu().numpy() == p).all()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,K", [(16, 128), (64, 768), (256, 1280), (768, 3072), (512, 4096)])
+def test_dequant_bit_exact(ops, dtype, N, K):
+    c = make_case(N, K, dtype, seed=N + K)
+    W = O.dequant_weight(c["q"], c["scales"], c["scaled_zeros"], 128)
+    got = ops.dequant_v2(c["qweight"].cuda(), c["scales"].cuda(), c["scaled_zeros"].cuda()).cpu()
+    assert torch.equal(got.view(torch.int16), W.view(torch.int16))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_dequant_adversarial_scales(ops, dtype):
+    """random scales over a wide exponent range + every zero point: rounding ties, subnormal fp16."""
+    g = torch.Generator().manual_seed(5)
+    N, K = 64, 512
+    q = torch.randint(0, 16, (N, K), generator=g).numpy().astype(np.uint8)
+    scales = torch.zeros(8, N, dtype=dtype)
+    scales[:4] = (torch.rand(4, N, generator=g) * 2 + 0.5) * torch.pow(2.0, torch.randint(-14, 3, (4, N), generator=g).float())
+    zeros = torch.randint(0, 16, (4, N), generator=g)
+    sz = torch.zeros(8, N, dtype=dtype)
+    sz[:4] = -(scales[:4] * zeros.float()).to(dtype)
+    W = O.dequant_weight(q, scales, sz, 128)
+    got = ops.dequant_v2(torch.from_numpy(O.pack_v2(q)).cuda(), scales.cuda(), sz.cuda()).cpu()
+    assert torch.equal(got.view(torch.int16), W.view(torch.int16))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 6, 7, 8, 13, 16])
+@pytest.mark.parametrize("N,K", [(768, 768), (3072, 768), (768, 3072), (256, 4096), (1032, 1280)])
+def test_gemv_vs_oracle(ops, dtype, M, N, K):
+    c = make_case(N, K, dtype, seed=M * 131 + N + K, M=M)
+    y = ops.gemv(c["x"].cuda(), c["qweight"].cuda(), c["scales"].cuda(), c["scaled_zeros"].cuda()).cpu()
+    check_forward(y, c["x"], c["q"], c["scales"], c["scaled_zeros"], dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [8, 17, 64, 100, 128, 129, 200, 512, 777])
+@pytest.mark.parametrize("N,K", [(768, 768), (3072, 768), (768, 3072), (136, 1280)])
+def test_gemm_vs_oracle(ops, dtype, M, N, K):
+    c = make_case(N, K, dtype, seed=M * 17 + N + K, M=M)
+    y = ops.gemm(c["x"].cuda(), c["qweight"].cuda(), c["scales"].cuda(), c["scaled_zeros"].cuda()).cpu()
+    check_forward(y, c["x"], c["q"], c["scales"], c["scaled_zeros"], dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [1, 7, 8, 300])
+def test_forward_dispatch_with_bias(ops, dtype, M):
+    c = make_case(768, 768, dtype, seed=M, M=M, bias=True)
+    y = ops.forward(c["x"].cuda(), c["qweight"].cuda(), c["scales"].cuda(), c["scaled_zeros"].cuda(),
+                    c["bias"].cuda()).cpu()
+    check_forward(y, c["x"], c["q"], c["scales"], c["scaled_zeros"], dtype, bias=c["bias"])
+
+
+def test_identity_activation_is_transpose_detecting(ops):
+    """x = I (K=128 rows of the identity): out[m, n] must equal W_T[n, m] exactly (catches an m/n swap
+    or any k permutation mismatch between the two MFMA operands)."""
+    for dtype in DTYPES:
+        N, K = 64, 128
+        c = make_case(N, K, dtype, seed=3)
+        W = O.dequant_weight(c["q"], c["scales"], c["scaled_zeros"], 128)
+        x = torch.eye(K, dtype=dtype)
+        for fn, rows in ((ops.gemm, K), (ops.gemv, 16)):
+            y = fn(x[:rows].contiguous().cuda(), c["qweight"].cuda(), c["scales"].cuda(), c["scaled_zeros"].cuda()).cpu()
+            assert torch.equal(y.view(torch.int16), W.t()[:rows].contiguous().view(torch.int16))
+
+
+def test_error_codes(ops):
+    from llm_awq_amd import _capi
+    c = make_case(64, 256, torch.float16, M=1)
+    args = [t.cuda() for t in (c["x"], c["qweight"], c["scales"], c["scaled_zeros"])]
+    with pytest.raises(_capi.AwqNativeError, match="group size"):
+        ops.gemv(*args, group_size=64)
+    x17 = torch.zeros(17, 256, dtype=torch.float16).cuda()
+    with pytest.raises(_capi.AwqNativeError, match="batch size"):
+        ops.gemv(x17, *args[1:])
+    with pytest.raises(_capi.AwqNativeError):
+        ops.gemv(c["x"], c["qweight"], c["scales"], c["scaled_zeros"])  # CPU tensors: no fallback
+
+
+def test_repack_v1_to_v2_golden(ops, golden):
+    g = golden("repack_v1_v2.npz")
+    for i in range(2):
+        dt = torch.float16 if int(g[f"dtype_{i}"][0]) == 0 else torch.bfloat16
+        qw1 = torch.from_numpy(g[f"qw1_{i}"]).cuda()
+        qz1 = torch.from_numpy(g[f"qz1_{i}"]).cuda()
+        sc1 = torch.from_numpy(g[f"sc1_{i}"]).view(dt).cuda()
+        qw2, s2, sz2 = ops.repack_v1_to_v2(qw1, sc1, qz1)
+        assert (qw2.cpu().numpy() == g[f"qw2_{i}"]).all()
+        assert (s2.cpu().view(torch.int16).numpy() == g[f"sc2_{i}"]).all()
+        assert (sz2.cpu().view(torch.int16).numpy() == g[f"sz2_{i}"]).all()
