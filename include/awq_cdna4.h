@@ -88,6 +88,11 @@ int awq_repack_v1_to_v2(const void* qweight_v1, const void* scales_v1, const voi
                         void* qweight_v2, void* scales_v2, void* scaled_zeros_v2,
                         int n, int k, int gpad, int dtype, void* stream);
 
+/* Tuning hook for experiments and benchmarks (not part of the reference surface): integer knobs such as
+ * "gemv_waves", "gemv_unroll", "gemv_xmode", "gemv_stream_only", "gemm_variant"; 0 restores the default
+ * heuristic.  Returns AWQ_OK or AWQ_ERR_SHAPE for an unknown key. Process-global, not thread-safe. */
+int awq_tune_set(const char* key, int value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,7 @@ SIGNATURES = {
     "awq_dequant_v2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "awq_pack_v2": (_i, [_vp, _vp, _i, _i, _vp]),
     "awq_repack_v1_to_v2": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "awq_tune_set": (_i, [ctypes.c_char_p, _i]),
 }
 
 
@@ -58,3 +59,9 @@ def check(status: int) -> None:
         if status == -8:
             msg += " " + L.awq_last_hip_error().decode()
         raise AwqNativeError(f"awq_cdna4 error {status}: {msg}")
+
+
+def tune(**knobs) -> None:
+    """awq_tune_set for each knob (experiments / benchmarks only)."""
+    for k, v in knobs.items():
+        check(lib().awq_tune_set(k.encode(), int(v)))

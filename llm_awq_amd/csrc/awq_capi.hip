@@ -127,4 +127,11 @@ int awq_repack_v1_to_v2(const void* qweight_v1, const void* scales_v1, const voi
   return finish_launch();
 }
 
+int awq_tune_set(const char* key, int value) {
+  if (!key) return AWQ_ERR_NULL;
+  if (awq::gemv_tune_set(key, value) == 0) return AWQ_OK;
+  if (awq::gemm_tune_set(key, value) == 0) return AWQ_OK;
+  return AWQ_ERR_SHAPE;
+}
+
 }  // extern "C"

@@ -129,6 +129,8 @@ __global__ __launch_bounds__(256) void gemm_w4a16_128x128_kernel(const uint16_t*
 
 size_t gemm_workspace_bytes(int, int, int) { return 0; }
 
+int gemm_tune_set(const char*, int) { return -1; }
+
 template <typename DT>
 static int launch_gemm_t(const void* x, const void* qw, const void* s, const void* z, void* out, int m, int n, int k,
                          hipStream_t st) {

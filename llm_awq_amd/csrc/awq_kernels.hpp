@@ -10,6 +10,8 @@ int launch_gemv(const void* x, const void* qw, const void* s, const void* z, voi
 int launch_gemm(const void* x, const void* qw, const void* s, const void* z, void* out, int m, int n, int k, int dtype,
                 void* ws, size_t ws_bytes, hipStream_t st);
 size_t gemm_workspace_bytes(int m, int n, int k);
+int gemv_tune_set(const char* key, int value);
+int gemm_tune_set(const char* key, int value);
 int launch_bias_add(void* out, const void* bias, int m, int n, int dtype, hipStream_t st);
 int launch_unpack_v2(const void* qw, void* out_u8, int n, int k, hipStream_t st);
 int launch_dequant_v2(const void* qw, const void* s, const void* z, void* out, int n, int k, int dtype, hipStream_t st);

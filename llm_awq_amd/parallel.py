@@ -1,0 +1,195 @@
+"""Tensor-parallel WQLinear over RCCL / xGMI (one process per GPU, torch.distributed backend "nccl").
+
+The reference has no multi-GPU path for this code (layer placement only), so this is
+new capability defined by BASELINE.json's north star: the `[N, K]` weight is sharded and the partial
+products are summed with ONE all-reduce.
+
+  * "row"    parallel (K-sharded): rank r owns k in [r*K/p, (r+1)*K/p) -- a plain column slice of the
+             int16 `[N/4, K]` buffer (cut at a multiple of 128 so whole quantisation groups and whole 64-k
+             pack blocks stay together) and the matching rows of scales / scaled_zeros.  It consumes
+             x[..., k-slice] and produces a partial y [M, N]; all-reduce(sum) over ranks; bias once, after.
+  * "column" parallel (N-sharded): rank r owns output rows [r*N/p, ...): no communication, sharded output.
+             Used for qkv / gate / up feeding row-parallel o / down (Megatron pairing: 2 all-reduces per
+             decoder block instead of 5).
+
+xGMI is point-to-point: decode all-reduces are tiny ([1, 4096] bf16 = 8 KiB, latency bound), prefill ones are
+MBs (bandwidth bound per link).  RCCL picks the algorithm; we keep one fused tensor per collective.
+"""
+from __future__ import annotations
+
+import time
+from typing import Callable, Optional
+
+import torch
+import torch.nn as nn
+
+from .qmodule import WQLinear, calculate_zeros_width
+
+GROUP = 128
+
+
+def shard_bounds(total: int, world: int, rank: int, multiple: int):
+    """Even split of `total` in units of `multiple`; the first (units % world) ranks get one more unit."""
+    units = total // multiple
+    assert units * multiple == total, f"{total} is not a multiple of {multiple}"
+    base, extra = divmod(units, world)
+    lo = rank * base + min(rank, extra)
+    hi = lo + base + (1 if rank < extra else 0)
+    return lo * multiple, hi * multiple
+
+
+def shard_row_parallel(qweight, scales, scaled_zeros, world: int, rank: int):
+    """K-shard of v2 buffers -> (qweight [N/4, Kr], scales [Gpad_r, N], scaled_zeros [Gpad_r, N], (k0, k1))."""
+    K = qweight.shape[1]
+    k0, k1 = shard_bounds(K, world, rank, GROUP)
+    assert k1 > k0, "more ranks than 128-k groups"
+    g0, g1 = k0 // GROUP, k1 // GROUP
+    gpad = calculate_zeros_width(k1 - k0, GROUP) * 8
+    N = scales.shape[1]
+    s = torch.zeros(gpad, N, dtype=scales.dtype, device=scales.device)
+    z = torch.zeros(gpad, N, dtype=scales.dtype, device=scales.device)
+    s[: g1 - g0] = scales[g0:g1]
+    z[: g1 - g0] = scaled_zeros[g0:g1]
+    return qweight[:, k0:k1].contiguous(), s, z, (k0, k1)
+
+
+def shard_column_parallel(qweight, scales, scaled_zeros, world: int, rank: int, multiple: int = 16):
+    """N-shard (cut at multiples of 16 rows = one MFMA slab) -> (qweight, scales, scaled_zeros, (n0, n1))."""
+    N = qweight.shape[0] * 4
+    n0, n1 = shard_bounds(N, world, rank, multiple)
+    return (qweight[n0 // 4: n1 // 4].contiguous(), scales[:, n0:n1].contiguous(),
+            scaled_zeros[:, n0:n1].contiguous(), (n0, n1))
+
+
+class TPWQLinear(nn.Module):
+    """A WQLinear shard + its collective.  `matmul(x, qweight, scales, scaled_zeros)` defaults to the HIP
+    engine (WQLinear.forward's dispatch); tests on CPU inject the oracle instead."""
+
+    def __init__(self, full: WQLinear, mode: str, group=None, world: Optional[int] = None, rank: Optional[int] = None,
+                 matmul: Optional[Callable] = None):
+        super().__init__()
+        import torch.distributed as dist
+
+        assert mode in ("row", "column")
+        self.mode, self.group = mode, group
+        self.world = world if world is not None else dist.get_world_size(group)
+        self.rank = rank if rank is not None else dist.get_rank(group)
+        self.in_features, self.out_features = full.in_features, full.out_features
+        fn = shard_row_parallel if mode == "row" else shard_column_parallel
+        qw, s, z, self.bounds = fn(full.qweight, full.scales, full.scaled_zeros, self.world, self.rank)
+        k_local = qw.shape[1]
+        n_local = qw.shape[0] * 4
+        self.shard = WQLinear(full.w_bit, full.group_size, k_local, n_local, False, qw.device, dtype=s.dtype)
+        self.shard.qweight, self.shard.scales, self.shard.scaled_zeros = qw, s, z
+        if full.bias is None:
+            self.bias = None
+        else:
+            self.bias = full.bias if mode == "row" else full.bias[self.bounds[0]: self.bounds[1]].contiguous()
+        self._matmul = matmul
+
+    @torch.no_grad()
+    def forward(self, x, input_is_sharded: bool = False):
+        import torch.distributed as dist
+
+        if self.mode == "row" and not input_is_sharded:
+            x = x[..., self.bounds[0]: self.bounds[1]].contiguous()
+        if self._matmul is None:
+            y = self.shard(x)
+        else:
+            y = self._matmul(x, self.shard.qweight, self.shard.scales, self.shard.scaled_zeros)
+        if self.mode == "row" and self.world > 1:
+            dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
+        return y + self.bias if self.bias is not None else y
+
+
+# ---------------------------------------------------------------------------------------------------
+# bench leg for N > 1 (called from bench.py): Llama-3-8B decode with Megatron-paired TP
+# ---------------------------------------------------------------------------------------------------
+
+def run_tp_bench(args, eng, dist, rank, world, dev, shapes, algo_bytes):
+    from . import synth
+
+    dtype = torch.bfloat16
+    L = args.layers
+    mode_of = {"qkv": "column", "gate": "column", "up": "column", "o": "row", "down": "row"}
+    # each rank generates ONLY its shard (same statistics as the full tensor; weights are synthetic)
+    shards = []
+    for li in range(L):
+        for si, (name, K, N) in enumerate(shapes):
+            if mode_of[name] == "row":
+                k0, k1 = shard_bounds(K, world, rank, GROUP)
+                kl, nl = k1 - k0, N
+            else:
+                n0, n1 = shard_bounds(N, world, rank, 16)
+                kl, nl = K, n1 - n0
+            w = synth.random_wq(kl, nl, dtype=dtype, device=dev, seed=(li * 16 + si) * 64 + rank, keep_q=False)
+            shards.append((name, kl, nl, w["qweight"], w["scales"], w["scaled_zeros"], mode_of[name]))
+    g = torch.Generator(device=dev).manual_seed(1 + rank)
+    xs = {}
+    for (_nm, kl, _nl, *_r) in shards:
+        if kl not in xs:
+            xs[kl] = torch.randn(1, kl, device=dev, generator=g).to(dtype)
+
+    def run_pass():
+        outs = []
+        for (_nm, kl, nl, qw, s, sz, mode) in shards:
+            y = eng.gemv_forward_cuda_new(xs[kl], qw, s, sz, 1, nl, kl, 128)
+            if mode == "row":
+                dist.all_reduce(y)
+            outs.append(y)
+        return outs
+
+    side = torch.cuda.Stream(device=dev)
+    graph = None
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            run_pass()  # communicator + lazy init outside capture
+        torch.cuda.synchronize()
+        if not args.no_graph:
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    keep = run_pass()  # noqa: F841
+                graph.replay()
+                torch.cuda.synchronize()
+            except Exception as e:  # RCCL capture not available -> eager launches
+                import sys
+                print(f"[bench rank {rank}] graph capture of the TP pass failed ({type(e).__name__}: {e}); eager", file=sys.stderr)
+                graph = None
+                torch.cuda.synchronize()
+        # all ranks must agree on the mode
+        flag = torch.tensor([1 if graph is not None else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if flag.item() == 0:
+            graph = None
+        step = (lambda: graph.replay()) if graph is not None else run_pass
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    ms_per_step = tmax.item() * 1e3 / args.steps
+    bytes_rank = sum(algo_bytes(1, kl, nl) for (_nm, kl, nl, *_r) in shards)
+    gbs_rank = bytes_rank / (ms_per_step * 1e-3) / 1e9
+    return {"metric": "W4A16 decode+prefill tok/s, Llama-3-8B; achieved %HBM (GEMV) / %MFMA (GEMM)",
+            "value": round(1e3 / ms_per_step * (L / 32), 2),
+            "unit": "decode tok/s (160 WQLinear calls per token; attention/norm/lm_head off-path)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"Llama-3-8B W4A16 g128 bf16, decode M=1, tensor parallel over {world} GPUs "
+                                   "(qkv/gate/up column-parallel, o/down K-sharded + RCCL all-reduce)",
+                       "layers": L, "decode_m": 1, "graph": graph is not None, "parallelism": f"tp{world}",
+                       "allreduces_per_step": 2 * L},
+            "roofline": {"bound": "hbm", "kernel": "gemv_w4a16_kernel<BF16>", "achieved": round(gbs_rank, 1),
+                         "peak": 8000.0, "unit": "GB/s per GPU (incl. all-reduce time)", "frac": round(gbs_rank / 8000.0, 4),
+                         "traffic": None},
+            "device": torch.cuda.get_device_name(dev)}

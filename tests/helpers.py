@@ -40,9 +40,11 @@ def check_forward(y_gpu: torch.Tensor, x, q, scales, scaled_zeros, dtype, bias=N
     err = (yg - y64).abs()
     worst = (err / bound).max().item()
     assert worst <= 1.0, f"elementwise bound violated: worst err/bound = {worst}"
-    rel = ((yg - y64).norm() / y64.norm()).item()
+    # BASELINE.json: "<= 1e-3 rel on the fp16/bf16 matmul result" -- norm-wise against the oracle's T-rounded
+    # output (the final rounding to bf16 alone is ~1.1e-3 rms per element, so it must be on both sides)
+    y_or = O.wqlinear_forward(x, None, scales, scaled_zeros, bias, 128, q_int=q).reshape(y64.shape).double()
+    rel = ((yg - y_or).norm() / y_or.norm()).item()
     assert rel <= 1e-3, rel
-    y_or = O.wqlinear_forward(x, None, scales, scaled_zeros, bias, 128, q_int=q).reshape(y64.shape)
-    mism = (y_or.double() != yg).double().mean().item()
+    mism = (y_or != yg).double().mean().item()
     assert mism <= 0.02, f"{mism*100:.2f}% of elements differ from the fp32-accumulate oracle"
     return worst, rel, mism

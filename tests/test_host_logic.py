@@ -1,0 +1,92 @@
+"""not-gpu: the product's host-side mirror of the reference interface (llm_awq_amd.qmodule) against the
+golden vectors, the WQLinear buffer contract, and the 'no CPU fallback' rule."""
+import numpy as np
+import pytest
+import torch
+
+from llm_awq_amd import qmodule as Q
+from tests.conftest import as_t
+
+
+def test_pack_intweight_golden(golden):
+    g = golden("pack_v2.npz")
+    for key in ["0", "1", "2", "3", "4", "_struct"]:
+        q = torch.from_numpy(g["q" + key].astype(np.int32))
+        p = Q.pack_intweight(q, interleave=4, kstride=64)
+        assert p.dtype == torch.int16 and (p.numpy() == g["p" + key]).all()
+        assert torch.equal(Q.unpack_intweight(p), q)
+    with pytest.raises(NotImplementedError):
+        Q.pack_intweight(q, interleave=2, kstride=64)
+
+
+def test_zeros_width(golden):
+    for K, G, w in golden("zeros_width.npz")["table"]:
+        assert Q.calculate_zeros_width(int(K), int(G)) == int(w)
+    with pytest.raises(NotImplementedError):
+        Q.calculate_zeros_width(256, 16)
+    assert Q.make_divisible(10, 8) == 2
+
+
+@pytest.mark.parametrize("name,dt,has_bias", [("f16_a", torch.float16, True), ("bf16_a", torch.bfloat16, False),
+                                              ("f16_b", torch.float16, False), ("bf16_b", torch.bfloat16, True)])
+def test_from_linear_golden(golden, name, dt, has_bias):
+    g = golden("from_linear.npz")
+    wf, s, z = (as_t(g[f"{name}_{k}"], dt) for k in ("wfake", "s", "z"))
+    lin = torch.nn.Linear(wf.shape[1], wf.shape[0], bias=has_bias).to(dt)
+    lin.weight.data = wf
+    if has_bias:
+        lin.bias.data = as_t(g[name + "_bias"], dt)
+    q = Q.WQLinear.from_linear(lin, 4, 128, False, s, z)
+    assert (q.qweight.numpy() == g[name + "_qweight"]).all()
+    assert torch.equal(q.scales, as_t(g[name + "_scales"], dt))
+    assert torch.equal(q.scaled_zeros, as_t(g[name + "_scaled_zeros"], dt))
+    if has_bias:
+        assert torch.equal(q.bias, as_t(g[name + "_bias"], dt))
+    else:
+        assert q.bias is None
+
+
+def test_buffer_contract():
+    """names, shapes and dtypes ARE the v2 checkpoint format."""
+    for K, N, gpad in [(768, 768, 8), (4096, 14336, 32), (11008, 4096, 88), (14336, 4096, 112)]:
+        m = Q.WQLinear(4, 128, K, N, True, "cpu", dtype=torch.bfloat16)
+        sd = m.state_dict()
+        assert list(sd) == ["qweight", "scales", "scaled_zeros", "bias"]
+        assert sd["qweight"].shape == (N // 4, K) and sd["qweight"].dtype == torch.int16
+        assert sd["scales"].shape == (gpad, N) and sd["scaled_zeros"].shape == (gpad, N)
+        assert sd["scales"].dtype == torch.bfloat16 and sd["bias"].shape == (N,)
+        assert (m.in_features, m.out_features, m.w_bit, m.group_size, m.split_k_iters, m.interleave) == (K, N, 4, 128, 8, 4)
+    m = Q.WQLinear(4, -1, 256, 64, False, "cpu")
+    assert m.group_size == 256 and m.bias is None and m.scales.dtype == torch.float16
+    assert "w_bit=4, group_size=256" in m.extra_repr()
+    m.split_k_iters = 16  # tinychat/utils/tune.py writes it
+    with pytest.raises(NotImplementedError):
+        Q.WQLinear(3, 128, 256, 64, False, "cpu")
+    with pytest.raises(AssertionError):
+        Q.WQLinear(4, 128, 200, 64, False, "cpu")
+    init = Q.WQLinear.from_linear(torch.nn.Linear(256, 64).half(), 4, 128, init_only=True)
+    assert init.qweight.abs().sum() == 0 and init.bias is not None
+    # make_quant_attn (fused_attn.py:581-594) reassigns the buffers with concatenated tensors
+    a, b = Q.WQLinear(4, 128, 256, 64, False, "cpu"), Q.WQLinear(4, 128, 256, 32, False, "cpu")
+    fused = Q.WQLinear(4, 128, 256, 96, False, "cpu")
+    fused.qweight = torch.cat([a.qweight, b.qweight], dim=0)
+    fused.scales = torch.cat([a.scales, b.scales], dim=1).contiguous()
+    fused.scaled_zeros = torch.cat([a.scaled_zeros, b.scaled_zeros], dim=1).contiguous()
+    assert fused.state_dict()["qweight"].shape == (24, 256)
+
+
+def test_scaled_activation():
+    act = Q.ScaledActivation(torch.nn.GELU(), torch.full((8,), 2.0))
+    x = torch.randn(2, 3, 8)
+    assert torch.allclose(act(x), torch.nn.functional.gelu(x) / 2.0)
+
+
+def test_forward_has_no_cpu_fallback():
+    m = Q.WQLinear(4, 128, 256, 64, False, "cpu")
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 256, dtype=torch.float16))
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(9, 256, dtype=torch.float16))
+    from llm_awq_amd import _capi, ops
+    with pytest.raises(_capi.AwqNativeError):
+        ops.gemv(torch.zeros(1, 256, dtype=torch.float16), m.qweight, m.scales, m.scaled_zeros)

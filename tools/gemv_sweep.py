@@ -1,0 +1,94 @@
+"""GPU experiment: time the decode GEMV (through the C ABI) for every Llama-3-8B layer shape across tuning
+knobs, rotating over enough distinct weight copies to defeat the 256 MB Infinity Cache.  Each
+measurement = one hipGraph of R back-to-back launches, replayed; HIP events on the capture stream.
+usage: python tools/gemv_sweep.py [--m 1] [--quick]"""
+import argparse
+import itertools
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from llm_awq_amd import _capi, ops, synth  # noqa: E402
+
+
+def algo_bytes(M, K, N):
+    return N * K // 2 + 2 * (K // 128) * N * 2 + M * K * 2 + M * N * 2
+
+
+def time_cfg(fn, copies, reps=5):
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for c in copies[:2]:
+            fn(c)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            for c in copies:
+                fn(c)
+        g.replay()
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            g.replay()
+            e1.record(s)
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+    return best * 1e3 / len(copies)  # us per launch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--m", type=int, nargs="+", default=[1])
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    shapes = [(4096, 4096), (4096, 6144), (4096, 14336), (14336, 4096), (4096, 28672)]
+    if args.quick:
+        shapes = [(4096, 4096), (4096, 14336), (14336, 4096)]
+    print(f"device {torch.cuda.get_device_name(0)}  dtype {args.dtype}")
+    for (K, N) in shapes:
+        nbytes = N * K // 2
+        R = max(8, min(48, (700 << 20) // nbytes))
+        copies = [synth.random_wq(K, N, dtype=dtype, seed=i, keep_q=False) for i in range(R)]
+        for M in args.m:
+            x = torch.randn(M, K, device="cuda").to(dtype)
+            out = torch.empty(M, N, device="cuda", dtype=dtype)
+            L = _capi.lib()
+            st = None
+
+            def fn(c):
+                _capi.check(L.awq_w4a16_gemv(x.data_ptr(), c["qweight"].data_ptr(), c["scales"].data_ptr(),
+                                             c["scaled_zeros"].data_ptr(), out.data_ptr(), M, N, K, 128,
+                                             1 if dtype == torch.bfloat16 else 0, torch.cuda.current_stream().cuda_stream))
+            ab = algo_bytes(M, K, N)
+            rows = []
+            cfgs = [dict(gemv_waves=0, gemv_unroll=0, gemv_xmode=1, gemv_stream_only=0)]
+            for so in (1, 0):
+                for w, u in itertools.product((4, 8, 16), (1, 2, 4)):
+                    if (w, u) in ((4, 1),):
+                        continue
+                    for xm in ((1,) if so else (0, 1, 2)):
+                        cfgs.append(dict(gemv_waves=w, gemv_unroll=u, gemv_xmode=xm, gemv_stream_only=so))
+            for cfg in cfgs:
+                _capi.tune(**cfg)
+                try:
+                    us = time_cfg(fn, copies)
+                except Exception as e:  # noqa
+                    print("   cfg failed", cfg, e)
+                    continue
+                rows.append((us, cfg))
+                print(f"K={K:6d} N={N:6d} M={M:2d} waves={cfg['gemv_waves']:2d} U={cfg['gemv_unroll']} x={cfg['gemv_xmode']} "
+                      f"stream_only={cfg['gemv_stream_only']}  {us:8.2f} us  {ab / us / 1e3:8.1f} GB/s  {ab / us / 1e3 / 80:5.1f}% of 8TB/s",
+                      flush=True)
+            _capi.tune(gemv_waves=0, gemv_unroll=0, gemv_xmode=1, gemv_stream_only=0)
+        del copies
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
