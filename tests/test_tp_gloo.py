@@ -1,0 +1,93 @@
+"""not-gpu: the N > 1 path (llm_awq_amd.parallel) on CPU with the gloo backend, world_size 2.
+The shard matmul is the ORACLE here (there is no GPU in this container, and the product never falls back
+to it: TPWQLinear takes the matmul as an injected test seam); what is under test is the sharding of the v2
+buffers, the collective, and bias-after-reduce."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from llm_awq_amd import parallel as P
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, dtype_name, result_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from llm_awq_amd.qmodule import WQLinear
+        from oracle import awq_oracle as O
+
+        dtype = getattr(torch, dtype_name)
+        K, N, M = 1280, 96, 5  # 10 groups -> 5 per rank; N/16 = 6 slabs -> 3 per rank
+        g = torch.Generator().manual_seed(11)
+        d = O.quantize_linear(torch.randn(N, K, generator=g) * 0.02, dtype=dtype)
+        full = WQLinear(4, 128, K, N, True, "cpu", dtype=dtype)
+        full.qweight, full.scales, full.scaled_zeros = d["qweight"], d["scales"], d["scaled_zeros"]
+        full.bias = (torch.randn(N, generator=g) * 0.02).to(dtype)
+        x = torch.randn(M, K, generator=g).to(dtype)
+
+        def oracle_mm(xs, qw, s, z):
+            return O.wqlinear_forward(xs, qw, s, z, None, 128)
+
+        ref = O.wqlinear_forward(x, d["qweight"], d["scales"], d["scaled_zeros"], full.bias, 128).float()
+        row = P.TPWQLinear(full, "row", matmul=oracle_mm)
+        y_row = row(x).float()
+        col = P.TPWQLinear(full, "column", matmul=oracle_mm)
+        y_col_local = col(x)
+        parts = [torch.empty_like(y_col_local) for _ in range(world)]
+        dist.all_gather(parts, y_col_local)
+        y_col = torch.cat(parts, dim=-1).float()
+        # shards are exact slices
+        k0, k1 = row.bounds
+        assert (O.unpack_v2(row.shard.qweight.numpy()) == d["intweight"].numpy()[:, k0:k1]).all()
+        n0, n1 = col.bounds
+        assert (O.unpack_v2(col.shard.qweight.numpy()) == d["intweight"].numpy()[n0:n1]).all()
+        assert row.shard.scales.shape[0] == 8 and torch.equal(row.shard.scales[: (k1 - k0) // 128], d["scales"][k0 // 128: k1 // 128])
+        result_q.put((rank, ((y_row - ref).norm() / ref.norm()).item(), torch.equal(y_col, ref), (k0, k1), (n0, n1)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
+def test_tp2_row_and_column_parallel_gloo(dtype_name):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, dtype_name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort()
+    assert res[0][3] == (0, 640) and res[1][3] == (640, 1280)
+    assert res[0][4] == (0, 48) and res[1][4] == (48, 96)
+    for _rank, rel, col_exact, _kb, _nb in res:
+        assert col_exact  # column-parallel is a pure partition of the outputs: bit exact
+        # row-parallel adds one rounding to T per partial before the sum
+        assert rel < (1e-3 if dtype_name == "float16" else 4e-3), rel
+
+
+def test_shard_bounds():
+    assert [P.shard_bounds(14336, 8, r, 128) for r in (0, 7)] == [(0, 1792), (12544, 14336)]
+    assert P.shard_bounds(11008, 8, 0, 128) == (0, 1408) and P.shard_bounds(11008, 8, 7, 128) == (9728, 11008)
+    covered = []
+    for r in range(8):
+        lo, hi = P.shard_bounds(11008, 8, r, 128)
+        covered += list(range(lo, hi, 128))
+    assert covered == list(range(0, 11008, 128))
+    with pytest.raises(AssertionError):
+        P.shard_bounds(1000, 2, 0, 128)

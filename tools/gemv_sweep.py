@@ -1,7 +1,7 @@
-"""GPU experiment: time the decode GEMV (through the C ABI) for every Llama-3-8B layer shape across tuning
+"""GPU experiment: time the decode GEMV (through the C ABI) for Llama-3-8B layer shapes across tuning
 knobs, rotating over enough distinct weight copies to defeat the 256 MB Infinity Cache.  Each
 measurement = one hipGraph of R back-to-back launches, replayed; HIP events on the capture stream.
-usage: python tools/gemv_sweep.py [--m 1] [--quick]"""
+usage: python tools/gemv_sweep.py [--m 1] [--quick] [--dtype bf16|f16]"""
 import argparse
 import itertools
 import os
@@ -10,7 +10,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from llm_awq_amd import _capi, ops, synth  # noqa: E402
+from llm_awq_amd import _capi, synth  # noqa: E402
+
+DEFAULT = dict(gemv_waves=0, gemv_pf=0, gemv_xlds=1, gemv_probe=0, gemv_order=0, gemv_probe_blocks=2048)
 
 
 def algo_bytes(M, K, N):
@@ -45,12 +47,14 @@ def main():
     ap.add_argument("--m", type=int, nargs="+", default=[1])
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--defaults-only", action="store_true")
     args = ap.parse_args()
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     shapes = [(4096, 4096), (4096, 6144), (4096, 14336), (14336, 4096), (4096, 28672)]
     if args.quick:
         shapes = [(4096, 4096), (4096, 14336), (14336, 4096)]
     print(f"device {torch.cuda.get_device_name(0)}  dtype {args.dtype}")
+    L = _capi.lib()
     for (K, N) in shapes:
         nbytes = N * K // 2
         R = max(8, min(48, (700 << 20) // nbytes))
@@ -58,22 +62,24 @@ def main():
         for M in args.m:
             x = torch.randn(M, K, device="cuda").to(dtype)
             out = torch.empty(M, N, device="cuda", dtype=dtype)
-            L = _capi.lib()
-            st = None
 
             def fn(c):
                 _capi.check(L.awq_w4a16_gemv(x.data_ptr(), c["qweight"].data_ptr(), c["scales"].data_ptr(),
                                              c["scaled_zeros"].data_ptr(), out.data_ptr(), M, N, K, 128,
                                              1 if dtype == torch.bfloat16 else 0, torch.cuda.current_stream().cuda_stream))
             ab = algo_bytes(M, K, N)
-            rows = []
-            cfgs = [dict(gemv_waves=0, gemv_unroll=0, gemv_xmode=1, gemv_stream_only=0)]
-            for so in (1, 0):
-                for w, u in itertools.product((4, 8, 16), (1, 2, 4)):
-                    if (w, u) in ((4, 1),):
-                        continue
-                    for xm in ((1,) if so else (0, 1, 2)):
-                        cfgs.append(dict(gemv_waves=w, gemv_unroll=u, gemv_xmode=xm, gemv_stream_only=so))
+            cfgs = [dict(DEFAULT)]
+            if not args.defaults_only:
+                cfgs.append(dict(DEFAULT, gemv_probe=3))
+                for pb in (512, 1024, 2048, 4096):
+                    cfgs.append(dict(DEFAULT, gemv_probe=2, gemv_probe_blocks=pb))
+                for probe in (1, 0):
+                    for w, pf in itertools.product((4, 8, 16), (2, 4, 8)):
+                        for order in (0, 1, 2):
+                            if probe == 0 and order == 1 and pf != 4:
+                                continue
+                            cfgs.append(dict(DEFAULT, gemv_waves=w, gemv_pf=pf, gemv_probe=probe, gemv_order=order))
+                cfgs.append(dict(DEFAULT, gemv_xlds=0))
             for cfg in cfgs:
                 _capi.tune(**cfg)
                 try:
@@ -81,11 +87,10 @@ def main():
                 except Exception as e:  # noqa
                     print("   cfg failed", cfg, e)
                     continue
-                rows.append((us, cfg))
-                print(f"K={K:6d} N={N:6d} M={M:2d} waves={cfg['gemv_waves']:2d} U={cfg['gemv_unroll']} x={cfg['gemv_xmode']} "
-                      f"stream_only={cfg['gemv_stream_only']}  {us:8.2f} us  {ab / us / 1e3:8.1f} GB/s  {ab / us / 1e3 / 80:5.1f}% of 8TB/s",
-                      flush=True)
-            _capi.tune(gemv_waves=0, gemv_unroll=0, gemv_xmode=1, gemv_stream_only=0)
+                print(f"K={K:6d} N={N:6d} M={M:2d} waves={cfg['gemv_waves']:2d} pf={cfg['gemv_pf']} xlds={cfg['gemv_xlds']} "
+                      f"order={cfg['gemv_order']} probe={cfg['gemv_probe']}/{cfg['gemv_probe_blocks']:4d}  {us:8.2f} us  "
+                      f"{ab / us / 1e3:8.1f} GB/s  {ab / us / 1e3 / 80:5.1f}%", flush=True)
+            _capi.tune(**DEFAULT)
         del copies
         torch.cuda.empty_cache()
 
