@@ -7,6 +7,8 @@
 // loaded once per block (16 B per thread per K-step), dequantised once (reference numerics:
 // round_T(q*s+sz)) and shared by all waves, so the unpack cost is amortised over 128 rows of M.
 // Global loads for step t+1 are issued before the MFMAs of step t (register staging).
+#include <string.h>
+
 #include "awq_device.hpp"
 #include "awq_kernels.hpp"
 
@@ -127,13 +129,180 @@ __global__ __launch_bounds__(256) void gemm_w4a16_128x128_kernel(const uint16_t*
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 256 x 256 x 64 tile, 8 waves (2 along M x 4 along N, 128 x 64 each), double-buffered LDS (2 x 64 KiB):
+//   * x tile: global_load_lds_dwordx4 straight into LDS (no VGPR round trip).  The LDS image is
+//     lane-linear, so the XOR swizzle is applied to the per-lane SOURCE address and to the ds_read.
+//   * weight tile: 16 B of packed int4 per thread per K-tile, prefetched two tiles ahead into VGPRs,
+//     dequantised (reference numerics) while the MFMAs of the current tile run, ds_write_b128 into the
+//     other buffer.  One barrier per K-tile.
+//   * epilogue: accumulators -> LDS (per-wave [128 m][64 n] image, 144-B rows) -> 16-byte row stores.
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int kBufBytes = (TM + TN) * TK * 2;  // 64 KiB per stage
+constexpr int kEpiRow = 144;                   // bytes per staged output row (64 n x 2 B + 16 pad)
+constexpr int kSmem256 = 8 * 128 * kEpiRow;    // 147456 >= 2 * kBufBytes
+}  // namespace
+
+template <typename DT>
+__global__ __launch_bounds__(512) void gemm_w4a16_256x256_kernel(const uint16_t* __restrict__ x,
+                                                                 const u32* __restrict__ qw,
+                                                                 const uint16_t* __restrict__ scales,
+                                                                 const uint16_t* __restrict__ zeros,
+                                                                 uint16_t* __restrict__ out, int M, int N, int K,
+                                                                 int tiles_m, int tiles_n) {
+  using vec8 = typename DT::vec8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int wm = wv >> 2, wn = wv & 3;
+
+  // XCD-aware tile order: block b runs on XCD b % 8; give every XCD a contiguous range of tiles so that
+  // the weight panels it touches stay in ITS L2 (bijective for any tile count).
+  const int T = tiles_m * tiles_n;
+  int tile;
+  {
+    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    const int q = T >> 3, r = T & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = tile % tiles_m, tn = tile / tiles_m;
+  const int m0 = tm * TM, n0 = tn * TN;
+
+  // ---- x staging (LDS-DMA): 4 granules per thread per K-tile ----
+  const uint16_t* a_src[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int p = q * 512 + tid, row = p >> 3, gcp = p & 7;
+    const int gc = gcp ^ ((row >> 1) & 7);  // LDS slot gcp of this row receives source granule gc
+    a_src[q] = x + (size_t)min(m0 + row, M - 1) * K + gc * 8;
+  }
+  // ---- weight staging: thread -> (row nl, 32-k chunk c) ----
+  const int nl = (tid >> 3) * 4 + ((tid >> 1) & 3), c = tid & 1;
+  const int nrow = min(n0 + nl, N - 1);
+  const u32* b_src = qw + v2_chunk_word(nrow, c, K);  // + kt*32 words
+  const uint16_t* s_src = scales + nrow;
+  const uint16_t* z_src = zeros + nrow;
+
+  auto issue_a = [&](int kt, int buf) {
+    char* dst = smem + buf * kBufBytes + wv * 1024;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[q] + (size_t)kt * TK),
+                                       (__attribute__((address_space(3))) void*)(dst + q * 8192), 16, 0, 0);
+  };
+  auto write_b = [&](const u32x4& rb, uint16_t rs, uint16_t rz, int buf) {
+    char* Bs = smem + buf * kBufBytes + TM * TK * 2;
+    vec8 wop[4];
+    dequant_chunk<DT>(rb, DT::make_sz(rs, rz), wop);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<vec8*>(Bs + tile_off(nl, c * 4 + j)) = wop[j];
+  };
+
+  f32x4 acc[4][8];  // [n-frag][m-frag]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / TK;
+  u32x4 rb_cur, rb_nxt;
+  uint16_t rs_cur, rz_cur, rs_nxt, rz_nxt;
+  auto load_b = [&](int kt, u32x4& rb, uint16_t& rs, uint16_t& rz) {
+    rb = *reinterpret_cast<const u32x4*>(b_src + (size_t)kt * 32);
+    const int grp = (kt * TK) / kGroup;
+    rs = s_src[(size_t)grp * N];
+    rz = z_src[(size_t)grp * N];
+  };
+
+  issue_a(0, 0);
+  load_b(0, rb_cur, rs_cur, rz_cur);
+  load_b(nk > 1 ? 1 : 0, rb_nxt, rs_nxt, rz_nxt);
+  // Drain EVERYTHING before the loop: hipcc waits vmcnt(0) at any use of an ordinary load while an
+  // LDS-DMA is in flight, so the loop is arranged such that ordinary loads are only consumed after a
+  // barrier that already drained them (the scoreboard must be provably empty at the loop header).
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  write_b(rb_cur, rs_cur, rz_cur, 0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const char* As = smem + buf * kBufBytes;
+    const char* Bs = As + TM * TK * 2;
+    if (kt + 1 < nk) issue_a(kt + 1, buf ^ 1);
+    rb_cur = rb_nxt;
+    rs_cur = rs_nxt;
+    rz_cur = rz_nxt;  // tile kt+1's packed weights (already in registers)
+    if (kt + 2 < nk) load_b(kt + 2, rb_nxt, rs_nxt, rz_nxt);
+
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      vec8 wf[4], xf[8];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const vec8*>(Bs + tile_off(wn * 64 + t * 16 + i, ks * 4 + g));
+#pragma unroll
+      for (int t = 0; t < 8; ++t) xf[t] = *reinterpret_cast<const vec8*>(As + tile_off(wm * 128 + t * 16 + i, ks * 4 + g));
+#pragma unroll
+      for (int b = 0; b < 8; ++b)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[a][b] = DT::mfma(wf[a], xf[b], acc[a][b]);
+      if (ks == 0 && kt + 1 < nk) write_b(rb_cur, rs_cur, rz_cur, buf ^ 1);  // VALU work to hide under the MFMAs
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue through LDS: acc[a][b][r] = C[n = wn*64 + a*16 + 4g + r][m = wm*128 + b*16 + i] ----
+  char* eb = smem + wv * (128 * kEpiRow);
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      u32x2 v;
+      v.x = (u32)DT::from_float(acc[a][b][0]) | ((u32)DT::from_float(acc[a][b][1]) << 16);
+      v.y = (u32)DT::from_float(acc[a][b][2]) | ((u32)DT::from_float(acc[a][b][3]) << 16);
+      *reinterpret_cast<u32x2*>(eb + (b * 16 + i) * kEpiRow + a * 32 + g * 8) = v;
+    }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's own LDS writes (region is wave-private)
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int ps = 0; ps < 16; ++ps) {
+    const int row = ps * 8 + (lane >> 3), gc = lane & 7;
+    const int m = m0 + wm * 128 + row, nn = n0 + wn * 64 + gc * 8;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(eb + row * kEpiRow + gc * 16);
+    if (m < M && nn < N) *reinterpret_cast<u32x4*>(out + (size_t)m * N + nn) = v;
+  }
+}
+
 size_t gemm_workspace_bytes(int, int, int) { return 0; }
 
-int gemm_tune_set(const char*, int) { return -1; }
+namespace {
+int g_gemm_variant = 0;  // 0 = auto, 1 = force 128x128, 2 = force 256x256
+}
+int gemm_tune_set(const char* key, int value) {
+  if (!strcmp(key, "gemm_variant")) {
+    g_gemm_variant = value;
+    return 0;
+  }
+  return -1;
+}
 
 template <typename DT>
 static int launch_gemm_t(const void* x, const void* qw, const void* s, const void* z, void* out, int m, int n, int k,
                          hipStream_t st) {
+  const bool big = g_gemm_variant == 2 || (g_gemm_variant == 0 && m > 128);
+  if (big) {
+    const int tiles_m = (m + TM - 1) / TM, tiles_n = (n + TN - 1) / TN;
+    auto kern = gemm_w4a16_256x256_kernel<DT>;
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem256);
+      attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), kSmem256, st, (const uint16_t*)x, (const u32*)qw,
+                       (const uint16_t*)s, (const uint16_t*)z, (uint16_t*)out, m, n, k, tiles_m, tiles_n);
+    return 0;
+  }
   const int tiles_m = (m + BM - 1) / BM, tiles_n = (n + BN - 1) / BN;
   dim3 grid(tiles_m * tiles_n), block(256);
   hipLaunchKernelGGL((gemm_w4a16_128x128_kernel<DT>), grid, block, 0, st, (const uint16_t*)x, (const u32*)qw,

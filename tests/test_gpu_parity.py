@@ -74,11 +74,16 @@ def test_gemv_vs_oracle(ops, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("variant", [0, 1, 2])  # auto / force 128x128 / force 256x256
 @pytest.mark.parametrize("M", [8, 17, 64, 100, 128, 129, 200, 512, 777])
 @pytest.mark.parametrize("N,K", [(768, 768), (3072, 768), (768, 3072), (136, 1280)])
-def test_gemm_vs_oracle(ops, dtype, M, N, K):
+def test_gemm_vs_oracle(ops, dtype, variant, M, N, K):
     c = make_case(N, K, dtype, seed=M * 17 + N + K, M=M)
-    y = ops.gemm(c["x"].cuda(), c["qweight"].cuda(), c["scales"].cuda(), c["scaled_zeros"].cuda()).cpu()
+    ops._capi.tune(gemm_variant=variant)
+    try:
+        y = ops.gemm(c["x"].cuda(), c["qweight"].cuda(), c["scales"].cuda(), c["scaled_zeros"].cuda()).cpu()
+    finally:
+        ops._capi.tune(gemm_variant=0)
     check_forward(y, c["x"], c["q"], c["scales"], c["scaled_zeros"], dtype)
 
 
