@@ -88,6 +88,20 @@ int awq_repack_v1_to_v2(const void* qweight_v1, const void* scales_v1, const voi
                         void* qweight_v2, void* scales_v2, void* scaled_zeros_v2,
                         int n, int k, int gpad, int dtype, void* stream);
 
+/* ---- "cdna4" interleave: this repository's MI355X-native int4 layout (what the rewritten
+ * tinychat/offline-weight-repacker.py equivalent emits; DESIGN.md "cdna4 interleave").  Same bytes and
+ * shape as v2 (int16 [N/4, K]); a pure nibble permutation that makes one 16-row x 128-k tile a contiguous
+ * 1-KiB wave-load and lets the weights be dequantised on the matrix core.  bf16 only; n % 16 == 0.
+ * scales / scaled_zeros keep the v2 contract. ---- */
+int awq_repack_v2_to_cdna4(const void* qweight_v2, void* qweight_cdna4, int n, int k, void* stream);
+int awq_repack_cdna4_to_v2(const void* qweight_cdna4, void* qweight_v2, int n, int k, void* stream);
+int awq_unpack_cdna4(const void* qweight_cdna4, void* out_u8, int n, int k, void* stream);
+int awq_dequant_cdna4(const void* qweight_cdna4, const void* scales, const void* scaled_zeros, void* out,
+                      int n, int k, int group_size, int dtype, void* stream);
+/* gemv on cdna4-interleaved weights (same contract as awq_w4a16_gemv otherwise) */
+int awq_w4a16_gemv_cdna4(const void* x, const void* qweight_cdna4, const void* scales, const void* scaled_zeros,
+                         void* out, int m, int n, int k, int group_size, int dtype, void* stream);
+
 /* Tuning hook for experiments and benchmarks (not part of the reference surface): integer knobs such as
  * "gemv_waves", "gemv_unroll", "gemv_xmode", "gemv_stream_only", "gemm_variant"; 0 restores the default
  * heuristic.  Returns AWQ_OK or AWQ_ERR_SHAPE for an unknown key. Process-global, not thread-safe. */

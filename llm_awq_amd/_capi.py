@@ -27,6 +27,11 @@ SIGNATURES = {
     "awq_dequant_v2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "awq_pack_v2": (_i, [_vp, _vp, _i, _i, _vp]),
     "awq_repack_v1_to_v2": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "awq_repack_v2_to_cdna4": (_i, [_vp, _vp, _i, _i, _vp]),
+    "awq_repack_cdna4_to_v2": (_i, [_vp, _vp, _i, _i, _vp]),
+    "awq_unpack_cdna4": (_i, [_vp, _vp, _i, _i, _vp]),
+    "awq_dequant_cdna4": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "awq_w4a16_gemv_cdna4": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "awq_tune_set": (_i, [ctypes.c_char_p, _i]),
 }
 

@@ -51,7 +51,10 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
     if force or _newer(LIB_PATH, deps):
         os.makedirs(LIB_DIR, exist_ok=True)
         cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-               "-Wno-unused-function", *srcs, "-o", LIB_PATH]
+               "-Wno-unused-function",
+               # keep MFMA results in VGPRs: the matrix-core dequant feeds v_cvt_pk_bf16_f32 directly
+               # (the AGPR form costs one v_accvgpr_read per value)
+               "-mllvm", "-amdgpu-mfma-vgpr-form", *srcs, "-o", LIB_PATH]
         dt = _run(cmd, "libawq_cdna4.so")
         if verbose:
             print(f"[llm_awq_amd.build] libawq_cdna4.so built in {dt:.1f}s")

@@ -63,7 +63,7 @@ int awq_w4a16_gemv(const void* x, const void* qweight, const void* scales, const
   if (m < 1 || m > 16) return AWQ_ERR_BATCH;
   int st = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
   if (st != AWQ_OK) return st;
-  awq::launch_gemv(x, qweight, scales, scaled_zeros, out, m, n, k, dtype, (hipStream_t)stream);
+  awq::launch_gemv(x, qweight, scales, scaled_zeros, out, m, n, k, dtype, 0, (hipStream_t)stream);
   return finish_launch();
 }
 
@@ -75,7 +75,7 @@ int awq_w4a16_gemm(const void* x, const void* qweight, const void* scales, const
   if (st != AWQ_OK) return st;
   const size_t need = awq::gemm_workspace_bytes(m, n, k);
   if (need > 0 && (!workspace || workspace_bytes < need)) return AWQ_ERR_WORKSPACE;
-  awq::launch_gemm(x, qweight, scales, scaled_zeros, out, m, n, k, dtype, workspace, workspace_bytes, (hipStream_t)stream);
+  awq::launch_gemm(x, qweight, scales, scaled_zeros, out, m, n, k, dtype, 0, workspace, workspace_bytes, (hipStream_t)stream);
   return finish_launch();
 }
 
@@ -124,6 +124,52 @@ int awq_repack_v1_to_v2(const void* qweight_v1, const void* scales_v1, const voi
   if (n < 4 || (n % 4) != 0 || k < 64 || (k % 64) != 0 || gpad < 8 || (gpad % 8) != 0) return AWQ_ERR_SHAPE;
   awq::launch_repack_v1_to_v2(qweight_v1, scales_v1, qzeros_v1, qweight_v2, scales_v2, scaled_zeros_v2, n, k, gpad, dtype,
                               (hipStream_t)stream);
+  return finish_launch();
+}
+
+// ---- cdna4 interleave (bf16) ----
+int awq_repack_v2_to_cdna4(const void* qweight_v2, void* qweight_cdna4, int n, int k, void* stream) {
+  if (!qweight_v2 || !qweight_cdna4) return AWQ_ERR_NULL;
+  if (qweight_v2 == qweight_cdna4) return AWQ_ERR_ALIGN;  // not an in-place permutation
+  if (n < 16 || (n % 16) != 0 || k < 128 || (k % 128) != 0) return AWQ_ERR_SHAPE;
+  awq::launch_repack_v2_cdna4(qweight_v2, qweight_cdna4, n, k, 1, (hipStream_t)stream);
+  return finish_launch();
+}
+
+int awq_repack_cdna4_to_v2(const void* qweight_cdna4, void* qweight_v2, int n, int k, void* stream) {
+  if (!qweight_v2 || !qweight_cdna4) return AWQ_ERR_NULL;
+  if (qweight_v2 == qweight_cdna4) return AWQ_ERR_ALIGN;
+  if (n < 16 || (n % 16) != 0 || k < 128 || (k % 128) != 0) return AWQ_ERR_SHAPE;
+  awq::launch_repack_v2_cdna4(qweight_cdna4, qweight_v2, n, k, 0, (hipStream_t)stream);
+  return finish_launch();
+}
+
+int awq_unpack_cdna4(const void* qweight, void* out_u8, int n, int k, void* stream) {
+  if (!qweight || !out_u8) return AWQ_ERR_NULL;
+  if (n < 16 || (n % 16) != 0 || k < 128 || (k % 128) != 0) return AWQ_ERR_SHAPE;
+  awq::launch_unpack_cdna4(qweight, out_u8, n, k, (hipStream_t)stream);
+  return finish_launch();
+}
+
+int awq_dequant_cdna4(const void* qweight, const void* scales, const void* scaled_zeros, void* out, int n, int k,
+                      int group_size, int dtype, void* stream) {
+  if (!qweight || !scales || !scaled_zeros || !out) return AWQ_ERR_NULL;
+  if (dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
+  if (group_size != 128) return AWQ_ERR_GROUP;
+  if (n < 16 || (n % 16) != 0 || k < 128 || (k % 128) != 0) return AWQ_ERR_SHAPE;
+  awq::launch_dequant_cdna4(qweight, scales, scaled_zeros, out, n, k, (hipStream_t)stream);
+  return finish_launch();
+}
+
+int awq_w4a16_gemv_cdna4(const void* x, const void* qweight, const void* scales, const void* scaled_zeros, void* out,
+                         int m, int n, int k, int group_size, int dtype, void* stream) {
+  if (group_size != 128) return AWQ_ERR_GROUP;
+  if (m < 1 || m > 16) return AWQ_ERR_BATCH;
+  if (dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
+  int st = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
+  if (st != AWQ_OK) return st;
+  if ((n % 16) != 0) return AWQ_ERR_SHAPE;
+  awq::launch_gemv(x, qweight, scales, scaled_zeros, out, m, n, k, dtype, 1, (hipStream_t)stream);
   return finish_launch();
 }
 

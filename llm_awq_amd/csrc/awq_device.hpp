@@ -146,4 +146,60 @@ __device__ __forceinline__ u32x4 ldg_nt_u32x4(const u32* p) {
   return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
 }
 
+
+// =============================================================================================
+// "cdna4" interleave (this repository's MI355X-native layout; emitted by the rewritten repacker).
+// Same bytes/shape as v2, nibbles permuted so that a 1-KiB tile = 16 rows x 128 k is ONE contiguous
+// wave-load and every extraction (word >> 4i) & 0x000F000F | 0x43004300 is directly the A-operand
+// register of a v_mfma_f32_16x16x16_bf16 that dequantises ON THE MATRIX CORE:
+//      D[k][n] = sum_n' (128 + Q[n'][k]) * (s_n [n'==n])  +  (sz_n - 128 s_n)  =  Q[n][k] s_n + sz_n   (exact in fp32)
+// lane l = 16 g + kl, word a, nibble p (i = p & 3, hi = p >> 2):
+//      n = 16 nb + 4 g + 2 (i & 1) + hi,   k = 128 kg + 32 a + 8 (kl / 4) + 4 (i >> 1) + kl % 4
+// D comes out with lane (n = l % 16, g = l / 16) holding k = 32 a + 8 g + {0..3} (first MFMA) and
+// + {4..7} (second): after v_cvt_pk_bf16_f32 that IS the operand of the matmul MFMA 16x16x32.
+// =============================================================================================
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ size_t cdna4_tile_word(int nb, int kg, int nit) { return ((size_t)nb * nit + kg) * 256; }
+
+struct Cdna4Dequant {
+  u32 m01, m23;  // lane masks selecting where s_n sits in the diagonal B operand
+  u32 kMagic, kMask;
+  __device__ __forceinline__ void init(int lane) {
+    const int pos = (lane & 15) - 4 * (lane >> 4);
+    m01 = pos == 0 ? 0x0000FFFFu : (pos == 1 ? 0xFFFF0000u : 0u);
+    m23 = pos == 2 ? 0x0000FFFFu : (pos == 3 ? 0xFFFF0000u : 0u);
+    // gfx950 VOP3 takes no 32-bit literal: park the magic in a VGPR and the mask in an SGPR so that
+    // (w & mask) | magic is ONE v_and_or_b32 instead of v_and_b32 + v_or_b32 with literals
+    kMagic = 0x43004300u;
+    kMask = 0x000F000Fu;
+    asm volatile("" : "+v"(kMagic));
+    asm volatile("" : "+s"(kMask));
+  }
+  // one word (two 16x16x16 MFMAs) -> one bf16x8 operand: W[n = lane%16][k = 32a + 8g + 0..7]
+  __device__ __forceinline__ bf16x8 word(u32 w, u32 b01, u32 b23, float cv) const {
+    const u32x2 a0 = {(w & kMask) | kMagic, ((w >> 4) & kMask) | kMagic};
+    const u32x2 a1 = {((w >> 8) & kMask) | kMagic, ((w >> 12) & kMask) | kMagic};
+    const u32x2 b = {b01, b23};
+    const f32x4 c = {cv, cv, cv, cv};
+    const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a0), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+    const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a1), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+    bf16x8 r = {(__bf16)d0[0], (__bf16)d0[1], (__bf16)d0[2], (__bf16)d0[3],
+                (__bf16)d1[0], (__bf16)d1[1], (__bf16)d1[2], (__bf16)d1[3]};
+    return r;
+  }
+  // whole 1-KiB tile -> 4 operands (op[a] covers k = 32a + 8g + 0..7 of the tile's 128 k)
+  __device__ __forceinline__ void tile(const u32x4& w, uint16_t s_bits, uint16_t z_bits, bf16x8 (&op)[4]) const {
+    const u32 sdup = (u32)s_bits * 0x00010001u;
+    const u32 b01 = sdup & m01, b23 = sdup & m23;
+    const float sf = __builtin_bit_cast(float, (u32)s_bits << 16);
+    const float zf = __builtin_bit_cast(float, (u32)z_bits << 16);
+    const float cv = __builtin_fmaf(-128.0f, sf, zf);  // exact: |sz| = s*z, z <= 15
+    op[0] = word(w.x, b01, b23, cv);
+    op[1] = word(w.y, b01, b23, cv);
+    op[2] = word(w.z, b01, b23, cv);
+    op[3] = word(w.w, b01, b23, cv);
+  }
+};
+
 }  // namespace awq

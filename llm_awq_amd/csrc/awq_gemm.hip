@@ -311,8 +311,9 @@ static int launch_gemm_t(const void* x, const void* qw, const void* s, const voi
 }
 
 int launch_gemm(const void* x, const void* qw, const void* s, const void* z, void* out, int m, int n, int k, int dtype,
-                void*, size_t, hipStream_t st) {
-  if (m <= 16) return launch_gemv(x, qw, s, z, out, m, n, k, dtype, st);
+                int layout, void*, size_t, hipStream_t st) {
+  if (m <= 16) return launch_gemv(x, qw, s, z, out, m, n, k, dtype, layout, st);
+  if (layout != 0) return -1;  // cdna4 GEMM: not yet
   return dtype == 0 ? launch_gemm_t<F16>(x, qw, s, z, out, m, n, k, st)
                     : launch_gemm_t<BF16>(x, qw, s, z, out, m, n, k, st);
 }

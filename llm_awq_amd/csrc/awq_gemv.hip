@@ -3,17 +3,21 @@
 // Replaces gemv_kernel<NPerBlock,Batch,BlockSize,GroupSize,T> (reference
 // awq/kernels/csrc/quantization_new/gemv/gemv_cuda.cu:74-229).  Design ("gemv"):
 //   * HBM-bound: every packed weight byte is read exactly once with 16-byte non-temporal loads,
-//     kept PF deep in flight per wave (register ring) so the stream never drains while a wave
-//     dequantises.
-//   * one wave owns 16 output rows x a K slice; per 16-byte load a lane holds 32 k of ONE row
-//     (the v2 interleave already has this shape), so it needs one (scale, scaled_zero) pair.
-//   * x (<= 16 rows), and the slab's scales / scaled_zeros are staged ONCE per block in LDS; the only
-//     global loads in the loop are the packed weights.
-//   * weights are dequantised in registers with the reference's exact numerics
-//     (round_T(q*s+sz)), then fed to v_mfma_f32_16x16x32 as the A operand; the activation rows are
-//     the B operand.  One MFMA per 512 weights whatever M is.
-//   * K is split across the WAVES waves of a block (interleaved 128-k steps) and reduced through LDS
-//     in fp32; one rounding to T at the end.
+//     kept PF deep in flight per wave in a register ring.  The steady-state loop has NO conditional
+//     loads, so hipcc emits counted s_waitcnt vmcnt(N) (a load inside a branch degrades every wait
+//     to vmcnt(0) and serialises the stream -- measured 2x).
+//   * one wave owns 16 output rows x a K slice (interleaved 128-k steps across the WAVES waves of a
+//     block); x (<= 16 rows) and the slab's scales / scaled_zeros are staged once per block in LDS, so
+//     the only global loads in the loop are the packed weights.
+//   * two weight layouts:
+//       LAYOUT 0  reference v2 interleave: 16 B per lane = 32 k of one row; unpack + dequant on the VALU
+//                 (round_T(q*s+sz), bit-exact with the reference's __hfma2), fp16 and bf16.
+//       LAYOUT 1  "cdna4" interleave (bf16): one contiguous 1-KiB tile per wave-load, dequantised ON THE
+//                 MATRIX CORE by two v_mfma_f32_16x16x16_bf16 per word (awq_device.hpp) -- ~2.5x fewer
+//                 VALU instructions per weight.
+//   * the dequantised weights are the A operand of v_mfma_f32_16x16x32, the activation rows the B
+//     operand: one MFMA per 512 weights whatever M is.  Split-K partials are reduced through LDS in fp32;
+//     one rounding to T at the end.
 #include <string.h>
 
 #include "awq_device.hpp"
@@ -21,106 +25,123 @@
 
 namespace awq {
 
-// XLDS: true  = x rows staged in LDS (padded rows), read with ds_read_b128 per MFMA
-//       false = only lanes with row < M load x from global (L2) per step (others keep 0)
-template <typename DT, int PF, int WAVES, bool XLDS, int PROBE>
+template <typename DT, int PF, int WAVES, int LAYOUT, int PROBE>
 __global__ __launch_bounds__(64 * WAVES) void gemv_w4a16_kernel(const uint16_t* __restrict__ x,
                                                                  const u32* __restrict__ qw,
                                                                  const uint16_t* __restrict__ scales,
                                                                  const uint16_t* __restrict__ zeros,
                                                                  uint16_t* __restrict__ out, int M, int N, int K,
-                                                                 int order) {
+                                                                 int seg_steps) {
   using vec8 = typename DT::vec8;
+  static_assert(LAYOUT == 0 || DT::id == 1, "the cdna4 interleave is defined for bf16");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int i = lane & 15;  // weight row inside the 16-row slab  /  activation row
-  const int g = lane >> 4;  // which 32-k chunk of the 128-k step
-  const int n0 = blockIdx.x * 16;
+  const int g = lane >> 4;  // which 32-k chunk of the 128-k step (v2) / which 8-k octet (cdna4)
+  const int nb = blockIdx.x;
+  const int n0 = nb * 16;
   const int n = min(n0 + i, N - 1);
   const int nit = K / kGroup;  // 128-k steps == quantisation groups
 
-  // this wave's steps: it(t) = (first + stride * t + rot) % nit, t in [0, cnt)
-  int first, stride, cnt;
-  if (order == 1) {  // contiguous K slice per wave
-    const int per = (nit + WAVES - 1) / WAVES;
-    first = wv * per;
-    stride = 1;
-    cnt = max(0, min(per, nit - first));
-  } else {  // interleaved
-    first = wv;
-    stride = WAVES;
-    cnt = (nit - wv + WAVES - 1) / WAVES;
-  }
-  const int rot = (order == 2) ? (int)((blockIdx.x * 5u) % (unsigned)nit) : 0;
-  auto step_of = [&](int t) {
-    int it = first + stride * t + rot;
-    return it >= nit ? it - nit : it;
-  };
-
-  const u32* wp = qw + v2_chunk_word(n, g, K);  // + it*64 words
+  const u32* wp;  // per-lane pointer of step 0; + it * WSTEP words
+  constexpr int WSTEP = LAYOUT == 0 ? 64 : 256;
+  if (LAYOUT == 0)
+    wp = qw + v2_chunk_word(n, g, K);
+  else
+    wp = qw + cdna4_tile_word(nb, 0, nit) + lane * 4;
   const int mrow = min(i, M - 1);
 
-  // ---- LDS carve: [reduce WAVES*1KiB][sz pairs nit*16*4B][x rows] ----
+  // ---- LDS carve: [reduce WAVES KiB][{scale | zero<<16} nit*16 words][x segment rows] ----
   float(*red)[4][64] = reinterpret_cast<float(*)[4][64]>(smem);
-  u32* szs = reinterpret_cast<u32*>(smem + WAVES * 1024);  // [nit][16] {scale | zero << 16}
+  u32* szs = reinterpret_cast<u32*>(smem + WAVES * 1024);
   char* xs = smem + WAVES * 1024 + nit * 64;
-  const int xrow_bytes = 2 * K + 16;
+  const int xrow_bytes = 2 * seg_steps * kGroup + 16;
 
-  // ---- prologue: start the weight stream first, then stage the small operands ----
-  u32x4 wq[PF];
-#pragma unroll
-  for (int u = 0; u < PF; ++u) {
-    const int it = min(step_of(min(u, max(cnt - 1, 0))), nit - 1);
-    wq[u] = ldg_nt_u32x4(wp + (size_t)it * 64);
-  }
-  for (int q = threadIdx.x; q < nit * 16; q += 64 * WAVES) {
-    const int gi = q >> 4, c = q & 15;
-    const int nn = min(n0 + c, N - 1);
-    szs[q] = (u32)scales[(size_t)gi * N + nn] | ((u32)zeros[(size_t)gi * N + nn] << 16);
-  }
-  if (XLDS) {
-    const int per_row = K / 8;  // 16-byte granules per row
-    for (int q = threadIdx.x; q < M * per_row; q += 64 * WAVES) {
-      const int r = q / per_row, c = q - r * per_row;
-      *reinterpret_cast<u32x4*>(xs + r * xrow_bytes + c * 16) = *reinterpret_cast<const u32x4*>(x + (size_t)r * K + c * 8);
-    }
-  }
-  __syncthreads();
+  Cdna4Dequant cd;
+  if (LAYOUT == 1) cd.init(lane);
 
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   u32 sink = 0;
-  u32x4 xg[4] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
 
-  for (int t0 = 0; t0 < cnt; t0 += PF) {
+  auto compute = [&](const u32x4& w, int it, int seg0) {
+    if (PROBE) {
+      sink ^= w.x ^ w.y ^ w.z ^ w.w;
+      return;
+    }
+    const u32 szv = szs[it * 16 + i];
+    const u32x4* xv = reinterpret_cast<const u32x4*>(xs + mrow * xrow_bytes + ((it - seg0) * 128 + g * 32) * 2);
+    vec8 wop[4];
+    if (LAYOUT == 0) {
+      dequant_chunk<DT>(w, DT::make_sz((uint16_t)(szv & 0xFFFFu), (uint16_t)(szv >> 16)), wop);
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const int t = t0 + u;
-      if (t < cnt) {  // wave-uniform
-        const int it = step_of(t);
-        const u32x4 w = wq[u];
-        if (t + PF < cnt) wq[u] = ldg_nt_u32x4(wp + (size_t)step_of(t + PF) * 64);
-        if (PROBE) {
-          sink ^= w.x ^ w.y ^ w.z ^ w.w;
-        } else {
-          const u32 szv = szs[it * 16 + i];
-          const u32x4* xv;
-          if (XLDS) {
-            xv = reinterpret_cast<const u32x4*>(xs + mrow * xrow_bytes + (it * 128 + g * 32) * 2);
+      for (int j = 0; j < 4; ++j) acc = DT::mfma(wop[j], __builtin_bit_cast(vec8, xv[j]), acc);
+    } else {
+      // operand a covers k = 32a + 8g + 0..7 of the step: x granule index 4a + g
+      const u32x4* xr = reinterpret_cast<const u32x4*>(xs + mrow * xrow_bytes + (it - seg0) * 256);
+      bf16x8 op[4];
+      cd.tile(w, (uint16_t)(szv & 0xFFFFu), (uint16_t)(szv >> 16), op);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xg[j] = xv[j];
-          } else if (i < M) {
-            xv = reinterpret_cast<const u32x4*>(x + (size_t)mrow * K + it * 128 + g * 32);
+      for (int a = 0; a < 4; ++a)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(op[a], __builtin_bit_cast(bf16x8, xr[4 * a + g]), acc, 0, 0, 0);
+      (void)xv;
+    }
+  };
+
+  for (int seg0 = 0; seg0 < nit; seg0 += seg_steps) {
+    const int seg1 = min(nit, seg0 + seg_steps);
+    // this wave's steps inside the segment: it(t) = seg0 + wv + WAVES * t, t in [0, cnt)
+    const int cnt = max(0, (seg1 - seg0 - wv + WAVES - 1) / WAVES);
+    const int groups = cnt / PF, rem = cnt - groups * PF;
+    auto step = [&](int t) { return seg0 + wv + WAVES * t; };
+
+    // ---- start the weight stream first (addresses clamped: no branches around loads) ----
+    u32x4 ring[PF];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xg[j] = xv[j];
-          }
-          vec8 wop[4];
-          dequant_chunk<DT>(w, DT::make_sz((uint16_t)(szv & 0xFFFFu), (uint16_t)(szv >> 16)), wop);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc = DT::mfma(wop[j], __builtin_bit_cast(vec8, xg[j]), acc);
-        }
+    for (int u = 0; u < PF; ++u) ring[u] = ldg_nt_u32x4(wp + (size_t)min(step(min(u, max(cnt - 1, 0))), nit - 1) * WSTEP);
+
+    // ---- stage the small operands ----
+    if (seg0 > 0) __syncthreads();  // previous segment's x fully consumed
+    if (seg0 == 0) {
+      for (int q = threadIdx.x; q < nit * 16; q += 64 * WAVES) {
+        const int gi = q >> 4, c = q & 15;
+        const int nn = min(n0 + c, N - 1);
+        szs[q] = (u32)scales[(size_t)gi * N + nn] | ((u32)zeros[(size_t)gi * N + nn] << 16);
       }
     }
+    if (!PROBE) {
+      const int per_row = (seg1 - seg0) * 16;  // 16-byte granules per row in this segment
+      for (int q = threadIdx.x; q < M * per_row; q += 64 * WAVES) {
+        const int r = q / per_row, c = q - r * per_row;
+        *reinterpret_cast<u32x4*>(xs + r * xrow_bytes + c * 16) =
+            *reinterpret_cast<const u32x4*>(x + (size_t)r * K + (size_t)seg0 * kGroup + c * 8);
+      }
+    }
+    __syncthreads();
+
+    // ---- steady state: consume slot u, refill it PF steps ahead (unconditional) ----
+    if (groups > 0) {
+      for (int grp = 0; grp + 1 < groups; ++grp) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+          const int t = grp * PF + u;
+          // consume, THEN refill the same registers: issuing the refill before the last use of the slot
+          // makes hipcc allocate a second register set + copies at the loop latch, whose waits drain the ring
+          compute(ring[u], step(t), seg0);
+          ring[u] = ldg_nt_u32x4(wp + (size_t)step(t + PF) * WSTEP);
+        }
+      }
+      // last full group: refill only the slots the remainder will use
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int t = (groups - 1) * PF + u;
+        compute(ring[u], step(t), seg0);
+        if (u < rem) ring[u] = ldg_nt_u32x4(wp + (size_t)step(t + PF) * WSTEP);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+      if (u < rem) compute(ring[u], step(groups * PF + u), seg0);
   }
   if (PROBE) acc[0] = __builtin_bit_cast(float, sink & 0x3fffffffu);
 
@@ -163,31 +184,35 @@ namespace {
 struct GemvTune {
   int waves = 0;  // 0 = auto
   int pf = 0;
-  int xlds = 1;
   int probe = 0;  // 1 = stream-only in the real access pattern, 2 = linear read, 3 = null kernel
-  int order = 0;
   int probe_blocks = 2048;
+  int x_budget_kib = 64;
 } g_tune;
-bool g_attr_done = false;
 }  // namespace
 
 int gemv_tune_set(const char* key, int value) {
   if (!strcmp(key, "gemv_waves")) g_tune.waves = value;
   else if (!strcmp(key, "gemv_pf")) g_tune.pf = value;
-  else if (!strcmp(key, "gemv_xlds")) g_tune.xlds = value;
   else if (!strcmp(key, "gemv_probe")) g_tune.probe = value;
-  else if (!strcmp(key, "gemv_order")) g_tune.order = value;
   else if (!strcmp(key, "gemv_probe_blocks")) g_tune.probe_blocks = value;
+  else if (!strcmp(key, "gemv_x_budget_kib")) g_tune.x_budget_kib = value;
   else return -1;
   return 0;
 }
 
-template <typename DT, int PF, int WAVES, bool XLDS, int PROBE>
+template <typename DT, int PF, int WAVES, int LAYOUT, int PROBE>
 static void launch_one(const void* x, const void* qw, const void* s, const void* z, void* out, int m, int n, int k,
                        hipStream_t st) {
+  const int nit = k / kGroup;
+  // x segment: as many 128-k steps (a multiple of WAVES) as fit the LDS budget
+  const long budget = (long)g_tune.x_budget_kib * 1024;
+  long seg = ((budget / m) - 16) / (2 * kGroup);
+  seg = seg / WAVES * WAVES;
+  if (seg < WAVES) seg = WAVES;
+  if (seg > nit) seg = (nit + WAVES - 1) / WAVES * WAVES;
+  const size_t smem = (size_t)WAVES * 1024 + (size_t)nit * 64 + (size_t)m * (2 * seg * kGroup + 16);
   dim3 grid((n + 15) / 16), block(64 * WAVES);
-  const size_t smem = WAVES * 1024 + (size_t)(k / kGroup) * 64 + (XLDS ? (size_t)m * (2 * k + 16) : 0);
-  auto kern = gemv_w4a16_kernel<DT, PF, WAVES, XLDS, PROBE>;
+  auto kern = gemv_w4a16_kernel<DT, PF, WAVES, LAYOUT, PROBE>;
   if (smem > 64 * 1024) {
     static bool done = false;  // per instantiation
     if (!done) {
@@ -196,18 +221,10 @@ static void launch_one(const void* x, const void* qw, const void* s, const void*
     }
   }
   hipLaunchKernelGGL(kern, grid, block, smem, st, (const uint16_t*)x, (const u32*)qw, (const uint16_t*)s,
-                     (const uint16_t*)z, (uint16_t*)out, m, n, k, g_tune.order);
+                     (const uint16_t*)z, (uint16_t*)out, m, n, k, (int)seg);
 }
 
-template <typename DT, int PF, int WAVES>
-static void launch_x(bool xlds, int probe, const void* x, const void* qw, const void* s, const void* z, void* out, int m,
-                     int n, int k, hipStream_t st) {
-  if (probe == 1) return launch_one<DT, PF, WAVES, false, 1>(x, qw, s, z, out, m, n, k, st);
-  if (xlds) return launch_one<DT, PF, WAVES, true, 0>(x, qw, s, z, out, m, n, k, st);
-  return launch_one<DT, PF, WAVES, false, 0>(x, qw, s, z, out, m, n, k, st);
-}
-
-template <typename DT>
+template <typename DT, int LAYOUT>
 static int launch_gemv_t(const void* x, const void* qw, const void* s, const void* z, void* out, int m, int n, int k,
                          hipStream_t st) {
   const int nit = k / kGroup;
@@ -225,26 +242,29 @@ static int launch_gemv_t(const void* x, const void* qw, const void* s, const voi
   if (waves == 0) waves = slabs >= 768 ? 4 : (slabs >= 320 ? 8 : 16);  // ~16 resident waves per CU
   while (waves > 4 && waves > nit) waves >>= 1;
   int pf = g_tune.pf;
-  if (pf == 0) pf = (nit / waves >= 8) ? 8 : 4;
-  // x in LDS when it fits next to the reduce + scale buffers (<= 150 KiB per block)
-  bool xlds = g_tune.xlds != 0;
-  if (xlds && (size_t)m * (2 * k + 16) + (size_t)nit * 64 + waves * 1024 > 150 * 1024) xlds = false;
-#define AWQ_GEMV_CASE(W_, P_)                                                      \
-  if (waves == W_ && pf == P_) {                                                   \
-    launch_x<DT, P_, W_>(xlds, g_tune.probe, x, qw, s, z, out, m, n, k, st);       \
-    return 0;                                                                      \
+  if (pf == 0) {
+    const int per = nit / waves;
+    pf = per >= 8 ? 8 : (per >= 4 ? 4 : 2);
+  }
+  const bool probe = g_tune.probe == 1;
+#define AWQ_GEMV_CASE(W_, P_)                                                                 \
+  if (waves == W_ && pf == P_) {                                                              \
+    if (probe) launch_one<DT, P_, W_, LAYOUT, 1>(x, qw, s, z, out, m, n, k, st);              \
+    else launch_one<DT, P_, W_, LAYOUT, 0>(x, qw, s, z, out, m, n, k, st);                    \
+    return 0;                                                                                 \
   }
   AWQ_GEMV_CASE(4, 4) AWQ_GEMV_CASE(4, 8) AWQ_GEMV_CASE(8, 4) AWQ_GEMV_CASE(8, 8) AWQ_GEMV_CASE(16, 4)
   AWQ_GEMV_CASE(16, 8) AWQ_GEMV_CASE(4, 2) AWQ_GEMV_CASE(8, 2) AWQ_GEMV_CASE(16, 2)
 #undef AWQ_GEMV_CASE
-  launch_x<DT, 4, 4>(xlds, g_tune.probe, x, qw, s, z, out, m, n, k, st);
+  launch_one<DT, 4, 4, LAYOUT, 0>(x, qw, s, z, out, m, n, k, st);
   return 0;
 }
 
 int launch_gemv(const void* x, const void* qw, const void* s, const void* z, void* out, int m, int n, int k, int dtype,
-                hipStream_t st) {
-  return dtype == 0 ? launch_gemv_t<F16>(x, qw, s, z, out, m, n, k, st)
-                    : launch_gemv_t<BF16>(x, qw, s, z, out, m, n, k, st);
+                int layout, hipStream_t st) {
+  if (layout == 1) return launch_gemv_t<BF16, 1>(x, qw, s, z, out, m, n, k, st);
+  return dtype == 0 ? launch_gemv_t<F16, 0>(x, qw, s, z, out, m, n, k, st)
+                    : launch_gemv_t<BF16, 0>(x, qw, s, z, out, m, n, k, st);
 }
 
 }  // namespace awq

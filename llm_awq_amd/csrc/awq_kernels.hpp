@@ -5,10 +5,14 @@
 #include <stdint.h>
 
 namespace awq {
+// layout: 0 = reference v2 interleave, 1 = cdna4 interleave (bf16 only)
 int launch_gemv(const void* x, const void* qw, const void* s, const void* z, void* out, int m, int n, int k, int dtype,
-                hipStream_t st);
+                int layout, hipStream_t st);
 int launch_gemm(const void* x, const void* qw, const void* s, const void* z, void* out, int m, int n, int k, int dtype,
-                void* ws, size_t ws_bytes, hipStream_t st);
+                int layout, void* ws, size_t ws_bytes, hipStream_t st);
+int launch_repack_v2_cdna4(const void* src, void* dst, int n, int k, int to_cdna4, hipStream_t st);
+int launch_unpack_cdna4(const void* qw, void* out_u8, int n, int k, hipStream_t st);
+int launch_dequant_cdna4(const void* qw, const void* s, const void* z, void* out, int n, int k, hipStream_t st);
 size_t gemm_workspace_bytes(int m, int n, int k);
 int gemv_tune_set(const char* key, int value);
 int gemm_tune_set(const char* key, int value);

@@ -103,10 +103,13 @@ __global__ void repack_scales_v1_to_v2_kernel(const uint16_t* __restrict__ s1, c
     s = (float)__builtin_bit_cast(_Float16, sb);
   else
     s = __builtin_bit_cast(float, (u32)sb << 16);
-  const uint16_t prod = DT::from_float(s * (float)zq);  // exact product, one rounding to T
+  u32 prod = DT::from_float(s * (float)zq);  // exact product, one rounding to T
   s2[(size_t)gi * N + n] = sb;
-  // -(x + 0*s): x + (+0) keeps x, unary minus flips the sign bit (also of zero: -(+0) = -0)
-  sz2[(size_t)gi * N + n] = prod ^ 0x8000u;
+  // -(x + 0*s): x + (+0) keeps x, unary minus flips the sign bit (also of zero: -(+0) = -0).
+  // The empty asm keeps the compiler from folding the sign flip into the multiply (it would emit
+  // fma(s, -z, +0), which turns the reference's -0.0 into +0.0).
+  asm volatile("" : "+v"(prod));
+  sz2[(size_t)gi * N + n] = (uint16_t)(prod ^ 0x8000u);
 }
 
 template <typename DT>
@@ -122,6 +125,82 @@ __global__ void bias_add_kernel(uint16_t* __restrict__ out, const uint16_t* __re
     b = __builtin_bit_cast(float, (u32)bias[t % N] << 16);
   }
   out[t] = DT::from_float(a + b);  // == T-precision add (sum of two T values rounded once)
+}
+
+// ---------------------------------------------------------------------------------------------
+// cdna4 interleave <-> v2 (pure nibble permutations, one thread per destination u32 word)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 v2_read_nibble(const u32* qw, int n, int k, int K) {
+  const int kl = k & 31;
+  const int a = (kl & 7) >> 1, nib = (kl >> 3) + 4 * (kl & 1);
+  return (qw[v2_chunk_word(n, k >> 5, K) + a] >> (4 * nib)) & 0xFu;
+}
+__device__ __forceinline__ u32 cdna4_read_nibble(const u32* qw, int n, int k, int K) {
+  const int nb = n >> 4, c = n & 15, g = c >> 2, j = c & 3;
+  const int kg = k >> 7, kk = k & 127, a = kk >> 5, r32 = kk & 31;
+  const int b8 = r32 >> 3, e = r32 & 7, th = e >> 2, rr = e & 3;
+  const int lane = 16 * g + 4 * b8 + rr;
+  const int p = (2 * th + (j >> 1)) + 4 * (j & 1);
+  return (qw[cdna4_tile_word(nb, kg, K >> 7) + lane * 4 + a] >> (4 * p)) & 0xFu;
+}
+
+__global__ void repack_v2_to_cdna4_kernel(const u32* __restrict__ src, u32* __restrict__ dst, int N, int K) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)N * K / 8) return;
+  const int a = (int)(t & 3), lane = (int)((t >> 2) & 63);
+  const size_t tile = t >> 8;
+  const int nit = K >> 7;
+  const int nb = (int)(tile / nit), kg = (int)(tile % nit);
+  const int g = lane >> 4, kl = lane & 15;
+  u32 w = 0;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int i = p & 3, hi = p >> 2;
+    const int n = 16 * nb + 4 * g + 2 * (i & 1) + hi;
+    const int k = 128 * kg + 32 * a + 8 * (kl >> 2) + 4 * (i >> 1) + (kl & 3);
+    w |= v2_read_nibble(src, n, k, K) << (4 * p);
+  }
+  dst[t] = w;
+}
+
+__global__ void repack_cdna4_to_v2_kernel(const u32* __restrict__ src, u32* __restrict__ dst, int N, int K) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)N * K / 8) return;
+  const size_t row_words = (size_t)K / 2;
+  const int r = (int)(t / row_words);
+  const int wi = (int)(t % row_words);
+  const int kb = wi / 32, in = wi % 32;
+  const int rr = in / 8, cc = (in % 8) / 4, a = in % 4;
+  const int n = r * 4 + rr, k0 = kb * 64 + cc * 32;
+  u32 w = 0;
+#pragma unroll
+  for (int nib = 0; nib < 8; ++nib) w |= cdna4_read_nibble(src, n, k0 + v2_nibble_k(a, nib), K) << (4 * nib);
+  dst[t] = w;
+}
+
+__global__ void unpack_cdna4_kernel(const u32* __restrict__ qw, uint8_t* __restrict__ out, int N, int K) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)N * K) return;
+  const int n = (int)(t / K), k = (int)(t % K);
+  out[t] = (uint8_t)cdna4_read_nibble(qw, n, k, K);
+}
+
+// one wave per 1-KiB tile, through the SAME matrix-core dequant as the cdna4 GEMV / GEMM
+__global__ __launch_bounds__(64) void dequant_cdna4_kernel(const u32* __restrict__ qw, const uint16_t* __restrict__ scales,
+                                                            const uint16_t* __restrict__ zeros, uint16_t* __restrict__ out,
+                                                            int N, int K) {
+  const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+  const int nit = K >> 7;
+  const int nb = blockIdx.x / nit, kg = blockIdx.x % nit;
+  Cdna4Dequant cd;
+  cd.init(lane);
+  const u32x4 w = *reinterpret_cast<const u32x4*>(qw + cdna4_tile_word(nb, kg, nit) + lane * 4);
+  const int n = nb * 16 + c;
+  bf16x8 op[4];
+  cd.tile(w, scales[(size_t)kg * N + n], zeros[(size_t)kg * N + n], op);
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+    *reinterpret_cast<bf16x8*>(out + (size_t)n * K + (size_t)kg * 128 + 32 * a + 8 * g) = op[a];
 }
 
 static inline unsigned nblk(size_t n, unsigned b) { return (unsigned)((n + b - 1) / b); }
@@ -161,6 +240,26 @@ int launch_repack_v1_to_v2(const void* qw1, const void* s1, const void* qz1, voi
   else
     hipLaunchKernelGGL((repack_scales_v1_to_v2_kernel<BF16>), dim3(nblk(items, 256)), dim3(256), 0, st,
                        (const uint16_t*)s1, (const u32*)qz1, (uint16_t*)s2, (uint16_t*)sz2, n, gpad);
+  return 0;
+}
+
+int launch_repack_v2_cdna4(const void* src, void* dst, int n, int k, int to_cdna4, hipStream_t st) {
+  const size_t words = (size_t)n * k / 8;
+  if (to_cdna4)
+    hipLaunchKernelGGL(repack_v2_to_cdna4_kernel, dim3(nblk(words, 256)), dim3(256), 0, st, (const u32*)src, (u32*)dst, n, k);
+  else
+    hipLaunchKernelGGL(repack_cdna4_to_v2_kernel, dim3(nblk(words, 256)), dim3(256), 0, st, (const u32*)src, (u32*)dst, n, k);
+  return 0;
+}
+
+int launch_unpack_cdna4(const void* qw, void* out_u8, int n, int k, hipStream_t st) {
+  hipLaunchKernelGGL(unpack_cdna4_kernel, dim3(nblk((size_t)n * k, 256)), dim3(256), 0, st, (const u32*)qw, (uint8_t*)out_u8, n, k);
+  return 0;
+}
+
+int launch_dequant_cdna4(const void* qw, const void* s, const void* z, void* out, int n, int k, hipStream_t st) {
+  hipLaunchKernelGGL(dequant_cdna4_kernel, dim3((n / 16) * (k / 128)), dim3(64), 0, st, (const u32*)qw, (const uint16_t*)s,
+                     (const uint16_t*)z, (uint16_t*)out, n, k);
   return 0;
 }
 

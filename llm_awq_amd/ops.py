@@ -121,3 +121,55 @@ def repack_v1_to_v2(qweight_v1, scales_v1, qzeros_v1):
                                                      qw2.data_ptr(), s2.data_ptr(), sz2.data_ptr(), n, k, gpad,
                                                      _dt(scales_v1), _stream(qweight_v1)))
     return qw2, s2, sz2
+
+
+# ---- cdna4 interleave (bf16) ----
+
+def repack_v2_to_cdna4(qweight_v2):
+    _need_gpu(qweight_v2)
+    n, k = qweight_v2.shape[0] * 4, qweight_v2.shape[1]
+    out = torch.empty_like(qweight_v2)
+    with torch.cuda.device(qweight_v2.device):
+        _capi.check(_capi.lib().awq_repack_v2_to_cdna4(qweight_v2.data_ptr(), out.data_ptr(), n, k, _stream(qweight_v2)))
+    return out
+
+
+def repack_cdna4_to_v2(qweight_cdna4):
+    _need_gpu(qweight_cdna4)
+    n, k = qweight_cdna4.shape[0] * 4, qweight_cdna4.shape[1]
+    out = torch.empty_like(qweight_cdna4)
+    with torch.cuda.device(qweight_cdna4.device):
+        _capi.check(_capi.lib().awq_repack_cdna4_to_v2(qweight_cdna4.data_ptr(), out.data_ptr(), n, k, _stream(qweight_cdna4)))
+    return out
+
+
+def unpack_cdna4(qweight):
+    _need_gpu(qweight)
+    n, k = qweight.shape[0] * 4, qweight.shape[1]
+    out = torch.empty(n, k, dtype=torch.uint8, device=qweight.device)
+    with torch.cuda.device(qweight.device):
+        _capi.check(_capi.lib().awq_unpack_cdna4(qweight.data_ptr(), out.data_ptr(), n, k, _stream(qweight)))
+    return out
+
+
+def dequant_cdna4(qweight, scales, scaled_zeros, group_size: int = 128):
+    _need_gpu(qweight, scales, scaled_zeros)
+    n, k = qweight.shape[0] * 4, qweight.shape[1]
+    out = torch.empty(n, k, dtype=scales.dtype, device=qweight.device)
+    with torch.cuda.device(qweight.device):
+        _capi.check(_capi.lib().awq_dequant_cdna4(qweight.data_ptr(), scales.data_ptr(), scaled_zeros.data_ptr(),
+                                                   out.data_ptr(), n, k, group_size, _dt(scales), _stream(qweight)))
+    return out
+
+
+def gemv_cdna4(x, qweight, scales, scaled_zeros, group_size: int = 128):
+    _need_gpu(x, qweight, scales, scaled_zeros)
+    k = x.shape[-1]
+    m = x.numel() // k
+    n = qweight.shape[0] * 4
+    out = torch.empty(*x.shape[:-1], n, dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _capi.check(_capi.lib().awq_w4a16_gemv_cdna4(x.data_ptr(), qweight.data_ptr(), scales.data_ptr(),
+                                                      scaled_zeros.data_ptr(), out.data_ptr(), m, n, k, group_size,
+                                                      _dt(x), _stream(x)))
+    return out

@@ -248,3 +248,57 @@ def pseudo_quant_linear(w: torch.Tensor, n_bit=4, group_size=128, dtype=torch.bf
     with torch.no_grad():
         lin.weight.data = pseudo_quantize(w.to(dtype), n_bit, group_size)[0]
     return lin
+
+
+# --------------------------------------------------------------------------------------
+# "cdna4" interleave -- THIS repository's MI355X-native int4 layout (no reference counterpart; it is
+# what the rewritten repacker emits, see DESIGN.md "cdna4 interleave").  Same size/dtype as v2
+# (int16 [N/4, K]), a pure permutation of nibbles:
+#   u32 words [N/16][K/128][64 lanes][4 words]; one 1-KiB tile = 16 rows x 128 k (one group).
+#   lane = 16*g + kl, word a, nibble p  (i = p & 3, hi = p >> 2)  holds
+#       Q[n = 16*nb + 4*g + 2*(i & 1) + hi][k = 128*kg + 32*a + 8*(kl // 4) + 4*(i >> 1) + kl % 4]
+# so that (word >> 4*i) & 0x000F000F | 0x43004300 is directly an MFMA 16x16x16 bf16 A-operand register
+# (rows = k, inner = n) of the "dequantise on the matrix core" step  W^T = (128+Q)^T . diag(s) + (sz-128 s).
+# --------------------------------------------------------------------------------------
+
+
+def cdna4_position(n, k, K):
+    """(word index into the flat u32 buffer, nibble index) of logical weight Q[n, k]."""
+    n = np.asarray(n)
+    k = np.asarray(k)
+    nb, c = n // 16, n % 16
+    g, j = c // 4, c % 4
+    kg, kk = k // 128, k % 128
+    a, r32 = kk // 32, kk % 32
+    b8, e = r32 // 8, r32 % 8
+    th, rr = e // 4, e % 4
+    kl = 4 * b8 + rr
+    lane = 16 * g + kl
+    i = 2 * th + (j >> 1)
+    p = i + 4 * (j & 1)
+    word = ((nb * (K // 128) + kg) * 64 + lane) * 4 + a
+    return word, p
+
+
+def pack_cdna4(q) -> np.ndarray:
+    """Logical ints [N, K] (0..15) -> cdna4 interleave, returned as int16 [N/4, K] (same shape as v2)."""
+    q = np.asarray(q).astype(np.int64)
+    N, K = q.shape
+    assert N % 16 == 0 and K % 128 == 0
+    nn, kk = np.meshgrid(np.arange(N), np.arange(K), indexing="ij")
+    word, p = cdna4_position(nn, kk, K)
+    out = np.zeros(N * K // 8, dtype=np.int64)
+    np.add.at(out, word.reshape(-1), ((q & 0xF) << (4 * p)).reshape(-1))
+    return out.astype(np.uint32).view(np.int16).reshape(N // 4, K)
+
+
+def unpack_cdna4(qweight) -> np.ndarray:
+    w = np.ascontiguousarray(np.asarray(qweight)).view(np.uint32).reshape(-1).astype(np.int64)
+    N, K = qweight.shape[0] * 4, qweight.shape[1]
+    nn, kk = np.meshgrid(np.arange(N), np.arange(K), indexing="ij")
+    word, p = cdna4_position(nn, kk, K)
+    return ((w[word] >> (4 * p)) & 0xF).astype(np.uint8)
+
+
+def v2_to_cdna4(qweight_v2) -> np.ndarray:
+    return pack_cdna4(unpack_v2(qweight_v2))

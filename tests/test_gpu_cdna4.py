@@ -1,0 +1,91 @@
+"""-m gpu: the "cdna4" interleave (this repository's MI355X-native int4 layout) and the kernels that
+consume it, through the C ABI, against the oracle.  Index work is bit exact; the matrix-core dequant
+must reproduce round_bf16(q*s+sz) bit for bit; matmul within the bounds of tests/helpers.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import awq_oracle as O
+from tests.helpers import check_forward, make_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from llm_awq_amd import ops as _ops
+    _ops._capi.lib()
+    return _ops
+
+
+@pytest.mark.parametrize("N,K", [(16, 128), (32, 256), (64, 768), (768, 3072), (1024, 4096)])
+def test_repack_bit_exact_and_roundtrip(ops, N, K):
+    rng = np.random.default_rng(N + K)
+    q = rng.integers(0, 16, size=(N, K)).astype(np.uint8)
+    v2 = torch.from_numpy(O.pack_v2(q)).cuda()
+    c4 = ops.repack_v2_to_cdna4(v2)
+    assert (c4.cpu().numpy() == O.pack_cdna4(q)).all()
+    assert (ops.unpack_cdna4(c4).cpu().numpy() == q).all()
+    assert torch.equal(ops.repack_cdna4_to_v2(c4), v2)
+
+
+def test_structured_tile_is_transpose_detecting(ops):
+    N, K = 32, 256
+    q = ((np.arange(N)[:, None] * 5 + np.arange(K)[None, :] * 3) % 16).astype(np.uint8)
+    c4 = ops.repack_v2_to_cdna4(torch.from_numpy(O.pack_v2(q)).cuda())
+    assert (c4.cpu().numpy() == O.pack_cdna4(q)).all()
+
+
+@pytest.mark.parametrize("N,K", [(16, 128), (64, 768), (256, 1280), (512, 4096)])
+def test_matrix_core_dequant_bit_exact(ops, N, K):
+    c = make_case(N, K, torch.bfloat16, seed=N + K)
+    W = O.dequant_weight(c["q"], c["scales"], c["scaled_zeros"], 128)
+    c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
+    got = ops.dequant_cdna4(c4, c["scales"].cuda(), c["scaled_zeros"].cuda()).cpu()
+    assert torch.equal(got.view(torch.int16), W.view(torch.int16))
+
+
+def test_matrix_core_dequant_adversarial_scales(ops):
+    g = torch.Generator().manual_seed(9)
+    N, K = 64, 512
+    q = torch.randint(0, 16, (N, K), generator=g).numpy().astype(np.uint8)
+    scales = torch.zeros(8, N, dtype=torch.bfloat16)
+    scales[:4] = (torch.rand(4, N, generator=g) * 2 + 0.5) * torch.pow(2.0, torch.randint(-30, 8, (4, N), generator=g).float())
+    zeros = torch.randint(0, 16, (4, N), generator=g)
+    sz = torch.zeros(8, N, dtype=torch.bfloat16)
+    sz[:4] = -(scales[:4] * zeros.float()).to(torch.bfloat16)
+    W = O.dequant_weight(q, scales, sz, 128)
+    c4 = ops.repack_v2_to_cdna4(torch.from_numpy(O.pack_v2(q)).cuda())
+    got = ops.dequant_cdna4(c4, scales.cuda(), sz.cuda()).cpu()
+    assert torch.equal(got.view(torch.int16), W.view(torch.int16))
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 7, 8, 13, 16])
+@pytest.mark.parametrize("N,K", [(768, 768), (3072, 768), (768, 3072), (256, 4096), (1040, 1280), (64, 11008)])
+def test_gemv_cdna4_vs_oracle(ops, M, N, K):
+    dtype = torch.bfloat16
+    c = make_case(N, K, dtype, seed=M * 131 + N + K, M=M)
+    c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
+    y = ops.gemv_cdna4(c["x"].cuda(), c4, c["scales"].cuda(), c["scaled_zeros"].cuda()).cpu()
+    check_forward(y, c["x"], c["q"], c["scales"], c["scaled_zeros"], dtype)
+
+
+@pytest.mark.parametrize("knobs", [dict(gemv_waves=4, gemv_pf=2), dict(gemv_waves=8, gemv_pf=4), dict(gemv_waves=16, gemv_pf=8),
+                                   dict(gemv_waves=4, gemv_pf=8, gemv_x_budget_kib=8)])
+def test_gemv_knobs_do_not_change_results(ops, knobs):
+    """every (waves, prefetch depth, x-segment) configuration: both layouts, M = 1 and 7, odd step counts."""
+    try:
+        for (N, K) in [(64, 11008), (128, 4096), (48, 1280)]:
+            for M in (1, 7):
+                c = make_case(N, K, torch.bfloat16, seed=N + M, M=M)
+                c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
+                ops._capi.tune(gemv_waves=0, gemv_pf=0, gemv_x_budget_kib=64)
+                ref4 = ops.gemv_cdna4(c["x"].cuda(), c4, c["scales"].cuda(), c["scaled_zeros"].cuda())
+                ops._capi.tune(**knobs)
+                y4 = ops.gemv_cdna4(c["x"].cuda(), c4, c["scales"].cuda(), c["scaled_zeros"].cuda())
+                y2 = ops.gemv(c["x"].cuda(), c["qweight"].cuda(), c["scales"].cuda(), c["scaled_zeros"].cuda())
+                check_forward(y4.cpu(), c["x"], c["q"], c["scales"], c["scaled_zeros"], torch.bfloat16)
+                check_forward(y2.cpu(), c["x"], c["q"], c["scales"], c["scaled_zeros"], torch.bfloat16)
+                assert ((y4 == ref4).float().mean() > 0.98)
+    finally:
+        ops._capi.tune(gemv_waves=0, gemv_pf=0, gemv_x_budget_kib=64)

@@ -10,9 +10,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from llm_awq_amd import _capi, synth  # noqa: E402
+from llm_awq_amd import _capi, ops, synth  # noqa: E402
 
-DEFAULT = dict(gemv_waves=0, gemv_pf=0, gemv_xlds=1, gemv_probe=0, gemv_order=0, gemv_probe_blocks=2048)
+DEFAULT = dict(gemv_waves=0, gemv_pf=0, gemv_probe=0, gemv_probe_blocks=2048)
 
 
 def algo_bytes(M, K, N):
@@ -57,39 +57,46 @@ def main():
     L = _capi.lib()
     for (K, N) in shapes:
         nbytes = N * K // 2
-        R = max(8, min(48, (700 << 20) // nbytes))
+        R = max(8, min(32, (450 << 20) // nbytes))
         copies = [synth.random_wq(K, N, dtype=dtype, seed=i, keep_q=False) for i in range(R)]
+        if dtype == torch.bfloat16:
+            for c in copies:
+                c["qweight_cdna4"] = ops.repack_v2_to_cdna4(c["qweight"])
         for M in args.m:
             x = torch.randn(M, K, device="cuda").to(dtype)
             out = torch.empty(M, N, device="cuda", dtype=dtype)
 
+            dt = 1 if dtype == torch.bfloat16 else 0
+            cur = {"layout": 0}
+
             def fn(c):
-                _capi.check(L.awq_w4a16_gemv(x.data_ptr(), c["qweight"].data_ptr(), c["scales"].data_ptr(),
-                                             c["scaled_zeros"].data_ptr(), out.data_ptr(), M, N, K, 128,
-                                             1 if dtype == torch.bfloat16 else 0, torch.cuda.current_stream().cuda_stream))
+                f = L.awq_w4a16_gemv_cdna4 if cur["layout"] else L.awq_w4a16_gemv
+                qw = c["qweight_cdna4"] if cur["layout"] else c["qweight"]
+                _capi.check(f(x.data_ptr(), qw.data_ptr(), c["scales"].data_ptr(), c["scaled_zeros"].data_ptr(),
+                              out.data_ptr(), M, N, K, 128, dt, torch.cuda.current_stream().cuda_stream))
             ab = algo_bytes(M, K, N)
-            cfgs = [dict(DEFAULT)]
+            layouts = (0, 1) if dtype == torch.bfloat16 else (0,)
+            cfgs = [dict(DEFAULT, layout=l) for l in layouts]
             if not args.defaults_only:
-                cfgs.append(dict(DEFAULT, gemv_probe=3))
-                for pb in (512, 1024, 2048, 4096):
-                    cfgs.append(dict(DEFAULT, gemv_probe=2, gemv_probe_blocks=pb))
-                for probe in (1, 0):
-                    for w, pf in itertools.product((4, 8, 16), (2, 4, 8)):
-                        for order in (0, 1, 2):
-                            if probe == 0 and order == 1 and pf != 4:
+                cfgs.append(dict(DEFAULT, gemv_probe=3, layout=0))
+                cfgs.append(dict(DEFAULT, gemv_probe=2, gemv_probe_blocks=4096, layout=0))
+                for layout in layouts:
+                    for probe in (1, 0):
+                        for w, pf in itertools.product((4, 8, 16), (2, 4, 8)):
+                            if (K // 128) // w < pf and pf > 2:
                                 continue
-                            cfgs.append(dict(DEFAULT, gemv_waves=w, gemv_pf=pf, gemv_probe=probe, gemv_order=order))
-                cfgs.append(dict(DEFAULT, gemv_xlds=0))
+                            cfgs.append(dict(DEFAULT, gemv_waves=w, gemv_pf=pf, gemv_probe=probe, layout=layout))
             for cfg in cfgs:
+                cfg = dict(cfg)
+                cur["layout"] = cfg.pop("layout")
                 _capi.tune(**cfg)
                 try:
                     us = time_cfg(fn, copies)
                 except Exception as e:  # noqa
                     print("   cfg failed", cfg, e)
                     continue
-                print(f"K={K:6d} N={N:6d} M={M:2d} waves={cfg['gemv_waves']:2d} pf={cfg['gemv_pf']} xlds={cfg['gemv_xlds']} "
-                      f"order={cfg['gemv_order']} probe={cfg['gemv_probe']}/{cfg['gemv_probe_blocks']:4d}  {us:8.2f} us  "
-                      f"{ab / us / 1e3:8.1f} GB/s  {ab / us / 1e3 / 80:5.1f}%", flush=True)
+                print(f"K={K:6d} N={N:6d} M={M:2d} layout={cur['layout']} waves={cfg['gemv_waves']:2d} pf={cfg['gemv_pf']} "
+                      f"probe={cfg['gemv_probe']}  {us:8.2f} us  {ab / us / 1e3:8.1f} GB/s  {ab / us / 1e3 / 80:5.1f}%", flush=True)
             _capi.tune(**DEFAULT)
         del copies
         torch.cuda.empty_cache()
