@@ -98,9 +98,20 @@ int awq_repack_cdna4_to_v2(const void* qweight_cdna4, void* qweight_v2, int n, i
 int awq_unpack_cdna4(const void* qweight_cdna4, void* out_u8, int n, int k, void* stream);
 int awq_dequant_cdna4(const void* qweight_cdna4, const void* scales, const void* scaled_zeros, void* out,
                       int n, int k, int group_size, int dtype, void* stream);
+/* sz_packed u32 [n/16][k/128][16] = {scale | scaled_zero << 16}: the scales re-laid next to the tiles so a lane
+ * fetches both with one dword load per step.  Optional for the matmul entry points (NULL = read scales/zeros). */
+int awq_pack_sz_cdna4(const void* scales, const void* scaled_zeros, void* sz_packed, int n, int k, void* stream);
 /* gemv on cdna4-interleaved weights (same contract as awq_w4a16_gemv otherwise) */
 int awq_w4a16_gemv_cdna4(const void* x, const void* qweight_cdna4, const void* scales, const void* scaled_zeros,
-                         void* out, int m, int n, int k, int group_size, int dtype, void* stream);
+                         const void* sz_packed, void* out, int m, int n, int k, int group_size, int dtype, void* stream);
+
+/* gemm / WQLinear.forward dispatch on cdna4-interleaved weights (any m >= 1; m <= 16 runs the GEMV) */
+int awq_w4a16_gemm_cdna4(const void* x, const void* qweight_cdna4, const void* scales, const void* scaled_zeros,
+                         const void* sz_packed, void* out, int m, int n, int k, int group_size, int dtype,
+                         void* workspace, size_t workspace_bytes, void* stream);
+int awq_w4a16_forward_cdna4(const void* x, const void* qweight_cdna4, const void* scales, const void* scaled_zeros,
+                            const void* sz_packed, const void* bias, void* out, int m, int n, int k, int group_size,
+                            int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Tuning hook for experiments and benchmarks (not part of the reference surface): integer knobs such as
  * "gemv_waves", "gemv_unroll", "gemv_xmode", "gemv_stream_only", "gemm_variant"; 0 restores the default

@@ -31,7 +31,10 @@ SIGNATURES = {
     "awq_repack_cdna4_to_v2": (_i, [_vp, _vp, _i, _i, _vp]),
     "awq_unpack_cdna4": (_i, [_vp, _vp, _i, _i, _vp]),
     "awq_dequant_cdna4": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "awq_w4a16_gemv_cdna4": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "awq_pack_sz_cdna4": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "awq_w4a16_gemv_cdna4": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "awq_w4a16_gemm_cdna4": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "awq_w4a16_forward_cdna4": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "awq_tune_set": (_i, [ctypes.c_char_p, _i]),
 }
 

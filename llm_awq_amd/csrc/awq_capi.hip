@@ -63,7 +63,7 @@ int awq_w4a16_gemv(const void* x, const void* qweight, const void* scales, const
   if (m < 1 || m > 16) return AWQ_ERR_BATCH;
   int st = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
   if (st != AWQ_OK) return st;
-  awq::launch_gemv(x, qweight, scales, scaled_zeros, out, m, n, k, dtype, 0, (hipStream_t)stream);
+  awq::launch_gemv(x, qweight, scales, scaled_zeros, nullptr, out, m, n, k, dtype, 0, (hipStream_t)stream);
   return finish_launch();
 }
 
@@ -75,7 +75,7 @@ int awq_w4a16_gemm(const void* x, const void* qweight, const void* scales, const
   if (st != AWQ_OK) return st;
   const size_t need = awq::gemm_workspace_bytes(m, n, k);
   if (need > 0 && (!workspace || workspace_bytes < need)) return AWQ_ERR_WORKSPACE;
-  awq::launch_gemm(x, qweight, scales, scaled_zeros, out, m, n, k, dtype, 0, workspace, workspace_bytes, (hipStream_t)stream);
+  awq::launch_gemm(x, qweight, scales, scaled_zeros, nullptr, out, m, n, k, dtype, 0, workspace, workspace_bytes, (hipStream_t)stream);
   return finish_launch();
 }
 
@@ -161,15 +161,43 @@ int awq_dequant_cdna4(const void* qweight, const void* scales, const void* scale
   return finish_launch();
 }
 
-int awq_w4a16_gemv_cdna4(const void* x, const void* qweight, const void* scales, const void* scaled_zeros, void* out,
-                         int m, int n, int k, int group_size, int dtype, void* stream) {
+int awq_pack_sz_cdna4(const void* scales, const void* scaled_zeros, void* sz_packed, int n, int k, void* stream) {
+  if (!scales || !scaled_zeros || !sz_packed) return AWQ_ERR_NULL;
+  if (n < 16 || (n % 16) != 0 || k < 128 || (k % 128) != 0) return AWQ_ERR_SHAPE;
+  awq::launch_pack_sz_cdna4(scales, scaled_zeros, sz_packed, n, k, (hipStream_t)stream);
+  return finish_launch();
+}
+
+int awq_w4a16_gemv_cdna4(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
+                         const void* sz_packed, void* out, int m, int n, int k, int group_size, int dtype, void* stream) {
   if (group_size != 128) return AWQ_ERR_GROUP;
   if (m < 1 || m > 16) return AWQ_ERR_BATCH;
   if (dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
   int st = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
   if (st != AWQ_OK) return st;
   if ((n % 16) != 0) return AWQ_ERR_SHAPE;
-  awq::launch_gemv(x, qweight, scales, scaled_zeros, out, m, n, k, dtype, 1, (hipStream_t)stream);
+  awq::launch_gemv(x, qweight, scales, scaled_zeros, sz_packed, out, m, n, k, dtype, 1, (hipStream_t)stream);
+  return finish_launch();
+}
+
+int awq_w4a16_gemm_cdna4(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
+                         const void* sz_packed, void* out, int m, int n, int k, int group_size, int dtype, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+  if (dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
+  int st = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
+  if (st != AWQ_OK) return st;
+  if ((n % 16) != 0) return AWQ_ERR_SHAPE;
+  awq::launch_gemm(x, qweight, scales, scaled_zeros, sz_packed, out, m, n, k, dtype, 1, workspace, workspace_bytes, (hipStream_t)stream);
+  return finish_launch();
+}
+
+int awq_w4a16_forward_cdna4(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
+                            const void* sz_packed, const void* bias, void* out, int m, int n, int k, int group_size,
+                            int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  int st = awq_w4a16_gemm_cdna4(x, qweight, scales, scaled_zeros, sz_packed, out, m, n, k, group_size, dtype, workspace,
+                                workspace_bytes, stream);  // m <= 16 is routed to the GEMV inside
+  if (st != AWQ_OK || !bias) return st;
+  awq::launch_bias_add(out, bias, m, n, dtype, (hipStream_t)stream);
   return finish_launch();
 }
 

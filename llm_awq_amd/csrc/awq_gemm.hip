@@ -23,7 +23,7 @@ constexpr int BM = 128, BN = 128, BK = 64;
 __device__ __forceinline__ int tile_off(int row, int gc) { return row * 128 + ((gc ^ ((row >> 1) & 7)) << 4); }
 }  // namespace
 
-template <typename DT>
+template <typename DT, int LAYOUT>
 __global__ __launch_bounds__(256) void gemm_w4a16_128x128_kernel(const uint16_t* __restrict__ x,
                                                                  const u32* __restrict__ qw,
                                                                  const uint16_t* __restrict__ scales,
@@ -52,12 +52,22 @@ __global__ __launch_bounds__(256) void gemm_w4a16_128x128_kernel(const uint16_t*
     a_src[p] = x + (size_t)min(m0 + row, M - 1) * K + gc * 8;
     a_dst[p] = tile_off(row, gc);
   }
-  // weights: thread -> (row nl, 32-k chunk c) ; 8 consecutive threads read one 128-B v2 block
-  const int nl = (tid >> 3) * 4 + ((tid >> 1) & 3), c = tid & 1;
-  const int nrow = min(n0 + nl, N - 1);
-  const u32* b_src = qw + v2_chunk_word(nrow, c, K);  // + kt*32 words per K-step (64 k)
+  // weights, LAYOUT 0 (v2): thread -> (row nl, 32-k chunk c); 8 consecutive threads read one 128-B v2 block.
+  // LAYOUT 1 (cdna4): wave wv dequantises slabs 2*wv, 2*wv+1 of the tile on the matrix core; per K-step (64 k)
+  // a lane needs words {2h, 2h+1} (h = K-step parity) of its 16 bytes of each slab's 1-KiB tile.
+  const int nl = LAYOUT == 0 ? (tid >> 3) * 4 + ((tid >> 1) & 3) : (2 * wv) * 16 + i;
+  const int c = tid & 1;
+  const int nit = K / kGroup;
+  const int sl0 = min((n0 >> 4) + 2 * wv, (N >> 4) - 1), sl1 = min((n0 >> 4) + 2 * wv + 1, (N >> 4) - 1);
+  const int nrow = LAYOUT == 0 ? min(n0 + nl, N - 1) : sl0 * 16 + i;
+  const int nrow1 = sl1 * 16 + i;  // cdna4: the wave's second slab
+  const u32* b_src = LAYOUT == 0 ? qw + v2_chunk_word(nrow, c, K)  // + kt*32 words per K-step (64 k)
+                                 : qw + cdna4_tile_word(sl0, 0, nit) + lane * 4;
+  const u32* b_src1 = qw + cdna4_tile_word(sl1, 0, nit) + lane * 4;
   const uint16_t* s_src = scales + nrow;
   const uint16_t* z_src = zeros + nrow;
+  Cdna4Dequant cd;
+  if (LAYOUT == 1) cd.init(lane);
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -66,13 +76,21 @@ __global__ __launch_bounds__(256) void gemm_w4a16_128x128_kernel(const uint16_t*
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = K / BK;
-  u32x4 ra[4], rb;
-  uint16_t rs, rz;
+  u32x4 ra[4], rb;       // rb: v2 = one 16-byte chunk; cdna4 = {slab0 words 2h,2h+1, slab1 words 2h,2h+1}
+  uint16_t rs, rz, rs1 = 0, rz1 = 0;
   auto load_tile = [&](int kt) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) ra[p] = *reinterpret_cast<const u32x4*>(a_src[p] + (size_t)kt * BK);
-    rb = *reinterpret_cast<const u32x4*>(b_src + (size_t)kt * 32);
     const int grp = (kt * BK) / kGroup;
+    if (LAYOUT == 0) {
+      rb = *reinterpret_cast<const u32x4*>(b_src + (size_t)kt * 32);
+    } else {
+      const u32x2 lo = *reinterpret_cast<const u32x2*>(b_src + (size_t)grp * 256 + 2 * (kt & 1));
+      const u32x2 hi = *reinterpret_cast<const u32x2*>(b_src1 + (size_t)grp * 256 + 2 * (kt & 1));
+      rb = u32x4{lo.x, lo.y, hi.x, hi.y};
+      rs1 = scales[(size_t)grp * N + nrow1];
+      rz1 = zeros[(size_t)grp * N + nrow1];
+    }
     rs = s_src[(size_t)grp * N];
     rz = z_src[(size_t)grp * N];
   };
@@ -82,11 +100,20 @@ __global__ __launch_bounds__(256) void gemm_w4a16_128x128_kernel(const uint16_t*
     // registers -> LDS (weights are dequantised here, once per block)
 #pragma unroll
     for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(As + a_dst[p]) = ra[p];
-    {
+    if (LAYOUT == 0) {
       vec8 wop[4];
       dequant_chunk<DT>(rb, DT::make_sz(rs, rz), wop);
 #pragma unroll
       for (int j = 0; j < 4; ++j) *reinterpret_cast<vec8*>(Bs + tile_off(nl, c * 4 + j)) = wop[j];
+    } else {
+      // lane (row i of the slab, octet g): word w covers k = 32w + 8g + 0..7 -> granule 4w + g
+      const u32 sd0 = (u32)rs * 0x00010001u, sd1 = (u32)rs1 * 0x00010001u;
+      const float c0 = __builtin_fmaf(-128.0f, __builtin_bit_cast(float, (u32)rs << 16), __builtin_bit_cast(float, (u32)rz << 16));
+      const float c1 = __builtin_fmaf(-128.0f, __builtin_bit_cast(float, (u32)rs1 << 16), __builtin_bit_cast(float, (u32)rz1 << 16));
+      *reinterpret_cast<bf16x8*>(Bs + tile_off(nl, 0 + g)) = cd.word(rb.x, sd0 & cd.m01, sd0 & cd.m23, c0);
+      *reinterpret_cast<bf16x8*>(Bs + tile_off(nl, 4 + g)) = cd.word(rb.y, sd0 & cd.m01, sd0 & cd.m23, c0);
+      *reinterpret_cast<bf16x8*>(Bs + tile_off(nl + 16, 0 + g)) = cd.word(rb.z, sd1 & cd.m01, sd1 & cd.m23, c1);
+      *reinterpret_cast<bf16x8*>(Bs + tile_off(nl + 16, 4 + g)) = cd.word(rb.w, sd1 & cd.m01, sd1 & cd.m23, c1);
     }
     __syncthreads();
     if (kt + 1 < nk) load_tile(kt + 1);
@@ -145,7 +172,7 @@ constexpr int kEpiRow = 144;                   // bytes per staged output row (6
 constexpr int kSmem256 = 8 * 128 * kEpiRow;    // 147456 >= 2 * kBufBytes
 }  // namespace
 
-template <typename DT>
+template <typename DT, int LAYOUT>
 __global__ __launch_bounds__(512) void gemm_w4a16_256x256_kernel(const uint16_t* __restrict__ x,
                                                                  const u32* __restrict__ qw,
                                                                  const uint16_t* __restrict__ scales,
@@ -178,12 +205,21 @@ __global__ __launch_bounds__(512) void gemm_w4a16_256x256_kernel(const uint16_t*
     const int gc = gcp ^ ((row >> 1) & 7);  // LDS slot gcp of this row receives source granule gc
     a_src[q] = x + (size_t)min(m0 + row, M - 1) * K + gc * 8;
   }
-  // ---- weight staging: thread -> (row nl, 32-k chunk c) ----
-  const int nl = (tid >> 3) * 4 + ((tid >> 1) & 3), c = tid & 1;
-  const int nrow = min(n0 + nl, N - 1);
-  const u32* b_src = qw + v2_chunk_word(nrow, c, K);  // + kt*32 words
+  // ---- weight staging.  LAYOUT 0: thread -> (row nl, 32-k chunk c).  LAYOUT 1 (cdna4): wave wv owns slabs
+  //      2*wv, 2*wv+1 of the 16 in the tile and dequantises them on the matrix core ----
+  const int nl = LAYOUT == 0 ? (tid >> 3) * 4 + ((tid >> 1) & 3) : (2 * wv) * 16 + i;
+  const int c = tid & 1;
+  const int nit = K / kGroup;
+  const int sl0 = min((n0 >> 4) + 2 * wv, (N >> 4) - 1), sl1 = min((n0 >> 4) + 2 * wv + 1, (N >> 4) - 1);
+  const int nrow = LAYOUT == 0 ? min(n0 + nl, N - 1) : sl0 * 16 + i;
+  const int nrow1 = sl1 * 16 + i;
+  const u32* b_src = LAYOUT == 0 ? qw + v2_chunk_word(nrow, c, K)  // + kt*32 words
+                                 : qw + cdna4_tile_word(sl0, 0, nit) + lane * 4;
+  const u32* b_src1 = qw + cdna4_tile_word(sl1, 0, nit) + lane * 4;
   const uint16_t* s_src = scales + nrow;
   const uint16_t* z_src = zeros + nrow;
+  Cdna4Dequant cd;
+  if (LAYOUT == 1) cd.init(lane);
 
   auto issue_a = [&](int kt, int buf) {
     char* dst = smem + buf * kBufBytes + wv * 1024;
@@ -192,12 +228,26 @@ __global__ __launch_bounds__(512) void gemm_w4a16_256x256_kernel(const uint16_t*
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[q] + (size_t)kt * TK),
                                        (__attribute__((address_space(3))) void*)(dst + q * 8192), 16, 0, 0);
   };
-  auto write_b = [&](const u32x4& rb, uint16_t rs, uint16_t rz, int buf) {
+  struct BRegs {
+    u32x4 w;
+    uint16_t s, z, s1, z1;
+  };
+  auto write_b = [&](const BRegs& r, int buf) {
     char* Bs = smem + buf * kBufBytes + TM * TK * 2;
-    vec8 wop[4];
-    dequant_chunk<DT>(rb, DT::make_sz(rs, rz), wop);
+    if (LAYOUT == 0) {
+      vec8 wop[4];
+      dequant_chunk<DT>(r.w, DT::make_sz(r.s, r.z), wop);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<vec8*>(Bs + tile_off(nl, c * 4 + j)) = wop[j];
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<vec8*>(Bs + tile_off(nl, c * 4 + j)) = wop[j];
+    } else {
+      const u32 sd0 = (u32)r.s * 0x00010001u, sd1 = (u32)r.s1 * 0x00010001u;
+      const float c0 = __builtin_fmaf(-128.0f, __builtin_bit_cast(float, (u32)r.s << 16), __builtin_bit_cast(float, (u32)r.z << 16));
+      const float c1 = __builtin_fmaf(-128.0f, __builtin_bit_cast(float, (u32)r.s1 << 16), __builtin_bit_cast(float, (u32)r.z1 << 16));
+      *reinterpret_cast<bf16x8*>(Bs + tile_off(nl, 0 + g)) = cd.word(r.w.x, sd0 & cd.m01, sd0 & cd.m23, c0);
+      *reinterpret_cast<bf16x8*>(Bs + tile_off(nl, 4 + g)) = cd.word(r.w.y, sd0 & cd.m01, sd0 & cd.m23, c0);
+      *reinterpret_cast<bf16x8*>(Bs + tile_off(nl + 16, 0 + g)) = cd.word(r.w.z, sd1 & cd.m01, sd1 & cd.m23, c1);
+      *reinterpret_cast<bf16x8*>(Bs + tile_off(nl + 16, 4 + g)) = cd.word(r.w.w, sd1 & cd.m01, sd1 & cd.m23, c1);
+    }
   };
 
   f32x4 acc[4][8];  // [n-frag][m-frag]
@@ -207,23 +257,31 @@ __global__ __launch_bounds__(512) void gemm_w4a16_256x256_kernel(const uint16_t*
     for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = K / TK;
-  u32x4 rb_cur, rb_nxt;
-  uint16_t rs_cur, rz_cur, rs_nxt, rz_nxt;
-  auto load_b = [&](int kt, u32x4& rb, uint16_t& rs, uint16_t& rz) {
-    rb = *reinterpret_cast<const u32x4*>(b_src + (size_t)kt * 32);
+  BRegs rb_cur, rb_nxt;
+  auto load_b = [&](int kt, BRegs& r) {
     const int grp = (kt * TK) / kGroup;
-    rs = s_src[(size_t)grp * N];
-    rz = z_src[(size_t)grp * N];
+    if (LAYOUT == 0) {
+      r.w = *reinterpret_cast<const u32x4*>(b_src + (size_t)kt * 32);
+      r.s1 = r.z1 = 0;
+    } else {
+      const u32x2 lo = *reinterpret_cast<const u32x2*>(b_src + (size_t)grp * 256 + 2 * (kt & 1));
+      const u32x2 hi = *reinterpret_cast<const u32x2*>(b_src1 + (size_t)grp * 256 + 2 * (kt & 1));
+      r.w = u32x4{lo.x, lo.y, hi.x, hi.y};
+      r.s1 = scales[(size_t)grp * N + nrow1];
+      r.z1 = zeros[(size_t)grp * N + nrow1];
+    }
+    r.s = s_src[(size_t)grp * N];
+    r.z = z_src[(size_t)grp * N];
   };
 
   issue_a(0, 0);
-  load_b(0, rb_cur, rs_cur, rz_cur);
-  load_b(nk > 1 ? 1 : 0, rb_nxt, rs_nxt, rz_nxt);
+  load_b(0, rb_cur);
+  load_b(nk > 1 ? 1 : 0, rb_nxt);
   // Drain EVERYTHING before the loop: hipcc waits vmcnt(0) at any use of an ordinary load while an
   // LDS-DMA is in flight, so the loop is arranged such that ordinary loads are only consumed after a
   // barrier that already drained them (the scoreboard must be provably empty at the loop header).
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-  write_b(rb_cur, rs_cur, rz_cur, 0);
+  write_b(rb_cur, 0);
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
@@ -231,10 +289,8 @@ __global__ __launch_bounds__(512) void gemm_w4a16_256x256_kernel(const uint16_t*
     const char* As = smem + buf * kBufBytes;
     const char* Bs = As + TM * TK * 2;
     if (kt + 1 < nk) issue_a(kt + 1, buf ^ 1);
-    rb_cur = rb_nxt;
-    rs_cur = rs_nxt;
-    rz_cur = rz_nxt;  // tile kt+1's packed weights (already in registers)
-    if (kt + 2 < nk) load_b(kt + 2, rb_nxt, rs_nxt, rz_nxt);
+    rb_cur = rb_nxt;  // tile kt+1's packed weights (already in registers)
+    if (kt + 2 < nk) load_b(kt + 2, rb_nxt);
 
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -247,7 +303,7 @@ __global__ __launch_bounds__(512) void gemm_w4a16_256x256_kernel(const uint16_t*
       for (int b = 0; b < 8; ++b)
 #pragma unroll
         for (int a = 0; a < 4; ++a) acc[a][b] = DT::mfma(wf[a], xf[b], acc[a][b]);
-      if (ks == 0 && kt + 1 < nk) write_b(rb_cur, rs_cur, rz_cur, buf ^ 1);  // VALU work to hide under the MFMAs
+      if (ks == 0 && kt + 1 < nk) write_b(rb_cur, buf ^ 1);  // dequant work to hide under the MFMAs
     }
     __syncthreads();
   }
@@ -287,13 +343,13 @@ int gemm_tune_set(const char* key, int value) {
   return -1;
 }
 
-template <typename DT>
+template <typename DT, int LAYOUT>
 static int launch_gemm_t(const void* x, const void* qw, const void* s, const void* z, void* out, int m, int n, int k,
                          hipStream_t st) {
   const bool big = g_gemm_variant == 2 || (g_gemm_variant == 0 && m > 128);
   if (big) {
     const int tiles_m = (m + TM - 1) / TM, tiles_n = (n + TN - 1) / TN;
-    auto kern = gemm_w4a16_256x256_kernel<DT>;
+    auto kern = gemm_w4a16_256x256_kernel<DT, LAYOUT>;
     static bool attr = false;
     if (!attr) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem256);
@@ -305,17 +361,17 @@ static int launch_gemm_t(const void* x, const void* qw, const void* s, const voi
   }
   const int tiles_m = (m + BM - 1) / BM, tiles_n = (n + BN - 1) / BN;
   dim3 grid(tiles_m * tiles_n), block(256);
-  hipLaunchKernelGGL((gemm_w4a16_128x128_kernel<DT>), grid, block, 0, st, (const uint16_t*)x, (const u32*)qw,
+  hipLaunchKernelGGL((gemm_w4a16_128x128_kernel<DT, LAYOUT>), grid, block, 0, st, (const uint16_t*)x, (const u32*)qw,
                      (const uint16_t*)s, (const uint16_t*)z, (uint16_t*)out, m, n, k, tiles_m);
   return 0;
 }
 
-int launch_gemm(const void* x, const void* qw, const void* s, const void* z, void* out, int m, int n, int k, int dtype,
-                int layout, void*, size_t, hipStream_t st) {
-  if (m <= 16) return launch_gemv(x, qw, s, z, out, m, n, k, dtype, layout, st);
-  if (layout != 0) return -1;  // cdna4 GEMM: not yet
-  return dtype == 0 ? launch_gemm_t<F16>(x, qw, s, z, out, m, n, k, st)
-                    : launch_gemm_t<BF16>(x, qw, s, z, out, m, n, k, st);
+int launch_gemm(const void* x, const void* qw, const void* s, const void* z, const void* szp, void* out, int m, int n,
+                int k, int dtype, int layout, void*, size_t, hipStream_t st) {
+  if (m <= 16) return launch_gemv(x, qw, s, z, szp, out, m, n, k, dtype, layout, st);
+  if (layout == 1) return launch_gemm_t<BF16, 1>(x, qw, s, z, out, m, n, k, st);
+  return dtype == 0 ? launch_gemm_t<F16, 0>(x, qw, s, z, out, m, n, k, st)
+                    : launch_gemm_t<BF16, 0>(x, qw, s, z, out, m, n, k, st);
 }
 
 }  // namespace awq

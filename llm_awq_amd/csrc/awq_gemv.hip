@@ -25,15 +25,25 @@
 
 namespace awq {
 
-template <typename DT, int PF, int WAVES, int LAYOUT, int PROBE>
+// One ring slot = everything a wave needs from global memory for one 128-k step.
+struct GemvSlot {
+  u32x4 w;   // 16 B of packed weights per lane
+  u32 s, z;  // scale / scaled_zero bits of the lane's row for this group (SZP: both packed in s)
+};
+
+// SZP: scales come from the packed {s | z << 16} array (one dword load per step) instead of two ushort loads
+template <typename DT, int PF, int WAVES, int LAYOUT, bool SZP, int PROBE>
 __global__ __launch_bounds__(64 * WAVES) void gemv_w4a16_kernel(const uint16_t* __restrict__ x,
                                                                  const u32* __restrict__ qw,
                                                                  const uint16_t* __restrict__ scales,
                                                                  const uint16_t* __restrict__ zeros,
+                                                                 const u32* __restrict__ szp,
                                                                  uint16_t* __restrict__ out, int M, int N, int K,
                                                                  int seg_steps) {
   using vec8 = typename DT::vec8;
   static_assert(LAYOUT == 0 || DT::id == 1, "the cdna4 interleave is defined for bf16");
+  constexpr int NT = 64 * WAVES;
+  constexpr int XS = 8;  // x granules (16 B) a thread can stage through registers ahead of the weight stream
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
@@ -50,41 +60,53 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_w4a16_kernel(const uint16_t* 
     wp = qw + v2_chunk_word(n, g, K);
   else
     wp = qw + cdna4_tile_word(nb, 0, nit) + lane * 4;
+  const u32* szl = szp + (size_t)nb * nit * 16 + i;  // packed {s,z}: + it * 16 (SZP only)
   const int mrow = min(i, M - 1);
 
-  // ---- LDS carve: [reduce WAVES KiB][{scale | zero<<16} nit*16 words][x segment rows] ----
+  // ---- LDS carve: [reduce WAVES KiB][x segment rows (padded)] ----
   float(*red)[4][64] = reinterpret_cast<float(*)[4][64]>(smem);
-  u32* szs = reinterpret_cast<u32*>(smem + WAVES * 1024);
-  char* xs = smem + WAVES * 1024 + nit * 64;
+  char* xs = smem + WAVES * 1024;
   const int xrow_bytes = 2 * seg_steps * kGroup + 16;
 
   Cdna4Dequant cd;
   if (LAYOUT == 1) cd.init(lane);
 
+  auto load_slot = [&](int it) {
+    GemvSlot r;
+    r.w = ldg_nt_u32x4(wp + (size_t)it * WSTEP);
+    if (SZP) {
+      r.s = szl[(size_t)it * 16];
+      r.z = 0;
+    } else {
+      r.s = scales[(size_t)it * N + n];
+      r.z = zeros[(size_t)it * N + n];
+    }
+    return r;
+  };
+
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   u32 sink = 0;
 
-  auto compute = [&](const u32x4& w, int it, int seg0) {
+  auto compute = [&](const GemvSlot& sl, int it, int seg0) {
     if (PROBE) {
-      sink ^= w.x ^ w.y ^ w.z ^ w.w;
+      sink ^= sl.w.x ^ sl.w.y ^ sl.w.z ^ sl.w.w ^ sl.s ^ sl.z;
       return;
     }
-    const u32 szv = szs[it * 16 + i];
-    const u32x4* xv = reinterpret_cast<const u32x4*>(xs + mrow * xrow_bytes + ((it - seg0) * 128 + g * 32) * 2);
-    vec8 wop[4];
+    const uint16_t sb = (uint16_t)(sl.s & 0xFFFFu), zb = SZP ? (uint16_t)(sl.s >> 16) : (uint16_t)sl.z;
     if (LAYOUT == 0) {
-      dequant_chunk<DT>(w, DT::make_sz((uint16_t)(szv & 0xFFFFu), (uint16_t)(szv >> 16)), wop);
+      const u32x4* xv = reinterpret_cast<const u32x4*>(xs + mrow * xrow_bytes + ((it - seg0) * 128 + g * 32) * 2);
+      vec8 wop[4];
+      dequant_chunk<DT>(sl.w, DT::make_sz(sb, zb), wop);
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc = DT::mfma(wop[j], __builtin_bit_cast(vec8, xv[j]), acc);
     } else {
       // operand a covers k = 32a + 8g + 0..7 of the step: x granule index 4a + g
       const u32x4* xr = reinterpret_cast<const u32x4*>(xs + mrow * xrow_bytes + (it - seg0) * 256);
       bf16x8 op[4];
-      cd.tile(w, (uint16_t)(szv & 0xFFFFu), (uint16_t)(szv >> 16), op);
+      cd.tile(sl.w, sb, zb, op);
 #pragma unroll
       for (int a = 0; a < 4; ++a)
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(op[a], __builtin_bit_cast(bf16x8, xr[4 * a + g]), acc, 0, 0, 0);
-      (void)xv;
     }
   };
 
@@ -95,40 +117,49 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_w4a16_kernel(const uint16_t* 
     const int groups = cnt / PF, rem = cnt - groups * PF;
     auto step = [&](int t) { return seg0 + wv + WAVES * t; };
 
-    // ---- start the weight stream first (addresses clamped: no branches around loads) ----
-    u32x4 ring[PF];
+    // ---- (1) x granules of this segment -> registers, issued BEFORE the weight stream: vmcnt retires in
+    //          order, so the wait in (3) must not sit behind the PF weight loads of (2) ----
+    const int per_row = (seg1 - seg0) * 16;  // 16-byte granules per x row in this segment
+    const int gran = PROBE ? 0 : M * per_row;
+    u32x4 xreg[XS];
 #pragma unroll
-    for (int u = 0; u < PF; ++u) ring[u] = ldg_nt_u32x4(wp + (size_t)min(step(min(u, max(cnt - 1, 0))), nit - 1) * WSTEP);
+    for (int e = 0; e < XS; ++e) {
+      const int q = min((int)threadIdx.x + e * NT, max(gran - 1, 0));
+      const int r = q / per_row, c = q - r * per_row;
+      xreg[e] = *reinterpret_cast<const u32x4*>(x + (size_t)r * K + (size_t)seg0 * kGroup + c * 8);
+    }
+    // ---- (2) start the weight stream (addresses clamped: no branches around loads) ----
+    GemvSlot ring[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) ring[u] = load_slot(min(step(min(u, max(cnt - 1, 0))), nit - 1));
 
-    // ---- stage the small operands ----
+    // ---- (3) x -> LDS ----
     if (seg0 > 0) __syncthreads();  // previous segment's x fully consumed
-    if (seg0 == 0) {
-      for (int q = threadIdx.x; q < nit * 16; q += 64 * WAVES) {
-        const int gi = q >> 4, c = q & 15;
-        const int nn = min(n0 + c, N - 1);
-        szs[q] = (u32)scales[(size_t)gi * N + nn] | ((u32)zeros[(size_t)gi * N + nn] << 16);
+#pragma unroll
+    for (int e = 0; e < XS; ++e) {
+      const int q = (int)threadIdx.x + e * NT;
+      if (q < gran) {
+        const int r = q / per_row, c = q - r * per_row;
+        *reinterpret_cast<u32x4*>(xs + r * xrow_bytes + c * 16) = xreg[e];
       }
     }
-    if (!PROBE) {
-      const int per_row = (seg1 - seg0) * 16;  // 16-byte granules per row in this segment
-      for (int q = threadIdx.x; q < M * per_row; q += 64 * WAVES) {
-        const int r = q / per_row, c = q - r * per_row;
-        *reinterpret_cast<u32x4*>(xs + r * xrow_bytes + c * 16) =
-            *reinterpret_cast<const u32x4*>(x + (size_t)r * K + (size_t)seg0 * kGroup + c * 8);
-      }
+    for (int q = threadIdx.x + XS * NT; q < gran; q += NT) {  // large M*K only (drains the ring once)
+      const int r = q / per_row, c = q - r * per_row;
+      *reinterpret_cast<u32x4*>(xs + r * xrow_bytes + c * 16) =
+          *reinterpret_cast<const u32x4*>(x + (size_t)r * K + (size_t)seg0 * kGroup + c * 8);
     }
     __syncthreads();
 
-    // ---- steady state: consume slot u, refill it PF steps ahead (unconditional) ----
+    // ---- (4) steady state: consume slot u, THEN refill the same registers PF steps ahead.  (Issuing the
+    //          refill before the last use makes hipcc allocate a second register set + copies at the loop
+    //          latch, whose waits drain the ring; a load inside a branch degrades every wait to vmcnt(0).) ----
     if (groups > 0) {
       for (int grp = 0; grp + 1 < groups; ++grp) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
           const int t = grp * PF + u;
-          // consume, THEN refill the same registers: issuing the refill before the last use of the slot
-          // makes hipcc allocate a second register set + copies at the loop latch, whose waits drain the ring
           compute(ring[u], step(t), seg0);
-          ring[u] = ldg_nt_u32x4(wp + (size_t)step(t + PF) * WSTEP);
+          ring[u] = load_slot(step(t + PF));
         }
       }
       // last full group: refill only the slots the remainder will use
@@ -136,7 +167,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_w4a16_kernel(const uint16_t* 
       for (int u = 0; u < PF; ++u) {
         const int t = (groups - 1) * PF + u;
         compute(ring[u], step(t), seg0);
-        if (u < rem) ring[u] = ldg_nt_u32x4(wp + (size_t)step(t + PF) * WSTEP);
+        if (u < rem) ring[u] = load_slot(step(t + PF));
       }
     }
 #pragma unroll
@@ -200,9 +231,9 @@ int gemv_tune_set(const char* key, int value) {
   return 0;
 }
 
-template <typename DT, int PF, int WAVES, int LAYOUT, int PROBE>
-static void launch_one(const void* x, const void* qw, const void* s, const void* z, void* out, int m, int n, int k,
-                       hipStream_t st) {
+template <typename DT, int PF, int WAVES, int LAYOUT, bool SZP, int PROBE>
+static void launch_one(const void* x, const void* qw, const void* s, const void* z, const void* szp, void* out, int m,
+                       int n, int k, hipStream_t st) {
   const int nit = k / kGroup;
   // x segment: as many 128-k steps (a multiple of WAVES) as fit the LDS budget
   const long budget = (long)g_tune.x_budget_kib * 1024;
@@ -210,9 +241,9 @@ static void launch_one(const void* x, const void* qw, const void* s, const void*
   seg = seg / WAVES * WAVES;
   if (seg < WAVES) seg = WAVES;
   if (seg > nit) seg = (nit + WAVES - 1) / WAVES * WAVES;
-  const size_t smem = (size_t)WAVES * 1024 + (size_t)nit * 64 + (size_t)m * (2 * seg * kGroup + 16);
+  const size_t smem = (size_t)WAVES * 1024 + (size_t)m * (2 * seg * kGroup + 16);
   dim3 grid((n + 15) / 16), block(64 * WAVES);
-  auto kern = gemv_w4a16_kernel<DT, PF, WAVES, LAYOUT, PROBE>;
+  auto kern = gemv_w4a16_kernel<DT, PF, WAVES, LAYOUT, SZP, PROBE>;
   if (smem > 64 * 1024) {
     static bool done = false;  // per instantiation
     if (!done) {
@@ -221,12 +252,12 @@ static void launch_one(const void* x, const void* qw, const void* s, const void*
     }
   }
   hipLaunchKernelGGL(kern, grid, block, smem, st, (const uint16_t*)x, (const u32*)qw, (const uint16_t*)s,
-                     (const uint16_t*)z, (uint16_t*)out, m, n, k, (int)seg);
+                     (const uint16_t*)z, (const u32*)szp, (uint16_t*)out, m, n, k, (int)seg);
 }
 
 template <typename DT, int LAYOUT>
-static int launch_gemv_t(const void* x, const void* qw, const void* s, const void* z, void* out, int m, int n, int k,
-                         hipStream_t st) {
+static int launch_gemv_t(const void* x, const void* qw, const void* s, const void* z, const void* szp, void* out, int m,
+                         int n, int k, hipStream_t st) {
   const int nit = k / kGroup;
   const int slabs = (n + 15) / 16;
   if (g_tune.probe == 2) {
@@ -249,22 +280,23 @@ static int launch_gemv_t(const void* x, const void* qw, const void* s, const voi
   const bool probe = g_tune.probe == 1;
 #define AWQ_GEMV_CASE(W_, P_)                                                                 \
   if (waves == W_ && pf == P_) {                                                              \
-    if (probe) launch_one<DT, P_, W_, LAYOUT, 1>(x, qw, s, z, out, m, n, k, st);              \
-    else launch_one<DT, P_, W_, LAYOUT, 0>(x, qw, s, z, out, m, n, k, st);                    \
+    if (probe) launch_one<DT, P_, W_, LAYOUT, false, 1>(x, qw, s, z, szp, out, m, n, k, st);  \
+    else if (LAYOUT == 1 && szp) launch_one<DT, P_, W_, LAYOUT, LAYOUT == 1, 0>(x, qw, s, z, szp, out, m, n, k, st); \
+    else launch_one<DT, P_, W_, LAYOUT, false, 0>(x, qw, s, z, szp, out, m, n, k, st);        \
     return 0;                                                                                 \
   }
   AWQ_GEMV_CASE(4, 4) AWQ_GEMV_CASE(4, 8) AWQ_GEMV_CASE(8, 4) AWQ_GEMV_CASE(8, 8) AWQ_GEMV_CASE(16, 4)
   AWQ_GEMV_CASE(16, 8) AWQ_GEMV_CASE(4, 2) AWQ_GEMV_CASE(8, 2) AWQ_GEMV_CASE(16, 2)
 #undef AWQ_GEMV_CASE
-  launch_one<DT, 4, 4, LAYOUT, 0>(x, qw, s, z, out, m, n, k, st);
+  launch_one<DT, 4, 4, LAYOUT, false, 0>(x, qw, s, z, szp, out, m, n, k, st);
   return 0;
 }
 
-int launch_gemv(const void* x, const void* qw, const void* s, const void* z, void* out, int m, int n, int k, int dtype,
-                int layout, hipStream_t st) {
-  if (layout == 1) return launch_gemv_t<BF16, 1>(x, qw, s, z, out, m, n, k, st);
-  return dtype == 0 ? launch_gemv_t<F16, 0>(x, qw, s, z, out, m, n, k, st)
-                    : launch_gemv_t<BF16, 0>(x, qw, s, z, out, m, n, k, st);
+int launch_gemv(const void* x, const void* qw, const void* s, const void* z, const void* szp, void* out, int m, int n,
+                int k, int dtype, int layout, hipStream_t st) {
+  if (layout == 1) return launch_gemv_t<BF16, 1>(x, qw, s, z, szp, out, m, n, k, st);
+  return dtype == 0 ? launch_gemv_t<F16, 0>(x, qw, s, z, nullptr, out, m, n, k, st)
+                    : launch_gemv_t<BF16, 0>(x, qw, s, z, nullptr, out, m, n, k, st);
 }
 
 }  // namespace awq

@@ -6,10 +6,12 @@
 
 namespace awq {
 // layout: 0 = reference v2 interleave, 1 = cdna4 interleave (bf16 only)
-int launch_gemv(const void* x, const void* qw, const void* s, const void* z, void* out, int m, int n, int k, int dtype,
-                int layout, hipStream_t st);
-int launch_gemm(const void* x, const void* qw, const void* s, const void* z, void* out, int m, int n, int k, int dtype,
-                int layout, void* ws, size_t ws_bytes, hipStream_t st);
+// szp: optional packed {scale | scaled_zero << 16} u32 [N/16][K/128][16] (cdna4 layout only), else nullptr
+int launch_gemv(const void* x, const void* qw, const void* s, const void* z, const void* szp, void* out, int m, int n,
+                int k, int dtype, int layout, hipStream_t st);
+int launch_pack_sz_cdna4(const void* s, const void* z, void* szp, int n, int k, hipStream_t st);
+int launch_gemm(const void* x, const void* qw, const void* s, const void* z, const void* szp, void* out, int m, int n,
+                int k, int dtype, int layout, void* ws, size_t ws_bytes, hipStream_t st);
 int launch_repack_v2_cdna4(const void* src, void* dst, int n, int k, int to_cdna4, hipStream_t st);
 int launch_unpack_cdna4(const void* qw, void* out_u8, int n, int k, hipStream_t st);
 int launch_dequant_cdna4(const void* qw, const void* s, const void* z, void* out, int n, int k, hipStream_t st);

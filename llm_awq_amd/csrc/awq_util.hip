@@ -203,6 +203,18 @@ __global__ __launch_bounds__(64) void dequant_cdna4_kernel(const u32* __restrict
     *reinterpret_cast<bf16x8*>(out + (size_t)n * K + (size_t)kg * 128 + 32 * a + 8 * g) = op[a];
 }
 
+// packed {scale | scaled_zero << 16} per (16-row slab, group, row): one dword load per lane per step
+__global__ void pack_sz_cdna4_kernel(const uint16_t* __restrict__ s, const uint16_t* __restrict__ z, u32* __restrict__ out,
+                                     int N, int nit) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)N * nit) return;
+  const int c = (int)(t & 15);
+  const size_t tile = t >> 4;
+  const int nb = (int)(tile / nit), kg = (int)(tile % nit);
+  const size_t src = (size_t)kg * N + nb * 16 + c;
+  out[t] = (u32)s[src] | ((u32)z[src] << 16);
+}
+
 static inline unsigned nblk(size_t n, unsigned b) { return (unsigned)((n + b - 1) / b); }
 
 int launch_unpack_v2(const void* qw, void* out_u8, int n, int k, hipStream_t st) {
@@ -249,6 +261,13 @@ int launch_repack_v2_cdna4(const void* src, void* dst, int n, int k, int to_cdna
     hipLaunchKernelGGL(repack_v2_to_cdna4_kernel, dim3(nblk(words, 256)), dim3(256), 0, st, (const u32*)src, (u32*)dst, n, k);
   else
     hipLaunchKernelGGL(repack_cdna4_to_v2_kernel, dim3(nblk(words, 256)), dim3(256), 0, st, (const u32*)src, (u32*)dst, n, k);
+  return 0;
+}
+
+int launch_pack_sz_cdna4(const void* s, const void* z, void* szp, int n, int k, hipStream_t st) {
+  const size_t items = (size_t)n * (k / kGroup);
+  hipLaunchKernelGGL(pack_sz_cdna4_kernel, dim3(nblk(items, 256)), dim3(256), 0, st, (const uint16_t*)s, (const uint16_t*)z,
+                     (u32*)szp, n, k / kGroup);
   return 0;
 }
 

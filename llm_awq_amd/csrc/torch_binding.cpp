@@ -92,6 +92,63 @@ torch::Tensor gemm_forward_cuda_new(torch::Tensor in_feats, torch::Tensor kernel
   return out;
 }
 
+// ---- MI355X-native "cdna4" interleave (bf16): same tensors / shapes, permuted qweight + packed scales ----
+torch::Tensor repack_v2_to_cdna4(torch::Tensor kernel) {
+  TORCH_CHECK(kernel.is_cuda() && kernel.is_contiguous() && kernel.scalar_type() == at::kShort && kernel.dim() == 2);
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(kernel.device());
+  at::Tensor out = torch::empty_like(kernel);
+  raise_on(awq_repack_v2_to_cdna4(kernel.data_ptr(), out.data_ptr(), (int)kernel.size(0) * 4, (int)kernel.size(1),
+                                  (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()));
+  return out;
+}
+
+torch::Tensor repack_cdna4_to_v2(torch::Tensor kernel) {
+  TORCH_CHECK(kernel.is_cuda() && kernel.is_contiguous() && kernel.scalar_type() == at::kShort && kernel.dim() == 2);
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(kernel.device());
+  at::Tensor out = torch::empty_like(kernel);
+  raise_on(awq_repack_cdna4_to_v2(kernel.data_ptr(), out.data_ptr(), (int)kernel.size(0) * 4, (int)kernel.size(1),
+                                  (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()));
+  return out;
+}
+
+torch::Tensor pack_sz_cdna4(torch::Tensor scales, torch::Tensor zeros, int k) {
+  TORCH_CHECK(scales.is_cuda() && zeros.is_cuda() && scales.is_contiguous() && zeros.is_contiguous());
+  TORCH_CHECK(scales.scalar_type() == zeros.scalar_type() && scales.sizes() == zeros.sizes() && scales.dim() == 2);
+  const int64_t n = scales.size(1);
+  TORCH_CHECK(n % 16 == 0 && k % 128 == 0 && scales.size(0) * 128 >= k);
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(scales.device());
+  at::Tensor out = torch::empty({n / 16, k / 128, 16}, scales.options().dtype(at::kInt));
+  raise_on(awq_pack_sz_cdna4(scales.data_ptr(), zeros.data_ptr(), out.data_ptr(), (int)n, k,
+                             (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()));
+  return out;
+}
+
+// WQLinear.forward on cdna4 buffers: any number of rows (<= 16 -> GEMV kernel), bias optional
+torch::Tensor forward_cdna4(torch::Tensor in_feats, torch::Tensor kernel, torch::Tensor scales, torch::Tensor zeros,
+                            torch::Tensor sz_packed, c10::optional<torch::Tensor> bias) {
+  check_inputs(in_feats, kernel, scales, zeros);
+  TORCH_CHECK(in_feats.scalar_type() == at::kBFloat16, "the cdna4 interleave is defined for bfloat16");
+  TORCH_CHECK(sz_packed.is_cuda() && sz_packed.is_contiguous() && sz_packed.scalar_type() == at::kInt);
+  const int64_t n = kernel.size(0) * 4, k = in_feats.size(-1);
+  TORCH_CHECK(k > 0 && in_feats.numel() % k == 0 && kernel.numel() == n / 4 * k);
+  TORCH_CHECK(sz_packed.numel() == n * (k / 128), "sz_packed must be int32 [n/16, k/128, 16]");
+  const int64_t m = in_feats.numel() / k;
+  std::vector<int64_t> shape = in_feats.sizes().vec();
+  shape.back() = n;
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(in_feats.device());
+  at::Tensor out = torch::empty(shape, in_feats.options());
+  if (m == 0) return out;
+  const void* bp = nullptr;
+  if (bias.has_value() && bias->defined()) {
+    TORCH_CHECK(bias->is_cuda() && bias->is_contiguous() && bias->scalar_type() == in_feats.scalar_type() && bias->numel() == n);
+    bp = bias->data_ptr();
+  }
+  raise_on(awq_w4a16_forward_cdna4(in_feats.data_ptr(), kernel.data_ptr(), scales.data_ptr(), zeros.data_ptr(),
+                                   sz_packed.data_ptr(), bp, out.data_ptr(), (int)m, (int)n, (int)k, 128, AWQ_BF16, nullptr,
+                                   0, (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()));
+  return out;
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -99,4 +156,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("gemm_forward_cuda_new", &gemm_forward_cuda_new, "New quantized GEMM kernel.");
   m.def("gemv_forward_cuda_new", &gemv_forward_cuda_new, "New quantized GEMV kernel.");
   m.def("abi_version", []() { return awq_abi_version(); });
+  // extras of the MI355X build (not part of the reference module)
+  m.def("repack_v2_to_cdna4", &repack_v2_to_cdna4, "qweight v2 -> cdna4 interleave (same shape)");
+  m.def("repack_cdna4_to_v2", &repack_cdna4_to_v2, "qweight cdna4 -> v2 interleave (same shape)");
+  m.def("pack_sz_cdna4", &pack_sz_cdna4, "scales/scaled_zeros [Gpad,N] -> packed int32 [N/16, K/128, 16]");
+  m.def("forward_cdna4", &forward_cdna4, "WQLinear forward on cdna4-interleaved buffers", py::arg("in_feats"),
+        py::arg("kernel"), py::arg("scales"), py::arg("zeros"), py::arg("sz_packed"), py::arg("bias") = py::none());
 }

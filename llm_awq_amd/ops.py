@@ -162,14 +162,42 @@ def dequant_cdna4(qweight, scales, scaled_zeros, group_size: int = 128):
     return out
 
 
-def gemv_cdna4(x, qweight, scales, scaled_zeros, group_size: int = 128):
-    _need_gpu(x, qweight, scales, scaled_zeros)
+def pack_sz_cdna4(scales, scaled_zeros, in_features: int):
+    """-> int32 [N/16, K/128, 16] packed {scale | scaled_zero << 16} (bit patterns)."""
+    _need_gpu(scales, scaled_zeros)
+    n, k = scales.shape[1], in_features
+    out = torch.empty(n // 16, k // 128, 16, dtype=torch.int32, device=scales.device)
+    with torch.cuda.device(scales.device):
+        _capi.check(_capi.lib().awq_pack_sz_cdna4(scales.data_ptr(), scaled_zeros.data_ptr(), out.data_ptr(), n, k,
+                                                   _stream(scales)))
+    return out
+
+
+def gemv_cdna4(x, qweight, scales, scaled_zeros, sz_packed=None, group_size: int = 128):
+    _need_gpu(x, qweight, scales, scaled_zeros, sz_packed)
     k = x.shape[-1]
     m = x.numel() // k
     n = qweight.shape[0] * 4
     out = torch.empty(*x.shape[:-1], n, dtype=x.dtype, device=x.device)
     with torch.cuda.device(x.device):
         _capi.check(_capi.lib().awq_w4a16_gemv_cdna4(x.data_ptr(), qweight.data_ptr(), scales.data_ptr(),
-                                                      scaled_zeros.data_ptr(), out.data_ptr(), m, n, k, group_size,
-                                                      _dt(x), _stream(x)))
+                                                      scaled_zeros.data_ptr(),
+                                                      sz_packed.data_ptr() if sz_packed is not None else None,
+                                                      out.data_ptr(), m, n, k, group_size, _dt(x), _stream(x)))
+    return out
+
+
+def gemm_cdna4(x, qweight, scales, scaled_zeros, bias=None, sz_packed=None, group_size: int = 128):
+    """C-ABI awq_w4a16_forward_cdna4: any M (M <= 16 -> GEMV), optional bias."""
+    _need_gpu(x, qweight, scales, scaled_zeros, bias, sz_packed)
+    k = x.shape[-1]
+    m = x.numel() // k
+    n = qweight.shape[0] * 4
+    out = torch.empty(*x.shape[:-1], n, dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _capi.check(_capi.lib().awq_w4a16_forward_cdna4(x.data_ptr(), qweight.data_ptr(), scales.data_ptr(),
+                                                         scaled_zeros.data_ptr(),
+                                                         sz_packed.data_ptr() if sz_packed is not None else None,
+                                                         bias.data_ptr() if bias is not None else None,
+                                                         out.data_ptr(), m, n, k, group_size, _dt(x), None, 0, _stream(x)))
     return out

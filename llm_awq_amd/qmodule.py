@@ -94,6 +94,8 @@ class WQLinear(nn.Module):
         self.group_size = group_size if group_size != -1 else in_features
         self.split_k_iters = 8  # kept writable for tinychat/utils/tune.py:51-65; unused by the HIP kernels
         self.interleave = 4
+        self.layout = "v2"  # "cdna4" after to_cdna4(): same buffers, qweight permuted for the matrix-core dequant
+        self.sz_cdna4 = None
         assert self.in_features % self.group_size == 0
         assert out_features % (32 // self.w_bit) == 0
         assert out_features % self.interleave == 0
@@ -137,12 +139,57 @@ class WQLinear(nn.Module):
         q.scaled_zeros = sz.transpose(1, 0).contiguous()
         return q
 
+    # ---- MI355X-native layout (no reference counterpart; what llm_awq_amd.repacker emits) ----
+    @torch.no_grad()
+    def to_cdna4(self):
+        """Permute `qweight` (same shape / dtype, so the checkpoint contract is unchanged) into the cdna4
+        interleave and build the packed {scale | scaled_zero} side buffer.  bf16, out_features % 16 == 0,
+        group_size 128; buffers must live on the GPU.  Idempotent."""
+        if self.layout == "cdna4":
+            return self
+        if self.scales.dtype != torch.bfloat16:
+            raise TypeError("the cdna4 interleave (matrix-core dequant) is defined for bfloat16 WQLinear only")
+        if self.out_features % 16 or self.group_size != 128:
+            raise ValueError("cdna4 interleave needs out_features % 16 == 0 and group_size == 128")
+        eng = load_engine()
+        self.qweight = eng.repack_v2_to_cdna4(self.qweight.contiguous())
+        self.sz_cdna4 = eng.pack_sz_cdna4(self.scales.contiguous(), self.scaled_zeros.contiguous(), self.in_features)
+        self.layout = "cdna4"
+        return self
+
+    @torch.no_grad()
+    def to_v2(self):
+        if self.layout == "v2":
+            return self
+        self.qweight = load_engine().repack_cdna4_to_v2(self.qweight)
+        self.sz_cdna4 = None
+        self.layout = "v2"
+        return self
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        if self.layout == "cdna4":  # marker key only for native checkpoints; v2 state dicts are unchanged
+            destination[prefix + "qweight_layout"] = torch.tensor(1, dtype=torch.uint8)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        marker = state_dict.pop(prefix + "qweight_layout", None)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+        if marker is not None and int(marker) == 1:
+            self.layout = "cdna4"
+            self.sz_cdna4 = None  # rebuilt lazily on the first forward
+        else:
+            self.layout, self.sz_cdna4 = "v2", None
+
     @torch.no_grad()
     def forward(self, x):
         """qmodule.py:201-224: fewer than 8 rows -> decode GEMV, else prefill GEMM; bias added after."""
         eng = load_engine()
         if not x.is_contiguous():
             x = x.contiguous()
+        if self.layout == "cdna4":
+            if self.sz_cdna4 is None or self.sz_cdna4.device != self.scales.device:
+                self.sz_cdna4 = eng.pack_sz_cdna4(self.scales, self.scaled_zeros, self.in_features)
+            return eng.forward_cdna4(x, self.qweight, self.scales, self.scaled_zeros, self.sz_cdna4, self.bias)
         rows = x.numel() // x.shape[-1]
         if rows < 8:
             out = eng.gemv_forward_cuda_new(x, self.qweight, self.scales, self.scaled_zeros, rows,

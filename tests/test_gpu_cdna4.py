@@ -68,6 +68,20 @@ def test_gemv_cdna4_vs_oracle(ops, M, N, K):
     c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
     y = ops.gemv_cdna4(c["x"].cuda(), c4, c["scales"].cuda(), c["scaled_zeros"].cuda()).cpu()
     check_forward(y, c["x"], c["q"], c["scales"], c["scaled_zeros"], dtype)
+    # same through the packed {scale | zero} array (one dword load per step)
+    szp = ops.pack_sz_cdna4(c["scales"].cuda(), c["scaled_zeros"].cuda(), K)
+    y2 = ops.gemv_cdna4(c["x"].cuda(), c4, c["scales"].cuda(), c["scaled_zeros"].cuda(), szp).cpu()
+    assert torch.equal(y2, y)
+
+
+def test_pack_sz_cdna4(ops):
+    c = make_case(64, 768, torch.bfloat16, seed=1)
+    szp = ops.pack_sz_cdna4(c["scales"].cuda(), c["scaled_zeros"].cuda(), 768).cpu().numpy().view(np.uint32)
+    s = c["scales"].view(torch.int16).numpy().view(np.uint16).astype(np.uint32)
+    z = c["scaled_zeros"].view(torch.int16).numpy().view(np.uint16).astype(np.uint32)
+    for nb in range(4):
+        for kg in range(6):
+            assert (szp[nb, kg] == (s[kg, nb * 16:(nb + 1) * 16] | (z[kg, nb * 16:(nb + 1) * 16] << 16))).all()
 
 
 @pytest.mark.parametrize("knobs", [dict(gemv_waves=4, gemv_pf=2), dict(gemv_waves=8, gemv_pf=4), dict(gemv_waves=16, gemv_pf=8),
@@ -89,3 +103,19 @@ def test_gemv_knobs_do_not_change_results(ops, knobs):
                 assert ((y4 == ref4).float().mean() > 0.98)
     finally:
         ops._capi.tune(gemv_waves=0, gemv_pf=0, gemv_x_budget_kib=64)
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("M", [17, 64, 128, 200, 512, 777])
+@pytest.mark.parametrize("N,K", [(768, 768), (3072, 768), (768, 3072), (144, 1280)])
+def test_gemm_cdna4_vs_oracle(ops, variant, M, N, K):
+    dtype = torch.bfloat16
+    c = make_case(N, K, dtype, seed=M * 17 + N + K, M=M, bias=(M == 64))
+    c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
+    ops._capi.tune(gemm_variant=variant)
+    try:
+        y = ops.gemm_cdna4(c["x"].cuda(), c4, c["scales"].cuda(), c["scaled_zeros"].cuda(),
+                           c["bias"].cuda() if c["bias"] is not None else None).cpu()
+    finally:
+        ops._capi.tune(gemm_variant=0)
+    check_forward(y, c["x"], c["q"], c["scales"], c["scaled_zeros"], dtype, bias=c["bias"])

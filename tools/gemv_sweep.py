@@ -62,6 +62,7 @@ def main():
         if dtype == torch.bfloat16:
             for c in copies:
                 c["qweight_cdna4"] = ops.repack_v2_to_cdna4(c["qweight"])
+                c["sz_packed"] = ops.pack_sz_cdna4(c["scales"], c["scaled_zeros"], K)
         for M in args.m:
             x = torch.randn(M, K, device="cuda").to(dtype)
             out = torch.empty(M, N, device="cuda", dtype=dtype)
@@ -70,10 +71,14 @@ def main():
             cur = {"layout": 0}
 
             def fn(c):
-                f = L.awq_w4a16_gemv_cdna4 if cur["layout"] else L.awq_w4a16_gemv
-                qw = c["qweight_cdna4"] if cur["layout"] else c["qweight"]
-                _capi.check(f(x.data_ptr(), qw.data_ptr(), c["scales"].data_ptr(), c["scaled_zeros"].data_ptr(),
-                              out.data_ptr(), M, N, K, 128, dt, torch.cuda.current_stream().cuda_stream))
+                st = torch.cuda.current_stream().cuda_stream
+                if cur["layout"]:
+                    _capi.check(L.awq_w4a16_gemv_cdna4(x.data_ptr(), c["qweight_cdna4"].data_ptr(), c["scales"].data_ptr(),
+                                                       c["scaled_zeros"].data_ptr(), c["sz_packed"].data_ptr(),
+                                                       out.data_ptr(), M, N, K, 128, dt, st))
+                else:
+                    _capi.check(L.awq_w4a16_gemv(x.data_ptr(), c["qweight"].data_ptr(), c["scales"].data_ptr(),
+                                                 c["scaled_zeros"].data_ptr(), out.data_ptr(), M, N, K, 128, dt, st))
             ab = algo_bytes(M, K, N)
             layouts = (0, 1) if dtype == torch.bfloat16 else (0,)
             cfgs = [dict(DEFAULT, layout=l) for l in layouts]
