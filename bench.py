@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--layers", type=int, default=LAYERS)
+    ap.add_argument("--layout", default="cdna4", choices=["cdna4", "v2"], help="cdna4 = what the rewritten repacker emits (default); v2 = reference checkpoint layout through gemv/gemm_forward_cuda_new")
+    ap.add_argument("--unfused-mlp", action="store_true", help="run gate and up as two launches (160 launches per token instead of 128)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -78,27 +80,50 @@ def main():
         dist.destroy_process_group()
         return
 
-    # ---------------- weights: every layer distinct (HBM-resident, 3.7 GB) ----------------
+    # ---------------- weights: every layer distinct (HBM-resident, 3.7 GB), in the layout the rewritten
+    # repacker emits (cdna4 interleave + packed scales); gate and up are stacked along N like tinychat fuses
+    # q/k/v (fused_attn.py:566-572) so that decode runs them with the SiLU*mul epilogue in ONE launch ----------------
     L = args.layers
+    fused = not args.unfused_mlp
+    layer_shapes = ([("qkv", 4096, 6144), ("o", 4096, 4096), ("gate_up", 4096, 28672), ("down", 14336, 4096)] if fused
+                    else SHAPES)
     weights = []
     for li in range(L):
-        for si, (name, K, N) in enumerate(SHAPES):
+        for si, (name, K, N) in enumerate(layer_shapes):
             w = synth.random_wq(K, N, dtype=dtype, device=dev, seed=li * 16 + si, keep_q=False)
-            weights.append((K, N, w["qweight"], w["scales"], w["scaled_zeros"]))
+            if args.layout == "cdna4":
+                qw = eng.repack_v2_to_cdna4(w["qweight"])
+                szp = eng.pack_sz_cdna4(w["scales"], w["scaled_zeros"], K)
+            else:
+                qw, szp = w["qweight"], None
+            weights.append((name, K, N, qw, w["scales"], w["scaled_zeros"], szp))
+            del w
     torch.cuda.synchronize()
 
     def run_pass(xs):
         outs = []
-        for (K, N, qw, s, sz) in weights:
+        for (name, K, N, qw, s, sz, szp) in weights:
             x = xs[K]
             m = x.numel() // K
-            if m < 8:
+            if szp is not None:
+                if name == "gate_up" and m <= 8:
+                    outs.append(eng.mlp_gate_up_cdna4(x, qw, szp))      # QuantLlamaMLP: gate, up, silu*mul
+                else:
+                    outs.append(eng.forward_cdna4(x, qw, s, sz, szp, None))
+            elif m < 8:
                 outs.append(eng.gemv_forward_cuda_new(x, qw, s, sz, m, N, K, 128))
             else:
                 outs.append(eng.gemm_forward_cuda_new(x, qw, s, sz))
         return outs
 
+    def bytes_of(name, M, K, N):
+        b = algo_bytes(M, K, N)
+        if name == "gate_up" and M <= 8 and args.layout == "cdna4":
+            b -= M * (N // 2) * 2  # fused epilogue writes [M, N/2]
+        return b
+
     g = torch.Generator(device=dev).manual_seed(1)
+
     def make_x(M):
         return {K: torch.randn(M, K, device=dev, generator=g).to(dtype) for K in (4096, 14336)}
 
@@ -128,10 +153,10 @@ def main():
         ev_ms = e0.elapsed_time(e1)
     ms_per_step = wall_ms / args.steps
     launches = len(weights)
-    bytes_step = sum(algo_bytes(1, K, N) for (K, N, *_r) in weights)
+    bytes_step = sum(bytes_of(name, 1, K, N) for (name, K, N, *_r) in weights)
     avg_launch_us = ev_ms * 1e3 / (args.steps * launches)
     gbs = bytes_step * args.steps / (ev_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "gemv_w4a16_kernel<BF16>", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+    roofline = {"bound": "hbm", "kernel": "gemv_cdna4_kernel" if args.layout == "cdna4" else "gemv_w4a16_kernel<BF16>", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
                 "avg_launch_us": round(avg_launch_us, 3), "algorithmic_bytes_per_launch": bytes_step // launches,
                 "launches_per_step": launches, "timing": "hip events on the launch stream over the timed region"}
@@ -139,12 +164,13 @@ def main():
 
     out = {"metric": "W4A16 decode+prefill tok/s, Llama-3-8B; achieved %HBM (GEMV) / %MFMA (GEMM)",
            "value": round(tok_s, 2),
-           "unit": "decode tok/s (160 WQLinear calls per token; attention/norm/lm_head off-path)",
+           "unit": "decode tok/s (the 160 quantised linears of one token: 32 x {qkv, o, gate, up, down}; attention/norm/lm_head off-path)",
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": "Llama-3-8B W4A16 g128 bf16 activations on 1xMI355X (decode GEMV + prefill GEMM)",
                       "layers": L, "decode_m": 1, "prefill_m": args.prefill_m, "graph": graph is not None,
-                      "parallelism": "tp1"},
+                      "layout": args.layout, "fused_gate_up_silu_mul": fused and args.layout == "cdna4",
+                      "launches_per_token": launches, "parallelism": "tp1"},
            "roofline": roofline, "device": torch.cuda.get_device_name(dev)}
 
     # ---------------- prefill leg ----------------
@@ -161,7 +187,7 @@ def main():
             e1.record(side)
             torch.cuda.synchronize()
             pms = e0.elapsed_time(e1) / args.prefill_iters
-        flops = sum(2.0 * M * K * N for (K, N, *_r) in weights)
+        flops = sum(2.0 * M * K * N for (_nm, K, N, *_r) in weights)
         tfl = flops / (pms * 1e-3) / 1e12
         out["prefill"] = {"m": M, "ms_per_pass": round(pms, 3), "tok_s": round(M / (pms * 1e-3) * (LAYERS / L), 1),
                           "roofline": {"bound": "mfma", "kernel": "gemm_w4a16<BF16>", "achieved": round(tfl, 1),

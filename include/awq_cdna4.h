@@ -105,6 +105,14 @@ int awq_pack_sz_cdna4(const void* scales, const void* scaled_zeros, void* sz_pac
 int awq_w4a16_gemv_cdna4(const void* x, const void* qweight_cdna4, const void* scales, const void* scaled_zeros,
                          const void* sz_packed, void* out, int m, int n, int k, int group_size, int dtype, void* stream);
 
+/* QuantLlamaMLP's gate/up pair + SiLU*mul in ONE launch (tinychat/modules/fused_mlp.py:36-83 issues two
+ * gemv_forward_cuda_new calls, F.silu and a multiply): qweight_gate_up = the gate and up projections' cdna4 buffers
+ * stacked along N (n2 = 2 * intermediate rows, exactly what torch.cat([gate.qweight, up.qweight], 0) gives),
+ * sz_packed built from the equally concatenated scales / scaled_zeros; out[m, n2/2] = silu(x.Wg^T) * (x.Wu^T), every
+ * intermediate rounded to T like the reference's separate ops.  1 <= m <= 8, bf16. */
+int awq_w4a16_mlp_gate_up_cdna4(const void* x, const void* qweight_gate_up, const void* sz_packed, void* out, int m,
+                                int n2, int k, int group_size, int dtype, void* stream);
+
 /* gemm / WQLinear.forward dispatch on cdna4-interleaved weights (any m >= 1; m <= 16 runs the GEMV) */
 int awq_w4a16_gemm_cdna4(const void* x, const void* qweight_cdna4, const void* scales, const void* scaled_zeros,
                          const void* sz_packed, void* out, int m, int n, int k, int group_size, int dtype,

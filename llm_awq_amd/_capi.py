@@ -33,6 +33,7 @@ SIGNATURES = {
     "awq_dequant_cdna4": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "awq_pack_sz_cdna4": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "awq_w4a16_gemv_cdna4": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "awq_w4a16_mlp_gate_up_cdna4": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "awq_w4a16_gemm_cdna4": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "awq_w4a16_forward_cdna4": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "awq_tune_set": (_i, [ctypes.c_char_p, _i]),

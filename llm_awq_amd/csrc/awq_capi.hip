@@ -176,7 +176,21 @@ int awq_w4a16_gemv_cdna4(const void* x, const void* qweight, const void* scales,
   int st = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
   if (st != AWQ_OK) return st;
   if ((n % 16) != 0) return AWQ_ERR_SHAPE;
-  awq::launch_gemv(x, qweight, scales, scaled_zeros, sz_packed, out, m, n, k, dtype, 1, (hipStream_t)stream);
+  if (!(sz_packed && m <= 8 && awq::launch_gemv_cdna4(x, qweight, sz_packed, nullptr, out, m, n, k, 0, (hipStream_t)stream) == 0))
+    awq::launch_gemv(x, qweight, scales, scaled_zeros, sz_packed, out, m, n, k, dtype, 1, (hipStream_t)stream);
+  return finish_launch();
+}
+
+int awq_w4a16_mlp_gate_up_cdna4(const void* x, const void* qweight_gate_up, const void* sz_packed, void* out, int m,
+                                int n2, int k, int group_size, int dtype, void* stream) {
+  if (!x || !qweight_gate_up || !sz_packed || !out) return AWQ_ERR_NULL;
+  if (group_size != 128) return AWQ_ERR_GROUP;
+  if (dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
+  if (m < 1 || m > 8) return AWQ_ERR_BATCH;
+  if (n2 < 32 || (n2 % 32) != 0 || k < 128 || (k % 128) != 0) return AWQ_ERR_SHAPE;
+  if (!aligned16(x) || !aligned16(qweight_gate_up) || !aligned16(out) || !aligned16(sz_packed)) return AWQ_ERR_ALIGN;
+  if (awq::launch_gemv_cdna4(x, qweight_gate_up, sz_packed, nullptr, out, m, n2, k, 1, (hipStream_t)stream) != 0)
+    return AWQ_ERR_SHAPE;
   return finish_launch();
 }
 
@@ -187,13 +201,20 @@ int awq_w4a16_gemm_cdna4(const void* x, const void* qweight, const void* scales,
   int st = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
   if (st != AWQ_OK) return st;
   if ((n % 16) != 0) return AWQ_ERR_SHAPE;
-  awq::launch_gemm(x, qweight, scales, scaled_zeros, sz_packed, out, m, n, k, dtype, 1, workspace, workspace_bytes, (hipStream_t)stream);
+  if (!(sz_packed && m <= 8 && awq::launch_gemv_cdna4(x, qweight, sz_packed, nullptr, out, m, n, k, 0, (hipStream_t)stream) == 0))
+    awq::launch_gemm(x, qweight, scales, scaled_zeros, sz_packed, out, m, n, k, dtype, 1, workspace, workspace_bytes, (hipStream_t)stream);
   return finish_launch();
 }
 
 int awq_w4a16_forward_cdna4(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
                             const void* sz_packed, const void* bias, void* out, int m, int n, int k, int group_size,
                             int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  if (m <= 8 && sz_packed && dtype == AWQ_BF16 && group_size == 128) {  // decode: bias fused into the GEMV epilogue
+    int st0 = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
+    if (st0 != AWQ_OK) return st0;
+    if ((n % 16) != 0) return AWQ_ERR_SHAPE;
+    if (awq::launch_gemv_cdna4(x, qweight, sz_packed, bias, out, m, n, k, 0, (hipStream_t)stream) == 0) return finish_launch();
+  }
   int st = awq_w4a16_gemm_cdna4(x, qweight, scales, scaled_zeros, sz_packed, out, m, n, k, group_size, dtype, workspace,
                                 workspace_bytes, stream);  // m <= 16 is routed to the GEMV inside
   if (st != AWQ_OK || !bias) return st;
@@ -205,6 +226,7 @@ int awq_tune_set(const char* key, int value) {
   if (!key) return AWQ_ERR_NULL;
   if (awq::gemv_tune_set(key, value) == 0) return AWQ_OK;
   if (awq::gemm_tune_set(key, value) == 0) return AWQ_OK;
+  if (awq::gemv_cdna4_tune_set(key, value) == 0) return AWQ_OK;
   return AWQ_ERR_SHAPE;
 }
 

@@ -1,0 +1,205 @@
+// Decode GEMV on cdna4-interleaved weights, 1 <= M <= 8, bf16 (gfx950).  The fast path of
+// WQLinear.forward for decode (replaces gemv_kernel, awq/kernels/csrc/quantization_new/gemv/gemv_cuda.cu:74-229)
+// and, with EPI = 1, of QuantLlamaMLP's gate/up pair + SiLU*mul (tinychat/modules/fused_mlp.py:36-83).
+//
+// Structure (measured on MI355X with tools/ubench/gemv_ubench.hip, see DESIGN.md "gemv"):
+//   * block = one 16-row slab (EPI 1: the gate slab and the matching up slab), WAVES waves split K in
+//     interleaved 128-k steps; a wave issues ALL loads of a chunk of S steps up front (S x 1 KiB of packed
+//     weights + S dwords of packed {scale|scaled_zero} + its own x slices), so there is no conditional load
+//     and no register ring: hipcc emits counted vmcnt waits and the HBM queue is full from the first cycle.
+//   * x slices are staged through a WAVE-PRIVATE LDS region (no block barrier before the final reduction).
+//   * weights are dequantised on the matrix core (Cdna4Dequant, awq_device.hpp: exact q*s+sz in fp32, one
+//     v_cvt_pk_bf16_f32 = the reference's rounding) and fed as the A operand of v_mfma_f32_16x16x32_bf16
+//     against the activation rows; fp32 accumulation; split-K partials reduced through LDS; one rounding.
+//   * the kernel is instruction-issue bound next to the HBM stream (about one wave instruction per 4.5 cycles
+//     per SIMD whatever the pipe), so everything per-step is kept to the minimum instruction count.
+#include <string.h>
+
+#include "awq_device.hpp"
+#include "awq_kernels.hpp"
+
+namespace awq {
+
+template <int WAVES, int S, int MB, int EPI>
+__global__ __launch_bounds__(64 * WAVES) void gemv_cdna4_kernel(const uint16_t* __restrict__ x,
+                                                                 const u32* __restrict__ qw,
+                                                                 const u32* __restrict__ szp,
+                                                                 const uint16_t* __restrict__ bias,
+                                                                 uint16_t* __restrict__ out, int M, int N, int K) {
+  constexpr int NS = EPI == 1 ? 2 : 1;  // slabs per block
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int nb = blockIdx.x, nit = K >> 7;
+  const int xstep = M * 256;  // bytes of x per 128-k step (M rows)
+  float(*red)[4][64] = reinterpret_cast<float(*)[4][64]>(smem);  // [NS * WAVES][4][64]
+  char* xs = smem + NS * WAVES * 1024 + wv * (S * xstep);
+
+  const u32* wp[NS];
+  const u32* sp[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const size_t slab = (size_t)nb + (size_t)s * (N >> 5);  // EPI 1: up slab = gate slab + (N/2)/16
+    wp[s] = qw + slab * nit * 256 + lane * 4;
+    sp[s] = szp + slab * nit * 16 + i;
+  }
+  Cdna4Dequant cd;
+  cd.init(lane);
+  const int mrow = min(i, M - 1);
+  const int cnt = (nit - wv + WAVES - 1) / WAVES;  // this wave's steps: kg = wv + WAVES * t
+
+  f32x4 acc[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int c0 = 0; c0 < cnt; c0 += S) {
+    u32x4 xr[S][MB];
+    u32x4 w[NS][S];
+    u32 sz[NS][S];
+    // x slices first (vmcnt retires in order: their wait must not sit behind the weight stream)
+#pragma unroll
+    for (int t = 0; t < S; ++t) {
+      const int kg = min(wv + WAVES * (c0 + t), nit - 1);
+#pragma unroll
+      for (int b = 0; b < MB; ++b) {
+        const int row = min(4 * b + g, M - 1);
+        xr[t][b] = *reinterpret_cast<const u32x4*>(x + (size_t)row * K + kg * 128 + i * 8);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < S; ++t) {
+      const int kg = min(wv + WAVES * (c0 + t), nit - 1);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        w[s][t] = ldg_nt_u32x4(wp[s] + (size_t)kg * 256);
+        sz[s][t] = sp[s][(size_t)kg * 16];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < S; ++t)
+#pragma unroll
+      for (int b = 0; b < MB; ++b)
+        if (4 * b + g < M) *reinterpret_cast<u32x4*>(xs + t * xstep + b * 1024 + lane * 16) = xr[t][b];
+#pragma unroll
+    for (int t = 0; t < S; ++t) {
+      const bool valid = wv + WAVES * (c0 + t) < nit;
+      const u32x4* xrow = reinterpret_cast<const u32x4*>(xs + t * xstep + mrow * 256);
+      bf16x8 xop[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) xop[a] = __builtin_bit_cast(bf16x8, xrow[4 * a + g]);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const u32 szv = valid ? sz[s][t] : 0u;  // scale 0, zero 0 -> the tile contributes exactly 0
+        bf16x8 op[4];
+        cd.tile(w[s][t], (uint16_t)(szv & 0xFFFFu), (uint16_t)(szv >> 16), op);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(op[a], xop[a], acc[s], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- split-K reduction across the block's waves (fp32).  acc[r] = C[n = 4g + r][m = i] ----
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[s * WAVES + wv][r][lane] = acc[s][r];
+  __syncthreads();
+  if (wv < 4 && i < M) {
+    const int r = wv;
+    float v[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < WAVES; ++q) t += red[s * WAVES + q][r][lane];
+      v[s] = t;
+    }
+    const int nn = nb * 16 + 4 * g + r;
+    auto to_f = [](uint16_t b) { return __builtin_bit_cast(float, (u32)b << 16); };
+    if (EPI == 0) {
+      uint16_t o = BF16::from_float(v[0]);
+      if (bias != nullptr) o = BF16::from_float(to_f(o) + to_f(bias[nn]));  // `out + self.bias` in T (qmodule.py:221)
+      out[(size_t)i * N + nn] = o;
+    } else {
+      // fused_mlp.py:79-82: c = F.silu(gate_output) * up_output, every op rounded to T
+      const float gt = to_f(BF16::from_float(v[0])), up = to_f(BF16::from_float(v[NS - 1]));
+      const float sl = to_f(BF16::from_float(gt / (1.0f + __expf(-gt))));
+      out[(size_t)i * (N >> 1) + nn] = BF16::from_float(sl * up);
+    }
+  }
+}
+
+namespace {
+struct Cfg {
+  int waves, s;
+};
+// choose the K split (waves per slab) and the chunk length so that ~6-7 k waves are in flight chip-wide
+// and the wave-private x staging stays within ~48 KiB of LDS per block
+Cfg pick_cfg(int m, int n_rows, int k, int ns, int force_waves, int force_s) {
+  const int nit = k / kGroup, slabs = n_rows / 16 / ns;
+  int waves = slabs >= 2048 ? 4 : (slabs >= 384 ? 8 : 16);
+  if (ns == 2 && waves > 4) waves >>= 1;  // two slabs per block: half the waves give the same bytes in flight
+  while (waves > 4 && waves * 2 > nit) waves >>= 1;
+  if (force_waves) waves = force_waves;
+  const int per = (nit + waves - 1) / waves;
+  int cap = (32 * 1024) / (m * 256 * waves);  // LDS budget for x
+  if (cap < 2) cap = 2;
+  int want = per < cap ? per : cap;
+  if (ns == 2 && want > 4) want = 4;  // registers: two weight streams
+  int s = want >= 8 ? 8 : (want >= 7 ? 7 : (want >= 4 ? 4 : 2));
+  if (per <= 2) s = 2;
+  if (force_s) s = force_s;
+  while (s > 2 && (size_t)waves * s * m * 256 > 96 * 1024) s = s == 8 ? 7 : (s == 7 ? 4 : 2);  // LDS
+  return {waves, s};
+}
+int g_force_waves = 0, g_force_s = 0;
+}  // namespace
+
+int gemv_cdna4_tune_set(const char* key, int value) {
+  if (!strcmp(key, "gemvc_waves")) g_force_waves = value;
+  else if (!strcmp(key, "gemvc_s")) g_force_s = value;
+  else return -1;
+  return 0;
+}
+
+template <int WAVES, int S, int MB, int EPI>
+static void launch_cfg(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
+                       hipStream_t st) {
+  constexpr int NS = EPI == 1 ? 2 : 1;
+  const size_t smem = (size_t)NS * WAVES * 1024 + (size_t)WAVES * S * m * 256;
+  auto kern = gemv_cdna4_kernel<WAVES, S, MB, EPI>;
+  if (smem > 64 * 1024) {
+    static bool done = false;
+    if (!done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      done = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(n / 16 / NS), dim3(64 * WAVES), smem, st, (const uint16_t*)x, (const u32*)qw,
+                     (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k);
+}
+
+template <int MB, int EPI>
+static int launch_mb(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
+                     hipStream_t st) {
+  const Cfg c = pick_cfg(m, n, k, EPI == 1 ? 2 : 1, g_force_waves, g_force_s);
+#define AWQ_CASE(W_, S_)                                                    \
+  if (c.waves == W_ && c.s == S_) {                                         \
+    launch_cfg<W_, S_, MB, EPI>(x, qw, szp, bias, out, m, n, k, st);        \
+    return 0;                                                               \
+  }
+  AWQ_CASE(4, 2) AWQ_CASE(4, 4) AWQ_CASE(4, 7) AWQ_CASE(4, 8) AWQ_CASE(8, 2) AWQ_CASE(8, 4) AWQ_CASE(8, 7) AWQ_CASE(8, 8)
+  AWQ_CASE(16, 2) AWQ_CASE(16, 4) AWQ_CASE(16, 7) AWQ_CASE(16, 8)
+#undef AWQ_CASE
+  return -1;
+}
+
+// epi 0: out[m, n] (+ bias);  epi 1: qw holds [gate; up] stacked along N (n = 2 * ffn rows), out[m, n/2] = silu(gate) * up
+int launch_gemv_cdna4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
+                      int epi, hipStream_t st) {
+  if (m < 1 || m > 8) return -1;
+  if (epi == 1) return m <= 4 ? launch_mb<1, 1>(x, qw, szp, bias, out, m, n, k, st) : launch_mb<2, 1>(x, qw, szp, bias, out, m, n, k, st);
+  return m <= 4 ? launch_mb<1, 0>(x, qw, szp, bias, out, m, n, k, st) : launch_mb<2, 0>(x, qw, szp, bias, out, m, n, k, st);
+}
+
+}  // namespace awq

@@ -9,6 +9,11 @@ namespace awq {
 // szp: optional packed {scale | scaled_zero << 16} u32 [N/16][K/128][16] (cdna4 layout only), else nullptr
 int launch_gemv(const void* x, const void* qw, const void* s, const void* z, const void* szp, void* out, int m, int n,
                 int k, int dtype, int layout, hipStream_t st);
+// fast decode path on cdna4 buffers (1 <= m <= 8, bf16, packed sz required).  epi 0: out[m,n] (+bias);
+// epi 1: qw = [gate; up] stacked (n = 2*ffn rows), out[m, n/2] = silu(gate) * up.  Returns -1 if unsupported.
+int launch_gemv_cdna4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
+                      int epi, hipStream_t st);
+int gemv_cdna4_tune_set(const char* key, int value);
 int launch_pack_sz_cdna4(const void* s, const void* z, void* szp, int n, int k, hipStream_t st);
 int launch_gemm(const void* x, const void* qw, const void* s, const void* z, const void* szp, void* out, int m, int n,
                 int k, int dtype, int layout, void* ws, size_t ws_bytes, hipStream_t st);

@@ -149,6 +149,26 @@ torch::Tensor forward_cdna4(torch::Tensor in_feats, torch::Tensor kernel, torch:
   return out;
 }
 
+// QuantLlamaMLP's gate/up + SiLU*mul in one launch (tinychat/modules/fused_mlp.py:36-83), decode rows only
+torch::Tensor mlp_gate_up_cdna4(torch::Tensor in_feats, torch::Tensor kernel_gate_up, torch::Tensor sz_packed) {
+  TORCH_CHECK(in_feats.is_cuda() && kernel_gate_up.is_cuda() && sz_packed.is_cuda());
+  TORCH_CHECK(in_feats.is_contiguous() && kernel_gate_up.is_contiguous() && sz_packed.is_contiguous());
+  TORCH_CHECK(in_feats.scalar_type() == at::kBFloat16 && kernel_gate_up.scalar_type() == at::kShort &&
+              sz_packed.scalar_type() == at::kInt);
+  const int64_t n2 = kernel_gate_up.size(0) * 4, k = in_feats.size(-1);
+  TORCH_CHECK(k > 0 && in_feats.numel() % k == 0 && kernel_gate_up.numel() == n2 / 4 * k);
+  TORCH_CHECK(sz_packed.numel() == n2 * (k / 128), "sz_packed must be int32 [n2/16, k/128, 16]");
+  const int64_t m = in_feats.numel() / k;
+  std::vector<int64_t> shape = in_feats.sizes().vec();
+  shape.back() = n2 / 2;
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(in_feats.device());
+  at::Tensor out = torch::empty(shape, in_feats.options());
+  raise_on(awq_w4a16_mlp_gate_up_cdna4(in_feats.data_ptr(), kernel_gate_up.data_ptr(), sz_packed.data_ptr(), out.data_ptr(),
+                                       (int)m, (int)n2, (int)k, 128, AWQ_BF16,
+                                       (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()));
+  return out;
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -162,4 +182,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("pack_sz_cdna4", &pack_sz_cdna4, "scales/scaled_zeros [Gpad,N] -> packed int32 [N/16, K/128, 16]");
   m.def("forward_cdna4", &forward_cdna4, "WQLinear forward on cdna4-interleaved buffers", py::arg("in_feats"),
         py::arg("kernel"), py::arg("scales"), py::arg("zeros"), py::arg("sz_packed"), py::arg("bias") = py::none());
+  m.def("mlp_gate_up_cdna4", &mlp_gate_up_cdna4, "silu(x Wg^T) * (x Wu^T) on stacked cdna4 gate/up buffers, <= 8 rows");
 }

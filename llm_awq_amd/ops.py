@@ -201,3 +201,17 @@ def gemm_cdna4(x, qweight, scales, scaled_zeros, bias=None, sz_packed=None, grou
                                                          bias.data_ptr() if bias is not None else None,
                                                          out.data_ptr(), m, n, k, group_size, _dt(x), None, 0, _stream(x)))
     return out
+
+
+def mlp_gate_up_cdna4(x, qweight_gate_up, sz_packed, group_size: int = 128):
+    """C-ABI awq_w4a16_mlp_gate_up_cdna4: silu(x.Wg^T) * (x.Wu^T) in one launch; qweight_gate_up = the gate and up
+    cdna4 buffers stacked along N, sz_packed from the equally stacked scales.  1 <= M <= 8, bf16."""
+    _need_gpu(x, qweight_gate_up, sz_packed)
+    k = x.shape[-1]
+    m = x.numel() // k
+    n2 = qweight_gate_up.shape[0] * 4
+    out = torch.empty(*x.shape[:-1], n2 // 2, dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _capi.check(_capi.lib().awq_w4a16_mlp_gate_up_cdna4(x.data_ptr(), qweight_gate_up.data_ptr(), sz_packed.data_ptr(),
+                                                             out.data_ptr(), m, n2, k, group_size, _dt(x), _stream(x)))
+    return out

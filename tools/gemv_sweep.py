@@ -72,7 +72,11 @@ def main():
 
             def fn(c):
                 st = torch.cuda.current_stream().cuda_stream
-                if cur["layout"]:
+                if cur["layout"] == 2:
+                    _capi.check(L.awq_w4a16_forward_cdna4(x.data_ptr(), c["qweight_cdna4"].data_ptr(), c["scales"].data_ptr(),
+                                                          c["scaled_zeros"].data_ptr(), c["sz_packed"].data_ptr(), None,
+                                                          out.data_ptr(), M, N, K, 128, dt, None, 0, st))
+                elif cur["layout"]:
                     _capi.check(L.awq_w4a16_gemv_cdna4(x.data_ptr(), c["qweight_cdna4"].data_ptr(), c["scales"].data_ptr(),
                                                        c["scaled_zeros"].data_ptr(), c["sz_packed"].data_ptr(),
                                                        out.data_ptr(), M, N, K, 128, dt, st))
@@ -81,7 +85,7 @@ def main():
                                                  c["scaled_zeros"].data_ptr(), out.data_ptr(), M, N, K, 128, dt, st))
             ab = algo_bytes(M, K, N)
             layouts = (0, 1) if dtype == torch.bfloat16 else (0,)
-            cfgs = [dict(DEFAULT, layout=l) for l in layouts]
+            cfgs = [dict(DEFAULT, layout=l) for l in (layouts + ((2,) if dtype == torch.bfloat16 else ()))]
             if not args.defaults_only:
                 cfgs.append(dict(DEFAULT, gemv_probe=3, layout=0))
                 cfgs.append(dict(DEFAULT, gemv_probe=2, gemv_probe_blocks=4096, layout=0))
