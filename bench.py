@@ -34,6 +34,25 @@ LAYERS = 32
 SHAPES = [("qkv", 4096, 6144), ("o", 4096, 4096), ("gate", 4096, 14336), ("up", 4096, 14336), ("down", 14336, 4096)]
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/*pmc_traffic.json, produced by
+    tools/rocpd_pmc.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script; FETCH_SIZE
+    doubled per MI355X_MICROARCH.md).  Counters cannot be read from inside the timed run, so this is the last
+    measured value for the same workload, or None if no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        ks = [k for k in json.load(open(files[-1]))["kernels"] if k["kernel"].startswith(kernel_prefix)]
+        calls = sum(k["calls"] for k in ks)
+        if not calls:
+            return None, None
+        return int(sum(k["hbm_bytes_per_launch_corrected"] * k["calls"] for k in ks) / calls), os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
 def algo_bytes(M, K, N, esz=2, group=128):
     """packed int4 + scales + scaled_zeros + x + out."""
     return N * K // 2 + 2 * (K // group) * N * esz + M * K * esz + M * N * esz
@@ -156,8 +175,9 @@ def main():
     bytes_step = sum(bytes_of(name, 1, K, N) for (name, K, N, *_r) in weights)
     avg_launch_us = ev_ms * 1e3 / (args.steps * launches)
     gbs = bytes_step * args.steps / (ev_ms * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic("awq::gemv_cdna4_kernel" if args.layout == "cdna4" else "awq::gemv_w4a16_kernel")
     roofline = {"bound": "hbm", "kernel": "gemv_cdna4_kernel" if args.layout == "cdna4" else "gemv_w4a16_kernel<BF16>", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_us": round(avg_launch_us, 3), "algorithmic_bytes_per_launch": bytes_step // launches,
                 "launches_per_step": launches, "timing": "hip events on the launch stream over the timed region"}
     tok_s = 1e3 / ms_per_step * (L / LAYERS)  # tokens/s of a full 32-layer model

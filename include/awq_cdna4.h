@@ -121,6 +121,32 @@ int awq_w4a16_forward_cdna4(const void* x, const void* qweight_cdna4, const void
                             const void* sz_packed, const void* bias, void* out, int m, int n, int k, int group_size,
                             int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- grouped (per-expert) W4A16 GEMM for MoE layers: BASELINE.json's Mixtral-8x7B configuration.  New capability
+ * (the reference has no MoE path).  Tokens are sorted by expert: expert e owns rows
+ * [expert_offsets[e], expert_offsets[e+1]) of x_sorted [T, k] / out [T, n]; expert_offsets is a DEVICE int32 [E+1]
+ * array (offsets[0] = 0, offsets[E] = T), so routing never synchronises the host.  Weights are stacked per expert:
+ * qweight int16 [E, n/4, k], scales / scaled_zeros T [E, gpad, n].  layout 0 = v2, 1 = cdna4 (bf16). ---- */
+int awq_w4a16_moe_gemm(const void* x_sorted, const void* qweight, const void* scales, const void* scaled_zeros,
+                       const void* expert_offsets, void* out, int total_tokens, int num_experts, int n, int k, int gpad,
+                       int group_size, int dtype, int layout, void* stream);
+
+/* ---- W3A16 ("w3c" tiles): BASELINE.json's INT3 configuration.  The reference has NO packed 3-bit format
+ * (awq/quantize/qmodule.py:82-83 raises for w_bit != 4; INT3 exists only as pseudo-quantisation,
+ * awq/quantize/quantizer.py:61-103 with n_bit = 3), so the format is this repository's: per 16-row x 128-k tile
+ * 64 lanes x 3 words (768 B) = the cdna4 W4 tile of the same integers (0..7) with its fourth word folded into the
+ * free bit 3 of every nibble of the other three.  qweight_w3 is int16 [N/4, 3K/4] (N*K*3/8 bytes); scales /
+ * scaled_zeros / sz_packed keep the W4 contract.  bf16 only, n % 16 == 0, k % 128 == 0. ---- */
+int awq_pack_w3(const void* q_u8 /* u8 [n, k], values 0..7 */, void* qweight_w3, int n, int k, void* stream);
+int awq_unpack_w3(const void* qweight_w3, void* out_u8, int n, int k, void* stream);
+int awq_dequant_w3(const void* qweight_w3, const void* scales, const void* scaled_zeros, void* out, int n, int k,
+                   int group_size, int dtype, void* stream);
+/* WQLinear.forward for w_bit = 3: m <= 8 streams the 3-bit tiles directly (decode GEMV); larger m expands them to
+ * W4 cdna4 tiles in `workspace` (awq_w3a16_forward_workspace_bytes = n*k/2) and runs the W4 GEMM. */
+size_t awq_w3a16_forward_workspace_bytes(int m, int n, int k);
+int awq_w3a16_forward(const void* x, const void* qweight_w3, const void* scales, const void* scaled_zeros,
+                      const void* sz_packed, const void* bias, void* out, int m, int n, int k, int group_size, int dtype,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
 /* Tuning hook for experiments and benchmarks (not part of the reference surface): integer knobs such as
  * "gemv_waves", "gemv_unroll", "gemv_xmode", "gemv_stream_only", "gemm_variant"; 0 restores the default
  * heuristic.  Returns AWQ_OK or AWQ_ERR_SHAPE for an unknown key. Process-global, not thread-safe. */

@@ -176,7 +176,7 @@ int awq_w4a16_gemv_cdna4(const void* x, const void* qweight, const void* scales,
   int st = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
   if (st != AWQ_OK) return st;
   if ((n % 16) != 0) return AWQ_ERR_SHAPE;
-  if (!(sz_packed && m <= 8 && awq::launch_gemv_cdna4(x, qweight, sz_packed, nullptr, out, m, n, k, 0, (hipStream_t)stream) == 0))
+  if (!(sz_packed && m <= 8 && awq::launch_gemv_cdna4(x, qweight, sz_packed, nullptr, out, m, n, k, 0, 4, (hipStream_t)stream) == 0))
     awq::launch_gemv(x, qweight, scales, scaled_zeros, sz_packed, out, m, n, k, dtype, 1, (hipStream_t)stream);
   return finish_launch();
 }
@@ -189,7 +189,7 @@ int awq_w4a16_mlp_gate_up_cdna4(const void* x, const void* qweight_gate_up, cons
   if (m < 1 || m > 8) return AWQ_ERR_BATCH;
   if (n2 < 32 || (n2 % 32) != 0 || k < 128 || (k % 128) != 0) return AWQ_ERR_SHAPE;
   if (!aligned16(x) || !aligned16(qweight_gate_up) || !aligned16(out) || !aligned16(sz_packed)) return AWQ_ERR_ALIGN;
-  if (awq::launch_gemv_cdna4(x, qweight_gate_up, sz_packed, nullptr, out, m, n2, k, 1, (hipStream_t)stream) != 0)
+  if (awq::launch_gemv_cdna4(x, qweight_gate_up, sz_packed, nullptr, out, m, n2, k, 1, 4, (hipStream_t)stream) != 0)
     return AWQ_ERR_SHAPE;
   return finish_launch();
 }
@@ -201,7 +201,7 @@ int awq_w4a16_gemm_cdna4(const void* x, const void* qweight, const void* scales,
   int st = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
   if (st != AWQ_OK) return st;
   if ((n % 16) != 0) return AWQ_ERR_SHAPE;
-  if (!(sz_packed && m <= 8 && awq::launch_gemv_cdna4(x, qweight, sz_packed, nullptr, out, m, n, k, 0, (hipStream_t)stream) == 0))
+  if (!(sz_packed && m <= 8 && awq::launch_gemv_cdna4(x, qweight, sz_packed, nullptr, out, m, n, k, 0, 4, (hipStream_t)stream) == 0))
     awq::launch_gemm(x, qweight, scales, scaled_zeros, sz_packed, out, m, n, k, dtype, 1, workspace, workspace_bytes, (hipStream_t)stream);
   return finish_launch();
 }
@@ -213,13 +213,77 @@ int awq_w4a16_forward_cdna4(const void* x, const void* qweight, const void* scal
     int st0 = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
     if (st0 != AWQ_OK) return st0;
     if ((n % 16) != 0) return AWQ_ERR_SHAPE;
-    if (awq::launch_gemv_cdna4(x, qweight, sz_packed, bias, out, m, n, k, 0, (hipStream_t)stream) == 0) return finish_launch();
+    if (awq::launch_gemv_cdna4(x, qweight, sz_packed, bias, out, m, n, k, 0, 4, (hipStream_t)stream) == 0) return finish_launch();
   }
   int st = awq_w4a16_gemm_cdna4(x, qweight, scales, scaled_zeros, sz_packed, out, m, n, k, group_size, dtype, workspace,
                                 workspace_bytes, stream);  // m <= 16 is routed to the GEMV inside
   if (st != AWQ_OK || !bias) return st;
   awq::launch_bias_add(out, bias, m, n, dtype, (hipStream_t)stream);
   return finish_launch();
+}
+
+int awq_w4a16_moe_gemm(const void* x_sorted, const void* qweight, const void* scales, const void* scaled_zeros,
+                       const void* expert_offsets, void* out, int total_tokens, int num_experts, int n, int k, int gpad,
+                       int group_size, int dtype, int layout, void* stream) {
+  if (!expert_offsets) return AWQ_ERR_NULL;
+  if (num_experts < 1 || gpad * 128 < k || total_tokens < 0) return AWQ_ERR_SHAPE;
+  if (layout != 0 && layout != 1) return AWQ_ERR_SHAPE;
+  if (layout == 1 && (dtype != AWQ_BF16 || (n % 16) != 0)) return AWQ_ERR_DTYPE;
+  if (total_tokens == 0) return AWQ_OK;
+  int st = check_common(x_sorted, qweight, scales, scaled_zeros, out, total_tokens, n, k, group_size, dtype);
+  if (st != AWQ_OK) return st;
+  awq::launch_moe_gemm(x_sorted, qweight, scales, scaled_zeros, expert_offsets, out, total_tokens, num_experts, n, k, gpad,
+                       dtype, layout, (hipStream_t)stream);
+  return finish_launch();
+}
+
+// ---- W3 ("w3c") : the repository's 3-bit format (bf16 only; no reference counterpart) ----
+static int check_w3_shape(int n, int k) { return (n < 16 || (n % 16) != 0 || k < 128 || (k % 128) != 0) ? AWQ_ERR_SHAPE : AWQ_OK; }
+
+int awq_pack_w3(const void* q_u8, void* qweight_w3, int n, int k, void* stream) {
+  if (!q_u8 || !qweight_w3) return AWQ_ERR_NULL;
+  if (check_w3_shape(n, k)) return AWQ_ERR_SHAPE;
+  awq::launch_pack_w3(q_u8, qweight_w3, n, k, (hipStream_t)stream);
+  return finish_launch();
+}
+
+int awq_unpack_w3(const void* qweight_w3, void* out_u8, int n, int k, void* stream) {
+  if (!qweight_w3 || !out_u8) return AWQ_ERR_NULL;
+  if (check_w3_shape(n, k)) return AWQ_ERR_SHAPE;
+  awq::launch_unpack_w3(qweight_w3, out_u8, n, k, (hipStream_t)stream);
+  return finish_launch();
+}
+
+int awq_dequant_w3(const void* qweight_w3, const void* scales, const void* scaled_zeros, void* out, int n, int k,
+                   int group_size, int dtype, void* stream) {
+  if (!qweight_w3 || !scales || !scaled_zeros || !out) return AWQ_ERR_NULL;
+  if (dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
+  if (group_size != 128) return AWQ_ERR_GROUP;
+  if (check_w3_shape(n, k)) return AWQ_ERR_SHAPE;
+  awq::launch_dequant_w3(qweight_w3, scales, scaled_zeros, out, n, k, (hipStream_t)stream);
+  return finish_launch();
+}
+
+size_t awq_w3a16_forward_workspace_bytes(int m, int n, int k) { return m <= 8 ? 0 : (size_t)n * (size_t)k / 2; }
+
+int awq_w3a16_forward(const void* x, const void* qweight_w3, const void* scales, const void* scaled_zeros,
+                      const void* sz_packed, const void* bias, void* out, int m, int n, int k, int group_size, int dtype,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+  if (!sz_packed) return AWQ_ERR_NULL;
+  if (dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
+  int st = check_common(x, qweight_w3, scales, scaled_zeros, out, m, n, k, group_size, dtype);
+  if (st != AWQ_OK) return st;
+  if (check_w3_shape(n, k)) return AWQ_ERR_SHAPE;
+  if (m <= 8) {
+    if (awq::launch_gemv_cdna4(x, qweight_w3, sz_packed, bias, out, m, n, k, 0, 3, (hipStream_t)stream) != 0) return AWQ_ERR_SHAPE;
+    return finish_launch();
+  }
+  // prefill: expand the 3-bit tiles to W4 cdna4 tiles in the workspace, then the W4 GEMM runs unchanged
+  const size_t need = awq_w3a16_forward_workspace_bytes(m, n, k);
+  if (!workspace || workspace_bytes < need || !aligned16(workspace)) return AWQ_ERR_WORKSPACE;
+  awq::launch_expand_w3_to_cdna4(qweight_w3, workspace, n, k, (hipStream_t)stream);
+  return awq_w4a16_forward_cdna4(x, workspace, scales, scaled_zeros, sz_packed, bias, out, m, n, k, group_size, dtype, nullptr, 0,
+                                 stream);
 }
 
 int awq_tune_set(const char* key, int value) {

@@ -165,14 +165,14 @@ __device__ __forceinline__ size_t cdna4_tile_word(int nb, int kg, int nit) { ret
 struct Cdna4Dequant {
   u32 m01, m23;  // lane masks selecting where s_n sits in the diagonal B operand
   u32 kMagic, kMask;
-  __device__ __forceinline__ void init(int lane) {
+  __device__ __forceinline__ void init(int lane, u32 nibble_mask = 0x000F000Fu) {
     const int pos = (lane & 15) - 4 * (lane >> 4);
     m01 = pos == 0 ? 0x0000FFFFu : (pos == 1 ? 0xFFFF0000u : 0u);
     m23 = pos == 2 ? 0x0000FFFFu : (pos == 3 ? 0xFFFF0000u : 0u);
     // gfx950 VOP3 takes no 32-bit literal: park the magic in a VGPR and the mask in an SGPR so that
     // (w & mask) | magic is ONE v_and_or_b32 instead of v_and_b32 + v_or_b32 with literals
     kMagic = 0x43004300u;
-    kMask = 0x000F000Fu;
+    kMask = nibble_mask;  // 0x00070007 for W3 tiles (bit 3 of every nibble carries the folded fourth word)
     asm volatile("" : "+v"(kMagic));
     asm volatile("" : "+s"(kMask));
   }
@@ -201,5 +201,28 @@ struct Cdna4Dequant {
     op[3] = word(w.w, b01, b23, cv);
   }
 };
+
+
+// =============================================================================================
+// W3 ("w3c") tiles: the repository's 3-bit format (the reference has none: qmodule.py:82-83 raises for
+// w_bit != 4; INT3 exists only as pseudo-quantisation, quantizer.py:61-103 with n_bit = 3).
+// One tile = 16 rows x 128 k = 64 lanes x 3 words (768 B, contiguous).  It is the cdna4 W4 tile of the same
+// integers (values 0..7, so bit 3 of every nibble is free) with logical word 3 folded into those free
+// bits: bit 3 of nibble j of stored word c holds bit c of nibble j of logical word 3.
+// =============================================================================================
+__device__ __forceinline__ size_t w3_tile_word(int nb, int kg, int nit) { return ((size_t)nb * nit + kg) * 192; }
+
+// stored (W0, W1, W2) -> the four logical words; words 0..2 keep the foreign bit 3 (consumers mask with 0x0007)
+__device__ __forceinline__ u32x4 w3_expand(u32 W0, u32 W1, u32 W2) {
+  u32 t = (W0 >> 3) & 0x11111111u;
+  t |= (W1 >> 2) & 0x22222222u;
+  t |= (W2 >> 1) & 0x44444444u;
+  return u32x4{W0, W1, W2, t};
+}
+__device__ __forceinline__ void w3_fold(const u32x4& w, u32 (&out)[3]) {
+  out[0] = (w.x & 0x77777777u) | ((w.w & 0x11111111u) << 3);
+  out[1] = (w.y & 0x77777777u) | ((w.w & 0x22222222u) << 2);
+  out[2] = (w.z & 0x77777777u) | ((w.w & 0x44444444u) << 1);
+}
 
 }  // namespace awq

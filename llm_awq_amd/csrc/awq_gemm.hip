@@ -23,23 +23,18 @@ constexpr int BM = 128, BN = 128, BK = 64;
 __device__ __forceinline__ int tile_off(int row, int gc) { return row * 128 + ((gc ^ ((row >> 1) & 7)) << 4); }
 }  // namespace
 
+// one 128 x 128 output tile (tm, tn) of out[M, N] = x[M, K] . Wdeq[N, K]^T; shared by the plain and the grouped kernel
 template <typename DT, int LAYOUT>
-__global__ __launch_bounds__(256) void gemm_w4a16_128x128_kernel(const uint16_t* __restrict__ x,
-                                                                 const u32* __restrict__ qw,
-                                                                 const uint16_t* __restrict__ scales,
-                                                                 const uint16_t* __restrict__ zeros,
-                                                                 uint16_t* __restrict__ out, int M, int N, int K,
-                                                                 int tiles_m) {
+__device__ __forceinline__ void gemm128_tile(char* smem, const uint16_t* __restrict__ x, const u32* __restrict__ qw,
+                                             const uint16_t* __restrict__ scales, const uint16_t* __restrict__ zeros,
+                                             uint16_t* __restrict__ out, int M, int N, int K, int tm, int tn) {
   using vec8 = typename DT::vec8;
-  __shared__ __attribute__((aligned(16))) char smem[2 * BM * BK * 2];
   char* As = smem;                 // x tile      [128][64] T
   char* Bs = smem + BM * BK * 2;   // weight tile [128][64] T (dequantised)
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
   const int wm = wv >> 1, wn = wv & 1;
-  // tile_m fastest: the blocks that share one weight panel run together (weights read once from HBM)
-  const int tm = blockIdx.x % tiles_m, tn = blockIdx.x / tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- staging assignments ----
@@ -154,6 +149,46 @@ __global__ __launch_bounds__(256) void gemm_w4a16_128x128_kernel(const uint16_t*
       }
     }
   }
+}
+
+template <typename DT, int LAYOUT>
+__global__ __launch_bounds__(256) void gemm_w4a16_128x128_kernel(const uint16_t* __restrict__ x,
+                                                                 const u32* __restrict__ qw,
+                                                                 const uint16_t* __restrict__ scales,
+                                                                 const uint16_t* __restrict__ zeros,
+                                                                 uint16_t* __restrict__ out, int M, int N, int K,
+                                                                 int tiles_m) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * BM * BK * 2];
+  // tile_m fastest: the blocks that share one weight panel run together (weights read once from HBM)
+  gemm128_tile<DT, LAYOUT>(smem, x, qw, scales, zeros, out, M, N, K, blockIdx.x % tiles_m, blockIdx.x / tiles_m);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Grouped (per-expert) GEMM for MoE layers (BASELINE.json config 5, Mixtral-8x7B; no reference counterpart):
+// tokens are sorted by expert, expert e owns rows [offsets[e], offsets[e+1]) of x / out and the e-th slice of the
+// stacked packed weights.  The grid is sized for the worst case sum_e ceil(m_e / 128) <= T / 128 + E row tiles; a
+// block finds its (expert, row tile) by walking the E + 1 offsets (E is small) and exits if there is none.
+// ---------------------------------------------------------------------------------------------
+template <typename DT, int LAYOUT>
+__global__ __launch_bounds__(256) void moe_gemm_w4a16_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
+                                                             const uint16_t* __restrict__ scales,
+                                                             const uint16_t* __restrict__ zeros,
+                                                             const int* __restrict__ offsets, uint16_t* __restrict__ out,
+                                                             int E, int N, int K, int gpad, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * BM * BK * 2];
+  const int tn = blockIdx.x % tiles_n;  // column tiles of one row tile run together (x tile shared through L2)
+  int mt = blockIdx.x / tiles_n;
+  int e = 0, m_e = 0, row0 = 0;
+  for (; e < E; ++e) {
+    row0 = offsets[e];
+    m_e = offsets[e + 1] - row0;
+    const int t = (m_e + BM - 1) / BM;
+    if (mt < t) break;
+    mt -= t;
+  }
+  if (e == E) return;
+  gemm128_tile<DT, LAYOUT>(smem, x + (size_t)row0 * K, qw + (size_t)e * ((size_t)N * K / 8), scales + (size_t)e * gpad * N,
+                           zeros + (size_t)e * gpad * N, out + (size_t)row0 * N, m_e, N, K, mt, tn);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -331,6 +366,22 @@ __global__ __launch_bounds__(512) void gemm_w4a16_256x256_kernel(const uint16_t*
 }
 
 size_t gemm_workspace_bytes(int, int, int) { return 0; }
+
+int launch_moe_gemm(const void* x, const void* qw, const void* s, const void* z, const void* offsets, void* out, int total_m,
+                    int experts, int n, int k, int gpad, int dtype, int layout, hipStream_t st) {
+  const int tiles_n = (n + BN - 1) / BN;
+  const int row_tiles = total_m / BM + experts;  // >= sum_e ceil(m_e / BM)
+  dim3 grid((unsigned)(row_tiles * tiles_n)), block(256);
+#define AWQ_MOE(DT_, L_)                                                                                              \
+  hipLaunchKernelGGL((moe_gemm_w4a16_kernel<DT_, L_>), grid, block, 0, st, (const uint16_t*)x, (const u32*)qw,      \
+                     (const uint16_t*)s, (const uint16_t*)z, (const int*)offsets, (uint16_t*)out, experts, n, k, gpad, \
+                     tiles_n)
+  if (layout == 1) AWQ_MOE(BF16, 1);
+  else if (dtype == 0) AWQ_MOE(F16, 0);
+  else AWQ_MOE(BF16, 0);
+#undef AWQ_MOE
+  return 0;
+}
 
 namespace {
 int g_gemm_variant = 0;  // 0 = auto, 1 = force 128x128, 2 = force 256x256

@@ -20,7 +20,7 @@
 
 namespace awq {
 
-template <int WAVES, int S, int MB, int EPI>
+template <int WAVES, int S, int MB, int EPI, int BITS>
 __global__ __launch_bounds__(64 * WAVES) void gemv_cdna4_kernel(const uint16_t* __restrict__ x,
                                                                  const u32* __restrict__ qw,
                                                                  const u32* __restrict__ szp,
@@ -40,11 +40,11 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_cdna4_kernel(const uint16_t* 
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const size_t slab = (size_t)nb + (size_t)s * (N >> 5);  // EPI 1: up slab = gate slab + (N/2)/16
-    wp[s] = qw + slab * nit * 256 + lane * 4;
+    wp[s] = BITS == 4 ? qw + slab * nit * 256 + lane * 4 : qw + slab * nit * 192 + lane * 3;  // W3: 768-B tiles
     sp[s] = szp + slab * nit * 16 + i;
   }
   Cdna4Dequant cd;
-  cd.init(lane);
+  cd.init(lane, BITS == 4 ? 0x000F000Fu : 0x00070007u);
   const int mrow = min(i, M - 1);
   const int cnt = (nit - wv + WAVES - 1) / WAVES;  // this wave's steps: kg = wv + WAVES * t
 
@@ -71,7 +71,13 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_cdna4_kernel(const uint16_t* 
       const int kg = min(wv + WAVES * (c0 + t), nit - 1);
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        w[s][t] = ldg_nt_u32x4(wp[s] + (size_t)kg * 256);
+        if (BITS == 4) {
+          w[s][t] = ldg_nt_u32x4(wp[s] + (size_t)kg * 256);
+        } else {
+          const u32* p3 = wp[s] + (size_t)kg * 192;  // 12 B per lane: hipcc merges the three into global_load_dwordx3
+          w[s][t] = u32x4{__builtin_nontemporal_load(p3), __builtin_nontemporal_load(p3 + 1),
+                          __builtin_nontemporal_load(p3 + 2), 0u};
+        }
         sz[s][t] = sp[s][(size_t)kg * 16];
       }
     }
@@ -91,7 +97,8 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_cdna4_kernel(const uint16_t* 
       for (int s = 0; s < NS; ++s) {
         const u32 szv = valid ? sz[s][t] : 0u;  // scale 0, zero 0 -> the tile contributes exactly 0
         bf16x8 op[4];
-        cd.tile(w[s][t], (uint16_t)(szv & 0xFFFFu), (uint16_t)(szv >> 16), op);
+        const u32x4 wt = BITS == 4 ? w[s][t] : w3_expand(w[s][t].x, w[s][t].y, w[s][t].z);
+        cd.tile(wt, (uint16_t)(szv & 0xFFFFu), (uint16_t)(szv >> 16), op);
 #pragma unroll
         for (int a = 0; a < 4; ++a) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(op[a], xop[a], acc[s], 0, 0, 0);
       }
@@ -162,12 +169,12 @@ int gemv_cdna4_tune_set(const char* key, int value) {
   return 0;
 }
 
-template <int WAVES, int S, int MB, int EPI>
+template <int WAVES, int S, int MB, int EPI, int BITS>
 static void launch_cfg(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                        hipStream_t st) {
   constexpr int NS = EPI == 1 ? 2 : 1;
   const size_t smem = (size_t)NS * WAVES * 1024 + (size_t)WAVES * S * m * 256;
-  auto kern = gemv_cdna4_kernel<WAVES, S, MB, EPI>;
+  auto kern = gemv_cdna4_kernel<WAVES, S, MB, EPI, BITS>;
   if (smem > 64 * 1024) {
     static bool done = false;
     if (!done) {
@@ -179,13 +186,13 @@ static void launch_cfg(const void* x, const void* qw, const void* szp, const voi
                      (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k);
 }
 
-template <int MB, int EPI>
+template <int MB, int EPI, int BITS>
 static int launch_mb(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                      hipStream_t st) {
   const Cfg c = pick_cfg(m, n, k, EPI == 1 ? 2 : 1, g_force_waves, g_force_s);
 #define AWQ_CASE(W_, S_)                                                    \
   if (c.waves == W_ && c.s == S_) {                                         \
-    launch_cfg<W_, S_, MB, EPI>(x, qw, szp, bias, out, m, n, k, st);        \
+    launch_cfg<W_, S_, MB, EPI, BITS>(x, qw, szp, bias, out, m, n, k, st);        \
     return 0;                                                               \
   }
   AWQ_CASE(4, 2) AWQ_CASE(4, 4) AWQ_CASE(4, 7) AWQ_CASE(4, 8) AWQ_CASE(8, 2) AWQ_CASE(8, 4) AWQ_CASE(8, 7) AWQ_CASE(8, 8)
@@ -195,11 +202,17 @@ static int launch_mb(const void* x, const void* qw, const void* szp, const void*
 }
 
 // epi 0: out[m, n] (+ bias);  epi 1: qw holds [gate; up] stacked along N (n = 2 * ffn rows), out[m, n/2] = silu(gate) * up
+// bits 4: cdna4 W4 tiles; bits 3: w3c tiles (epi 0 only)
 int launch_gemv_cdna4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                      int epi, hipStream_t st) {
+                      int epi, int bits, hipStream_t st) {
   if (m < 1 || m > 8) return -1;
-  if (epi == 1) return m <= 4 ? launch_mb<1, 1>(x, qw, szp, bias, out, m, n, k, st) : launch_mb<2, 1>(x, qw, szp, bias, out, m, n, k, st);
-  return m <= 4 ? launch_mb<1, 0>(x, qw, szp, bias, out, m, n, k, st) : launch_mb<2, 0>(x, qw, szp, bias, out, m, n, k, st);
+  if (bits == 3) {
+    if (epi != 0) return -1;
+    return m <= 4 ? launch_mb<1, 0, 3>(x, qw, szp, bias, out, m, n, k, st) : launch_mb<2, 0, 3>(x, qw, szp, bias, out, m, n, k, st);
+  }
+  if (epi == 1)
+    return m <= 4 ? launch_mb<1, 1, 4>(x, qw, szp, bias, out, m, n, k, st) : launch_mb<2, 1, 4>(x, qw, szp, bias, out, m, n, k, st);
+  return m <= 4 ? launch_mb<1, 0, 4>(x, qw, szp, bias, out, m, n, k, st) : launch_mb<2, 0, 4>(x, qw, szp, bias, out, m, n, k, st);
 }
 
 }  // namespace awq

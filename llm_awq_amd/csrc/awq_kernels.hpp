@@ -12,7 +12,12 @@ int launch_gemv(const void* x, const void* qw, const void* s, const void* z, con
 // fast decode path on cdna4 buffers (1 <= m <= 8, bf16, packed sz required).  epi 0: out[m,n] (+bias);
 // epi 1: qw = [gate; up] stacked (n = 2*ffn rows), out[m, n/2] = silu(gate) * up.  Returns -1 if unsupported.
 int launch_gemv_cdna4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                      int epi, hipStream_t st);
+                      int epi, int bits, hipStream_t st);
+// W3 ("w3c") format helpers (awq_w3.hip)
+int launch_pack_w3(const void* q_u8, void* qw3, int n, int k, hipStream_t st);
+int launch_unpack_w3(const void* qw3, void* out_u8, int n, int k, hipStream_t st);
+int launch_dequant_w3(const void* qw3, const void* s, const void* z, void* out, int n, int k, hipStream_t st);
+int launch_expand_w3_to_cdna4(const void* qw3, void* qw4, int n, int k, hipStream_t st);
 int gemv_cdna4_tune_set(const char* key, int value);
 int launch_pack_sz_cdna4(const void* s, const void* z, void* szp, int n, int k, hipStream_t st);
 int launch_gemm(const void* x, const void* qw, const void* s, const void* z, const void* szp, void* out, int m, int n,
@@ -21,6 +26,8 @@ int launch_repack_v2_cdna4(const void* src, void* dst, int n, int k, int to_cdna
 int launch_unpack_cdna4(const void* qw, void* out_u8, int n, int k, hipStream_t st);
 int launch_dequant_cdna4(const void* qw, const void* s, const void* z, void* out, int n, int k, hipStream_t st);
 size_t gemm_workspace_bytes(int m, int n, int k);
+int launch_moe_gemm(const void* x, const void* qw, const void* s, const void* z, const void* offsets, void* out, int total_m,
+                    int experts, int n, int k, int gpad, int dtype, int layout, hipStream_t st);
 int gemv_tune_set(const char* key, int value);
 int gemm_tune_set(const char* key, int value);
 int launch_bias_add(void* out, const void* bias, int m, int n, int dtype, hipStream_t st);

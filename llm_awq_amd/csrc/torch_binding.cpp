@@ -149,6 +149,63 @@ torch::Tensor forward_cdna4(torch::Tensor in_feats, torch::Tensor kernel, torch:
   return out;
 }
 
+// grouped (per-expert) GEMM for MoE layers: tokens sorted by expert, stacked expert weights
+torch::Tensor moe_gemm_forward(torch::Tensor x_sorted, torch::Tensor kernel, torch::Tensor scales, torch::Tensor zeros,
+                               torch::Tensor expert_offsets, bool cdna4) {
+  check_inputs(x_sorted, kernel, scales, zeros);
+  TORCH_CHECK(expert_offsets.is_cuda() && expert_offsets.is_contiguous() && expert_offsets.scalar_type() == at::kInt);
+  TORCH_CHECK(kernel.dim() == 3 && scales.dim() == 3 && zeros.dim() == 3 && x_sorted.dim() == 2);
+  const int64_t e = kernel.size(0), n = kernel.size(1) * 4, k = kernel.size(2), t = x_sorted.size(0);
+  TORCH_CHECK(x_sorted.size(1) == k && scales.size(0) == e && scales.size(2) == n && expert_offsets.numel() == e + 1);
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(x_sorted.device());
+  at::Tensor out = torch::empty({t, n}, x_sorted.options());
+  raise_on(awq_w4a16_moe_gemm(x_sorted.data_ptr(), kernel.data_ptr(), scales.data_ptr(), zeros.data_ptr(),
+                              expert_offsets.data_ptr(), out.data_ptr(), (int)t, (int)e, (int)n, (int)k, (int)scales.size(1), 128,
+                              dtype_code(x_sorted), cdna4 ? 1 : 0,
+                              (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()));
+  return out;
+}
+
+// ---- W3 ("w3c" tiles, bf16): pack from logical integers, and WQLinear.forward for w_bit = 3 ----
+torch::Tensor pack_w3(torch::Tensor q_u8) {
+  TORCH_CHECK(q_u8.is_cuda() && q_u8.is_contiguous() && q_u8.scalar_type() == at::kByte && q_u8.dim() == 2);
+  const int64_t n = q_u8.size(0), k = q_u8.size(1);
+  TORCH_CHECK(n % 16 == 0 && k % 128 == 0, "w3c tiles need n % 16 == 0 and k % 128 == 0");
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(q_u8.device());
+  at::Tensor out = torch::empty({n / 4, k * 3 / 4}, q_u8.options().dtype(at::kShort));
+  raise_on(awq_pack_w3(q_u8.data_ptr(), out.data_ptr(), (int)n, (int)k,
+                       (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()));
+  return out;
+}
+
+torch::Tensor forward_w3(torch::Tensor in_feats, torch::Tensor kernel, torch::Tensor scales, torch::Tensor zeros,
+                         torch::Tensor sz_packed, c10::optional<torch::Tensor> bias) {
+  check_inputs(in_feats, kernel, scales, zeros);
+  TORCH_CHECK(in_feats.scalar_type() == at::kBFloat16, "the W3 path is defined for bfloat16");
+  TORCH_CHECK(sz_packed.is_cuda() && sz_packed.is_contiguous() && sz_packed.scalar_type() == at::kInt);
+  const int64_t n = kernel.size(0) * 4, k = in_feats.size(-1);
+  TORCH_CHECK(k > 0 && in_feats.numel() % k == 0 && kernel.numel() == n / 4 * (k * 3 / 4), "qweight must be int16 [n/4, 3k/4]");
+  TORCH_CHECK(sz_packed.numel() == n * (k / 128), "sz_packed must be int32 [n/16, k/128, 16]");
+  const int64_t m = in_feats.numel() / k;
+  std::vector<int64_t> shape = in_feats.sizes().vec();
+  shape.back() = n;
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(in_feats.device());
+  at::Tensor out = torch::empty(shape, in_feats.options());
+  if (m == 0) return out;
+  const void* bp = nullptr;
+  if (bias.has_value() && bias->defined()) {
+    TORCH_CHECK(bias->is_cuda() && bias->is_contiguous() && bias->scalar_type() == in_feats.scalar_type() && bias->numel() == n);
+    bp = bias->data_ptr();
+  }
+  const size_t wsb = awq_w3a16_forward_workspace_bytes((int)m, (int)n, (int)k);
+  at::Tensor ws;
+  if (wsb) ws = torch::empty({(int64_t)wsb}, in_feats.options().dtype(at::kByte));
+  raise_on(awq_w3a16_forward(in_feats.data_ptr(), kernel.data_ptr(), scales.data_ptr(), zeros.data_ptr(), sz_packed.data_ptr(),
+                             bp, out.data_ptr(), (int)m, (int)n, (int)k, 128, AWQ_BF16, wsb ? ws.data_ptr() : nullptr, wsb,
+                             (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()));
+  return out;
+}
+
 // QuantLlamaMLP's gate/up + SiLU*mul in one launch (tinychat/modules/fused_mlp.py:36-83), decode rows only
 torch::Tensor mlp_gate_up_cdna4(torch::Tensor in_feats, torch::Tensor kernel_gate_up, torch::Tensor sz_packed) {
   TORCH_CHECK(in_feats.is_cuda() && kernel_gate_up.is_cuda() && sz_packed.is_cuda());
@@ -182,5 +239,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("pack_sz_cdna4", &pack_sz_cdna4, "scales/scaled_zeros [Gpad,N] -> packed int32 [N/16, K/128, 16]");
   m.def("forward_cdna4", &forward_cdna4, "WQLinear forward on cdna4-interleaved buffers", py::arg("in_feats"),
         py::arg("kernel"), py::arg("scales"), py::arg("zeros"), py::arg("sz_packed"), py::arg("bias") = py::none());
+  m.def("moe_gemm_forward", &moe_gemm_forward, "grouped per-expert W4A16 GEMM (tokens sorted by expert)", py::arg("x_sorted"),
+        py::arg("kernel"), py::arg("scales"), py::arg("zeros"), py::arg("expert_offsets"), py::arg("cdna4") = false);
+  m.def("pack_w3", &pack_w3, "logical uint8 [N, K] (0..7) -> w3c tiles int16 [N/4, 3K/4]");
+  m.def("forward_w3", &forward_w3, "WQLinear forward for w_bit = 3 (w3c tiles)", py::arg("in_feats"), py::arg("kernel"),
+        py::arg("scales"), py::arg("zeros"), py::arg("sz_packed"), py::arg("bias") = py::none());
   m.def("mlp_gate_up_cdna4", &mlp_gate_up_cdna4, "silu(x Wg^T) * (x Wu^T) on stacked cdna4 gate/up buffers, <= 8 rows");
 }

@@ -215,3 +215,70 @@ def mlp_gate_up_cdna4(x, qweight_gate_up, sz_packed, group_size: int = 128):
         _capi.check(_capi.lib().awq_w4a16_mlp_gate_up_cdna4(x.data_ptr(), qweight_gate_up.data_ptr(), sz_packed.data_ptr(),
                                                              out.data_ptr(), m, n2, k, group_size, _dt(x), _stream(x)))
     return out
+
+
+# ---- W3 ("w3c" tiles, bf16) ----
+
+def pack_w3(q_u8):
+    """uint8 [N, K] (0..7) -> int16 [N/4, 3K/4] w3c tiles (GPU kernel)."""
+    _need_gpu(q_u8)
+    assert q_u8.dtype == torch.uint8
+    n, k = q_u8.shape
+    out = torch.empty(n // 4, k * 3 // 4, dtype=torch.int16, device=q_u8.device)
+    with torch.cuda.device(q_u8.device):
+        _capi.check(_capi.lib().awq_pack_w3(q_u8.data_ptr(), out.data_ptr(), n, k, _stream(q_u8)))
+    return out
+
+
+def unpack_w3(qweight_w3):
+    _need_gpu(qweight_w3)
+    n, k = qweight_w3.shape[0] * 4, qweight_w3.shape[1] * 4 // 3
+    out = torch.empty(n, k, dtype=torch.uint8, device=qweight_w3.device)
+    with torch.cuda.device(qweight_w3.device):
+        _capi.check(_capi.lib().awq_unpack_w3(qweight_w3.data_ptr(), out.data_ptr(), n, k, _stream(qweight_w3)))
+    return out
+
+
+def dequant_w3(qweight_w3, scales, scaled_zeros, group_size: int = 128):
+    _need_gpu(qweight_w3, scales, scaled_zeros)
+    n, k = qweight_w3.shape[0] * 4, qweight_w3.shape[1] * 4 // 3
+    out = torch.empty(n, k, dtype=scales.dtype, device=qweight_w3.device)
+    with torch.cuda.device(qweight_w3.device):
+        _capi.check(_capi.lib().awq_dequant_w3(qweight_w3.data_ptr(), scales.data_ptr(), scaled_zeros.data_ptr(),
+                                                out.data_ptr(), n, k, group_size, _dt(scales), _stream(qweight_w3)))
+    return out
+
+
+def forward_w3(x, qweight_w3, scales, scaled_zeros, sz_packed, bias=None, group_size: int = 128):
+    """C-ABI awq_w3a16_forward: any M (M <= 8 streams the 3-bit tiles; larger M expands to W4 tiles in a workspace)."""
+    _need_gpu(x, qweight_w3, scales, scaled_zeros, sz_packed, bias)
+    k = x.shape[-1]
+    m = x.numel() // k
+    n = qweight_w3.shape[0] * 4
+    out = torch.empty(*x.shape[:-1], n, dtype=x.dtype, device=x.device)
+    L = _capi.lib()
+    wsb = L.awq_w3a16_forward_workspace_bytes(m, n, k)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
+    with torch.cuda.device(x.device):
+        _capi.check(L.awq_w3a16_forward(x.data_ptr(), qweight_w3.data_ptr(), scales.data_ptr(), scaled_zeros.data_ptr(),
+                                        sz_packed.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(),
+                                        m, n, k, group_size, _dt(x), ws.data_ptr() if wsb else None, wsb, _stream(x)))
+    return out
+
+
+# ---- grouped (per-expert) GEMM for MoE layers ----
+
+def moe_gemm(x_sorted, qweight, scales, scaled_zeros, expert_offsets, layout: str = "v2", group_size: int = 128):
+    """C-ABI awq_w4a16_moe_gemm.  x_sorted [T, K] (tokens sorted by expert), qweight int16 [E, N/4, K],
+    scales / scaled_zeros T [E, Gpad, N], expert_offsets int32 [E + 1] on the device -> out [T, N]."""
+    _need_gpu(x_sorted, qweight, scales, scaled_zeros, expert_offsets)
+    assert expert_offsets.dtype == torch.int32 and qweight.dim() == 3 and scales.dim() == 3
+    e, n, k = qweight.shape[0], qweight.shape[1] * 4, qweight.shape[2]
+    t = x_sorted.shape[0]
+    out = torch.empty(t, n, dtype=x_sorted.dtype, device=x_sorted.device)
+    with torch.cuda.device(x_sorted.device):
+        _capi.check(_capi.lib().awq_w4a16_moe_gemm(x_sorted.data_ptr(), qweight.data_ptr(), scales.data_ptr(),
+                                                    scaled_zeros.data_ptr(), expert_offsets.data_ptr(), out.data_ptr(), t, e,
+                                                    n, k, scales.shape[1], group_size, _dt(x_sorted),
+                                                    1 if layout == "cdna4" else 0, _stream(x_sorted)))
+    return out

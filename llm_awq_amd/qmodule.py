@@ -71,6 +71,33 @@ def unpack_intweight(qweight: torch.Tensor) -> torch.Tensor:
     return out.reshape(R * 4, K)
 
 
+def _cdna4_gather_index(N: int, K: int, device) -> torch.Tensor:
+    """flat index n*K + k of the logical weight held by nibble p of logical word a of lane `lane` of cdna4 tile
+    (nb, kg) -> int64 [N/16, K/128, 64, 4, 8] (the interleave defined in include/awq_cdna4.h / DESIGN.md)."""
+    ar = lambda n, pos: torch.arange(n, device=device).view([n if d == pos else 1 for d in range(5)])
+    nb, kg, lane, a, p = ar(N // 16, 0), ar(K // 128, 1), ar(64, 2), ar(4, 3), ar(8, 4)
+    g, kl, i, hi = lane // 16, lane % 16, p & 3, p >> 2
+    n = 16 * nb + 4 * g + 2 * (i & 1) + hi
+    k = 128 * kg + 32 * a + 8 * (kl // 4) + 4 * (i >> 1) + kl % 4
+    return n * K + k
+
+
+def pack_w3c(unpacked_qweight: torch.Tensor) -> torch.Tensor:
+    """int [N, K] (values 0..7) -> `int16 [N/4, 3K/4]` w3c tiles (this repository's 3-bit format, see
+    include/awq_cdna4.h): the cdna4 tile of the same integers with its fourth word folded into bit 3 of every
+    nibble of the other three.  Host-side torch index arithmetic (the GPU twin is awq_pack_w3)."""
+    N, K = unpacked_qweight.shape
+    assert N % 16 == 0 and K % 128 == 0, "w3c tiles need out_features % 16 == 0 and in_features % 128 == 0"
+    q = unpacked_qweight.reshape(-1).to(torch.int64)
+    idx = _cdna4_gather_index(N, K, q.device)
+    sh = (4 * torch.arange(8, device=q.device)).view(1, 1, 1, 1, 8)
+    w = ((q[idx] & 7) << sh).sum(-1)  # [N/16, K/128, 64, 4] logical words
+    w3 = w[..., 3]
+    words = torch.stack([(w[..., c] & 0x77777777) | (((w3 >> c) & 0x11111111) << 3) for c in range(3)], dim=-1)
+    words = ((words + 0x80000000) % 0x100000000 - 0x80000000).to(torch.int32)  # two's-complement wrap
+    return words.contiguous().view(torch.int16).reshape(N // 4, K * 3 // 4)
+
+
 class ScaledActivation(nn.Module):
     """qmodule.py:68-75 (imported by awq/quantize/quantizer.py:5 and auto_scale.py:11)."""
 
@@ -86,24 +113,29 @@ class ScaledActivation(nn.Module):
 class WQLinear(nn.Module):
     def __init__(self, w_bit, group_size, in_features, out_features, bias, dev, dtype=torch.float16):
         super().__init__()
-        if w_bit not in [4]:
-            raise NotImplementedError("Only 4-bit are supported for now.")  # qmodule.py:82-83
+        if w_bit not in [3, 4]:
+            # the reference supports 4 only (qmodule.py:82-83); 3 is this repository's INT3 extension (bf16, w3c tiles)
+            raise NotImplementedError("Only 4-bit (and the MI355X build's 3-bit) are supported for now.")
+        if w_bit == 3 and dtype != torch.bfloat16:
+            raise NotImplementedError("w_bit=3 (w3c tiles, matrix-core dequant) is defined for bfloat16 only")
         self.in_features = in_features
         self.out_features = out_features
         self.w_bit = w_bit
         self.group_size = group_size if group_size != -1 else in_features
         self.split_k_iters = 8  # kept writable for tinychat/utils/tune.py:51-65; unused by the HIP kernels
         self.interleave = 4
-        self.layout = "v2"  # "cdna4" after to_cdna4(): same buffers, qweight permuted for the matrix-core dequant
+        # "v2" = reference interleave; "cdna4" after to_cdna4() (same buffers, qweight permuted for the matrix-core
+        # dequant); "w3c" = the 3-bit tiles (w_bit == 3, always)
+        self.layout = "v2" if w_bit == 4 else "w3c"
         self.sz_cdna4 = None
         assert self.in_features % self.group_size == 0
-        assert out_features % (32 // self.w_bit) == 0
+        assert out_features % 8 == 0  # 32 // w_bit for the reference's w_bit = 4 (qmodule.py:93)
         assert out_features % self.interleave == 0
-        gpad = calculate_zeros_width(in_features, self.group_size) * (32 // self.w_bit)
-        self.register_buffer(
-            "qweight",
-            torch.zeros((out_features // self.interleave, in_features // (16 // self.w_bit) * self.interleave),
-                        dtype=torch.int16, device=dev))
+        gpad = calculate_zeros_width(in_features, self.group_size) * 8
+        if w_bit == 3:
+            assert out_features % 16 == 0 and in_features % 128 == 0 and self.group_size == 128
+        cols = in_features if w_bit == 4 else in_features * 3 // 4  # int16 [N/4, K] (4 bit) / [N/4, 3K/4] (3 bit)
+        self.register_buffer("qweight", torch.zeros((out_features // self.interleave, cols), dtype=torch.int16, device=dev))
         self.register_buffer("scales", torch.zeros((gpad, out_features), dtype=dtype, device=dev))
         self.register_buffer("scaled_zeros", torch.zeros((gpad, out_features), dtype=dtype, device=dev))
         if bias:
@@ -121,7 +153,7 @@ class WQLinear(nn.Module):
         assert scales is not None and zeros is not None
         G = q.group_size
         dtype = scales.dtype
-        gpad = calculate_zeros_width(linear.in_features, group_size) * (32 // q.w_bit)
+        gpad = calculate_zeros_width(linear.in_features, group_size) * 8
         qscales = torch.zeros((scales.shape[0], gpad), dtype=dtype, device=scales.device)
         qscales[:, : scales.shape[1]] = scales
         q.scales = qscales.transpose(1, 0).contiguous()
@@ -132,7 +164,10 @@ class WQLinear(nn.Module):
         gi = torch.arange(q.in_features, device=scales.device) // G
         scale_zeros = zeros * scales
         intweight = torch.round((linear.weight.data + scale_zeros[:, gi]) / qscales[:, gi]).to(torch.int32)
-        q.qweight = pack_intweight(intweight.contiguous(), interleave=4, kstride=64)
+        if w_bit == 4:
+            q.qweight = pack_intweight(intweight.contiguous(), interleave=4, kstride=64)
+        else:
+            q.qweight = pack_w3c(intweight.contiguous())
         zi = zeros.to(dtype=torch.int32)
         sz = torch.zeros_like(qscales)
         sz[:, : scales.shape[1]] = -(qscales[:, : scales.shape[1]] * zi.to(torch.float32)).to(dtype)
@@ -145,7 +180,7 @@ class WQLinear(nn.Module):
         """Permute `qweight` (same shape / dtype, so the checkpoint contract is unchanged) into the cdna4
         interleave and build the packed {scale | scaled_zero} side buffer.  bf16, out_features % 16 == 0,
         group_size 128; buffers must live on the GPU.  Idempotent."""
-        if self.layout == "cdna4":
+        if self.layout in ("cdna4", "w3c"):
             return self
         if self.scales.dtype != torch.bfloat16:
             raise TypeError("the cdna4 interleave (matrix-core dequant) is defined for bfloat16 WQLinear only")
@@ -159,7 +194,7 @@ class WQLinear(nn.Module):
 
     @torch.no_grad()
     def to_v2(self):
-        if self.layout == "v2":
+        if self.layout in ("v2", "w3c"):
             return self
         self.qweight = load_engine().repack_cdna4_to_v2(self.qweight)
         self.sz_cdna4 = None
@@ -174,7 +209,9 @@ class WQLinear(nn.Module):
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
         marker = state_dict.pop(prefix + "qweight_layout", None)
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
-        if marker is not None and int(marker) == 1:
+        if self.w_bit == 3:
+            self.layout, self.sz_cdna4 = "w3c", None
+        elif marker is not None and int(marker) == 1:
             self.layout = "cdna4"
             self.sz_cdna4 = None  # rebuilt lazily on the first forward
         else:
@@ -186,10 +223,11 @@ class WQLinear(nn.Module):
         eng = load_engine()
         if not x.is_contiguous():
             x = x.contiguous()
-        if self.layout == "cdna4":
+        if self.layout in ("cdna4", "w3c"):
             if self.sz_cdna4 is None or self.sz_cdna4.device != self.scales.device:
                 self.sz_cdna4 = eng.pack_sz_cdna4(self.scales, self.scaled_zeros, self.in_features)
-            return eng.forward_cdna4(x, self.qweight, self.scales, self.scaled_zeros, self.sz_cdna4, self.bias)
+            fwd = eng.forward_cdna4 if self.layout == "cdna4" else eng.forward_w3
+            return fwd(x, self.qweight, self.scales, self.scaled_zeros, self.sz_cdna4, self.bias)
         rows = x.numel() // x.shape[-1]
         if rows < 8:
             out = eng.gemv_forward_cuda_new(x, self.qweight, self.scales, self.scaled_zeros, rows,

@@ -302,3 +302,50 @@ def unpack_cdna4(qweight) -> np.ndarray:
 
 def v2_to_cdna4(qweight_v2) -> np.ndarray:
     return pack_cdna4(unpack_v2(qweight_v2))
+
+
+# --------------------------------------------------------------------------------------
+# W3 ("w3c" tiles) -- THIS repository's 3-bit format; the reference has none (qmodule.py:82-83 raises for
+# w_bit != 4) and only defines the 3-bit GRID: pseudo_quantize_tensor(n_bit=3), quantizer.py:61-103, restated by
+# pseudo_quantize() above and pinned by tests/golden/pseudo_w3.npz.  A tile is the cdna4 tile of the same integers
+# (values 0..7) whose fourth word (a = 3) is folded into the free bit 3 of every nibble of words 0..2:
+# bit 3 of nibble p of stored word c = bit c of nibble p of logical word 3.  768 B per tile, int16 [N/4, 3K/4] overall.
+# --------------------------------------------------------------------------------------
+
+
+def pack_w3(q) -> np.ndarray:
+    q = np.asarray(q).astype(np.int64)
+    assert q.max(initial=0) <= 7 and q.min(initial=0) >= 0
+    N, K = q.shape
+    w4 = np.ascontiguousarray(pack_cdna4(q)).view(np.uint32).reshape(-1, 4).astype(np.int64)  # [tiles*64, 4]
+    out = np.empty((w4.shape[0], 3), dtype=np.int64)
+    for c in range(3):
+        bit_c = (w4[:, 3] >> c) & 0x11111111      # bit c of every nibble of word 3, at nibble bit 0
+        out[:, c] = (w4[:, c] & 0x77777777) | (bit_c << 3)
+    return out.astype(np.uint32).view(np.int16).reshape(N // 4, K * 3 // 4)
+
+
+def unpack_w3(qweight_w3) -> np.ndarray:
+    w3 = np.ascontiguousarray(np.asarray(qweight_w3)).view(np.uint32).reshape(-1, 3).astype(np.int64)
+    N, K = qweight_w3.shape[0] * 4, qweight_w3.shape[1] * 4 // 3
+    w4 = np.zeros((w3.shape[0], 4), dtype=np.int64)
+    for c in range(3):
+        w4[:, c] = w3[:, c] & 0x77777777
+        w4[:, 3] |= ((w3[:, c] >> 3) & 0x11111111) << c
+    return unpack_cdna4(w4.astype(np.uint32).view(np.int16).reshape(N // 4, K))
+
+
+def quantize_linear_w3(w: torch.Tensor, dtype=torch.bfloat16, group_size: int = 128):
+    """real-quantise recipe (quantizer.py:143-157 with n_bit = 3) + from_linear's integer recovery and scale layout
+    (qmodule.py:155-197) + the w3c packing."""
+    wt = w.to(dtype)
+    fake, s, z = pseudo_quantize(wt, 3, group_size)
+    N, K = wt.shape
+    gp = padded_groups(K, group_size)
+    qs = torch.zeros((N, gp), dtype=dtype)
+    qs[:, : s.shape[1]] = s
+    iw = intweight_from_fake(fake, s, z, group_size)
+    sz = torch.zeros_like(qs)
+    sz[:, : s.shape[1]] = -(qs[:, : s.shape[1]] * z.to(torch.int32).to(torch.float32)).to(dtype)
+    return dict(w_fake=fake, s=s, z=z, qweight=torch.from_numpy(pack_w3(iw.numpy())), scales=qs.t().contiguous(),
+                scaled_zeros=sz.t().contiguous(), intweight=iw)

@@ -1,0 +1,143 @@
+"""W3A16 (BASELINE.json config 3, Llama-2-7B shapes): the reference only defines the 3-bit GRID
+(pseudo_quantize_tensor, awq/quantize/quantizer.py:61-103, pinned by tests/golden/pseudo_w3.npz); the packed
+"w3c" format is this repository's.  not-gpu: oracle grid vs golden, oracle pack <-> unpack, product host pack vs
+oracle, WQLinear(w_bit=3) contract.  -m gpu: HIP pack/unpack/dequant bit exact, GEMV / expand+GEMM vs oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import awq_oracle as O
+from tests.conftest import as_t
+from tests.helpers import check_forward
+
+
+def make_case_w3(N, K, seed=0, M=1, bias=False):
+    g = torch.Generator().manual_seed(seed)
+    d = O.quantize_linear_w3(torch.randn(N, K, generator=g) * 0.02)
+    d["x"] = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    d["bias"] = (torch.randn(N, generator=g) * 0.02).to(torch.bfloat16) if bias else None
+    d["q"] = d["intweight"].numpy().astype(np.uint8)
+    return d
+
+
+def test_grid_matches_reference_golden(golden):
+    g = golden("pseudo_w3.npz")
+    for name, dt in [("f16", torch.float16), ("bf16", torch.bfloat16), ("f32", torch.float32)]:
+        cv = (lambda a: as_t(a, dt)) if dt != torch.float32 else torch.from_numpy
+        fake, s, z = O.pseudo_quantize(cv(g[name + "_w0"]), 3, 128)
+        assert torch.equal(fake, cv(g[name + "_wfake"])) and torch.equal(s, cv(g[name + "_s"])) and torch.equal(z, cv(g[name + "_z"]))
+        assert z.max() <= 7 and z.min() >= 0
+
+
+@pytest.mark.parametrize("N,K", [(16, 128), (32, 256), (48, 1280), (64, 11008)])
+def test_pack_unpack_oracle_and_host(N, K):
+    from llm_awq_amd import qmodule as Q
+    rng = np.random.default_rng(N + K)
+    q = rng.integers(0, 8, size=(N, K)).astype(np.uint8)
+    p = O.pack_w3(q)
+    assert p.shape == (N // 4, 3 * K // 4) and p.dtype == np.int16 and p.nbytes == N * K * 3 // 8
+    assert (O.unpack_w3(p) == q).all()
+    assert (Q.pack_w3c(torch.from_numpy(q.astype(np.int32))).numpy() == p).all()
+    # a single flipped integer changes exactly the words of its own lane
+    q2 = q.copy()
+    q2[N // 2, K // 3] ^= 5
+    diff = (O.pack_w3(q2).view(np.uint32) != p.view(np.uint32))
+    assert 1 <= diff.sum() <= 2
+
+
+def test_wqlinear_w3_contract():
+    from llm_awq_amd import qmodule as Q
+    m = Q.WQLinear(3, 128, 11008, 4096, True, "cpu", dtype=torch.bfloat16)
+    sd = m.state_dict()
+    assert list(sd) == ["qweight", "scales", "scaled_zeros", "bias"]
+    assert sd["qweight"].shape == (1024, 8256) and sd["qweight"].dtype == torch.int16
+    assert sd["scales"].shape == (88, 4096) and m.layout == "w3c" and m.w_bit == 3
+    with pytest.raises(NotImplementedError):
+        Q.WQLinear(3, 128, 256, 64, False, "cpu", dtype=torch.float16)
+    with pytest.raises(NotImplementedError):
+        Q.WQLinear(2, 128, 256, 64, False, "cpu", dtype=torch.bfloat16)
+    d = make_case_w3(32, 256, seed=3)
+    lin = torch.nn.Linear(256, 32, bias=False).to(torch.bfloat16)
+    lin.weight.data = d["w_fake"]
+    q = Q.WQLinear.from_linear(lin, 3, 128, False, d["s"], d["z"])
+    assert torch.equal(q.qweight, d["qweight"]) and torch.equal(q.scaled_zeros, d["scaled_zeros"])
+    with pytest.raises(RuntimeError):
+        q(torch.zeros(1, 256, dtype=torch.bfloat16))  # no CPU fallback
+
+
+def test_w3_dequant_equals_fake_weight():
+    """dequant(from_linear(fake)) == fake to <= 1 ulp: the 'real == fake quantisation' equivalence the README evaluates."""
+    d = make_case_w3(64, 512, seed=11)
+    W = O.dequant_weight(d["q"], d["scales"], d["scaled_zeros"], 128)
+    # (q - z) * s vs q * s + round_T(-s * z): they differ by the rounding of the folded zero point (<= 1/2 ulp of
+    # s*z, z <= 7) plus the final rounding -- an ABSOLUTE error of the order of ulp_T(7 s), not a relative one
+    err = (W.float() - d["w_fake"].float()).abs()
+    assert err.max() <= 2.0 ** -7 * 7 * d["scales"].float().max()
+
+
+# ---------------------------------------------- GPU ----------------------------------------------
+@pytest.fixture(scope="module")
+def ops():
+    from llm_awq_amd import ops as _ops
+    _ops._capi.lib()
+    return _ops
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,K", [(16, 128), (64, 768), (256, 1280), (4096, 11008)])
+def test_gpu_pack_unpack_bit_exact(ops, N, K):
+    rng = np.random.default_rng(N * 3 + K)
+    q = rng.integers(0, 8, size=(N, K)).astype(np.uint8)
+    p = ops.pack_w3(torch.from_numpy(q).cuda())
+    if N * K <= 1 << 20:
+        assert (p.cpu().numpy() == O.pack_w3(q)).all()
+    assert (ops.unpack_w3(p).cpu().numpy() == q).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,K", [(16, 128), (64, 768), (256, 1280)])
+def test_gpu_dequant_bit_exact(ops, N, K):
+    d = make_case_w3(N, K, seed=N + K)
+    W = O.dequant_weight(d["q"], d["scales"], d["scaled_zeros"], 128)
+    got = ops.dequant_w3(d["qweight"].cuda(), d["scales"].cuda(), d["scaled_zeros"].cuda()).cpu()
+    assert torch.equal(got.view(torch.int16), W.view(torch.int16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [1, 2, 4, 7, 8, 9, 64, 200])
+@pytest.mark.parametrize("N,K", [(768, 768), (256, 4096), (64, 11008), (1040, 1280)])
+def test_gpu_forward_vs_oracle(ops, M, N, K):
+    d = make_case_w3(N, K, seed=M * 13 + N + K, M=M, bias=(M in (4, 64)))
+    szp = ops.pack_sz_cdna4(d["scales"].cuda(), d["scaled_zeros"].cuda(), K)
+    y = ops.forward_w3(d["x"].cuda(), d["qweight"].cuda(), d["scales"].cuda(), d["scaled_zeros"].cuda(), szp,
+                       d["bias"].cuda() if d["bias"] is not None else None).cpu()
+    check_forward(y, d["x"], d["q"], d["scales"], d["scaled_zeros"], torch.bfloat16, bias=d["bias"])
+
+
+@pytest.mark.gpu
+def test_gpu_wqlinear_w3_module(ops):
+    """WQLinear(w_bit=3) end to end on Llama-2-7B's down_proj shape: module forward == C-ABI forward, and the
+    fake-vs-real equivalence against F.linear on the fake-quantised weight."""
+    from llm_awq_amd.qmodule import WQLinear
+    K, N = 11008, 4096
+    g = torch.Generator(device="cuda").manual_seed(0)
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.02).to(torch.bfloat16)
+    # the grid on the GPU with torch ops (same formulae as quantizer.py:61-103)
+    grp = w.reshape(-1, 128)
+    hi, lo = grp.amax(1, keepdim=True), grp.amin(1, keepdim=True)
+    s = (hi - lo).clamp(min=1e-5) / 7
+    z = (-torch.round(lo / s)).clamp_(0, 7)
+    fake = ((torch.clamp(torch.round(grp / s) + z, 0, 7) - z) * s).reshape(N, K)
+    lin = torch.nn.Linear(K, N, bias=False, device="cuda", dtype=torch.bfloat16)
+    lin.weight.data = fake
+    m = WQLinear.from_linear(lin, 3, 128, False, s.view(N, -1), z.view(N, -1))
+    assert m.qweight.shape == (N // 4, 3 * K // 4)
+    W = ops.dequant_w3(m.qweight, m.scales, m.scaled_zeros)
+    assert (W.float() - fake.float()).abs().max() <= 2.0 ** -7 * 7 * m.scales.float().max()
+    for M in (1, 7, 64):
+        x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+        y = m(x)
+        ref = (x.float() @ W.float().t())
+        rel = ((y.float() - ref).norm() / ref.norm()).item()
+        assert rel < 2.5e-3, (M, rel)
+        assert (ref.to(torch.bfloat16) == y).float().mean() > 0.97
