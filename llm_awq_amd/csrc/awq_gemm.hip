@@ -384,7 +384,7 @@ int launch_moe_gemm(const void* x, const void* qw, const void* s, const void* z,
 }
 
 namespace {
-int g_gemm_variant = 0;  // 0 = auto, 1 = force 128x128, 2 = force 256x256
+int g_gemm_variant = 0;  // 0 = auto, 1 = force 128x128, 2 = force 256x256, 3 = force 256x256 v3 (cdna4 layout)
 }
 int gemm_tune_set(const char* key, int value) {
   if (!strcmp(key, "gemm_variant")) {
@@ -420,7 +420,10 @@ static int launch_gemm_t(const void* x, const void* qw, const void* s, const voi
 int launch_gemm(const void* x, const void* qw, const void* s, const void* z, const void* szp, void* out, int m, int n,
                 int k, int dtype, int layout, void*, size_t, hipStream_t st) {
   if (m <= 16) return launch_gemv(x, qw, s, z, szp, out, m, n, k, dtype, layout, st);
-  if (layout == 1) return launch_gemm_t<BF16, 1>(x, qw, s, z, out, m, n, k, st);
+  if (layout == 1) {
+    if ((g_gemm_variant == 3 || (g_gemm_variant == 0 && m > 128)) && launch_gemm_cdna4_v3(x, qw, szp, out, m, n, k, st) == 0) return 0;
+    return launch_gemm_t<BF16, 1>(x, qw, s, z, out, m, n, k, st);
+  }
   return dtype == 0 ? launch_gemm_t<F16, 0>(x, qw, s, z, out, m, n, k, st)
                     : launch_gemm_t<BF16, 0>(x, qw, s, z, out, m, n, k, st);
 }
