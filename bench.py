@@ -63,7 +63,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--prefill-m", type=int, default=2048)
+    ap.add_argument("--prefill-m", type=int, default=4096, help="prefill rows of the headline GEMM figure (the reference quotes TTFT up to 4096 tokens, tinychat/README.md:174-178)")
+    ap.add_argument("--prefill-m2", type=int, default=2048, help="second prefill size reported beside it (0 = skip)")
     ap.add_argument("--prefill-iters", type=int, default=3)
     ap.add_argument("--no-prefill", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -194,8 +195,7 @@ def main():
            "roofline": roofline, "device": torch.cuda.get_device_name(dev)}
 
     # ---------------- prefill leg ----------------
-    if not args.no_prefill:
-        M = args.prefill_m
+    def prefill(M):
         xsm = make_x(M)
         with torch.cuda.stream(side):
             run_pass(xsm)
@@ -209,10 +209,15 @@ def main():
             pms = e0.elapsed_time(e1) / args.prefill_iters
         flops = sum(2.0 * M * K * N for (_nm, K, N, *_r) in weights)
         tfl = flops / (pms * 1e-3) / 1e12
-        out["prefill"] = {"m": M, "ms_per_pass": round(pms, 3), "tok_s": round(M / (pms * 1e-3) * (LAYERS / L), 1),
-                          "roofline": {"bound": "mfma", "kernel": "gemm_w4a16<BF16>", "achieved": round(tfl, 1),
-                                       "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / MFMA_PEAK_TFLOPS, 4),
-                                       "traffic": None}}
+        return {"m": M, "ms_per_pass": round(pms, 3), "tok_s": round(M / (pms * 1e-3) * (LAYERS / L), 1),
+                "roofline": {"bound": "mfma", "kernel": "gemm_cdna4_v3_kernel" if args.layout == "cdna4" else "gemm_w4a16_256x256_kernel",
+                             "achieved": round(tfl, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(tfl / MFMA_PEAK_TFLOPS, 4), "traffic": None}}
+
+    if not args.no_prefill:
+        out["prefill"] = prefill(args.prefill_m)
+        if args.prefill_m2 and args.prefill_m2 != args.prefill_m:
+            out["prefill_m%d" % args.prefill_m2] = prefill(args.prefill_m2)
 
     # ---------------- CPU baseline (reference's pseudo-quant Linear on the host cores) ----------------
     if not args.no_cpu_baseline:

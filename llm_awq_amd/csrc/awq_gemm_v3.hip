@@ -36,6 +36,7 @@ struct Group {       // one quantisation group (128 k) of the wave's two slabs
 };
 }  // namespace
 
+template <int BARMID>
 __global__ __launch_bounds__(512) void gemm_cdna4_v3_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                             const u32* __restrict__ szp,
                                                             uint16_t* __restrict__ out, int M, int N, int K, int tiles_m,
@@ -139,9 +140,20 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v3_kernel(const uint16_t* __re
   };
   auto x_addr = [&](int stage, int ks, int t) { return smem + stage * kTile + tile_off(wm * 128 + t * 32 + l32, 2 * ks + hk); };
   // one k-step: 8 MFMAs while the fragments of k-step (stage_n, ks_n) stream in
-  auto step = [&](int stage_n, int ks_n, bool rd) {
+  // `bar`: the block barrier sits AFTER the a = 0 sweep of the last k-step of a tile: the fragment reads issued at the
+  // end of the previous k-step have had four MFMAs to land, so the lgkmcnt(0) in front of the barrier is (nearly) free,
+  // and every read of the next tile's stage comes after it
+  auto step = [&](int stage_n, int ks_n, bool rd, bool bar = false) {
+    if (bar && !BARMID) {  // experiment arm: barrier in front of the whole k-step
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __syncthreads();
+    }
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[b], acc[0][b], 0, 0, 0);
+    if (bar && BARMID) {
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+      __syncthreads();
+    }
     if (rd) wf[0] = *reinterpret_cast<const bf16x8*>(w_addr(stage_n, ks_n, 0));
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -179,13 +191,12 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v3_kernel(const uint16_t* __re
     job(gc, 1, 2, 1);
     step(0, 3, true);
     job(gc, 1, 3, 1);
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-    __syncthreads();             // tile 2q+1 complete in stage 1; every read of stage 0 retired; all loads drained
+    // last k-step of tile 2q; barrier inside: tile 2q+1 complete in stage 1, every read of stage 0 retired, loads drained
+    step(1, 0, true, true);
     if (more) {
       gc = prep(rn);             // group q+1: loaded one iteration ago, drained by the barrier above
       rn = load_group(min(q + 2, nit - 1));  // consumed after the NEXT iteration's first barrier
     }
-    step(1, 0, true);         // last k-step of tile 2q while the first fragments of tile 2q+1 stream in
     if (more) {
       issue_a(2 * q + 2, 0);
       job(gc, 0, 0, 0);          // first word of tile 2q+2 = (group q+1, half 0)
@@ -197,9 +208,7 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v3_kernel(const uint16_t* __re
     if (more) job(gc, 0, 2, 0);
     step(1, 3, true);
     if (more) job(gc, 0, 3, 0);
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __syncthreads();             // tile 2q+2 complete in stage 0; every read of stage 1 retired
-    step(0, 0, more);
+    step(0, 0, more, true);      // barrier inside: tile 2q+2 complete in stage 0; every read of stage 1 retired
     if (more) {
       issue_a(2 * q + 3, 1);
       job(gc, 1, 0, 1);          // first word of tile 2q+3 = (group q+1, half 1)
@@ -235,17 +244,22 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v3_kernel(const uint16_t* __re
   }
 }
 
+int g_v3_barmid = 1;
 int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, void* out, int m, int n, int k, hipStream_t st) {
   if (!szp || m < TM || (n % 16) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return -1;
   const int tiles_m = (m + TM - 1) / TM, tiles_n = (n + TN - 1) / TN;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cdna4_v3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              kSmemV3);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cdna4_v3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemV3);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cdna4_v3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemV3);
     attr = true;
   }
-  hipLaunchKernelGGL(gemm_cdna4_v3_kernel, dim3(tiles_m * tiles_n), dim3(512), kSmemV3, st, (const uint16_t*)x, (const u32*)qw,
-                     (const u32*)szp, (uint16_t*)out, m, n, k, tiles_m, tiles_n);
+  if (g_v3_barmid)
+    hipLaunchKernelGGL(gemm_cdna4_v3_kernel<1>, dim3(tiles_m * tiles_n), dim3(512), kSmemV3, st, (const uint16_t*)x,
+                       (const u32*)qw, (const u32*)szp, (uint16_t*)out, m, n, k, tiles_m, tiles_n);
+  else
+    hipLaunchKernelGGL(gemm_cdna4_v3_kernel<0>, dim3(tiles_m * tiles_n), dim3(512), kSmemV3, st, (const uint16_t*)x,
+                       (const u32*)qw, (const u32*)szp, (uint16_t*)out, m, n, k, tiles_m, tiles_n);
   return 0;
 }
 

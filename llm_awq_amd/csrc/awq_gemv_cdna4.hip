@@ -88,14 +88,14 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_cdna4_kernel(const uint16_t* 
         if (4 * b + g < M) *reinterpret_cast<u32x4*>(xs + t * xstep + b * 1024 + lane * 16) = xr[t][b];
 #pragma unroll
     for (int t = 0; t < S; ++t) {
-      const bool valid = wv + WAVES * (c0 + t) < nit;
+      if (wv + WAVES * (c0 + t) >= nit) continue;  // ragged tail: wave-uniform skip (the loads above were clamped)
       const u32x4* xrow = reinterpret_cast<const u32x4*>(xs + t * xstep + mrow * 256);
       bf16x8 xop[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) xop[a] = __builtin_bit_cast(bf16x8, xrow[4 * a + g]);
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        const u32 szv = valid ? sz[s][t] : 0u;  // scale 0, zero 0 -> the tile contributes exactly 0
+        const u32 szv = sz[s][t];
         bf16x8 op[4];
         const u32x4 wt = BITS == 4 ? w[s][t] : w3_expand(w[s][t].x, w[s][t].y, w[s][t].z);
         cd.tile(wt, (uint16_t)(szv & 0xFFFFu), (uint16_t)(szv >> 16), op);
@@ -143,20 +143,19 @@ struct Cfg {
 // choose the K split (waves per slab) and the chunk length so that ~6-7 k waves are in flight chip-wide
 // and the wave-private x staging stays within ~48 KiB of LDS per block
 Cfg pick_cfg(int m, int n_rows, int k, int ns, int force_waves, int force_s) {
+  // measured on MI355X (tools/gemvc_sweep.py, profiles/r01_gemvc_sweep.txt): short chunks (2..4 steps, 7 when the
+  // step count is a multiple of 7) and ~7 k waves in flight chip-wide; a chunk longer than the wave's step count
+  // only adds clamped loads
   const int nit = k / kGroup, slabs = n_rows / 16 / ns;
-  int waves = slabs >= 2048 ? 4 : (slabs >= 384 ? 8 : 16);
+  int waves = slabs >= 2048 ? 4 : (slabs >= 384 ? 8 : (nit >= 64 ? 8 : 16));
   if (ns == 2 && waves > 4) waves >>= 1;  // two slabs per block: half the waves give the same bytes in flight
   while (waves > 4 && waves * 2 > nit) waves >>= 1;
   if (force_waves) waves = force_waves;
   const int per = (nit + waves - 1) / waves;
-  int cap = (32 * 1024) / (m * 256 * waves);  // LDS budget for x
-  if (cap < 2) cap = 2;
-  int want = per < cap ? per : cap;
-  if (ns == 2 && want > 4) want = 4;  // registers: two weight streams
-  int s = want >= 8 ? 8 : (want >= 7 ? 7 : (want >= 4 ? 4 : 2));
-  if (per <= 2) s = 2;
+  int s = (per >= 7 && per % 7 == 0) ? 7 : (per >= 4 ? 4 : 2);
+  if (ns == 2) s = 2;  // registers: two weight streams
   if (force_s) s = force_s;
-  while (s > 2 && (size_t)waves * s * m * 256 > 96 * 1024) s = s == 8 ? 7 : (s == 7 ? 4 : 2);  // LDS
+  while (s > 2 && (size_t)waves * s * m * 256 > 48 * 1024) s = s == 8 ? 7 : (s == 7 ? 4 : 2);  // LDS for the x slices
   return {waves, s};
 }
 int g_force_waves = 0, g_force_s = 0;

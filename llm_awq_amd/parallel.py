@@ -61,6 +61,24 @@ def shard_column_parallel(qweight, scales, scaled_zeros, world: int, rank: int, 
             scaled_zeros[:, n0:n1].contiguous(), (n0, n1))
 
 
+def shard_stacked_column_parallel(qweight, scales, scaled_zeros, world: int, rank: int, parts: int = 2, multiple: int = 16):
+    """N-shard of a buffer that stacks `parts` projections along N (the fused gate/up pair, or q/k/v as tinychat's
+    make_quant_attn concatenates them, fused_attn.py:566-572): every projection is sharded on its own and the rank's
+    pieces are re-stacked, so rank r holds [gate_r; up_r] and the fused SiLU*mul epilogue still pairs matching rows."""
+    N = qweight.shape[0] * 4
+    assert N % parts == 0
+    sec = N // parts
+    qs, ss, zs, bounds = [], [], [], []
+    for p in range(parts):
+        n0, n1 = shard_bounds(sec, world, rank, multiple)
+        lo, hi = p * sec + n0, p * sec + n1
+        qs.append(qweight[lo // 4: hi // 4])
+        ss.append(scales[:, lo:hi])
+        zs.append(scaled_zeros[:, lo:hi])
+        bounds.append((lo, hi))
+    return torch.cat(qs, 0).contiguous(), torch.cat(ss, 1).contiguous(), torch.cat(zs, 1).contiguous(), bounds
+
+
 class TPWQLinear(nn.Module):
     """A WQLinear shard + its collective.  `matmul(x, qweight, scales, scaled_zeros)` defaults to the HIP
     engine (WQLinear.forward's dispatch); tests on CPU inject the oracle instead."""
@@ -107,33 +125,43 @@ class TPWQLinear(nn.Module):
 # ---------------------------------------------------------------------------------------------------
 
 def run_tp_bench(args, eng, dist, rank, world, dev, shapes, algo_bytes):
+    """Llama-3-8B decode (M = 1) under Megatron-paired tensor parallelism, in the layout the rewritten repacker emits:
+    qkv and the stacked gate/up pair are N-sharded (no communication; gate/up run with the SiLU*mul epilogue), o and
+    down are K-sharded with one RCCL all-reduce each.  Every rank builds ONLY its own shard (weights are synthetic)."""
     from . import synth
 
     dtype = torch.bfloat16
     L = args.layers
-    mode_of = {"qkv": "column", "gate": "column", "up": "column", "o": "row", "down": "row"}
-    # each rank generates ONLY its shard (same statistics as the full tensor; weights are synthetic)
+    # (name, K, N, mode) of the unsharded linears of one decoder block
+    block = [("qkv", 4096, 6144, "column"), ("o", 4096, 4096, "row"), ("gate_up", 4096, 28672, "column"),
+             ("down", 14336, 4096, "row")]
     shards = []
     for li in range(L):
-        for si, (name, K, N) in enumerate(shapes):
-            if mode_of[name] == "row":
+        for si, (name, K, N, mode) in enumerate(block):
+            if mode == "row":
                 k0, k1 = shard_bounds(K, world, rank, GROUP)
                 kl, nl = k1 - k0, N
             else:
-                n0, n1 = shard_bounds(N, world, rank, 16)
+                n0, n1 = shard_bounds(N, world, rank, 32)  # 32: the stacked gate/up pair splits in matching 16-row slabs
                 kl, nl = K, n1 - n0
             w = synth.random_wq(kl, nl, dtype=dtype, device=dev, seed=(li * 16 + si) * 64 + rank, keep_q=False)
-            shards.append((name, kl, nl, w["qweight"], w["scales"], w["scaled_zeros"], mode_of[name]))
+            qw = eng.repack_v2_to_cdna4(w["qweight"])
+            szp = eng.pack_sz_cdna4(w["scales"], w["scaled_zeros"], kl)
+            shards.append((name, kl, nl, qw, w["scales"], w["scaled_zeros"], szp, mode))
+            del w
     g = torch.Generator(device=dev).manual_seed(1 + rank)
     xs = {}
-    for (_nm, kl, _nl, *_r) in shards:
+    for (_nm, kl, *_r) in shards:
         if kl not in xs:
             xs[kl] = torch.randn(1, kl, device=dev, generator=g).to(dtype)
 
     def run_pass():
         outs = []
-        for (_nm, kl, nl, qw, s, sz, mode) in shards:
-            y = eng.gemv_forward_cuda_new(xs[kl], qw, s, sz, 1, nl, kl, 128)
+        for (name, kl, nl, qw, s, sz, szp, mode) in shards:
+            if name == "gate_up":
+                y = eng.mlp_gate_up_cdna4(xs[kl], qw, szp)
+            else:
+                y = eng.forward_cdna4(xs[kl], qw, s, sz, szp, None)
             if mode == "row":
                 dist.all_reduce(y)
             outs.append(y)
@@ -180,16 +208,18 @@ def run_tp_bench(args, eng, dist, rank, world, dev, shapes, algo_bytes):
     ms_per_step = tmax.item() * 1e3 / args.steps
     bytes_rank = sum(algo_bytes(1, kl, nl) for (_nm, kl, nl, *_r) in shards)
     gbs_rank = bytes_rank / (ms_per_step * 1e-3) / 1e9
+    launches = len(shards)
     return {"metric": "W4A16 decode+prefill tok/s, Llama-3-8B; achieved %HBM (GEMV) / %MFMA (GEMM)",
             "value": round(1e3 / ms_per_step * (L / 32), 2),
-            "unit": "decode tok/s (160 WQLinear calls per token; attention/norm/lm_head off-path)",
+            "unit": "decode tok/s (the 160 quantised linears of one token: 32 x {qkv, o, gate, up, down}; attention/norm/lm_head off-path)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"Llama-3-8B W4A16 g128 bf16, decode M=1, tensor parallel over {world} GPUs "
-                                   "(qkv/gate/up column-parallel, o/down K-sharded + RCCL all-reduce)",
-                       "layers": L, "decode_m": 1, "graph": graph is not None, "parallelism": f"tp{world}",
+                                   "(qkv and gate/up N-sharded, o/down K-sharded + RCCL all-reduce)",
+                       "layers": L, "decode_m": 1, "graph": graph is not None, "layout": "cdna4",
+                       "fused_gate_up_silu_mul": True, "launches_per_token": launches, "parallelism": f"tp{world}",
                        "allreduces_per_step": 2 * L},
-            "roofline": {"bound": "hbm", "kernel": "gemv_w4a16_kernel<BF16>", "achieved": round(gbs_rank, 1),
+            "roofline": {"bound": "hbm", "kernel": "gemv_cdna4_kernel", "achieved": round(gbs_rank, 1),
                          "peak": 8000.0, "unit": "GB/s per GPU (incl. all-reduce time)", "frac": round(gbs_rank / 8000.0, 4),
                          "traffic": None},
             "device": torch.cuda.get_device_name(dev)}

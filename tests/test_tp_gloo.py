@@ -91,3 +91,28 @@ def test_shard_bounds():
     assert covered == list(range(0, 11008, 128))
     with pytest.raises(AssertionError):
         P.shard_bounds(1000, 2, 0, 128)
+
+
+def test_stacked_gate_up_column_shards_pair_matching_rows():
+    """N-sharding the stacked [gate; up] buffer per projection: silu(gate_r) * up_r of every rank, concatenated,
+    equals the unsharded fused result (what the fused SiLU*mul launch computes per rank in bench.py --gpus N)."""
+    import torch
+    from llm_awq_amd.parallel import shard_stacked_column_parallel
+    from oracle import awq_oracle as O
+    from tests.helpers import make_case
+    F, K, world = 128, 256, 4
+    cg, cu = make_case(F, K, torch.bfloat16, seed=1, M=3), make_case(F, K, torch.bfloat16, seed=2, M=3)
+    x = cg["x"]
+    qgu = torch.cat([cg["qweight"], cu["qweight"]], 0)
+    s = torch.cat([cg["scales"], cu["scales"]], 1)
+    z = torch.cat([cg["scaled_zeros"], cu["scaled_zeros"]], 1)
+    full = O.wqlinear_forward(x, qgu, s, z, None, 128)
+    ref = torch.nn.functional.silu(full[:, :F]) * full[:, F:]
+    outs = []
+    for r in range(world):
+        q_r, s_r, z_r, bounds = shard_stacked_column_parallel(qgu, s, z, world, r, parts=2, multiple=16)
+        assert q_r.shape == (2 * F // world // 4, K) and bounds[0] == (r * F // world, (r + 1) * F // world)
+        y = O.wqlinear_forward(x, q_r, s_r, z_r, None, 128)
+        h = y.shape[1] // 2
+        outs.append(torch.nn.functional.silu(y[:, :h]) * y[:, h:])
+    assert torch.equal(torch.cat(outs, 1), ref)
