@@ -421,9 +421,10 @@ int launch_gemm(const void* x, const void* qw, const void* s, const void* z, con
                 int k, int dtype, int layout, void*, size_t, hipStream_t st) {
   if (m <= 16) return launch_gemv(x, qw, s, z, szp, out, m, n, k, dtype, layout, st);
   if (layout == 1) {
-    extern int g_v3_barmid;
-    g_v3_barmid = g_gemm_variant == 4 ? 0 : 1;
-    if ((g_gemm_variant == 3 || g_gemm_variant == 4 || (g_gemm_variant == 0 && m > 128)) && launch_gemm_cdna4_v3(x, qw, szp, out, m, n, k, st) == 0) return 0;
+    // variant 3 / auto: v3 kernel with the tile width picked by chip fill; 4 = force 256 x 256; 5 = force 256 x 128
+    if ((g_gemm_variant >= 3 || (g_gemm_variant == 0 && m > 128)) &&
+        launch_gemm_cdna4_v3(x, qw, szp, out, m, n, k, g_gemm_variant == 4 ? 256 : (g_gemm_variant == 5 ? 128 : 0), st) == 0)
+      return 0;
     return launch_gemm_t<BF16, 1>(x, qw, s, z, out, m, n, k, st);
   }
   return dtype == 0 ? launch_gemm_t<F16, 0>(x, qw, s, z, out, m, n, k, st)

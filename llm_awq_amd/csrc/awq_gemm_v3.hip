@@ -1,17 +1,18 @@
-// Prefill GEMM v3 on cdna4-interleaved weights (bf16, gfx950): 256 x 256 x 64 tile, 8 waves (2 along M x 4 along N,
-// 128 x 64 each), v_mfma_f32_32x32x16_bf16, double-buffered LDS (2 x 64 KiB).
+// Prefill GEMM v3 on cdna4-interleaved weights (bf16, gfx950): 256 x (128 * NSL) x 64 tile, 8 waves (2 along M x 4
+// along N, 128 x (32 * NSL) each), v_mfma_f32_32x32x16_bf16, double-buffered LDS.
 //
 // Replaces gemm_w4a16_T1 / gemm_w4a16_T2 (reference awq/kernels/csrc/quantization_new/gemm/gemm_cuda.cu:312-1124) for
-// the layout the rewritten repacker emits.  What changed against the 256x256 kernel in awq_gemm.hip (DESIGN.md "gemm"):
-//   * the block barrier sits BEFORE the last k-step of a K-tile, not after it: the fragments of the next tile's first
-//     k-step are read while the last 8 MFMAs of the current tile run, so no wave ever waits for LDS with an idle
-//     matrix pipe (fragments are double-buffered in registers, one k-step ahead everywhere);
+// the layout the rewritten repacker emits.  Against the 256x256 kernel in awq_gemm.hip (DESIGN.md "gemm"):
+//   * the block barrier sits INSIDE the last k-step of a K-tile, so the fragments of the next tile's first k-step are
+//     read while the remaining MFMAs of the current tile run and the lgkmcnt(0) in front of the barrier is nearly free;
 //   * the weight tile of the NEXT K-tile is produced one 32-bit word (8 weights per lane, two dequant MFMAs, four
 //     v_cvt_pk, one ds_write_b128) per k-step instead of in one block, and its packed words are fetched one
 //     quantisation group (two K-tiles) ahead with one 16-byte load per slab;
-//   * 32x32x16 MFMAs: half the matrix instructions per flop and the higher measured ceiling of the two shapes.
+//   * no ordinary load is ever consumed while an LDS-DMA is in flight (hipcc would drain the DMA queue there);
+//   * 32x32x16 MFMAs: half the matrix instructions per flop and the higher measured ceiling of the two shapes;
+//   * NSL = 1 (256 x 128 tiles) doubles the tile count for shapes that would fill only half the chip with 256 x 256.
 // Numerics are those of every other kernel here: W = round_bf16(q*s + sz) exactly (matrix-core dequant), fp32
-// accumulation, one rounding of the result.
+// accumulation in K order, one rounding of the result -- bit-identical to the 128x128 kernel.
 #include <type_traits>
 
 #include "awq_device.hpp"
@@ -20,27 +21,34 @@
 namespace awq {
 
 namespace {
-constexpr int TM = 256, TN = 256, TK = 64;
-constexpr int kTile = TM * TK * 2;           // 32 KiB: one [256][64] bf16 tile
-constexpr int kWBase = 2 * kTile;            // LDS: x stage 0 | x stage 1 | w stage 0 | w stage 1 (every ds offset stays < 64 KiB from its base)
-constexpr int kEpiRow = 144;                 // bytes per staged output row (64 n x 2 B + 16 pad)
-constexpr int kSmemV3 = 8 * 128 * kEpiRow;   // 147456 >= 4 * kTile
+constexpr int TM = 256, TK = 64;
+constexpr int kTileX = TM * TK * 2;  // 32 KiB: the x tile [256][64] bf16; LDS: x stage 0 | x stage 1 | w stage 0 | w stage 1
+constexpr int kWBase = 2 * kTileX;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ int tile_off(int row, int gc) { return row * 128 + ((gc ^ ((row >> 1) & 7)) << 4); }
 
-struct Group {       // one quantisation group (128 k) of the wave's two slabs
-  u32x4 w0, w1;      // slab 0 / slab 1: the lane's 16 bytes of the 1-KiB tile
-  u32 b01_0, b23_0, b01_1, b23_1;  // diagonal scale operands of the dequant MFMA
-  float c0, c1;      // sz - 128 s
+template <int NSL>
+struct Group {  // one quantisation group (128 k) of the wave's NSL slabs
+  u32x4 w[NSL];   // the lane's 16 bytes of each slab's 1-KiB tile
+  u32 b01[NSL], b23[NSL];  // diagonal scale operands of the dequant MFMA
+  float c[NSL];   // sz - 128 s
+};
+template <int NSL>
+struct Raw {
+  u32x4 w[NSL];
+  u32 sz[NSL];
 };
 }  // namespace
 
-template <int BARMID>
+template <int NSL>
 __global__ __launch_bounds__(512) void gemm_cdna4_v3_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
-                                                            const u32* __restrict__ szp,
-                                                            uint16_t* __restrict__ out, int M, int N, int K, int tiles_m,
-                                                            int tiles_n) {
+                                                            const u32* __restrict__ szp, uint16_t* __restrict__ out,
+                                                            int M, int N, int K, int tiles_m, int tiles_n) {
+  constexpr int TN = 128 * NSL;            // weight rows per block
+  constexpr int WN = 32 * NSL;             // weight rows per wave
+  constexpr int kTileW = TN * TK * 2;      // 16 / 32 KiB per weight stage
+  constexpr int kEpiRow = 2 * WN + 16;     // bytes per staged output row (+16 pad)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
@@ -69,7 +77,7 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v3_kernel(const uint16_t* __re
     a_off0 = (u32)(m0 + row) * (u32)K + gc * 8;
   }
   auto issue_a = [&](int kt, int stage) {
-    char* dst = smem + stage * kTile + wv * 1024;
+    char* dst = smem + stage * kTileX + wv * 1024;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const uint16_t* xq = x + (size_t)kt * TK + (size_t)q * 64 * K;  // wave-uniform part (SGPRs)
@@ -78,154 +86,175 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v3_kernel(const uint16_t* __re
     }
   };
 
-  // ---- weight tile: wave wv owns slabs 2*wv, 2*wv+1 (rows 32*wv .. +31 of the 256-row tile) ----
+  // ---- weight tile: wave wv owns slabs NSL*wv .. NSL*wv + NSL-1 (rows 16*NSL*wv .. of the TN-row tile) ----
   const int nslab = N >> 4;
-  const int sl0 = min((n0 >> 4) + 2 * wv, nslab - 1), sl1 = min((n0 >> 4) + 2 * wv + 1, nslab - 1);
-  // word offsets (N * K / 8 < 2^31 words for every supported shape): tile (slab, grp) at (slab * nit + grp) * 256 + 4 * lane
-  const u32 b_off0 = (u32)sl0 * nit * 256 + lane * 4, b_off1 = (u32)sl1 * nit * 256 + lane * 4;
-  const u32 sz_off0 = (u32)sl0 * nit * 16 + i, sz_off1 = (u32)sl1 * nit * 16 + i;  // packed {scale | scaled_zero << 16}
-  const int nl = 32 * wv + i;  // tile row of slab 0's lane row; slab 1 = + 16
+  u32 b_off[NSL], sz_off[NSL];  // word offsets (N * K / 8 < 2^31): tile (slab, grp) at (slab * nit + grp) * 256 + 4 * lane
+#pragma unroll
+  for (int s = 0; s < NSL; ++s) {
+    const int sl = min((n0 >> 4) + NSL * wv + s, nslab - 1);
+    b_off[s] = (u32)sl * nit * 256 + lane * 4;
+    sz_off[s] = (u32)sl * nit * 16 + i;  // packed {scale | scaled_zero << 16}
+  }
+  const int nl = 16 * NSL * wv + i;  // tile row of slab 0's lane row; slab s = + 16 s
   Cdna4Dequant cd;
   cd.init(lane);
 
-  struct Raw {
-    u32x4 w0, w1;
-    u32 sz0, sz1;
-  };
   auto load_group = [&](int grp) {
-    Raw r;
+    Raw<NSL> r;
     const u32* qg = qw + (size_t)grp * 256;
     const u32* sg = szp + (size_t)grp * 16;
-    r.w0 = *reinterpret_cast<const u32x4*>(qg + b_off0);
-    r.w1 = *reinterpret_cast<const u32x4*>(qg + b_off1);
-    r.sz0 = sg[sz_off0];
-    r.sz1 = sg[sz_off1];
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) {
+      r.w[s] = *reinterpret_cast<const u32x4*>(qg + b_off[s]);
+      r.sz[s] = sg[sz_off[s]];
+    }
     return r;
   };
-  auto prep = [&](const Raw& r) {
-    Group gq;
-    gq.w0 = r.w0;
-    gq.w1 = r.w1;
-    const u32 sd0 = (r.sz0 & 0xFFFFu) * 0x00010001u, sd1 = (r.sz1 & 0xFFFFu) * 0x00010001u;
-    gq.b01_0 = sd0 & cd.m01;
-    gq.b23_0 = sd0 & cd.m23;
-    gq.b01_1 = sd1 & cd.m01;
-    gq.b23_1 = sd1 & cd.m23;
-    gq.c0 = __builtin_fmaf(-128.0f, __builtin_bit_cast(float, r.sz0 << 16), __builtin_bit_cast(float, r.sz0 & 0xFFFF0000u));
-    gq.c1 = __builtin_fmaf(-128.0f, __builtin_bit_cast(float, r.sz1 << 16), __builtin_bit_cast(float, r.sz1 & 0xFFFF0000u));
+  auto prep = [&](const Raw<NSL>& r) {
+    Group<NSL> gq;
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) {
+      gq.w[s] = r.w[s];
+      const u32 sd = (r.sz[s] & 0xFFFFu) * 0x00010001u;
+      gq.b01[s] = sd & cd.m01;
+      gq.b23[s] = sd & cd.m23;
+      gq.c[s] = __builtin_fmaf(-128.0f, __builtin_bit_cast(float, r.sz[s] << 16), __builtin_bit_cast(float, r.sz[s] & 0xFFFF0000u));
+    }
     return gq;
   };
-  // job j of K-tile half h: word 2h + (j & 1) of slab (j >> 1) -> weight tile of `stage`, granule 4 (j & 1) + g
-  auto job = [&](const Group& gq, int h, int j, int stage) {
-    char* Bs = smem + kWBase + stage * kTile;
-    const int widx = 2 * h + (j & 1);
-    const u32x4& wsl = (j >> 1) ? gq.w1 : gq.w0;
-    const u32 word = widx == 0 ? wsl.x : (widx == 1 ? wsl.y : (widx == 2 ? wsl.z : wsl.w));
-    const bf16x8 v = (j >> 1) ? cd.word(word, gq.b01_1, gq.b23_1, gq.c1) : cd.word(word, gq.b01_0, gq.b23_0, gq.c0);
-    *reinterpret_cast<bf16x8*>(Bs + tile_off(nl + 16 * (j >> 1), 4 * (j & 1) + g)) = v;
+  // job j (0 .. 2 NSL - 1) of K-tile half h: word 2h + (j & 1) of slab (j >> 1) -> weight tile of `stage`, granule 4 (j & 1) + g
+  auto job = [&](const Group<NSL>& gq, int h, int j, int stage) {
+    char* Bs = smem + kWBase + stage * kTileW;
+    const int widx = 2 * h + (j & 1), s = j >> 1;
+    const u32 word = widx == 0 ? gq.w[s].x : (widx == 1 ? gq.w[s].y : (widx == 2 ? gq.w[s].z : gq.w[s].w));
+    const bf16x8 v = cd.word(word, gq.b01[s], gq.b23[s], gq.c[s]);
+    *reinterpret_cast<bf16x8*>(Bs + tile_off(nl + 16 * s, 4 * (j & 1) + g)) = v;
   };
-  // fragments (single set, 24 VGPRs): each one is re-read for the NEXT k-step right after the last MFMA of this
-  // k-step that consumes it -- wf[0] after the a = 0 sweep, xf[b] after its a = 1 MFMA, wf[1] at the end -- so every
-  // ds_read has at least three MFMAs (plus the other wave of the SIMD) to land
-  bf16x8 wf[2], xf[4];
-  f32x16 acc[2][4];
+  // the 2 NSL word jobs of a K-tile are spread over its four production slots (slot 0 = right after the barrier of
+  // the previous tile, slots 1..3 = its own first three k-steps)
+  auto slot = [&](const Group<NSL>& gq, int h, int sl, int stage) {
+    if (NSL == 2) job(gq, h, sl, stage);
+    else if ((sl & 1) == 0) job(gq, h, sl >> 1, stage);
+  };
+
+  // fragments (single set): each one is re-read for the NEXT k-step right after the last MFMA of this k-step that
+  // consumes it, so every ds_read has several MFMAs (plus the other wave of the SIMD) to land
+  bf16x8 wf[NSL], xf[4];
+  f32x16 acc[NSL][4];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < NSL; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   auto w_addr = [&](int stage, int ks, int t) {
-    return smem + kWBase + stage * kTile + tile_off(wn * 64 + t * 32 + l32, 2 * ks + hk);
+    return smem + kWBase + stage * kTileW + tile_off(wn * WN + t * 32 + l32, 2 * ks + hk);
   };
-  auto x_addr = [&](int stage, int ks, int t) { return smem + stage * kTile + tile_off(wm * 128 + t * 32 + l32, 2 * ks + hk); };
-  // one k-step: 8 MFMAs while the fragments of k-step (stage_n, ks_n) stream in
-  // `bar`: the block barrier sits AFTER the a = 0 sweep of the last k-step of a tile: the fragment reads issued at the
-  // end of the previous k-step have had four MFMAs to land, so the lgkmcnt(0) in front of the barrier is (nearly) free,
-  // and every read of the next tile's stage comes after it
+  auto x_addr = [&](int stage, int ks, int t) { return smem + stage * kTileX + tile_off(wm * 128 + t * 32 + l32, 2 * ks + hk); };
+  // one k-step: 4 NSL MFMAs while the fragments of k-step (stage_n, ks_n) stream in.  `bar`: the block barrier sits
+  // after the first MFMAs of the last k-step of a tile: the reads issued at the end of the previous k-step have had
+  // time to land, so the lgkmcnt(0) in front of the barrier is (nearly) free, and every read of the next tile's stage
+  // comes after it
   auto step = [&](int stage_n, int ks_n, bool rd, bool bar = false) {
-    if (bar && !BARMID) {  // experiment arm: barrier in front of the whole k-step
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      __syncthreads();
-    }
+    if (NSL == 2) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[b], acc[0][b], 0, 0, 0);
-    if (bar && BARMID) {
-      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-      __syncthreads();
-    }
-    if (rd) wf[0] = *reinterpret_cast<const bf16x8*>(w_addr(stage_n, ks_n, 0));
+      for (int b = 0; b < 4; ++b) acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[b], acc[0][b], 0, 0, 0);
+      if (bar) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+        __syncthreads();
+      }
+      if (rd) wf[0] = *reinterpret_cast<const bf16x8*>(w_addr(stage_n, ks_n, 0));
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1], xf[b], acc[1][b], 0, 0, 0);
-      if (rd) xf[b] = *reinterpret_cast<const bf16x8*>(x_addr(stage_n, ks_n, b));
+      for (int b = 0; b < 4; ++b) {
+        acc[NSL - 1][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[NSL - 1], xf[b], acc[NSL - 1][b], 0, 0, 0);
+        if (rd) xf[b] = *reinterpret_cast<const bf16x8*>(x_addr(stage_n, ks_n, b));
+      }
+      if (rd) wf[NSL - 1] = *reinterpret_cast<const bf16x8*>(w_addr(stage_n, ks_n, NSL - 1));
+    } else {
+      // one weight fragment: the first two MFMAs run in front of the barrier, x fragments are re-read behind it
+      bf16x8 xn[2];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[0], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[1], acc[0][1], 0, 0, 0);
+      if (bar) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __syncthreads();
+      }
+      if (rd) {
+        xn[0] = *reinterpret_cast<const bf16x8*>(x_addr(stage_n, ks_n, 0));
+        xn[1] = *reinterpret_cast<const bf16x8*>(x_addr(stage_n, ks_n, 1));
+      }
+      acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[2], acc[0][2], 0, 0, 0);
+      if (rd) xf[2] = *reinterpret_cast<const bf16x8*>(x_addr(stage_n, ks_n, 2));
+      acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[3], acc[0][3], 0, 0, 0);
+      if (rd) {
+        xf[3] = *reinterpret_cast<const bf16x8*>(x_addr(stage_n, ks_n, 3));
+        wf[0] = *reinterpret_cast<const bf16x8*>(w_addr(stage_n, ks_n, 0));
+        xf[0] = xn[0];
+        xf[1] = xn[1];
+      }
     }
-    if (rd) wf[1] = *reinterpret_cast<const bf16x8*>(w_addr(stage_n, ks_n, 1));
   };
 
   // ---------------- prologue: tile 0 complete in stage 0, tile 1's x tile in flight, its first weight word written ----
   issue_a(0, 0);
-  Group gc = prep(load_group(0));  // the group whose words are being written (one expanded group live at a time)
-  Raw rn = load_group(nit > 1 ? 1 : 0);
+  Group<NSL> gc = prep(load_group(0));  // the group whose words are being written (one expanded group live at a time)
+  Raw<NSL> rn = load_group(nit > 1 ? 1 : 0);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) job(gc, 0, j, 0);
+  for (int j = 0; j < 2 * NSL; ++j) job(gc, 0, j, 0);
   __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and the ds_writes
 #pragma unroll
-  for (int t = 0; t < 2; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(w_addr(0, 0, t));
+  for (int t = 0; t < NSL; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(w_addr(0, 0, t));
 #pragma unroll
   for (int t = 0; t < 4; ++t) xf[t] = *reinterpret_cast<const bf16x8*>(x_addr(0, 0, t));
   // pin the prefetched group into registers BEFORE the next LDS-DMA goes out: otherwise the loop header inherits a
   // pending ordinary load from this path and hipcc drains the DMA queue (vmcnt(0)) at the top of every iteration
-  asm volatile("" : "+v"(rn.w0), "+v"(rn.w1), "+v"(rn.sz0), "+v"(rn.sz1));
+#pragma unroll
+  for (int s = 0; s < NSL; ++s) asm volatile("" : "+v"(rn.w[s]), "+v"(rn.sz[s]));
   issue_a(1, 1);  // K is a multiple of 128: there are always at least two K-tiles
-  job(gc, 1, 0, 1);
+  slot(gc, 1, 0, 1);
 
   // One iteration = one quantisation group = two K-tiles (2q in stage 0, 2q + 1 in stage 1).  `more` is a compile-time
   // flag (the last group is peeled) so that every iteration is ONE basic block the scheduler can interleave freely.
   auto group_iter = [&](int q, auto more_tag) {
     constexpr bool more = decltype(more_tag)::value;
-    // ---------- K-tile 2q (stage 0); writes words 1..3 of tile 2q+1 = (group q, half 1) into stage 1 ----------
+    // ---------- K-tile 2q (stage 0); writes the remaining words of tile 2q+1 = (group q, half 1) into stage 1 ----------
     step(0, 1, true);
-    job(gc, 1, 1, 1);
+    slot(gc, 1, 1, 1);
     step(0, 2, true);
-    job(gc, 1, 2, 1);
+    slot(gc, 1, 2, 1);
     step(0, 3, true);
-    job(gc, 1, 3, 1);
+    slot(gc, 1, 3, 1);
     // last k-step of tile 2q; barrier inside: tile 2q+1 complete in stage 1, every read of stage 0 retired, loads drained
     step(1, 0, true, true);
     if (more) {
       gc = prep(rn);             // group q+1: loaded one iteration ago, drained by the barrier above
       rn = load_group(min(q + 2, nit - 1));  // consumed after the NEXT iteration's first barrier
-    }
-    if (more) {
       issue_a(2 * q + 2, 0);
-      job(gc, 0, 0, 0);          // first word of tile 2q+2 = (group q+1, half 0)
+      slot(gc, 0, 0, 0);         // first word of tile 2q+2 = (group q+1, half 0)
     }
-    // ---------- K-tile 2q+1 (stage 1); writes words 1..3 of tile 2q+2 into stage 0 ----------
+    // ---------- K-tile 2q+1 (stage 1); writes the remaining words of tile 2q+2 into stage 0 ----------
     step(1, 1, true);
-    if (more) job(gc, 0, 1, 0);
+    if (more) slot(gc, 0, 1, 0);
     step(1, 2, true);
-    if (more) job(gc, 0, 2, 0);
+    if (more) slot(gc, 0, 2, 0);
     step(1, 3, true);
-    if (more) job(gc, 0, 3, 0);
+    if (more) slot(gc, 0, 3, 0);
     step(0, 0, more, true);      // barrier inside: tile 2q+2 complete in stage 0; every read of stage 1 retired
     if (more) {
       issue_a(2 * q + 3, 1);
-      job(gc, 1, 0, 1);          // first word of tile 2q+3 = (group q+1, half 1)
+      slot(gc, 1, 0, 1);         // first word of tile 2q+3 = (group q+1, half 1)
     }
   };
-  for (int q = 0; q + 1 < nit; ++q) {
-    group_iter(q, std::true_type{});
-  }
+  for (int q = 0; q + 1 < nit; ++q) group_iter(q, std::true_type{});
   group_iter(nit - 1, std::false_type{});
 
-  // ---------------- epilogue through LDS: acc[a][b][r] = C[n = wn*64 + a*32 + (r&3) + 8 (r>>2) + 4 hk][m = wm*128 + b*32 + l32] ----
+  // ---------------- epilogue through LDS: acc[a][b][r] = C[n = wn*WN + a*32 + (r&3) + 8 (r>>2) + 4 hk][m = wm*128 + b*32 + l32] ----
   __syncthreads();  // stage memory is re-used as the output staging area
   char* eb = smem + wv * (128 * kEpiRow);
 #pragma unroll
   for (int b = 0; b < 4; ++b)
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NSL; ++a)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         u32x2 v;
@@ -235,31 +264,51 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v3_kernel(const uint16_t* __re
       }
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's own LDS writes (region is wave-private)
   __builtin_amdgcn_wave_barrier();
+  constexpr int GR = WN / 8;        // 16-byte granules per staged row (4 or 8)
+  constexpr int RP = 64 / GR;       // rows per pass
 #pragma unroll
-  for (int ps = 0; ps < 16; ++ps) {
-    const int row = ps * 8 + (lane >> 3), gc = lane & 7;
-    const int m = m0 + wm * 128 + row, nn = n0 + wn * 64 + gc * 8;
-    const u32x4 v = *reinterpret_cast<const u32x4*>(eb + row * kEpiRow + gc * 16);
-    if (m < M && nn < N) *reinterpret_cast<u32x4*>(out + (size_t)m * N + nn) = v;
+  for (int ps = 0; ps < 128 / RP; ++ps) {
+    const int row = ps * RP + lane / GR, gc2 = lane % GR;
+    const int m = m0 + wm * 128 + row, nn = n0 + wn * WN + gc2 * 8;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(eb + row * kEpiRow + gc2 * 16);
+    if (nn < N) *reinterpret_cast<u32x4*>(out + (size_t)m * N + nn) = v;
   }
 }
 
-int g_v3_barmid = 1;
-int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, void* out, int m, int n, int k, hipStream_t st) {
-  if (!szp || m < TM || (n % 16) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return -1;
+namespace {
+template <int NSL>
+void launch_v3(const void* x, const void* qw, const void* szp, void* out, int m, int n, int k, hipStream_t st) {
+  constexpr int TN = 128 * NSL;
+  constexpr int smem_main = 2 * kTileX + 2 * TN * TK * 2;
+  constexpr int smem_epi = 8 * 128 * (64 * NSL + 16);
+  constexpr int smem = smem_main > smem_epi ? smem_main : smem_epi;
   const int tiles_m = (m + TM - 1) / TM, tiles_n = (n + TN - 1) / TN;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cdna4_v3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemV3);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cdna4_v3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemV3);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cdna4_v3_kernel<NSL>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr = true;
   }
-  if (g_v3_barmid)
-    hipLaunchKernelGGL(gemm_cdna4_v3_kernel<1>, dim3(tiles_m * tiles_n), dim3(512), kSmemV3, st, (const uint16_t*)x,
-                       (const u32*)qw, (const u32*)szp, (uint16_t*)out, m, n, k, tiles_m, tiles_n);
-  else
-    hipLaunchKernelGGL(gemm_cdna4_v3_kernel<0>, dim3(tiles_m * tiles_n), dim3(512), kSmemV3, st, (const uint16_t*)x,
-                       (const u32*)qw, (const u32*)szp, (uint16_t*)out, m, n, k, tiles_m, tiles_n);
+  hipLaunchKernelGGL(gemm_cdna4_v3_kernel<NSL>, dim3(tiles_m * tiles_n), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw,
+                     (const u32*)szp, (uint16_t*)out, m, n, k, tiles_m, tiles_n);
+}
+}  // namespace
+
+// tile_n: 0 = pick by chip fill (256 CUs, one block per CU), 128 / 256 = force
+int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, void* out, int m, int n, int k, int tile_n,
+                         hipStream_t st) {
+  if (!szp || m < TM || (n % 16) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return -1;
+  if (tile_n == 0) {
+    const long tiles_m = (m + TM - 1) / TM;
+    auto fill = [&](int tn) {  // useful fraction of the block rounds
+      const long t = tiles_m * ((n + tn - 1) / tn);
+      return (double)t / (double)(((t + 255) / 256) * 256);
+    };
+    // the narrow tile reads each weight fragment for half as many MFMAs (measured 0.84x the 256 x 256 rate at equal
+    // fill, profiles/r01_gemm_v3_tiles.txt): worth it only when it fills the chip that much better
+    tile_n = (fill(128) * 0.84 > fill(256)) ? 128 : 256;
+  }
+  if (tile_n == 128) launch_v3<1>(x, qw, szp, out, m, n, k, st);
+  else launch_v3<2>(x, qw, szp, out, m, n, k, st);
   return 0;
 }
 

@@ -26,7 +26,8 @@ int launch_repack_v2_cdna4(const void* src, void* dst, int n, int k, int to_cdna
 int launch_unpack_cdna4(const void* qw, void* out_u8, int n, int k, hipStream_t st);
 int launch_dequant_cdna4(const void* qw, const void* s, const void* z, void* out, int n, int k, hipStream_t st);
 size_t gemm_workspace_bytes(int m, int n, int k);
-int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, void* out, int m, int n, int k, hipStream_t st);
+int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, void* out, int m, int n, int k, int tile_n,
+                         hipStream_t st);
 int launch_moe_gemm(const void* x, const void* qw, const void* s, const void* z, const void* offsets, void* out, int total_m,
                     int experts, int n, int k, int gpad, int dtype, int layout, hipStream_t st);
 int gemv_tune_set(const char* key, int value);
