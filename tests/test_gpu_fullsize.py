@@ -46,3 +46,69 @@ def test_gemv_gemm_agree_and_scaling(env):
     assert same > 0.98, same
     y2 = ops.gemv((x[:7] * 4).contiguous(), w["qweight"], w["scales"], w["scaled_zeros"])
     assert torch.equal(y2, yv * 4)  # power-of-two scaling commutes with every rounding
+
+
+# ---------------- the product path of bench.py: cdna4 interleave, decode fast path, fused MLP, GEMM v3 ----------------
+@pytest.mark.parametrize("K,N", [(4096, 6144), (4096, 4096), (4096, 28672), (14336, 4096), (11008, 4096), (8192, 10240)])
+def test_fullsize_cdna4_vs_torch_fp32(env, K, N):
+    """BASELINE.json shapes (Llama-3-8B, the stacked gate/up pair, Llama-2-7B's 11008, Llama-3-70B's 8192 x 10240) on the
+    layout the repacker emits: dequant kernels of both layouts agree bit for bit, and every M bucket of forward_cdna4
+    (decode fast path <= 8, old GEMV <= 16, 128x128 GEMM, GEMM v3 with both tile widths) matches a torch fp32 matmul."""
+    ops, synth = env
+    dtype = torch.bfloat16
+    w = synth.random_wq(K, N, dtype=dtype, seed=K + N + 1, keep_q=False)
+    c4 = ops.repack_v2_to_cdna4(w["qweight"])
+    szp = ops.pack_sz_cdna4(w["scales"], w["scaled_zeros"], K)
+    W2 = ops.dequant_v2(w["qweight"], w["scales"], w["scaled_zeros"])
+    W4 = ops.dequant_cdna4(c4, w["scales"], w["scaled_zeros"])
+    assert torch.equal(W2, W4)
+    W = W4.float()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    bias = (torch.randn(N, device="cuda", generator=g) * 0.02).to(dtype)
+    for M in (1, 3, 8, 13, 64, 256, 300, 2048):
+        x = torch.randn(M, K, device="cuda", generator=g).to(dtype)
+        for b in (None, bias):
+            y = ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], b, szp)
+            ref = (x.float() @ W.t()).to(dtype)
+            if b is not None:
+                ref = ref + b
+            rel = ((y.float() - ref.float()).norm() / ref.float().norm()).item()
+            assert rel < 1e-3, (M, rel)
+            assert (ref == y).float().mean().item() > 0.97, M
+
+
+@pytest.mark.parametrize("variant", [4, 5])  # GEMM v3: force 256 x 256 / 256 x 128 tiles
+def test_gemm_v3_tile_widths_identical(env, variant):
+    ops, synth = env
+    K, N = 4096, 6144
+    w = synth.random_wq(K, N, dtype=torch.bfloat16, seed=3, keep_q=False)
+    c4 = ops.repack_v2_to_cdna4(w["qweight"])
+    szp = ops.pack_sz_cdna4(w["scales"], w["scaled_zeros"], K)
+    for M in (256, 257, 1000, 2048):
+        x = torch.randn(M, K, device="cuda").bfloat16()
+        ops._capi.tune(gemm_variant=1)
+        ref = ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], None, szp)
+        ops._capi.tune(gemm_variant=variant)
+        try:
+            y = ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], None, szp)
+        finally:
+            ops._capi.tune(gemm_variant=0)
+        assert torch.equal(y, ref), M  # same K order, same numerics: bit-identical to the 128 x 128 kernel
+
+
+def test_fused_mlp_fullsize(env):
+    """Llama-3-8B gate/up (2 x 14336 x 4096) in one launch == two GEMVs + F.silu + mul on the same buffers."""
+    ops, synth = env
+    K, F = 4096, 14336
+    w = synth.random_wq(K, 2 * F, dtype=torch.bfloat16, seed=5, keep_q=False)
+    c4 = ops.repack_v2_to_cdna4(w["qweight"])
+    szp = ops.pack_sz_cdna4(w["scales"], w["scaled_zeros"], K)
+    for M in (1, 4, 7):
+        x = torch.randn(M, K, device="cuda").bfloat16()
+        y = ops.mlp_gate_up_cdna4(x, c4, szp)
+        full = ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], None, szp)
+        ref = torch.nn.functional.silu(full[:, :F]) * full[:, F:]
+        assert y.shape == (M, F)
+        assert (ref == y).float().mean().item() > 0.98
+        rel = ((y.float() - ref.float()).norm() / ref.float().norm()).item()
+        assert rel < 2e-3, rel
