@@ -82,7 +82,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    force_tp = os.environ.get("AWQ_BENCH_FORCE_TP") == "1"  # exercise the tensor-parallel leg on one GPU (world size 1)
+    if world > 1 or force_tp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
@@ -92,7 +93,7 @@ def main():
     eng = llm_awq_amd.load_engine()
     dtype = torch.bfloat16
 
-    if world > 1:
+    if world > 1 or force_tp:
         from llm_awq_amd.parallel import run_tp_bench
         out = run_tp_bench(args, eng, dist, rank, world, dev, SHAPES, algo_bytes)
         if rank == 0:

@@ -44,7 +44,8 @@ struct Raw {
 template <int NSL>
 __global__ __launch_bounds__(512) void gemm_cdna4_v3_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                             const u32* __restrict__ szp, uint16_t* __restrict__ out,
-                                                            int M, int N, int K, int tiles_m, int tiles_n) {
+                                                            int M, int N, int K, int tiles_m, int tiles_n, int n_begin,
+                                                            int n_end) {
   constexpr int TN = 128 * NSL;            // weight rows per block
   constexpr int WN = 32 * NSL;             // weight rows per wave
   constexpr int kTileW = TN * TK * 2;      // 16 / 32 KiB per weight stage
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v3_kernel(const uint16_t* __re
   const int tm = tile % tiles_m, tn = tile / tiles_m;
   // the last row tile is shifted up to end at row M - 1 (M >= 256): it recomputes a few rows of its neighbour with
   // identical results, and no row index ever needs clamping, so the four x granule addresses differ by constants
-  const int m0 = min(tm * TM, M - TM), n0 = tn * TN;
+  const int m0 = min(tm * TM, M - TM), n0 = n_begin + tn * TN;  // this launch covers weight rows [n_begin, n_end)
   const int nit = K >> 7;
 
   // ---- x tile: LDS-DMA, 4 x 16 B per thread per K-tile; swizzle applied to the SOURCE granule ----
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v3_kernel(const uint16_t* __re
   u32 b_off[NSL], sz_off[NSL];  // word offsets (N * K / 8 < 2^31): tile (slab, grp) at (slab * nit + grp) * 256 + 4 * lane
 #pragma unroll
   for (int s = 0; s < NSL; ++s) {
-    const int sl = min((n0 >> 4) + NSL * wv + s, nslab - 1);
+    const int sl = min((n0 >> 4) + NSL * wv + s, min(nslab, n_end >> 4) - 1);
     b_off[s] = (u32)sl * nit * 256 + lane * 4;
     sz_off[s] = (u32)sl * nit * 16 + i;  // packed {scale | scaled_zero << 16}
   }
@@ -271,44 +272,64 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v3_kernel(const uint16_t* __re
     const int row = ps * RP + lane / GR, gc2 = lane % GR;
     const int m = m0 + wm * 128 + row, nn = n0 + wn * WN + gc2 * 8;
     const u32x4 v = *reinterpret_cast<const u32x4*>(eb + row * kEpiRow + gc2 * 16);
-    if (nn < N) *reinterpret_cast<u32x4*>(out + (size_t)m * N + nn) = v;
+    if (nn < n_end) *reinterpret_cast<u32x4*>(out + (size_t)m * N + nn) = v;
   }
 }
 
 namespace {
 template <int NSL>
-void launch_v3(const void* x, const void* qw, const void* szp, void* out, int m, int n, int k, hipStream_t st) {
+void launch_v3(const void* x, const void* qw, const void* szp, void* out, int m, int n, int k, int n_begin, int n_end,
+               hipStream_t st) {
   constexpr int TN = 128 * NSL;
   constexpr int smem_main = 2 * kTileX + 2 * TN * TK * 2;
   constexpr int smem_epi = 8 * 128 * (64 * NSL + 16);
   constexpr int smem = smem_main > smem_epi ? smem_main : smem_epi;
-  const int tiles_m = (m + TM - 1) / TM, tiles_n = (n + TN - 1) / TN;
+  const int tiles_m = (m + TM - 1) / TM, tiles_n = (n_end - n_begin + TN - 1) / TN;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cdna4_v3_kernel<NSL>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr = true;
   }
   hipLaunchKernelGGL(gemm_cdna4_v3_kernel<NSL>, dim3(tiles_m * tiles_n), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw,
-                     (const u32*)szp, (uint16_t*)out, m, n, k, tiles_m, tiles_n);
+                     (const u32*)szp, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end);
 }
+constexpr double kNarrowRate = 0.84;  // 256 x 128 tiles vs 256 x 256 at equal chip fill (profiles/r01_gemm_v3_tiles.txt)
 }  // namespace
 
-// tile_n: 0 = pick by chip fill (256 CUs, one block per CU), 128 / 256 = force
+// tile_n: 0 = pick by chip fill (256 CUs, one block per CU), 128 / 256 = force one width for the whole matrix.
+// In auto mode a matrix whose 256-wide tile count is k full rounds plus a partial one runs the full rounds with 256-wide
+// tiles and the remaining weight rows with 128-wide tiles in a second launch when that is faster.
 int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, void* out, int m, int n, int k, int tile_n,
                          hipStream_t st) {
   if (!szp || m < TM || (n % 16) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return -1;
-  if (tile_n == 0) {
-    const long tiles_m = (m + TM - 1) / TM;
-    auto fill = [&](int tn) {  // useful fraction of the block rounds
-      const long t = tiles_m * ((n + tn - 1) / tn);
-      return (double)t / (double)(((t + 255) / 256) * 256);
-    };
-    // the narrow tile reads each weight fragment for half as many MFMAs (measured 0.84x the 256 x 256 rate at equal
-    // fill, profiles/r01_gemm_v3_tiles.txt): worth it only when it fills the chip that much better
-    tile_n = (fill(128) * 0.84 > fill(256)) ? 128 : 256;
+  if (tile_n == 128) {
+    launch_v3<1>(x, qw, szp, out, m, n, k, 0, n, st);
+    return 0;
   }
-  if (tile_n == 128) launch_v3<1>(x, qw, szp, out, m, n, k, st);
-  else launch_v3<2>(x, qw, szp, out, m, n, k, st);
+  if (tile_n == 256) {
+    launch_v3<2>(x, qw, szp, out, m, n, k, 0, n, st);
+    return 0;
+  }
+  const long tiles_m = (m + TM - 1) / TM;
+  auto rounds = [](long t) { return (double)((t + 255) / 256); };
+  const long cols256 = (n + 255) / 256, t256 = tiles_m * cols256;
+  const double cost_wide = rounds(t256);
+  const double cost_narrow = rounds(tiles_m * ((n + 127) / 128)) * 0.5 / kNarrowRate;
+  // mixed: as many whole rounds of 256-wide tiles as fit, the remaining rows 128-wide
+  const long cols_main = (t256 / 256) * 256 / tiles_m;  // 256-wide column tiles that fill whole rounds
+  double cost_mixed = 1e30;
+  if (cols_main > 0 && cols_main < cols256) {
+    const long n_rest = n - cols_main * 256;
+    cost_mixed = rounds(tiles_m * cols_main) + rounds(tiles_m * ((n_rest + 127) / 128)) * 0.5 / kNarrowRate + 0.02;
+  }
+  if (cost_mixed < cost_wide && cost_mixed < cost_narrow) {
+    launch_v3<2>(x, qw, szp, out, m, n, k, 0, (int)(cols_main * 256), st);
+    launch_v3<1>(x, qw, szp, out, m, n, k, (int)(cols_main * 256), n, st);
+  } else if (cost_narrow < cost_wide) {
+    launch_v3<1>(x, qw, szp, out, m, n, k, 0, n, st);
+  } else {
+    launch_v3<2>(x, qw, szp, out, m, n, k, 0, n, st);
+  }
   return 0;
 }
 

@@ -1,10 +1,10 @@
 #!/bin/bash
-# quick iteration: cdna4 parity tests, GEMV sweep (defaults), bench.  Outputs under gpurun_out/.
+# quick iteration: selected parity tests, TP leg on one GPU, bench.  Outputs under gpurun_out/.
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 O=gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
-( timeout 600 python -m pytest tests/test_gpu_cdna4.py -m gpu -x -q 2>&1 | tail -15 ) > $O/pytest_cdna4.log
-( timeout 300 python tools/gemv_sweep.py --defaults-only --m 1 4 8 2>&1 | grep -v "^/opt" | tail -60 ) > $O/gemv_sweep.log
-( timeout 600 python bench.py 2>&1 | tail -3 ) > $O/bench.log
-tail -4 $O/pytest_cdna4.log; cat $O/bench.log
+( timeout 900 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_cdna4.py -m gpu -x -q 2>&1 | tail -15 ) > $O/pytest_quick.log
+( AWQ_BENCH_FORCE_TP=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 2>&1 | tail -3 ) > $O/bench_tp1.log
+( timeout 600 python bench.py 2>&1 | tail -2 ) > $O/bench.log
+tail -4 $O/pytest_quick.log; cat $O/bench_tp1.log | cut -c1-600; cat $O/bench.log
