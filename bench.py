@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--layers", type=int, default=LAYERS)
+    ap.add_argument("--tune", action="append", default=[], help="experiments only: awq_tune_set knobs as key=value (e.g. gemv_probe=2 with --layout v2 turns every decode launch into a linear read of the same weight bytes: the streaming floor of this harness)")
     ap.add_argument("--layout", default="cdna4", choices=["cdna4", "v2"], help="cdna4 = what the rewritten repacker emits (default); v2 = reference checkpoint layout through gemv/gemm_forward_cuda_new")
     ap.add_argument("--unfused-mlp", action="store_true", help="run gate and up as two launches (160 launches per token instead of 128)")
     args = ap.parse_args()
@@ -92,6 +93,9 @@ def main():
     from llm_awq_amd import synth
     eng = llm_awq_amd.load_engine()
     dtype = torch.bfloat16
+    if args.tune:
+        from llm_awq_amd import _capi
+        _capi.tune(**{kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tune})
 
     if world > 1 or force_tp:
         from llm_awq_amd.parallel import run_tp_bench
@@ -192,7 +196,7 @@ def main():
            "config": {"workload": "Llama-3-8B W4A16 g128 bf16 activations on 1xMI355X (decode GEMV + prefill GEMM)",
                       "layers": L, "decode_m": 1, "prefill_m": args.prefill_m, "graph": graph is not None,
                       "layout": args.layout, "fused_gate_up_silu_mul": fused and args.layout == "cdna4",
-                      "launches_per_token": launches, "parallelism": "tp1"},
+                      "launches_per_token": launches, "parallelism": "tp1", **({"tune": args.tune} if args.tune else {})},
            "roofline": roofline, "device": torch.cuda.get_device_name(dev)}
 
     # ---------------- prefill leg ----------------

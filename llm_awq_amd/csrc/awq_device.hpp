@@ -190,11 +190,14 @@ struct Cdna4Dequant {
   }
   // whole 1-KiB tile -> 4 operands (op[a] covers k = 32a + 8g + 0..7 of the tile's 128 k)
   __device__ __forceinline__ void tile(const u32x4& w, uint16_t s_bits, uint16_t z_bits, bf16x8 (&op)[4]) const {
-    const u32 sdup = (u32)s_bits * 0x00010001u;
+    tile_packed(w, (u32)s_bits | ((u32)z_bits << 16), op);
+  }
+  // same, from the packed {scale | scaled_zero << 16} dword: one v_perm for the splat, one v_dot2 for sz - 128 s
+  // (s * -128 and sz * 1 are exact products and their sum is exactly representable: |sz| = s*z, z <= 15)
+  __device__ __forceinline__ void tile_packed(const u32x4& w, u32 sz, bf16x8 (&op)[4]) const {
+    const u32 sdup = __builtin_amdgcn_perm(sz, sz, 0x01000100u);  // {s, s}
     const u32 b01 = sdup & m01, b23 = sdup & m23;
-    const float sf = __builtin_bit_cast(float, (u32)s_bits << 16);
-    const float zf = __builtin_bit_cast(float, (u32)z_bits << 16);
-    const float cv = __builtin_fmaf(-128.0f, sf, zf);  // exact: |sz| = s*z, z <= 15
+    const float cv = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, sz), __builtin_bit_cast(bf16x2, 0x3F80C300u), 0.0f, false);
     op[0] = word(w.x, b01, b23, cv);
     op[1] = word(w.y, b01, b23, cv);
     op[2] = word(w.z, b01, b23, cv);

@@ -64,7 +64,21 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v3_kernel(const uint16_t* __re
     const int q = T >> 3, r = T & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tm = tile % tiles_m, tn = tile / tiles_m;
+  // within that order tiles are walked in bands of two row tiles, column tiles fastest: the ~32 tiles an XCD runs at
+  // once then cover 2 x panels (2 MiB each at K = 4096) x 16 weight panels (0.5 MiB each) instead of 16 x 2 -- about
+  // a third of the L2-miss traffic of a row-tile-fastest walk
+  int tm, tn;
+  {
+    const int full = (tiles_m >> 1) * 2 * tiles_n;  // tiles inside complete two-row bands
+    if (tile < full) {
+      const int band = tile / (2 * tiles_n), rem = tile - band * 2 * tiles_n;
+      tn = rem >> 1;
+      tm = 2 * band + (rem & 1);
+    } else {
+      tn = tile - full;
+      tm = tiles_m - 1;
+    }
+  }
   // the last row tile is shifted up to end at row M - 1 (M >= 256): it recomputes a few rows of its neighbour with
   // identical results, and no row index ever needs clamping, so the four x granule addresses differ by constants
   const int m0 = min(tm * TM, M - TM), n0 = n_begin + tn * TN;  // this launch covers weight rows [n_begin, n_end)

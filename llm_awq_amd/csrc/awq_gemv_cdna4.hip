@@ -28,21 +28,27 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_cdna4_kernel(const uint16_t* 
                                                                  uint16_t* __restrict__ out, int M, int N, int K) {
   constexpr int NS = EPI == 1 ? 2 : 1;  // slabs per block
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // the wave index is wave-uniform: taking it through readfirstlane puts every tile / step address computation on
+  // the scalar unit (the kernel is VALU-issue bound: ~5 cycles per VALU instruction per SIMD, DESIGN.md "gemv")
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, g = lane >> 4;
   const int nb = blockIdx.x, nit = K >> 7;
   const int xstep = M * 256;  // bytes of x per 128-k step (M rows)
   float(*red)[4][64] = reinterpret_cast<float(*)[4][64]>(smem);  // [NS * WAVES][4][64]
   char* xs = smem + NS * WAVES * 1024 + wv * (S * xstep);
 
-  const u32* wp[NS];
-  const u32* sp[NS];
+  // Every global load is a raw buffer load: SGPR descriptor + loop-invariant VGPR lane offset + SGPR tile offset, so
+  // the per-step address arithmetic runs on the scalar unit and costs no VALU issue slot (out-of-range reads, which
+  // cannot happen here, would return 0).  All three tensors are < 4 GiB.
+  const int tile_bytes = BITS == 4 ? 1024 : 768;
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(qw), 0, (N >> 4) * nit * tile_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(szp), 0, (N >> 4) * nit * 64, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(x), 0, M * K * 2, 0x00020000);
+  u32 slab_tile[NS];  // first tile index of the block's slab(s)
 #pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const size_t slab = (size_t)nb + (size_t)s * (N >> 5);  // EPI 1: up slab = gate slab + (N/2)/16
-    wp[s] = BITS == 4 ? qw + slab * nit * 256 + lane * 4 : qw + slab * nit * 192 + lane * 3;  // W3: 768-B tiles
-    sp[s] = szp + slab * nit * 16 + i;
-  }
+  for (int s = 0; s < NS; ++s) slab_tile[s] = ((u32)nb + (u32)s * (u32)(N >> 5)) * (u32)nit;  // EPI 1: up slab = gate slab + (N/2)/16
+  const u32 wlane_b = BITS == 4 ? lane * 16u : lane * 12u;
+  const u32 ilane_b = (u32)i * 4u;
   Cdna4Dequant cd;
   cd.init(lane, BITS == 4 ? 0x000F000Fu : 0x00070007u);
   const int mrow = min(i, M - 1);
@@ -62,8 +68,8 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_cdna4_kernel(const uint16_t* 
       const int kg = min(wv + WAVES * (c0 + t), nit - 1);
 #pragma unroll
       for (int b = 0; b < MB; ++b) {
-        const int row = min(4 * b + g, M - 1);
-        xr[t][b] = *reinterpret_cast<const u32x4*>(x + (size_t)row * K + kg * 128 + i * 8);
+        const u32 xoff_b = ((u32)min(4 * b + g, M - 1) * (u32)K + (u32)i * 8u) * 2u;  // M * K * 2 < 2^32
+        xr[t][b] = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff_b, (u32)kg * 256u, 0);
       }
     }
 #pragma unroll
@@ -71,21 +77,24 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_cdna4_kernel(const uint16_t* 
       const int kg = min(wv + WAVES * (c0 + t), nit - 1);
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
+        const u32 tidx = slab_tile[s] + (u32)kg;
         if (BITS == 4) {
-          w[s][t] = ldg_nt_u32x4(wp[s] + (size_t)kg * 256);
+          w[s][t] = __builtin_amdgcn_raw_buffer_load_b128(rw, wlane_b, tidx * 1024u, 2);  // aux 2 = nt (streamed once)
         } else {
-          const u32* p3 = wp[s] + (size_t)kg * 192;  // 12 B per lane: hipcc merges the three into global_load_dwordx3
-          w[s][t] = u32x4{__builtin_nontemporal_load(p3), __builtin_nontemporal_load(p3 + 1),
-                          __builtin_nontemporal_load(p3 + 2), 0u};
+          typedef u32 u32x3 __attribute__((ext_vector_type(3)));
+          const u32x3 w3 = __builtin_amdgcn_raw_buffer_load_b96(rw, wlane_b, tidx * 768u, 2);
+          w[s][t] = u32x4{w3.x, w3.y, w3.z, 0u};
         }
-        sz[s][t] = sp[s][(size_t)kg * 16];
+        sz[s][t] = __builtin_amdgcn_raw_buffer_load_b32(rs, ilane_b, tidx * 64u, 0);
       }
     }
 #pragma unroll
     for (int t = 0; t < S; ++t)
 #pragma unroll
       for (int b = 0; b < MB; ++b)
-        if (4 * b + g < M) *reinterpret_cast<u32x4*>(xs + t * xstep + b * 1024 + lane * 16) = xr[t][b];
+        // unconditional: lanes past the last row hold a copy of row M - 1 and write it to that row's slot (same bytes).
+        // A branch here lets hipcc sink the x loads behind the weight stream, whose in-order vmcnt then stalls the staging
+        *reinterpret_cast<u32x4*>(xs + t * xstep + min(4 * b + g, M - 1) * 256 + i * 16) = xr[t][b];
 #pragma unroll
     for (int t = 0; t < S; ++t) {
       if (wv + WAVES * (c0 + t) >= nit) continue;  // ragged tail: wave-uniform skip (the loads above were clamped)
@@ -98,7 +107,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_cdna4_kernel(const uint16_t* 
         const u32 szv = sz[s][t];
         bf16x8 op[4];
         const u32x4 wt = BITS == 4 ? w[s][t] : w3_expand(w[s][t].x, w[s][t].y, w[s][t].z);
-        cd.tile(wt, (uint16_t)(szv & 0xFFFFu), (uint16_t)(szv >> 16), op);
+        cd.tile_packed(wt, szv, op);
 #pragma unroll
         for (int a = 0; a < 4; ++a) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(op[a], xop[a], acc[s], 0, 0, 0);
       }

@@ -328,10 +328,6 @@ int main(int argc, char** argv) {
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
   printf("device %s CUs %d clock %d MHz\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1000);
-  mfma_rate<0>("16x16x32_bf16");
-  mfma_rate<1>("16x16x16bf16_1k");
-  mfma_rate<2>("4x4x4bf16_1k");
-  mfma_rate<3>("16x16x32_fp8_fp8");
   Shape shapes[] = {{4096, 4096}, {14336, 4096}, {4096, 14336}};
   for (auto sh : shapes) {
     Ctx c;
@@ -339,9 +335,10 @@ int main(int argc, char** argv) {
     c.K = sh.K;
     c.M = M;
     const size_t wbytes = (size_t)c.N * c.K / 2;
-    c.R = (int)((600ull << 20) / wbytes);
+    const size_t rot_mb = getenv("UB_ROT_MB") ? (size_t)atoi(getenv("UB_ROT_MB")) : 600;
+    c.R = (int)((rot_mb << 20) / wbytes);
     if (c.R < 6) c.R = 6;
-    if (c.R > 40) c.R = 40;
+    if (c.R > 400) c.R = 400;
     const int nit = c.K / 128;
     const size_t words = wbytes / 4, nsz = (size_t)(c.N / 16) * nit * 16;
     c.h_qw.resize(words);
@@ -384,12 +381,6 @@ int main(int argc, char** argv) {
     run_all_ws<0, 1>(c, 0, "strm");
     run_all_ws<1, 1>(c, 0, "mfma");
     run_all_ws<3, 1>(c, 0, "raw");
-    run_all_ws<4, 1>(c, 0, "dqonly");
-    run_all_ws<0, 1>(c, 2, "strmL2");
-    run_all_ws<1, 1>(c, 2, "mfmaL2");
-    run_all_ws<2, 1>(c, 2, "dot2L2");
-    run_all_ws<3, 1>(c, 2, "rawL2");
-    run_all_ws<4, 1>(c, 2, "dqonlyL2");
     for (int r = 0; r < c.R; ++r) {
       CK(hipFree(c.qw[r]));
       CK(hipFree(c.szp[r]));
