@@ -201,7 +201,9 @@ int awq_w4a16_gemm_cdna4(const void* x, const void* qweight, const void* scales,
   int st = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
   if (st != AWQ_OK) return st;
   if ((n % 16) != 0) return AWQ_ERR_SHAPE;
-  if (!(sz_packed && m <= 8 && awq::launch_gemv_cdna4(x, qweight, sz_packed, nullptr, out, m, n, k, 0, 4, (hipStream_t)stream) == 0))
+  const bool skinny = sz_packed && m > 8 && m < 256 && awq::gemm_variant_get() == 0 &&
+                      awq::launch_skinny_cdna4(x, qweight, sz_packed, nullptr, out, m, n, k, (hipStream_t)stream) == 0;
+  if (!skinny && !(sz_packed && m <= 8 && awq::launch_gemv_cdna4(x, qweight, sz_packed, nullptr, out, m, n, k, 0, 4, (hipStream_t)stream) == 0))
     awq::launch_gemm(x, qweight, scales, scaled_zeros, sz_packed, out, m, n, k, dtype, 1, workspace, workspace_bytes, (hipStream_t)stream);
   return finish_launch();
 }
@@ -214,6 +216,20 @@ int awq_w4a16_forward_cdna4(const void* x, const void* qweight, const void* scal
     if (st0 != AWQ_OK) return st0;
     if ((n % 16) != 0) return AWQ_ERR_SHAPE;
     if (awq::launch_gemv_cdna4(x, qweight, sz_packed, bias, out, m, n, k, 0, 4, (hipStream_t)stream) == 0) return finish_launch();
+  }
+  if (m > 8 && m < 256 && sz_packed && dtype == AWQ_BF16 && group_size == 128 && awq::gemm_variant_get() == 0) {
+    // short prompts / batched decode: skinny kernel, bias fused
+    int st0 = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
+    if (st0 != AWQ_OK) return st0;
+    if ((n % 16) != 0) return AWQ_ERR_SHAPE;
+    if (awq::launch_skinny_cdna4(x, qweight, sz_packed, bias, out, m, n, k, (hipStream_t)stream) == 0) return finish_launch();
+  }
+  if (bias && m > 128 && sz_packed && dtype == AWQ_BF16 && group_size == 128 && awq::gemm_variant_get() == 0) {
+    // prefill: bias fused into the GEMM v3 epilogue (no second kernel)
+    int st0 = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
+    if (st0 != AWQ_OK) return st0;
+    if ((n % 16) != 0 || !aligned16(bias)) return (n % 16) ? AWQ_ERR_SHAPE : AWQ_ERR_ALIGN;
+    if (awq::launch_gemm_cdna4_v3(x, qweight, sz_packed, bias, out, m, n, k, 0, (hipStream_t)stream) == 0) return finish_launch();
   }
   int st = awq_w4a16_gemm_cdna4(x, qweight, scales, scaled_zeros, sz_packed, out, m, n, k, group_size, dtype, workspace,
                                 workspace_bytes, stream);  // m <= 16 is routed to the GEMV inside

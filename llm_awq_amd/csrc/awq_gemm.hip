@@ -386,6 +386,7 @@ int launch_moe_gemm(const void* x, const void* qw, const void* s, const void* z,
 namespace {
 int g_gemm_variant = 0;  // 0 = auto, 1 = force 128x128, 2 = force 256x256, 3 = force 256x256 v3 (cdna4 layout)
 }
+int gemm_variant_get() { return g_gemm_variant; }
 int gemm_tune_set(const char* key, int value) {
   if (!strcmp(key, "gemm_variant")) {
     g_gemm_variant = value;
@@ -423,7 +424,7 @@ int launch_gemm(const void* x, const void* qw, const void* s, const void* z, con
   if (layout == 1) {
     // variant 3 / auto: v3 kernel with the tile width picked by chip fill; 4 = force 256 x 256; 5 = force 256 x 128
     if ((g_gemm_variant >= 3 || (g_gemm_variant == 0 && m > 128)) &&
-        launch_gemm_cdna4_v3(x, qw, szp, out, m, n, k, g_gemm_variant == 4 ? 256 : (g_gemm_variant == 5 ? 128 : 0), st) == 0)
+        launch_gemm_cdna4_v3(x, qw, szp, nullptr, out, m, n, k, g_gemm_variant == 4 ? 256 : (g_gemm_variant == 5 ? 128 : 0), st) == 0)
       return 0;
     return launch_gemm_t<BF16, 1>(x, qw, s, z, out, m, n, k, st);
   }

@@ -43,9 +43,9 @@ struct Raw {
 
 template <int NSL>
 __global__ __launch_bounds__(512) void gemm_cdna4_v3_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
-                                                            const u32* __restrict__ szp, uint16_t* __restrict__ out,
-                                                            int M, int N, int K, int tiles_m, int tiles_n, int n_begin,
-                                                            int n_end) {
+                                                            const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
+                                                            uint16_t* __restrict__ out, int M, int N, int K, int tiles_m,
+                                                            int tiles_n, int n_begin, int n_end) {
   constexpr int TN = 128 * NSL;            // weight rows per block
   constexpr int WN = 32 * NSL;             // weight rows per wave
   constexpr int kTileW = TN * TK * 2;      // 16 / 32 KiB per weight stage
@@ -285,15 +285,26 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v3_kernel(const uint16_t* __re
   for (int ps = 0; ps < 128 / RP; ++ps) {
     const int row = ps * RP + lane / GR, gc2 = lane % GR;
     const int m = m0 + wm * 128 + row, nn = n0 + wn * WN + gc2 * 8;
-    const u32x4 v = *reinterpret_cast<const u32x4*>(eb + row * kEpiRow + gc2 * 16);
-    if (nn < n_end) *reinterpret_cast<u32x4*>(out + (size_t)m * N + nn) = v;
+    u32x4 v = *reinterpret_cast<const u32x4*>(eb + row * kEpiRow + gc2 * 16);
+    if (nn < n_end) {
+      if (bias != nullptr) {  // `out + self.bias` in T (qmodule.py:221): the matmul result was already rounded to bf16
+        const u32x4 bv = *reinterpret_cast<const u32x4*>(bias + nn);
+        auto add2 = [](u32 a, u32 b) {
+          const float lo = __builtin_bit_cast(float, a << 16) + __builtin_bit_cast(float, b << 16);
+          const float hi = __builtin_bit_cast(float, a & 0xFFFF0000u) + __builtin_bit_cast(float, b & 0xFFFF0000u);
+          return (u32)BF16::from_float(lo) | ((u32)BF16::from_float(hi) << 16);
+        };
+        v = u32x4{add2(v.x, bv.x), add2(v.y, bv.y), add2(v.z, bv.z), add2(v.w, bv.w)};
+      }
+      *reinterpret_cast<u32x4*>(out + (size_t)m * N + nn) = v;
+    }
   }
 }
 
 namespace {
 template <int NSL>
-void launch_v3(const void* x, const void* qw, const void* szp, void* out, int m, int n, int k, int n_begin, int n_end,
-               hipStream_t st) {
+void launch_v3(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
+               int n_end, hipStream_t st) {
   constexpr int TN = 128 * NSL;
   constexpr int smem_main = 2 * kTileX + 2 * TN * TK * 2;
   constexpr int smem_epi = 8 * 128 * (64 * NSL + 16);
@@ -305,7 +316,7 @@ void launch_v3(const void* x, const void* qw, const void* szp, void* out, int m,
     attr = true;
   }
   hipLaunchKernelGGL(gemm_cdna4_v3_kernel<NSL>, dim3(tiles_m * tiles_n), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw,
-                     (const u32*)szp, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end);
+                     (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end);
 }
 constexpr double kNarrowRate = 0.84;  // 256 x 128 tiles vs 256 x 256 at equal chip fill (profiles/r01_gemm_v3_tiles.txt)
 }  // namespace
@@ -313,15 +324,15 @@ constexpr double kNarrowRate = 0.84;  // 256 x 128 tiles vs 256 x 256 at equal c
 // tile_n: 0 = pick by chip fill (256 CUs, one block per CU), 128 / 256 = force one width for the whole matrix.
 // In auto mode a matrix whose 256-wide tile count is k full rounds plus a partial one runs the full rounds with 256-wide
 // tiles and the remaining weight rows with 128-wide tiles in a second launch when that is faster.
-int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, void* out, int m, int n, int k, int tile_n,
-                         hipStream_t st) {
+int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
+                         int tile_n, hipStream_t st) {
   if (!szp || m < TM || (n % 16) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return -1;
   if (tile_n == 128) {
-    launch_v3<1>(x, qw, szp, out, m, n, k, 0, n, st);
+    launch_v3<1>(x, qw, szp, bias, out, m, n, k, 0, n, st);
     return 0;
   }
   if (tile_n == 256) {
-    launch_v3<2>(x, qw, szp, out, m, n, k, 0, n, st);
+    launch_v3<2>(x, qw, szp, bias, out, m, n, k, 0, n, st);
     return 0;
   }
   const long tiles_m = (m + TM - 1) / TM;
@@ -337,12 +348,12 @@ int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, void* o
     cost_mixed = rounds(tiles_m * cols_main) + rounds(tiles_m * ((n_rest + 127) / 128)) * 0.5 / kNarrowRate + 0.02;
   }
   if (cost_mixed < cost_wide && cost_mixed < cost_narrow) {
-    launch_v3<2>(x, qw, szp, out, m, n, k, 0, (int)(cols_main * 256), st);
-    launch_v3<1>(x, qw, szp, out, m, n, k, (int)(cols_main * 256), n, st);
+    launch_v3<2>(x, qw, szp, bias, out, m, n, k, 0, (int)(cols_main * 256), st);
+    launch_v3<1>(x, qw, szp, bias, out, m, n, k, (int)(cols_main * 256), n, st);
   } else if (cost_narrow < cost_wide) {
-    launch_v3<1>(x, qw, szp, out, m, n, k, 0, n, st);
+    launch_v3<1>(x, qw, szp, bias, out, m, n, k, 0, n, st);
   } else {
-    launch_v3<2>(x, qw, szp, out, m, n, k, 0, n, st);
+    launch_v3<2>(x, qw, szp, bias, out, m, n, k, 0, n, st);
   }
   return 0;
 }

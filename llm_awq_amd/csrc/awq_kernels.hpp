@@ -26,8 +26,13 @@ int launch_repack_v2_cdna4(const void* src, void* dst, int n, int k, int to_cdna
 int launch_unpack_cdna4(const void* qw, void* out_u8, int n, int k, hipStream_t st);
 int launch_dequant_cdna4(const void* qw, const void* s, const void* z, void* out, int n, int k, hipStream_t st);
 size_t gemm_workspace_bytes(int m, int n, int k);
-int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, void* out, int m, int n, int k, int tile_n,
-                         hipStream_t st);
+// bias may be nullptr; when given it is added in the epilogue (`out + bias` in T)
+int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
+                         int tile_n, hipStream_t st);
+int gemm_variant_get();
+// skinny GEMM, 9 <= m <= 255 (row chunks of <= 64), cdna4 layout + packed sz (awq_skinny_cdna4.hip); bias may be nullptr; -1 if unsupported
+int launch_skinny_cdna4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
+                        hipStream_t st);
 int launch_moe_gemm(const void* x, const void* qw, const void* s, const void* z, const void* offsets, void* out, int total_m,
                     int experts, int n, int k, int gpad, int dtype, int layout, hipStream_t st);
 int gemv_tune_set(const char* key, int value);

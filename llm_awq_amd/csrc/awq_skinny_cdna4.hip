@@ -1,0 +1,192 @@
+// Skinny GEMM on cdna4-interleaved weights, 9 <= M <= 64, bf16 (gfx950): short prompts / chunk prefill / batched decode --
+// the M range between the decode GEMV (awq_gemv_cdna4.hip) and the tiled prefill GEMM (awq_gemm_v3.hip), which the
+// reference serves with gemm_w4a16_T1's 16/32-row tiles + split-K (gemm_cuda.cu:1155-1193).
+//
+// Still weight-stream bound (every packed byte is read once), but the activations are no longer negligible: a block
+// owns NS 16-row slabs that share every x operand, WAVES waves split K in interleaved 128-k steps, and per step a wave
+//   * stages its x slice (16 CB rows x 128 k) through a wave-private, XOR-swizzled LDS region (conflict-free
+//     ds_read_b128 for the 16 x rows of an MFMA operand), prefetched one step ahead through registers;
+//   * dequantises NS 1-KiB tiles on the matrix core (Cdna4Dequant) -- their packed words are prefetched one step ahead;
+//   * issues NS x CB x 4 v_mfma_f32_16x16x32_bf16 (weights = A operand, 16 x rows = B operand), fp32 accumulation.
+// Split-K partials are reduced through LDS in fp32; one rounding; bias fused.  Numerics as everywhere else.
+#include "awq_device.hpp"
+#include "awq_kernels.hpp"
+
+namespace awq {
+
+template <int WAVES, int NS, int CB>
+__global__ __launch_bounds__(64 * WAVES) void skinny_cdna4_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
+                                                                   const u32* __restrict__ szp,
+                                                                   const uint16_t* __restrict__ bias,
+                                                                   uint16_t* __restrict__ out, int M, int N, int K) {
+  constexpr int XB = 4 * CB;            // staging pieces per step: 4 x rows (1 KiB) each
+  constexpr int XBYTES = 16 * CB * 256; // wave-private x region: 16 CB rows x 256 B
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int nb = blockIdx.x, nit = K >> 7, nslab = N >> 4;
+  char* xs = smem + wv * XBYTES;
+
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(qw), 0, nslab * nit * 1024, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(szp), 0, nslab * nit * 64, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(x), 0, M * K * 2, 0x00020000);
+  u32 slab_tile[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) slab_tile[s] = (u32)min(nb * NS + s, nslab - 1) * (u32)nit;
+  const u32 wlane_b = lane * 16u, ilane_b = (u32)i * 4u;
+  // staging piece b: LDS row r = 4b + g, slot i  <-  source row min(r, M-1), granule i ^ (r & 15)
+  u32 xsrc_b[XB];
+#pragma unroll
+  for (int b = 0; b < XB; ++b) {
+    const int r = 4 * b + g;
+    xsrc_b[b] = ((u32)min(r, M - 1) * (u32)K + (u32)((i ^ (r & 15)) * 8)) * 2u;
+  }
+
+  Cdna4Dequant cd;
+  cd.init(lane);
+  const int cnt = (nit - wv + WAVES - 1) / WAVES;  // this wave's steps: kg = wv + WAVES * t
+
+  f32x4 acc[NS][CB];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int c = 0; c < CB; ++c) acc[s][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 w[NS], xr[XB];
+  u32 sz[NS];
+  auto load_step = [&](int t) {
+    const int kg = min(wv + WAVES * t, nit - 1);
+#pragma unroll
+    for (int b = 0; b < XB; ++b) xr[b] = __builtin_amdgcn_raw_buffer_load_b128(rx, xsrc_b[b], (u32)kg * 256u, 0);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const u32 tidx = slab_tile[s] + (u32)kg;
+      w[s] = __builtin_amdgcn_raw_buffer_load_b128(rw, wlane_b, tidx * 1024u, 2);  // aux 2 = nt
+      sz[s] = __builtin_amdgcn_raw_buffer_load_b32(rs, ilane_b, tidx * 64u, 0);
+    }
+  };
+  if (cnt > 0) load_step(0);
+  for (int t = 0; t < cnt; ++t) {
+    // this step's operands: x slice -> LDS (the previous step's reads of the region are retired: same wave, in order)
+#pragma unroll
+    for (int b = 0; b < XB; ++b) *reinterpret_cast<u32x4*>(xs + b * 1024 + lane * 16) = xr[b];
+    u32x4 wc[NS];
+    u32 szc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      wc[s] = w[s];
+      szc[s] = sz[s];
+    }
+    if (t + 1 < cnt) load_step(t + 1);  // next step's packed words and x slice stream in under this step's math
+    // x operands of the step, shared by the block's NS slabs: xo[c][a] = rows 16c .. 16c+15, k = 32a + 8g .. +8
+    bf16x8 xo[CB][4];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+      const char* xrow = xs + (c * 16 + i) * 256;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) xo[c][a] = *reinterpret_cast<const bf16x8*>(xrow + (((4 * a + g) ^ i) << 4));
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      bf16x8 op[4];
+      cd.tile_packed(wc[s], szc[s], op);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)  // a outer: consecutive MFMAs hit different accumulators
+#pragma unroll
+        for (int c = 0; c < CB; ++c) acc[s][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(op[a], xo[c][a], acc[s][c], 0, 0, 0);
+    }
+  }
+
+  // ---- split-K reduction across the block's waves (fp32), x regions re-used.  acc[s][c][r] = C[n = 4g + r][m = 16c + i] ----
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);  // [wave][blk = s * CB + c][r][lane]
+  constexpr int NBLK = NS * CB;
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[((wv * NBLK + s * CB + c) * 4 + r) * 64 + lane] = acc[s][c][r];
+  __syncthreads();
+  for (int blk = wv; blk < NBLK; blk += WAVES) {
+    const int s = blk / CB, c = blk - s * CB;
+    const int slab = nb * NS + s, m = 16 * c + i;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < WAVES; ++q) t += red[((q * NBLK + blk) * 4 + r) * 64 + lane];
+      v[r] = t;
+    }
+    if (slab < nslab && m < M) {
+      const int nn = slab * 16 + 4 * g;
+      auto to_f = [](uint16_t b) { return __builtin_bit_cast(float, (u32)b << 16); };
+      uint16_t o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        o[r] = BF16::from_float(v[r]);
+        if (bias != nullptr) o[r] = BF16::from_float(to_f(o[r]) + to_f(bias[nn + r]));  // `out + self.bias` in T
+      }
+      *reinterpret_cast<u32x2*>(out + (size_t)m * N + nn) = u32x2{(u32)o[0] | ((u32)o[1] << 16), (u32)o[2] | ((u32)o[3] << 16)};
+    }
+  }
+}
+
+template <int WAVES, int NS, int CB>
+static void launch_skinny(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
+                          hipStream_t st) {
+  const size_t xbytes = (size_t)WAVES * 16 * CB * 256, rbytes = (size_t)WAVES * NS * CB * 1024;
+  const size_t smem = xbytes > rbytes ? xbytes : rbytes;
+  auto kern = skinny_cdna4_kernel<WAVES, NS, CB>;
+  if (smem > 64 * 1024) {
+    static bool done = false;
+    if (!done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      done = true;
+    }
+  }
+  const int nslab = n / 16;
+  hipLaunchKernelGGL(kern, dim3((nslab + NS - 1) / NS), dim3(64 * WAVES), smem, st, (const uint16_t*)x, (const u32*)qw,
+                     (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k);
+}
+
+static int launch_skinny_64(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
+                            hipStream_t st);
+
+// 9 <= m <= 255, cdna4 layout, packed sz required.  Returns -1 if unsupported.  65 <= m <= 255 (below the 256-row tile of
+// the prefill GEMM) runs as row chunks of <= 64: the weights are re-streamed per chunk, which still beats the 128 x 128
+// kernel's long serial K loop on one wave of tiles (measured: profiles/r01_skinny_sweep.txt) except for very wide N.
+int launch_skinny_cdna4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
+                        hipStream_t st) {
+  if (!szp || m < 1 || m > 255 || (n % 16) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return -1;
+  if (m > 128 && n >= 16384) return -1;
+  const int chunks = (m + 63) / 64, rows = (m + chunks - 1) / chunks;
+  for (int r0 = 0; r0 < m; r0 += rows) {
+    const int mr = m - r0 < rows ? m - r0 : rows;
+    launch_skinny_64(static_cast<const uint16_t*>(x) + (size_t)r0 * k, qw, szp, bias, static_cast<uint16_t*>(out) + (size_t)r0 * n, mr, n,
+                     k, st);
+  }
+  return 0;
+}
+
+static int launch_skinny_64(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
+                            hipStream_t st) {
+  const int nslab = n / 16;
+  if (m <= 16) {
+    if (nslab >= 1024) launch_skinny<8, 2, 1>(x, qw, szp, bias, out, m, n, k, st);
+    else launch_skinny<8, 1, 1>(x, qw, szp, bias, out, m, n, k, st);
+  } else if (m <= 32) {
+    if (nslab >= 512) launch_skinny<8, 2, 2>(x, qw, szp, bias, out, m, n, k, st);
+    else launch_skinny<8, 1, 2>(x, qw, szp, bias, out, m, n, k, st);
+  } else if (m <= 48) {
+    if (nslab >= 512) launch_skinny<4, 4, 3>(x, qw, szp, bias, out, m, n, k, st);
+    else launch_skinny<8, 2, 3>(x, qw, szp, bias, out, m, n, k, st);
+  } else {
+    if (nslab >= 512) launch_skinny<4, 4, 4>(x, qw, szp, bias, out, m, n, k, st);
+    else launch_skinny<8, 2, 4>(x, qw, szp, bias, out, m, n, k, st);
+  }
+  return 0;
+}
+
+}  // namespace awq

@@ -159,3 +159,17 @@ def test_fused_gate_up_silu_mul(ops, M, F, K):
     rel = ((y.float() - ref.float()).norm() / ref.float().norm()).item()
     assert rel <= 1e-3 * 3, rel   # three bf16 roundings deep; exact-match fraction is the sharper check
     assert (y == ref).float().mean() > 0.95
+
+
+@pytest.mark.parametrize("M", [9, 16, 17, 31, 32, 33, 48, 49, 63, 64, 65, 100, 129, 200, 255])
+@pytest.mark.parametrize("N,K", [(768, 768), (1040, 1280), (64, 11008), (8192, 512), (16400, 256)])
+def test_skinny_gemm_vs_oracle(ops, M, N, K):
+    """9 <= M <= 255 (short prompts / batched decode; above 64 rows in chunks): the skinny kernel, every column-block count, slab counts that do not
+    divide the slabs-per-block, ragged K splits, wide N (both slab groupings), bias fused."""
+    dtype = torch.bfloat16
+    c = make_case(N, K, dtype, seed=M * 7 + N + K, M=M, bias=(M % 2 == 1))
+    c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
+    szp = ops.pack_sz_cdna4(c["scales"].cuda(), c["scaled_zeros"].cuda(), K)
+    y = ops.gemm_cdna4(c["x"].cuda(), c4, c["scales"].cuda(), c["scaled_zeros"].cuda(),
+                       c["bias"].cuda() if c["bias"] is not None else None, szp).cpu()
+    check_forward(y, c["x"], c["q"], c["scales"], c["scaled_zeros"], dtype, bias=c["bias"])

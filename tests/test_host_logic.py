@@ -90,3 +90,16 @@ def test_forward_has_no_cpu_fallback():
     from llm_awq_amd import _capi, ops
     with pytest.raises(_capi.AwqNativeError):
         ops.gemv(torch.zeros(1, 256, dtype=torch.float16), m.qweight, m.scales, m.scaled_zeros)
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under llm_awq_amd/ (the product path) may import or call it."""
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "llm_awq_amd")
+    for dp, _dn, fns in os.walk(root):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                src = open(os.path.join(dp, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(dp, fn)
+                assert "awq_oracle" not in src, os.path.join(dp, fn)

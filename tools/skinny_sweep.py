@@ -1,0 +1,27 @@
+"""GPU experiment: forward_cdna4 latency across M for the Llama-3-8B shapes (decode fast path, skinny kernel, 128x128, GEMM v3)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from llm_awq_amd import ops, synth  # noqa: E402
+
+for (K, N) in [(4096, 4096), (4096, 6144), (4096, 28672), (14336, 4096)]:
+    w = synth.random_wq(K, N, dtype=torch.bfloat16, seed=1, keep_q=False)
+    c4 = ops.repack_v2_to_cdna4(w["qweight"])
+    szp = ops.pack_sz_cdna4(w["scales"], w["scaled_zeros"], K)
+    for M in (1, 8, 9, 16, 32, 48, 64, 65, 128, 256):
+        x = torch.randn(M, K, device="cuda").bfloat16()
+        for _ in range(3):
+            ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], None, szp)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        it = 20
+        e0.record()
+        for _ in range(it):
+            ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], None, szp)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / it
+        print(f"K={K:6d} N={N:6d} M={M:4d}  {us:8.1f} us  (weights L2/MALL-warm: same buffer every call)", flush=True)

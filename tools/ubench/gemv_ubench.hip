@@ -107,7 +107,25 @@ __global__ __launch_bounds__(64 * WAVES) void gemv2(const u32* __restrict__ qw, 
     sz[t] = szp[tile * 16 + i];
   }
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  if (DQ == 0) {
+  if (DQ == 5) {
+    Cdna4Dequant cd;
+    cd.init(lane);
+    u32x4 fake = {(u32)lane * 0x9E3779B9u, (u32)wv, (u32)nb, 0x12345u};
+    bf16x8 xo = __builtin_bit_cast(bf16x8, fake);
+#pragma unroll
+    for (int t = 0; t < S; ++t) {
+      bf16x8 op[4];
+      cd.tile(fake, (uint16_t)(0x3C00 + t), (uint16_t)0xBC00, op);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(op[a], xo, acc, 0, 0, 0);
+      fake.x += 0x01010101u;
+      fake.z ^= fake.x >> 3;
+    }
+    u32 sink = 0;
+#pragma unroll
+    for (int t = 0; t < S; ++t) sink ^= w[t].x ^ w[t].y ^ w[t].z ^ w[t].w ^ sz[t];
+    acc[1] += __builtin_bit_cast(float, sink & 0x3fffffffu);
+  } else if (DQ == 0) {
     u32 sink = 0;
 #pragma unroll
     for (int t = 0; t < S; ++t) sink ^= w[t].x ^ w[t].y ^ w[t].z ^ w[t].w ^ sz[t];
@@ -381,6 +399,9 @@ int main(int argc, char** argv) {
     run_all_ws<0, 1>(c, 0, "strm");
     run_all_ws<1, 1>(c, 0, "mfma");
     run_all_ws<3, 1>(c, 0, "raw");
+    run_all_ws<5, 1>(c, 0, "indep");
+    run_all_ws<5, 1>(c, 2, "indepL2");
+    run_all_ws<1, 1>(c, 2, "mfmaL2");
     for (int r = 0; r < c.R; ++r) {
       CK(hipFree(c.qw[r]));
       CK(hipFree(c.szp[r]));
