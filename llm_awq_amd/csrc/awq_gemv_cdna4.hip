@@ -68,7 +68,10 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_cdna4_kernel(const uint16_t* 
       const int kg = min(wv + WAVES * (c0 + t), nit - 1);
 #pragma unroll
       for (int b = 0; b < MB; ++b) {
-        const u32 xoff_b = ((u32)min(4 * b + g, M - 1) * (u32)K + (u32)i * 8u) * 2u;  // M * K * 2 < 2^32
+        // LDS slot i of row r receives granule i ^ (r & 15): the M rows of an MFMA operand are 256 B apart (one full
+        // bank sweep), the XOR spreads their equal granule indices over different banks
+        const int r = min(4 * b + g, M - 1);
+        const u32 xoff_b = ((u32)r * (u32)K + (u32)((i ^ (r & 15)) * 8)) * 2u;  // M * K * 2 < 2^32
         xr[t][b] = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff_b, (u32)kg * 256u, 0);
       }
     }
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_cdna4_kernel(const uint16_t* 
       const u32x4* xrow = reinterpret_cast<const u32x4*>(xs + t * xstep + mrow * 256);
       bf16x8 xop[4];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) xop[a] = __builtin_bit_cast(bf16x8, xrow[4 * a + g]);
+      for (int a = 0; a < 4; ++a) xop[a] = __builtin_bit_cast(bf16x8, xrow[(4 * a + g) ^ (mrow & 15)]);
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         const u32 szv = sz[s][t];

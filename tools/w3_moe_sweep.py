@@ -1,0 +1,90 @@
+"""GPU experiment: the two parity-only configurations of BASELINE.json timed on their real shapes.
+ * W3A16 (Llama-2-7B shapes), decode M = 1 over rotating weight copies + prefill M = 2048 (expand + GEMM v3)
+ * Mixtral-8x7B grouped per-expert GEMM (E = 8, top-2), 2048 tokens."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from llm_awq_amd import _capi, ops  # noqa: E402
+from llm_awq_amd.moe import sort_by_expert  # noqa: E402
+
+
+def graph_time(fn, items, reps=5):
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for it in items[:2]:
+            fn(it)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            for it in items:
+                fn(it)
+        g.replay()
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            g.replay()
+            e1.record(s)
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+    return best * 1e3 / len(items)
+
+
+def rand_sz(K, N, dev="cuda"):
+    G, gpad = K // 128, ((K // 128 + 7) // 8) * 8
+    s = torch.zeros(gpad, N, dtype=torch.bfloat16, device=dev)
+    z = torch.zeros(gpad, N, dtype=torch.bfloat16, device=dev)
+    s[:G] = ((5.2 + 0.8 * torch.rand(G, N, device=dev)) * 0.02 / 7.0).bfloat16()
+    z[:G] = -(s[:G].float() * torch.randint(2, 6, (G, N), device=dev).float()).bfloat16()
+    return s, z
+
+
+def main():
+    dt = torch.bfloat16
+    print("== W3A16, Llama-2-7B shapes (w3c tiles, 0.375 B / weight) ==")
+    for (K, N) in [(4096, 12288), (4096, 4096), (4096, 22016), (11008, 4096)]:
+        R = max(8, min(40, (900 << 20) // (N * K * 3 // 8)))
+        items = []
+        for i in range(R):
+            q = torch.randint(0, 8, (N, K), dtype=torch.uint8, device="cuda")
+            s, z = rand_sz(K, N)
+            items.append(dict(qw=ops.pack_w3(q), s=s, z=z, szp=ops.pack_sz_cdna4(s, z, K)))
+            del q
+        x1 = torch.randn(1, K, device="cuda").to(dt)
+        us = graph_time(lambda c: ops.forward_w3(x1, c["qw"], c["s"], c["z"], c["szp"]), items)
+        by = N * K * 3 // 8 + 4 * (K // 128) * N + 2 * K + 2 * N
+        print(f"K={K:6d} N={N:6d} decode M=1   {us:8.2f} us  {by / us / 1e3:8.1f} GB/s  {by / us / 1e3 / 80:5.1f}% of 8 TB/s", flush=True)
+        xm = torch.randn(2048, K, device="cuda").to(dt)
+        us = graph_time(lambda c: ops.forward_w3(xm, c["qw"], c["s"], c["z"], c["szp"]), items[:4])
+        tf = 2.0 * 2048 * N * K / us / 1e6
+        print(f"K={K:6d} N={N:6d} prefill M=2048 {us:8.1f} us  {tf:7.1f} TFLOP/s  {tf / 25:5.1f}% of 2.5 PF", flush=True)
+        del items
+        torch.cuda.empty_cache()
+    print("== Mixtral-8x7B grouped GEMM: E = 8, top-2, 2048 tokens (4096 sorted rows) ==")
+    E, H, F, T = 8, 4096, 14336, 2048
+    for (K, N, name) in [(H, F, "w1/w3"), (F, H, "w2")]:
+        qws, ss, zs = [], [], []
+        for e in range(E):
+            q = torch.randint(0, 16, (N, K), dtype=torch.uint8, device="cuda")
+            qws.append(ops.repack_v2_to_cdna4(ops.pack_v2(q)))
+            s, z = rand_sz(K, N)
+            ss.append(s)
+            zs.append(z)
+            del q
+        qw, s, z = torch.stack(qws), torch.stack(ss), torch.stack(zs)
+        ids = torch.stack([torch.randperm(E, device="cuda")[:2] for _ in range(T)])
+        order, off = sort_by_expert(ids, E)
+        xs = torch.randn(2 * T, K, device="cuda").to(dt)
+        us = graph_time(lambda _c: ops.moe_gemm(xs, qw, s, z, off, layout="cdna4"), [0, 1, 2, 3])
+        tf = 2.0 * 2 * T * N * K / us / 1e6
+        print(f"{name:6s} K={K:6d} N={N:6d} rows={2 * T}  {us:8.1f} us  {tf:7.1f} TFLOP/s  {tf / 25:5.1f}% of 2.5 PF", flush=True)
+        del qw, s, z, qws, ss, zs
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
