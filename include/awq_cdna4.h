@@ -130,6 +130,13 @@ int awq_w4a16_moe_gemm(const void* x_sorted, const void* qweight, const void* sc
                        const void* expert_offsets, void* out, int total_tokens, int num_experts, int n, int k, int gpad,
                        int group_size, int dtype, int layout, void* stream);
 
+/* the same on cdna4 buffers with the stacked packed scales (int32 [E, n/16, k/128, 16]): decode batches (total_tokens <= 8,
+ * hence at most 8 rows per expert) stream each expert's tiles once with the GEMV structure (block = (expert, slab));
+ * larger batches run the grouped GEMM.  bf16 only. */
+int awq_w4a16_moe_forward_cdna4(const void* x_sorted, const void* qweight, const void* scales, const void* scaled_zeros,
+                                const void* sz_packed, const void* expert_offsets, void* out, int total_tokens,
+                                int num_experts, int n, int k, int gpad, int group_size, int dtype, void* stream);
+
 /* ---- W3A16 ("w3c" tiles): BASELINE.json's INT3 configuration.  The reference has NO packed 3-bit format
  * (awq/quantize/qmodule.py:82-83 raises for w_bit != 4; INT3 exists only as pseudo-quantisation,
  * awq/quantize/quantizer.py:61-103 with n_bit = 3), so the format is this repository's: per 16-row x 128-k tile

@@ -253,6 +253,23 @@ int awq_w4a16_moe_gemm(const void* x_sorted, const void* qweight, const void* sc
   return finish_launch();
 }
 
+int awq_w4a16_moe_forward_cdna4(const void* x_sorted, const void* qweight, const void* scales, const void* scaled_zeros,
+                                const void* sz_packed, const void* expert_offsets, void* out, int total_tokens,
+                                int num_experts, int n, int k, int gpad, int group_size, int dtype, void* stream) {
+  if (!expert_offsets || !sz_packed) return AWQ_ERR_NULL;
+  if (dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
+  if (num_experts < 1 || gpad * 128 < k || total_tokens < 0 || (n % 16) != 0) return AWQ_ERR_SHAPE;
+  if (total_tokens == 0) return AWQ_OK;
+  int st = check_common(x_sorted, qweight, scales, scaled_zeros, out, total_tokens, n, k, group_size, dtype);
+  if (st != AWQ_OK) return st;
+  if (total_tokens <= 8 && awq::launch_moe_gemv_cdna4(x_sorted, qweight, sz_packed, expert_offsets, out, total_tokens, num_experts, n,
+                                                      k, (hipStream_t)stream) == 0)
+    return finish_launch();
+  awq::launch_moe_gemm(x_sorted, qweight, scales, scaled_zeros, expert_offsets, out, total_tokens, num_experts, n, k, gpad, dtype, 1,
+                       (hipStream_t)stream);
+  return finish_launch();
+}
+
 // ---- W3 ("w3c") : the repository's 3-bit format (bf16 only; no reference counterpart) ----
 static int check_w3_shape(int n, int k) { return (n < 16 || (n % 16) != 0 || k < 128 || (k % 128) != 0) ? AWQ_ERR_SHAPE : AWQ_OK; }
 

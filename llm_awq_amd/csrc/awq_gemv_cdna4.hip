@@ -20,19 +20,17 @@
 
 namespace awq {
 
+// the whole block's work for slab `nb`: shared by the plain kernel and the grouped (per-expert) kernel
 template <int WAVES, int S, int MB, int EPI, int BITS>
-__global__ __launch_bounds__(64 * WAVES) void gemv_cdna4_kernel(const uint16_t* __restrict__ x,
-                                                                 const u32* __restrict__ qw,
-                                                                 const u32* __restrict__ szp,
-                                                                 const uint16_t* __restrict__ bias,
-                                                                 uint16_t* __restrict__ out, int M, int N, int K) {
+__device__ __forceinline__ void gemv_cdna4_body(char* smem, const uint16_t* __restrict__ x, const u32* __restrict__ qw,
+                                                const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
+                                                uint16_t* __restrict__ out, int M, int N, int K, int nb) {
   constexpr int NS = EPI == 1 ? 2 : 1;  // slabs per block
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   // the wave index is wave-uniform: taking it through readfirstlane puts every tile / step address computation on
   // the scalar unit (the kernel is VALU-issue bound: ~5 cycles per VALU instruction per SIMD, DESIGN.md "gemv")
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, g = lane >> 4;
-  const int nb = blockIdx.x, nit = K >> 7;
+  const int nit = K >> 7;
   const int xstep = M * 256;  // bytes of x per 128-k step (M rows)
   float(*red)[4][64] = reinterpret_cast<float(*)[4][64]>(smem);  // [NS * WAVES][4][64]
   char* xs = smem + NS * WAVES * 1024 + wv * (S * xstep);
@@ -148,6 +146,33 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_cdna4_kernel(const uint16_t* 
   }
 }
 
+template <int WAVES, int S, int MB, int EPI, int BITS>
+__global__ __launch_bounds__(64 * WAVES) void gemv_cdna4_kernel(const uint16_t* __restrict__ x,
+                                                                 const u32* __restrict__ qw,
+                                                                 const u32* __restrict__ szp,
+                                                                 const uint16_t* __restrict__ bias,
+                                                                 uint16_t* __restrict__ out, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemv_cdna4_body<WAVES, S, MB, EPI, BITS>(smem, x, qw, szp, bias, out, M, N, K, blockIdx.x);
+}
+
+// Grouped (per-expert) decode GEMV for MoE layers: block = (expert, slab); expert e owns rows [offsets[e], offsets[e+1]) of
+// the sorted x / out (at most 4 MB rows: the host only routes here when the TOTAL row count is that small) and the
+// e-th slice of the stacked cdna4 weights / packed scales.  Experts without tokens cost one offsets read per block.
+template <int WAVES, int S, int MB>
+__global__ __launch_bounds__(64 * WAVES) void moe_gemv_cdna4_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
+                                                                     const u32* __restrict__ szp,
+                                                                     const int* __restrict__ offsets,
+                                                                     uint16_t* __restrict__ out, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nslab = N >> 4, nit = K >> 7;
+  const int e = blockIdx.x / nslab, nb = blockIdx.x - e * nslab;
+  const int row0 = offsets[e], m_e = offsets[e + 1] - row0;
+  if (m_e <= 0) return;
+  gemv_cdna4_body<WAVES, S, MB, 0, 4>(smem, x + (size_t)row0 * K, qw + (size_t)e * nslab * nit * 256,
+                                      szp + (size_t)e * nslab * nit * 16, nullptr, out + (size_t)row0 * N, min(m_e, 4 * MB), N, K, nb);
+}
+
 namespace {
 struct Cfg {
   int waves, s;
@@ -224,6 +249,26 @@ int launch_gemv_cdna4(const void* x, const void* qw, const void* szp, const void
   if (epi == 1)
     return m <= 4 ? launch_mb<1, 1, 4>(x, qw, szp, bias, out, m, n, k, st) : launch_mb<2, 1, 4>(x, qw, szp, bias, out, m, n, k, st);
   return m <= 4 ? launch_mb<1, 0, 4>(x, qw, szp, bias, out, m, n, k, st) : launch_mb<2, 0, 4>(x, qw, szp, bias, out, m, n, k, st);
+}
+
+// grouped decode GEMV: total_rows <= 8 (so every expert has <= 8 rows), cdna4 layout, stacked packed sz [E][N/16][K/128][16]
+int launch_moe_gemv_cdna4(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total_rows,
+                          int experts, int n, int k, hipStream_t st) {
+  if (total_rows < 1 || total_rows > 8 || (n % 16) != 0 || (k % 128) != 0) return -1;
+  const int nit = k / kGroup;
+  constexpr int WAVES = 8, S = 2;
+  if (nit < WAVES) return -1;
+  const int grid = experts * (n / 16);
+  if (total_rows <= 4) {
+    const size_t smem = (size_t)WAVES * 1024 + (size_t)WAVES * S * 4 * 256;
+    hipLaunchKernelGGL((moe_gemv_cdna4_kernel<WAVES, S, 1>), dim3(grid), dim3(64 * WAVES), smem, st, (const uint16_t*)x,
+                       (const u32*)qw, (const u32*)szp, (const int*)offsets, (uint16_t*)out, n, k);
+  } else {
+    const size_t smem = (size_t)WAVES * 1024 + (size_t)WAVES * S * 8 * 256;
+    hipLaunchKernelGGL((moe_gemv_cdna4_kernel<WAVES, S, 2>), dim3(grid), dim3(64 * WAVES), smem, st, (const uint16_t*)x,
+                       (const u32*)qw, (const u32*)szp, (const int*)offsets, (uint16_t*)out, n, k);
+  }
+  return 0;
 }
 
 }  // namespace awq

@@ -166,6 +166,26 @@ torch::Tensor moe_gemm_forward(torch::Tensor x_sorted, torch::Tensor kernel, tor
   return out;
 }
 
+// grouped forward on cdna4 buffers: decode batches (<= 8 sorted rows) take the grouped GEMV
+torch::Tensor moe_forward_cdna4(torch::Tensor x_sorted, torch::Tensor kernel, torch::Tensor scales, torch::Tensor zeros,
+                                torch::Tensor sz_packed, torch::Tensor expert_offsets) {
+  check_inputs(x_sorted, kernel, scales, zeros);
+  TORCH_CHECK(x_sorted.scalar_type() == at::kBFloat16, "the cdna4 interleave is defined for bfloat16");
+  TORCH_CHECK(expert_offsets.is_cuda() && expert_offsets.is_contiguous() && expert_offsets.scalar_type() == at::kInt);
+  TORCH_CHECK(sz_packed.is_cuda() && sz_packed.is_contiguous() && sz_packed.scalar_type() == at::kInt);
+  TORCH_CHECK(kernel.dim() == 3 && scales.dim() == 3 && zeros.dim() == 3 && x_sorted.dim() == 2);
+  const int64_t e = kernel.size(0), n = kernel.size(1) * 4, k = kernel.size(2), t = x_sorted.size(0);
+  TORCH_CHECK(x_sorted.size(1) == k && scales.size(0) == e && scales.size(2) == n && expert_offsets.numel() == e + 1);
+  TORCH_CHECK(sz_packed.numel() == e * n * (k / 128), "sz_packed must be int32 [E, n/16, k/128, 16]");
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(x_sorted.device());
+  at::Tensor out = torch::empty({t, n}, x_sorted.options());
+  raise_on(awq_w4a16_moe_forward_cdna4(x_sorted.data_ptr(), kernel.data_ptr(), scales.data_ptr(), zeros.data_ptr(),
+                                       sz_packed.data_ptr(), expert_offsets.data_ptr(), out.data_ptr(), (int)t, (int)e, (int)n,
+                                       (int)k, (int)scales.size(1), 128, AWQ_BF16,
+                                       (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()));
+  return out;
+}
+
 // ---- W3 ("w3c" tiles, bf16): pack from logical integers, and WQLinear.forward for w_bit = 3 ----
 torch::Tensor pack_w3(torch::Tensor q_u8) {
   TORCH_CHECK(q_u8.is_cuda() && q_u8.is_contiguous() && q_u8.scalar_type() == at::kByte && q_u8.dim() == 2);
@@ -241,6 +261,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("kernel"), py::arg("scales"), py::arg("zeros"), py::arg("sz_packed"), py::arg("bias") = py::none());
   m.def("moe_gemm_forward", &moe_gemm_forward, "grouped per-expert W4A16 GEMM (tokens sorted by expert)", py::arg("x_sorted"),
         py::arg("kernel"), py::arg("scales"), py::arg("zeros"), py::arg("expert_offsets"), py::arg("cdna4") = false);
+  m.def("moe_forward_cdna4", &moe_forward_cdna4, "grouped per-expert forward on cdna4 buffers (GEMV for <= 8 rows, GEMM otherwise)");
   m.def("pack_w3", &pack_w3, "logical uint8 [N, K] (0..7) -> w3c tiles int16 [N/4, 3K/4]");
   m.def("forward_w3", &forward_w3, "WQLinear forward for w_bit = 3 (w3c tiles)", py::arg("in_feats"), py::arg("kernel"),
         py::arg("scales"), py::arg("zeros"), py::arg("sz_packed"), py::arg("bias") = py::none());

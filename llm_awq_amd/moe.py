@@ -43,13 +43,29 @@ class GroupedWQLinear(nn.Module):
         self.register_buffer("scales", torch.stack([e.scales for e in experts]).contiguous())
         self.register_buffer("scaled_zeros", torch.stack([e.scaled_zeros for e in experts]).contiguous())
         self._matmul = matmul
+        self.sz_cdna4 = None  # stacked packed scales int32 [E, N/16, K/128, 16], built lazily for the cdna4 layout
+
+    @torch.no_grad()
+    def to_cdna4(self):
+        """Permute every expert's qweight into the cdna4 interleave (bf16; what the repacker emits) -- idempotent."""
+        if self.layout != "cdna4":
+            eng = load_engine()
+            self.qweight = torch.stack([eng.repack_v2_to_cdna4(self.qweight[e].contiguous()) for e in range(self.num_experts)])
+            self.layout = "cdna4"
+        return self
 
     @torch.no_grad()
     def forward(self, x_sorted: torch.Tensor, expert_offsets: torch.Tensor) -> torch.Tensor:
         if self._matmul is not None:
             return self._matmul(x_sorted, self.qweight, self.scales, self.scaled_zeros, expert_offsets)
-        return load_engine().moe_gemm_forward(x_sorted.contiguous(), self.qweight, self.scales, self.scaled_zeros,
-                                              expert_offsets, self.layout == "cdna4")
+        eng = load_engine()
+        if self.layout == "cdna4":
+            if self.sz_cdna4 is None or self.sz_cdna4.device != self.scales.device:
+                self.sz_cdna4 = torch.stack([eng.pack_sz_cdna4(self.scales[e].contiguous(), self.scaled_zeros[e].contiguous(),
+                                                                self.in_features) for e in range(self.num_experts)])
+            return eng.moe_forward_cdna4(x_sorted.contiguous(), self.qweight, self.scales, self.scaled_zeros, self.sz_cdna4,
+                                         expert_offsets)
+        return eng.moe_gemm_forward(x_sorted.contiguous(), self.qweight, self.scales, self.scaled_zeros, expert_offsets, False)
 
 
 class SparseMoeMLP(nn.Module):

@@ -282,3 +282,18 @@ def moe_gemm(x_sorted, qweight, scales, scaled_zeros, expert_offsets, layout: st
                                                     n, k, scales.shape[1], group_size, _dt(x_sorted),
                                                     1 if layout == "cdna4" else 0, _stream(x_sorted)))
     return out
+
+
+def moe_forward_cdna4(x_sorted, qweight, scales, scaled_zeros, sz_packed, expert_offsets, group_size: int = 128):
+    """C-ABI awq_w4a16_moe_forward_cdna4: grouped GEMV for <= 8 sorted rows (decode), grouped GEMM otherwise."""
+    _need_gpu(x_sorted, qweight, scales, scaled_zeros, sz_packed, expert_offsets)
+    assert expert_offsets.dtype == torch.int32 and qweight.dim() == 3 and sz_packed.dtype == torch.int32
+    e, n, k = qweight.shape[0], qweight.shape[1] * 4, qweight.shape[2]
+    t = x_sorted.shape[0]
+    out = torch.empty(t, n, dtype=x_sorted.dtype, device=x_sorted.device)
+    with torch.cuda.device(x_sorted.device):
+        _capi.check(_capi.lib().awq_w4a16_moe_forward_cdna4(x_sorted.data_ptr(), qweight.data_ptr(), scales.data_ptr(),
+                                                             scaled_zeros.data_ptr(), sz_packed.data_ptr(),
+                                                             expert_offsets.data_ptr(), out.data_ptr(), t, e, n, k,
+                                                             scales.shape[1], group_size, _dt(x_sorted), _stream(x_sorted)))
+    return out

@@ -116,3 +116,24 @@ def test_gpu_mixtral_block_shapes():
         if hi > lo:
             ref = ops.gemm(xs[lo:hi].contiguous(), qw[e], s[e], z[e])
             assert (ref == y[lo:hi]).float().mean() > 0.98
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("counts", [[1, 0, 0, 1], [2, 2, 0, 0], [0, 0, 0, 3], [3, 1, 2, 2], [0, 8, 0, 0], [4, 3, 2, 4]])
+def test_gpu_grouped_decode_and_module(counts):
+    """decode batches: <= 8 sorted rows take the grouped GEMV (block = (expert, slab)); more rows the grouped GEMM; both
+    through GroupedWQLinear.to_cdna4().forward and against the per-expert oracle."""
+    dtype = torch.bfloat16
+    E, N, K = len(counts), 384, 1280
+    mods, cases = _experts(E, N, K, dtype, seed=sum(counts) + 3)
+    grp = MOE.GroupedWQLinear(mods).cuda().to_cdna4()
+    T = sum(counts)
+    g = torch.Generator().manual_seed(T + 1)
+    x = torch.randn(T, K, generator=g).to(dtype)
+    off = torch.tensor([0] + list(np.cumsum(counts)), dtype=torch.int32)
+    y = grp(x.cuda(), off.cuda()).cpu()
+    assert y.shape == (T, N)
+    for e in range(E):
+        lo, hi = int(off[e]), int(off[e + 1])
+        if hi > lo:
+            check_forward(y[lo:hi], x[lo:hi], cases[e]["q"], cases[e]["scales"], cases[e]["scaled_zeros"], dtype)

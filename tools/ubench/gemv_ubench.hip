@@ -85,6 +85,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemv2(const u32* __restrict__ qw, 
   const int rows = min(M, 4), xstep = rows * 256;
   char* xs = smem + wv * (S * xstep);
 
+  if (kmajor & 4) __builtin_amdgcn_s_setprio(3);  // experiment: the load-issue phase of a new wave outranks older waves' math
   // ---- x slices of this wave's steps: lane -> (row lane>>4 (clamped), granule lane&15) ----
   u32x4 xr[S];
   if (DQ != 0) {
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemv2(const u32* __restrict__ qw, 
     w[t] = NT ? __builtin_nontemporal_load(p) : *p;
     sz[t] = szp[tile * 16 + i];
   }
+  if (kmajor & 4) __builtin_amdgcn_s_setprio(0);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   if (DQ == 5) {
     Cdna4Dequant cd;
@@ -398,10 +400,9 @@ int main(int argc, char** argv) {
     }
     run_all_ws<0, 1>(c, 0, "strm");
     run_all_ws<1, 1>(c, 0, "mfma");
-    run_all_ws<3, 1>(c, 0, "raw");
+    run_all_ws<1, 1>(c, 4, "mfmaP");
     run_all_ws<5, 1>(c, 0, "indep");
-    run_all_ws<5, 1>(c, 2, "indepL2");
-    run_all_ws<1, 1>(c, 2, "mfmaL2");
+    run_all_ws<5, 1>(c, 4, "indepP");
     for (int r = 0; r < c.R; ++r) {
       CK(hipFree(c.qw[r]));
       CK(hipFree(c.szp[r]));
