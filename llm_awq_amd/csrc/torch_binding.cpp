@@ -10,8 +10,11 @@
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/extension.h>
 
+#include <cstdlib>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 
 #include "../../include/awq_cdna4.h"
 
@@ -44,6 +47,74 @@ void check_inputs(const torch::Tensor& x, const torch::Tensor& kernel, const tor
               "awq_inference_engine: tensors must be on the same device");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Lazy v2 -> cdna4 cache.  tinychat hands the extension RAW reference-layout buffers (fused_mlp.py:40-77 passes
+// gate_proj_qweight etc. directly, make_quant_attn concatenates v2 buffers after load), so the drop-in entry points
+// cannot assume the repacker ran.  For bf16 weights the first call with a given (qweight, scales, zeros) triple repacks
+// them once on the GPU (awq_repack_v2_to_cdna4 + awq_pack_sz_cdna4, tens of microseconds) and later calls run the
+// cdna4 kernels.  An entry is tied to the IDENTITY of the three tensors (weak TensorImpl references, so a freed
+// tensor whose address is re-used can never hit) and to their version counters (an in-place update re-packs).
+// Cost: a second packed copy of the weights (N*K/2 + N*K/32 bytes).  AWQ_CDNA4_AUTOCACHE=0 disables it; it is also
+// bypassed while the stream is being captured into a hipGraph (no allocations inside a capture).
+// ---------------------------------------------------------------------------------------------------------------
+struct CacheEntry {
+  c10::weak_intrusive_ptr<c10::TensorImpl> w, s, z;
+  uint32_t vw, vs, vz;
+  at::Tensor c4, szp;
+  CacheEntry(const torch::Tensor& tw, const torch::Tensor& ts, const torch::Tensor& tz)
+      : w(tw.getIntrusivePtr()), s(ts.getIntrusivePtr()), z(tz.getIntrusivePtr()), vw(tw._version()), vs(ts._version()),
+        vz(tz._version()) {}
+};
+std::mutex g_cache_mu;
+std::unordered_map<const void*, CacheEntry> g_cache;
+int g_cache_enabled = -1;
+int64_t g_cache_hits = 0, g_cache_builds = 0;
+
+bool cache_enabled() {
+  if (g_cache_enabled < 0) {
+    const char* e = std::getenv("AWQ_CDNA4_AUTOCACHE");
+    g_cache_enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_cache_enabled == 1;
+}
+
+// returns true and fills (c4, szp) when the cdna4 kernels can serve this call
+bool cdna4_view(const torch::Tensor& kernel, const torch::Tensor& scales, const torch::Tensor& zeros, int64_t n, int64_t k,
+                hipStream_t stream, at::Tensor& c4, at::Tensor& szp) {
+  if (!cache_enabled() || kernel.scalar_type() != at::kShort || scales.scalar_type() != at::kBFloat16) return false;
+  if (n % 16 != 0 || k % 128 != 0 || kernel.numel() != n / 4 * k) return false;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
+  std::lock_guard<std::mutex> lock(g_cache_mu);
+  const void* key = kernel.data_ptr();
+  auto it = g_cache.find(key);
+  if (it != g_cache.end()) {
+    CacheEntry& e = it->second;
+    auto lw = e.w.lock(), ls = e.s.lock(), lz = e.z.lock();
+    if (lw.get() == kernel.unsafeGetTensorImpl() && ls.get() == scales.unsafeGetTensorImpl() &&
+        lz.get() == zeros.unsafeGetTensorImpl() && e.vw == kernel._version() && e.vs == scales._version() &&
+        e.vz == zeros._version()) {
+      c4 = e.c4;
+      szp = e.szp;
+      ++g_cache_hits;
+      return true;
+    }
+    g_cache.erase(it);
+  }
+  // drop entries whose tensors died (keeps the map from growing when models are reloaded)
+  for (auto i2 = g_cache.begin(); i2 != g_cache.end();) i2 = i2->second.w.expired() ? g_cache.erase(i2) : std::next(i2);
+  CacheEntry e(kernel, scales, zeros);
+  e.c4 = torch::empty_like(kernel);
+  e.szp = torch::empty({n / 16, k / 128, 16}, scales.options().dtype(at::kInt));
+  if (awq_repack_v2_to_cdna4(kernel.data_ptr(), e.c4.data_ptr(), (int)n, (int)k, (void*)stream) != AWQ_OK) return false;
+  if (awq_pack_sz_cdna4(scales.data_ptr(), zeros.data_ptr(), e.szp.data_ptr(), (int)n, (int)k, (void*)stream) != AWQ_OK) return false;
+  c4 = e.c4;
+  szp = e.szp;
+  g_cache.emplace(key, std::move(e));
+  ++g_cache_builds;
+  return true;
+}
+
 torch::Tensor gemv_forward_cuda_new(torch::Tensor in_feats, torch::Tensor kernel, torch::Tensor scaling_factors,
                                     torch::Tensor zeros, int m, int n, int k, int group_size) {
   check_inputs(in_feats, kernel, scaling_factors, zeros);
@@ -59,6 +130,12 @@ torch::Tensor gemv_forward_cuda_new(torch::Tensor in_feats, torch::Tensor kernel
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(in_feats.device());
   at::Tensor out = torch::empty(shape, in_feats.options());
   auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+  at::Tensor c4, szp;
+  if (cdna4_view(kernel, scaling_factors, zeros, n, k, stream, c4, szp)) {
+    raise_on(awq_w4a16_forward_cdna4(in_feats.data_ptr(), c4.data_ptr(), scaling_factors.data_ptr(), zeros.data_ptr(), szp.data_ptr(),
+                                     nullptr, out.data_ptr(), m, n, k, group_size, AWQ_BF16, nullptr, 0, (void*)stream));
+    return out;
+  }
   raise_on(awq_w4a16_gemv(in_feats.data_ptr(), kernel.data_ptr(), scaling_factors.data_ptr(), zeros.data_ptr(),
                           out.data_ptr(), m, n, k, group_size, dtype_code(in_feats), (void*)stream));
   return out;
@@ -80,6 +157,14 @@ torch::Tensor gemm_forward_cuda_new(torch::Tensor in_feats, torch::Tensor kernel
   at::Tensor out = torch::empty(shape, in_feats.options());
   if (m == 0) return out;
   auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+  {
+    at::Tensor c4, szp;
+    if (cdna4_view(kernel, scales, zeros, n, k, stream, c4, szp)) {
+      raise_on(awq_w4a16_forward_cdna4(in_feats.data_ptr(), c4.data_ptr(), scales.data_ptr(), zeros.data_ptr(), szp.data_ptr(), nullptr,
+                                       out.data_ptr(), (int)m, (int)n, (int)k, 128, AWQ_BF16, nullptr, 0, (void*)stream));
+      return out;
+    }
+  }
   const size_t ws_bytes = awq_w4a16_gemm_workspace_bytes((int)m, (int)n, (int)k);
   at::Tensor ws;
   void* wsp = nullptr;
@@ -253,6 +338,16 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("gemm_forward_cuda_new", &gemm_forward_cuda_new, "New quantized GEMM kernel.");
   m.def("gemv_forward_cuda_new", &gemv_forward_cuda_new, "New quantized GEMV kernel.");
   m.def("abi_version", []() { return awq_abi_version(); });
+  m.def("cdna4_cache_info", []() {
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    return py::dict(py::arg("enabled") = cache_enabled(), py::arg("entries") = (int64_t)g_cache.size(), py::arg("hits") = g_cache_hits,
+                    py::arg("builds") = g_cache_builds);
+  }, "state of the lazy v2 -> cdna4 weight cache behind gemv/gemm_forward_cuda_new");
+  m.def("cdna4_cache_clear", []() {
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    g_cache.clear();
+  });
+  m.def("cdna4_cache_enable", [](bool on) { g_cache_enabled = on ? 1 : 0; });
   // extras of the MI355X build (not part of the reference module)
   m.def("repack_v2_to_cdna4", &repack_v2_to_cdna4, "qweight v2 -> cdna4 interleave (same shape)");
   m.def("repack_cdna4_to_v2", &repack_cdna4_to_v2, "qweight cdna4 -> v2 interleave (same shape)");

@@ -1,0 +1,84 @@
+"""-m gpu: the lazy v2 -> cdna4 weight cache behind the drop-in entry points (awq_inference_engine.gemv_forward_cuda_new /
+gemm_forward_cuda_new): tinychat passes raw reference-layout buffers, so the extension re-packs them once per tensor
+identity + version and must never serve a stale entry."""
+import pytest
+import torch
+
+from tests.helpers import check_forward, make_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def eng():
+    import llm_awq_amd
+    e = llm_awq_amd.load_engine()
+    e.cdna4_cache_enable(True)
+    e.cdna4_cache_clear()
+    yield e
+    e.cdna4_cache_enable(True)
+    e.cdna4_cache_clear()
+
+
+def _dev(c):
+    return c["qweight"].cuda(), c["scales"].cuda(), c["scaled_zeros"].cuda()
+
+
+def test_cache_builds_once_and_matches_oracle(eng):
+    N, K = 768, 1280
+    c = make_case(N, K, torch.bfloat16, seed=1, M=300)
+    qw, s, z = _dev(c)
+    b0 = eng.cdna4_cache_info()
+    for M in (1, 7, 8, 40, 300):
+        x = c["x"][:M].contiguous()
+        y = (eng.gemv_forward_cuda_new(x.cuda(), qw, s, z, M, N, K, 128) if M < 8 else eng.gemm_forward_cuda_new(x.cuda(), qw, s, z)).cpu()
+        check_forward(y, x, c["q"], c["scales"], c["scaled_zeros"], torch.bfloat16)
+    info = eng.cdna4_cache_info()
+    assert info["builds"] == b0["builds"] + 1 and info["hits"] >= b0["hits"] + 4 and info["entries"] == 1
+
+
+def test_in_place_update_and_address_reuse_never_serve_stale_weights(eng):
+    N, K = 256, 512
+    a, b = make_case(N, K, torch.bfloat16, seed=2, M=4), make_case(N, K, torch.bfloat16, seed=3, M=4)
+    qw, s, z = _dev(a)
+    x = a["x"].cuda()
+    check_forward(eng.gemv_forward_cuda_new(x, qw, s, z, 4, N, K, 128).cpu(), a["x"], a["q"], a["scales"], a["scaled_zeros"], torch.bfloat16)
+    # in-place overwrite with other weights: version counters change -> re-pack
+    qw.copy_(b["qweight"].cuda())
+    s.copy_(b["scales"].cuda())
+    z.copy_(b["scaled_zeros"].cuda())
+    check_forward(eng.gemv_forward_cuda_new(x, qw, s, z, 4, N, K, 128).cpu(), a["x"], b["q"], b["scales"], b["scaled_zeros"], torch.bfloat16)
+    # free and re-allocate: the caching allocator hands the same addresses to NEW tensors
+    ptr = qw.data_ptr()
+    del qw, s, z
+    qw2, s2, z2 = _dev(a)
+    y = eng.gemv_forward_cuda_new(x, qw2, s2, z2, 4, N, K, 128).cpu()
+    check_forward(y, a["x"], a["q"], a["scales"], a["scaled_zeros"], torch.bfloat16)
+    assert eng.cdna4_cache_info()["entries"] == 1, (ptr, qw2.data_ptr())
+
+
+def test_fp16_and_disabled_and_capture_bypass_the_cache(eng):
+    N, K = 256, 512
+    c16 = make_case(N, K, torch.float16, seed=4, M=2)
+    qw, s, z = _dev(c16)
+    y = eng.gemv_forward_cuda_new(c16["x"].cuda(), qw, s, z, 2, N, K, 128).cpu()
+    check_forward(y, c16["x"], c16["q"], c16["scales"], c16["scaled_zeros"], torch.float16)
+    assert eng.cdna4_cache_info()["entries"] == 0
+    c = make_case(N, K, torch.bfloat16, seed=5, M=2)
+    qw, s, z = _dev(c)
+    eng.cdna4_cache_enable(False)
+    y = eng.gemv_forward_cuda_new(c["x"].cuda(), qw, s, z, 2, N, K, 128).cpu()
+    check_forward(y, c["x"], c["q"], c["scales"], c["scaled_zeros"], torch.bfloat16)
+    assert eng.cdna4_cache_info()["entries"] == 0
+    eng.cdna4_cache_enable(True)
+    # a first call INSIDE a hipGraph capture must not allocate / re-pack: it runs the reference-layout kernels
+    x = c["x"].cuda()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            yg = eng.gemv_forward_cuda_new(x, qw, s, z, 2, N, K, 128)
+        g.replay()
+    torch.cuda.synchronize()
+    assert eng.cdna4_cache_info()["entries"] == 0
+    check_forward(yg.cpu(), c["x"], c["q"], c["scales"], c["scaled_zeros"], torch.bfloat16)
