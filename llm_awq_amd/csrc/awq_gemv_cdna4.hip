@@ -21,7 +21,7 @@
 namespace awq {
 
 // the whole block's work for slab `nb`: shared by the plain kernel and the grouped (per-expert) kernel
-template <int WAVES, int S, int MB, int EPI, int BITS>
+template <int WAVES, int S, int MB, int EPI, int BITS, int PIPE>
 __device__ __forceinline__ void gemv_cdna4_body(char* smem, const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                 const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
                                                 uint16_t* __restrict__ out, int M, int N, int K, int nb) {
@@ -56,10 +56,12 @@ __device__ __forceinline__ void gemv_cdna4_body(char* smem, const uint16_t* __re
 #pragma unroll
   for (int s = 0; s < NS; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int c0 = 0; c0 < cnt; c0 += S) {
+  struct Regs {  // everything a wave needs from global memory for one chunk of S steps
     u32x4 xr[S][MB];
     u32x4 w[NS][S];
     u32 sz[NS][S];
+  };
+  auto load_chunk = [&](int c0, Regs& R) {
     // x slices first (vmcnt retires in order: their wait must not sit behind the weight stream)
 #pragma unroll
     for (int t = 0; t < S; ++t) {
@@ -70,7 +72,7 @@ __device__ __forceinline__ void gemv_cdna4_body(char* smem, const uint16_t* __re
         // bank sweep), the XOR spreads their equal granule indices over different banks
         const int r = min(4 * b + g, M - 1);
         const u32 xoff_b = ((u32)r * (u32)K + (u32)((i ^ (r & 15)) * 8)) * 2u;  // M * K * 2 < 2^32
-        xr[t][b] = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff_b, (u32)kg * 256u, 0);
+        R.xr[t][b] = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff_b, (u32)kg * 256u, 0);
       }
     }
 #pragma unroll
@@ -80,37 +82,63 @@ __device__ __forceinline__ void gemv_cdna4_body(char* smem, const uint16_t* __re
       for (int s = 0; s < NS; ++s) {
         const u32 tidx = slab_tile[s] + (u32)kg;
         if (BITS == 4) {
-          w[s][t] = __builtin_amdgcn_raw_buffer_load_b128(rw, wlane_b, tidx * 1024u, 2);  // aux 2 = nt (streamed once)
+          R.w[s][t] = __builtin_amdgcn_raw_buffer_load_b128(rw, wlane_b, tidx * 1024u, 2);  // aux 2 = nt (streamed once)
         } else {
           typedef u32 u32x3 __attribute__((ext_vector_type(3)));
           const u32x3 w3 = __builtin_amdgcn_raw_buffer_load_b96(rw, wlane_b, tidx * 768u, 2);
-          w[s][t] = u32x4{w3.x, w3.y, w3.z, 0u};
+          R.w[s][t] = u32x4{w3.x, w3.y, w3.z, 0u};
         }
-        sz[s][t] = __builtin_amdgcn_raw_buffer_load_b32(rs, ilane_b, tidx * 64u, 0);
+        R.sz[s][t] = __builtin_amdgcn_raw_buffer_load_b32(rs, ilane_b, tidx * 64u, 0);
       }
     }
+  };
+  auto compute_chunk = [&](int c0, const Regs& R) {
 #pragma unroll
     for (int t = 0; t < S; ++t)
 #pragma unroll
       for (int b = 0; b < MB; ++b)
         // unconditional: lanes past the last row hold a copy of row M - 1 and write it to that row's slot (same bytes).
         // A branch here lets hipcc sink the x loads behind the weight stream, whose in-order vmcnt then stalls the staging
-        *reinterpret_cast<u32x4*>(xs + t * xstep + min(4 * b + g, M - 1) * 256 + i * 16) = xr[t][b];
+        *reinterpret_cast<u32x4*>(xs + t * xstep + min(4 * b + g, M - 1) * 256 + i * 16) = R.xr[t][b];
 #pragma unroll
     for (int t = 0; t < S; ++t) {
-      if (wv + WAVES * (c0 + t) >= nit) continue;  // ragged tail: wave-uniform skip (the loads above were clamped)
+      if (wv + WAVES * (c0 + t) >= nit) continue;  // ragged tail: wave-uniform skip (the loads were clamped)
       const u32x4* xrow = reinterpret_cast<const u32x4*>(xs + t * xstep + mrow * 256);
       bf16x8 xop[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) xop[a] = __builtin_bit_cast(bf16x8, xrow[(4 * a + g) ^ (mrow & 15)]);
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        const u32 szv = sz[s][t];
+        const u32 szv = R.sz[s][t];
         bf16x8 op[4];
-        const u32x4 wt = BITS == 4 ? w[s][t] : w3_expand(w[s][t].x, w[s][t].y, w[s][t].z);
+        const u32x4 wt = BITS == 4 ? R.w[s][t] : w3_expand(R.w[s][t].x, R.w[s][t].y, R.w[s][t].z);
         cd.tile_packed(wt, szv, op);
 #pragma unroll
         for (int a = 0; a < 4; ++a) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(op[a], xop[a], acc[s], 0, 0, 0);
+      }
+    }
+  };
+  if (PIPE == 0) {
+    // every load of a chunk up front, then its math
+    for (int c0 = 0; c0 < cnt; c0 += S) {
+      Regs R;
+      load_chunk(c0, R);
+      compute_chunk(c0, R);
+    }
+  } else {
+    // software pipeline over a ring of PIPE register sets: the loads of the next PIPE - 1 chunks are in flight while a
+    // chunk is dequantised.  A wave keeps at most PIPE * S tiles in flight and -- with ~7 waves per SIMD -- the memory
+    // system serves the waves breadth first, so all of them compute at the same time instead of one after the other
+    // (loads past the end are clamped: L2 hits on the slab's last tile)
+    constexpr int D = PIPE > 0 ? PIPE : 1;  // (PIPE == 0 never gets here; keeps the array non-empty)
+    Regs R[D];
+#pragma unroll
+    for (int j = 0; j + 1 < D; ++j) load_chunk(j * S, R[j]);
+    for (int c0 = 0; c0 < cnt; c0 += D * S) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        load_chunk(c0 + (j + D - 1) * S, R[(j + D - 1) % D]);
+        compute_chunk(c0 + j * S, R[j]);
       }
     }
   }
@@ -146,14 +174,14 @@ __device__ __forceinline__ void gemv_cdna4_body(char* smem, const uint16_t* __re
   }
 }
 
-template <int WAVES, int S, int MB, int EPI, int BITS>
+template <int WAVES, int S, int MB, int EPI, int BITS, int PIPE>
 __global__ __launch_bounds__(64 * WAVES) void gemv_cdna4_kernel(const uint16_t* __restrict__ x,
                                                                  const u32* __restrict__ qw,
                                                                  const u32* __restrict__ szp,
                                                                  const uint16_t* __restrict__ bias,
                                                                  uint16_t* __restrict__ out, int M, int N, int K) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemv_cdna4_body<WAVES, S, MB, EPI, BITS>(smem, x, qw, szp, bias, out, M, N, K, blockIdx.x);
+  gemv_cdna4_body<WAVES, S, MB, EPI, BITS, PIPE>(smem, x, qw, szp, bias, out, M, N, K, blockIdx.x);
 }
 
 // Grouped (per-expert) decode GEMV for MoE layers: block = (expert, slab); expert e owns rows [offsets[e], offsets[e+1]) of
@@ -169,7 +197,7 @@ __global__ __launch_bounds__(64 * WAVES) void moe_gemv_cdna4_kernel(const uint16
   const int e = blockIdx.x / nslab, nb = blockIdx.x - e * nslab;
   const int row0 = offsets[e], m_e = offsets[e + 1] - row0;
   if (m_e <= 0) return;
-  gemv_cdna4_body<WAVES, S, MB, 0, 4>(smem, x + (size_t)row0 * K, qw + (size_t)e * nslab * nit * 256,
+  gemv_cdna4_body<WAVES, S, MB, 0, 4, 0>(smem, x + (size_t)row0 * K, qw + (size_t)e * nslab * nit * 256,
                                       szp + (size_t)e * nslab * nit * 16, nullptr, out + (size_t)row0 * N, min(m_e, 4 * MB), N, K, nb);
 }
 
@@ -177,14 +205,13 @@ namespace {
 struct Cfg {
   int waves, s;
 };
-// choose the K split (waves per slab) and the chunk length so that ~6-7 k waves are in flight chip-wide
-// and the wave-private x staging stays within ~48 KiB of LDS per block
+// choose the K split (waves per slab) and, for the chunk mode, the chunk length
 Cfg pick_cfg(int m, int n_rows, int k, int ns, int force_waves, int force_s) {
   // measured on MI355X (tools/gemvc_sweep.py, profiles/r01_gemvc_sweep.txt): short chunks (2..4 steps, 7 when the
   // step count is a multiple of 7) and ~7 k waves in flight chip-wide; a chunk longer than the wave's step count
   // only adds clamped loads
   const int nit = k / kGroup, slabs = n_rows / 16 / ns;
-  int waves = slabs >= 2048 ? 4 : (slabs >= 384 ? 8 : (nit >= 64 ? 8 : 16));
+  int waves = slabs >= 768 ? 4 : (slabs >= 384 ? 8 : (nit >= 64 ? 8 : 16));
   if (ns == 2 && waves > 4) waves >>= 1;  // two slabs per block: half the waves give the same bytes in flight
   while (waves > 4 && waves * 2 > nit) waves >>= 1;
   if (force_waves) waves = force_waves;
@@ -196,21 +223,26 @@ Cfg pick_cfg(int m, int n_rows, int k, int ns, int force_waves, int force_s) {
   return {waves, s};
 }
 int g_force_waves = 0, g_force_s = 0;
+// g_pipe: -1 = default (ring of 2, the measured optimum: profiles/r01_gemvc_ring_sweep.txt), 0 = all-loads-up-front chunks,
+// >= 2 = ring depth of the software pipeline; g_pipe_s: steps per chunk (0 = by steps per wave)
+int g_pipe = -1, g_pipe_s = 0;
 }  // namespace
 
 int gemv_cdna4_tune_set(const char* key, int value) {
   if (!strcmp(key, "gemvc_waves")) g_force_waves = value;
   else if (!strcmp(key, "gemvc_s")) g_force_s = value;
+  else if (!strcmp(key, "gemvc_pipe")) g_pipe = value;
+  else if (!strcmp(key, "gemvc_pipe_s")) g_pipe_s = value;
   else return -1;
   return 0;
 }
 
-template <int WAVES, int S, int MB, int EPI, int BITS>
+template <int WAVES, int S, int MB, int EPI, int BITS, int PIPE>
 static void launch_cfg(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                        hipStream_t st) {
   constexpr int NS = EPI == 1 ? 2 : 1;
   const size_t smem = (size_t)NS * WAVES * 1024 + (size_t)WAVES * S * m * 256;
-  auto kern = gemv_cdna4_kernel<WAVES, S, MB, EPI, BITS>;
+  auto kern = gemv_cdna4_kernel<WAVES, S, MB, EPI, BITS, PIPE>;
   if (smem > 64 * 1024) {
     static bool done = false;
     if (!done) {
@@ -226,10 +258,25 @@ template <int MB, int EPI, int BITS>
 static int launch_mb(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                      hipStream_t st) {
   const Cfg c = pick_cfg(m, n, k, EPI == 1 ? 2 : 1, g_force_waves, g_force_s);
-#define AWQ_CASE(W_, S_)                                                    \
-  if (c.waves == W_ && c.s == S_) {                                         \
-    launch_cfg<W_, S_, MB, EPI, BITS>(x, qw, szp, bias, out, m, n, k, st);        \
-    return 0;                                                               \
+  const int pipe = g_pipe < 0 ? 2 : g_pipe;
+  if (pipe >= 2) {  // software-pipelined variant: ring of `pipe` chunks of `ps` steps
+    const int per = (k / kGroup + c.waves - 1) / c.waves;
+    const int ps = g_pipe_s ? g_pipe_s : ((EPI == 1 || per >= 8) ? 2 : 1);
+#define AWQ_PCASE(W_, S_, D_)                                                  \
+  if (c.waves == W_ && ps == S_ && pipe == D_ && (size_t)W_ * S_ * m * 256 <= 96 * 1024) { \
+    launch_cfg<W_, S_, MB, EPI, BITS, D_>(x, qw, szp, bias, out, m, n, k, st); \
+    return 0;                                                                  \
+  }
+    AWQ_PCASE(4, 1, 2) AWQ_PCASE(4, 2, 2) AWQ_PCASE(8, 1, 2) AWQ_PCASE(8, 2, 2) AWQ_PCASE(16, 1, 2) AWQ_PCASE(16, 2, 2)
+    if (BITS == 4 && EPI == 0) {
+      AWQ_PCASE(4, 1, 3) AWQ_PCASE(8, 1, 3) AWQ_PCASE(16, 1, 3)
+    }
+#undef AWQ_PCASE
+  }
+#define AWQ_CASE(W_, S_)                                                      \
+  if (c.waves == W_ && c.s == S_) {                                           \
+    launch_cfg<W_, S_, MB, EPI, BITS, 0>(x, qw, szp, bias, out, m, n, k, st); \
+    return 0;                                                                 \
   }
   AWQ_CASE(4, 2) AWQ_CASE(4, 4) AWQ_CASE(4, 7) AWQ_CASE(4, 8) AWQ_CASE(8, 2) AWQ_CASE(8, 4) AWQ_CASE(8, 7) AWQ_CASE(8, 8)
   AWQ_CASE(16, 2) AWQ_CASE(16, 4) AWQ_CASE(16, 7) AWQ_CASE(16, 8)

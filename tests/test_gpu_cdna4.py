@@ -122,8 +122,11 @@ def test_gemm_cdna4_vs_oracle(ops, variant, M, N, K):
     check_forward(y, c["x"], c["q"], c["scales"], c["scaled_zeros"], dtype, bias=c["bias"])
 
 
-@pytest.mark.parametrize("knobs", [dict(gemvc_waves=4, gemvc_s=2), dict(gemvc_waves=4, gemvc_s=8), dict(gemvc_waves=8, gemvc_s=7),
-                                   dict(gemvc_waves=16, gemvc_s=4), dict(gemvc_waves=16, gemvc_s=8)])
+@pytest.mark.parametrize("knobs", [dict(gemvc_pipe=0, gemvc_waves=4, gemvc_s=2), dict(gemvc_pipe=0, gemvc_waves=4, gemvc_s=8),
+                                   dict(gemvc_pipe=0, gemvc_waves=8, gemvc_s=7), dict(gemvc_pipe=0, gemvc_waves=16, gemvc_s=4),
+                                   dict(gemvc_pipe=0, gemvc_waves=16, gemvc_s=8), dict(gemvc_pipe=2, gemvc_pipe_s=1, gemvc_waves=4),
+                                   dict(gemvc_pipe=2, gemvc_pipe_s=2, gemvc_waves=8), dict(gemvc_pipe=2, gemvc_pipe_s=2, gemvc_waves=16),
+                                   dict(gemvc_pipe=3, gemvc_pipe_s=1, gemvc_waves=8), dict(gemvc_pipe=2, gemvc_pipe_s=1, gemvc_waves=16)])
 def test_fast_gemv_knobs(ops, knobs):
     """decode fast path: every (waves, chunk) configuration incl. ragged step counts and more waves than steps."""
     try:
@@ -136,7 +139,7 @@ def test_fast_gemv_knobs(ops, knobs):
                 y = ops.gemm_cdna4(c["x"].cuda(), c4, c["scales"].cuda(), c["scaled_zeros"].cuda(), c["bias"].cuda(), szp)
                 check_forward(y.cpu(), c["x"], c["q"], c["scales"], c["scaled_zeros"], torch.bfloat16, bias=c["bias"])
     finally:
-        ops._capi.tune(gemvc_waves=0, gemvc_s=0)
+        ops._capi.tune(gemvc_waves=0, gemvc_s=0, gemvc_pipe=-1, gemvc_pipe_s=0)
 
 
 @pytest.mark.parametrize("M", [1, 2, 4, 7, 8])

@@ -60,6 +60,18 @@ def main():
                 _capi.check(L.awq_w4a16_forward_cdna4(x.data_ptr(), c["qw"].data_ptr(), c["s"].data_ptr(), c["z"].data_ptr(),
                                                       c["szp"].data_ptr(), None, out.data_ptr(), M, N, K, 128, 1, None, 0, st))
         ab = algo_bytes(M, K, N)
+        pipe_mode = os.environ.get("GEMVC_PIPE")
+        if pipe_mode:
+            for (pipe, ps) in ((0, 1), (2, 1), (2, 2), (3, 1)):
+                for waves in (4, 8, 16):
+                    _capi.tune(gemvc_waves=waves, gemvc_s=0, gemvc_pipe=pipe, gemvc_pipe_s=ps)
+                    us = time_graph(fn, copies)
+                    print(f"K={K:6d} N={N:6d} M={M} fused={fused} ring={pipe} step={ps} waves={waves:2d}  {us:8.2f} us  {ab / us / 1e3:8.1f} GB/s  "
+                          f"{ab / us / 1e3 / 80:5.1f}%", flush=True)
+            _capi.tune(gemvc_waves=0, gemvc_s=0, gemvc_pipe=-1, gemvc_pipe_s=0)
+            del copies
+            torch.cuda.empty_cache()
+            continue
         for waves in (0, 4, 8, 16):
             for s_ in ((0,) if waves == 0 else (2, 4, 7, 8)):
                 nit = K // 128

@@ -109,7 +109,31 @@ __global__ __launch_bounds__(64 * WAVES) void gemv2(const u32* __restrict__ qw, 
   }
   if (kmajor & 4) __builtin_amdgcn_s_setprio(0);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  if (DQ == 5) {
+  if (DQ == 6 || DQ == 7) {
+    // independent VALU-only (6) / MFMA-only (7) work of roughly the dequant's instruction count per step
+    u32 a0 = lane * 0x9E3779B9u, a1 = wv, a2 = nb, a3 = 0x12345u;
+    u32x4 fake = {a0, a1, a2, a3};
+    bf16x8 xo = __builtin_bit_cast(bf16x8, fake);
+#pragma unroll
+    for (int t = 0; t < S; ++t) {
+      if (DQ == 6) {
+#pragma unroll
+        for (int r = 0; r < 13; ++r) {
+          a0 = ((a0 >> 4) & 0x000F000Fu) | 0x43004300u;
+          a1 = ((a1 >> 8) & 0x000F000Fu) | (a0 + r);
+          a2 = ((a2 >> 12) & 0x000F000Fu) | (a1 ^ t);
+          a3 = ((a3 >> 4) & 0x000F000Fu) | a2;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 12; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xo, xo, acc, 0, 0, 0);
+      }
+    }
+    u32 sink = a0 ^ a1 ^ a2 ^ a3;
+#pragma unroll
+    for (int t = 0; t < S; ++t) sink ^= w[t].x ^ w[t].y ^ w[t].z ^ w[t].w ^ sz[t];
+    acc[1] += __builtin_bit_cast(float, sink & 0x3fffffffu);
+  } else if (DQ == 5) {
     Cdna4Dequant cd;
     cd.init(lane);
     u32x4 fake = {(u32)lane * 0x9E3779B9u, (u32)wv, (u32)nb, 0x12345u};
@@ -399,10 +423,11 @@ int main(int argc, char** argv) {
       }
     }
     run_all_ws<0, 1>(c, 0, "strm");
-    run_all_ws<1, 1>(c, 0, "mfma");
-    run_all_ws<1, 1>(c, 4, "mfmaP");
     run_all_ws<5, 1>(c, 0, "indep");
-    run_all_ws<5, 1>(c, 4, "indepP");
+    run_all_ws<6, 1>(c, 0, "valu");
+    run_all_ws<6, 1>(c, 2, "valuL2");
+    run_all_ws<7, 1>(c, 0, "mfmao");
+    run_all_ws<7, 1>(c, 2, "mfmaoL2");
     for (int r = 0; r < c.R; ++r) {
       CK(hipFree(c.qw[r]));
       CK(hipFree(c.szp[r]));
