@@ -218,6 +218,7 @@ struct GemvTune {
   int probe = 0;  // 1 = stream-only in the real access pattern, 2 = linear read, 3 = null kernel
   int probe_blocks = 2048;
   int x_budget_kib = 64;
+  int v2fast = 1;
 } g_tune;
 }  // namespace
 
@@ -227,9 +228,12 @@ int gemv_tune_set(const char* key, int value) {
   else if (!strcmp(key, "gemv_probe")) g_tune.probe = value;
   else if (!strcmp(key, "gemv_probe_blocks")) g_tune.probe_blocks = value;
   else if (!strcmp(key, "gemv_x_budget_kib")) g_tune.x_budget_kib = value;
+  else if (!strcmp(key, "gemv_v2fast")) g_tune.v2fast = value;
   else return -1;
   return 0;
 }
+
+bool gemv_v2fast_enabled() { return g_tune.v2fast && g_tune.probe == 0 && g_tune.waves == 0 && g_tune.pf == 0; }
 
 template <typename DT, int PF, int WAVES, int LAYOUT, bool SZP, int PROBE>
 static void launch_one(const void* x, const void* qw, const void* s, const void* z, const void* szp, void* out, int m,
@@ -295,6 +299,9 @@ static int launch_gemv_t(const void* x, const void* qw, const void* s, const voi
 int launch_gemv(const void* x, const void* qw, const void* s, const void* z, const void* szp, void* out, int m, int n,
                 int k, int dtype, int layout, hipStream_t st) {
   if (layout == 1) return launch_gemv_t<BF16, 1>(x, qw, s, z, szp, out, m, n, k, st);
+  // reference layout, m <= 8: the pipelined kernel of awq_gemv_v2fast.hip unless a knob of this file's kernel is set
+  if (gemv_v2fast_enabled() && launch_gemv_v2fast(x, qw, s, z, nullptr, out, m, n, k, k / kGroup, dtype, st) == 0)
+    return 0;
   return dtype == 0 ? launch_gemv_t<F16, 0>(x, qw, s, z, nullptr, out, m, n, k, st)
                     : launch_gemv_t<BF16, 0>(x, qw, s, z, nullptr, out, m, n, k, st);
 }

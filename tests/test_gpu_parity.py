@@ -74,6 +74,28 @@ def test_gemv_vs_oracle(ops, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [1, 4, 5, 8])
+@pytest.mark.parametrize("N,K", [(768, 768), (1024, 4096), (512, 14336)])
+def test_gemv_reference_layout_kernels_agree(ops, dtype, M, N, K):
+    """The pipelined reference-layout decode kernel (awq_gemv_v2fast.hip, default for M <= 8, N % 16 == 0) and the older
+    kernel of awq_gemv.hip (knob gemv_v2fast=0) both meet the oracle; they differ only in fp32 summation order."""
+    c = make_case(N, K, dtype, seed=M + N + K, M=M)
+    args = (c["x"].cuda(), c["qweight"].cuda(), c["scales"].cuda(), c["scaled_zeros"].cuda())
+    y_new = ops.gemv(*args).cpu()
+    ops._capi.tune(gemv_v2fast=0)
+    try:
+        y_old = ops.gemv(*args).cpu()
+    finally:
+        ops._capi.tune(gemv_v2fast=1)
+    check_forward(y_new, c["x"], c["q"], c["scales"], c["scaled_zeros"], dtype)
+    check_forward(y_old, c["x"], c["q"], c["scales"], c["scaled_zeros"], dtype)
+    # one-ulp-of-T differences at most (same products, same fp32 accumulator width)
+    d = (y_new.float() - y_old.float()).abs().max().item()
+    ref = y_old.float().abs().max().item()
+    assert d <= ref * (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -9)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("variant", [0, 1, 2])  # auto / force 128x128 / force 256x256
 @pytest.mark.parametrize("M", [8, 17, 64, 100, 128, 129, 200, 512, 777])
 @pytest.mark.parametrize("N,K", [(768, 768), (3072, 768), (768, 3072), (136, 1280)])
