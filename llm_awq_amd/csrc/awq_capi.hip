@@ -328,6 +328,7 @@ int awq_tune_set(const char* key, int value) {
   if (awq::gemv_tune_set(key, value) == 0) return AWQ_OK;
   if (awq::gemm_tune_set(key, value) == 0) return AWQ_OK;
   if (awq::gemv_cdna4_tune_set(key, value) == 0) return AWQ_OK;
+  if (awq::gemm_v3_tune_set(key, value) == 0) return AWQ_OK;
   return AWQ_ERR_SHAPE;
 }
 

@@ -188,6 +188,25 @@ struct Cdna4Dequant {
                 (__bf16)d1[0], (__bf16)d1[1], (__bf16)d1[2], (__bf16)d1[3]};
     return r;
   }
+  // the same in two halves, for kernels that put other work between the dequant MFMAs and the use of their results
+  struct Pending {
+    f32x4 d0, d1;
+  };
+  __device__ __forceinline__ Pending word_issue(u32 w, u32 b01, u32 b23, float cv) const {
+    const u32x2 a0 = {(w & kMask) | kMagic, ((w >> 4) & kMask) | kMagic};
+    const u32x2 a1 = {((w >> 8) & kMask) | kMagic, ((w >> 12) & kMask) | kMagic};
+    const u32x2 b = {b01, b23};
+    const f32x4 c = {cv, cv, cv, cv};
+    Pending p;
+    p.d0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a0), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+    p.d1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a1), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+    return p;
+  }
+  static __device__ __forceinline__ bf16x8 word_finish(const Pending& p) {
+    bf16x8 r = {(__bf16)p.d0[0], (__bf16)p.d0[1], (__bf16)p.d0[2], (__bf16)p.d0[3],
+                (__bf16)p.d1[0], (__bf16)p.d1[1], (__bf16)p.d1[2], (__bf16)p.d1[3]};
+    return r;
+  }
   // whole 1-KiB tile -> 4 operands (op[a] covers k = 32a + 8g + 0..7 of the tile's 128 k)
   __device__ __forceinline__ void tile(const u32x4& w, uint16_t s_bits, uint16_t z_bits, bf16x8 (&op)[4]) const {
     tile_packed(w, (u32)s_bits | ((u32)z_bits << 16), op);

@@ -13,6 +13,8 @@
 //   * NSL = 1 (256 x 128 tiles) doubles the tile count for shapes that would fill only half the chip with 256 x 256.
 // Numerics are those of every other kernel here: W = round_bf16(q*s + sz) exactly (matrix-core dequant), fp32
 // accumulation in K order, one rounding of the result -- bit-identical to the 128x128 kernel.
+#include <string.h>
+
 #include <type_traits>
 
 #include "awq_device.hpp"
@@ -318,8 +320,21 @@ void launch_v3(const void* x, const void* qw, const void* szp, const void* bias,
   hipLaunchKernelGGL(gemm_cdna4_v3_kernel<NSL>, dim3(tiles_m * tiles_n), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw,
                      (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end);
 }
-constexpr double kNarrowRate = 0.84;  // 256 x 128 tiles vs 256 x 256 at equal chip fill (profiles/r01_gemm_v3_tiles.txt)
+constexpr double kNarrowRate = 0.77;  // 256 x 128 tiles (v3 K loop) vs 256 x 256 (v4 K loop) at equal chip fill (profiles/r01_gemm_v4.txt)
+int g_v4 = 1;  // 1 (default): 256-wide tiles run the hand-scheduled K loop of awq_gemm_v4.hip; 0: v3's compiler-scheduled loop
+void launch_wide(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
+                 int n_end, hipStream_t st) {
+  if (g_v4) launch_gemm_cdna4_v4(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
+  else launch_v3<2>(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
+}
 }  // namespace
+
+int gemm_v3_tune_set(const char* key, int value) {
+  if (!strcmp(key, "gemm_v4")) g_v4 = value;
+  else if (!strcmp(key, "gemm_v4_probe")) gemm_v4_set_probe(value);
+  else return -1;
+  return 0;
+}
 
 // tile_n: 0 = pick by chip fill (256 CUs, one block per CU), 128 / 256 = force one width for the whole matrix.
 // In auto mode a matrix whose 256-wide tile count is k full rounds plus a partial one runs the full rounds with 256-wide
@@ -332,7 +347,7 @@ int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, const v
     return 0;
   }
   if (tile_n == 256) {
-    launch_v3<2>(x, qw, szp, bias, out, m, n, k, 0, n, st);
+    launch_wide(x, qw, szp, bias, out, m, n, k, 0, n, st);
     return 0;
   }
   const long tiles_m = (m + TM - 1) / TM;
@@ -348,12 +363,12 @@ int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, const v
     cost_mixed = rounds(tiles_m * cols_main) + rounds(tiles_m * ((n_rest + 127) / 128)) * 0.5 / kNarrowRate + 0.02;
   }
   if (cost_mixed < cost_wide && cost_mixed < cost_narrow) {
-    launch_v3<2>(x, qw, szp, bias, out, m, n, k, 0, (int)(cols_main * 256), st);
+    launch_wide(x, qw, szp, bias, out, m, n, k, 0, (int)(cols_main * 256), st);
     launch_v3<1>(x, qw, szp, bias, out, m, n, k, (int)(cols_main * 256), n, st);
   } else if (cost_narrow < cost_wide) {
     launch_v3<1>(x, qw, szp, bias, out, m, n, k, 0, n, st);
   } else {
-    launch_v3<2>(x, qw, szp, bias, out, m, n, k, 0, n, st);
+    launch_wide(x, qw, szp, bias, out, m, n, k, 0, n, st);
   }
   return 0;
 }

@@ -1,0 +1,357 @@
+// Prefill GEMM v4 on cdna4-interleaved weights (bf16, gfx950): the tiling and data flow of awq_gemm_v3.hip's 256 x 256 x 64
+// kernel (8 waves = 2 along M x 4 along N, 128 x 64 each, v_mfma_f32_32x32x16_bf16, x tile by LDS-DMA, weight tile
+// dequantised on the matrix core one word per k-step, double-buffered LDS) with every LDS access of the K loop placed by
+// hand.
+//
+// Why: at 256 VGPRs hipcc shortens live ranges by sinking v3's fragment reads next to their uses -- its K loop has two
+// exposed LDS round trips per k-step ([4 MFMA] read wait [4 MFMA] 5 reads wait) and the matrix pipe is busy 66 % of the
+// time (profiles/r01_pmc_gemm_v3.txt).  Here the fragment reads and the weight-tile writes are `asm volatile`
+// statements hipcc neither counts nor moves, each fragment is re-read for the NEXT k-step right after the last MFMA
+// that consumes it, and the waits are counted `s_waitcnt lgkmcnt(N)` ladders naming the registers they guard:
+//
+//   k-step:   A1 A2 A3 A4 | D1 D2 | [barrier] | R(w0') | B1 | cvt, W | R(x0') B2 R(x1') B3 R(x2') B4 R(x3') R(w1')
+//
+// (A_b = MFMA(w0, x_b), B_b = MFMA(w1, x_b), D = the two dequant MFMAs of this step's weight word, W = its ds_write,
+// R = ds_read_b128 of a fragment of the next k-step.)  LDS operations return in order, so in front of A1 the queue is
+// [w0' W x0' x1' x2' x3' w1']: A1 needs lgkmcnt(4), A2 (3), A3 (2), A4 (1), B1 needs w1' = lgkmcnt(1) behind R(w0'').
+// Numerics are v3's (same products, same fp32 accumulation order): results are bit-identical.
+#include <type_traits>
+
+#include "awq_device.hpp"
+#include "awq_kernels.hpp"
+
+namespace awq {
+
+namespace {
+constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int kTileX = TM * TK * 2;  // 32 KiB: x tile [256][64] bf16; LDS: x stage 0 | x stage 1 | w stage 0 | w stage 1
+constexpr int kTileW = TN * TK * 2;  // 32 KiB
+constexpr int kWBase = 2 * kTileX;
+constexpr int WN = 64;               // weight rows per wave
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int tile_off(int row, int gc) { return row * 128 + ((gc ^ ((row >> 1) & 7)) << 4); }
+
+struct Group {  // one quantisation group (128 k) of the wave's two slabs
+  u32x4 w[2];
+  u32 b01[2], b23[2];
+  float c[2];
+};
+struct Raw {
+  u32x4 w[2];
+  u32 sz[2];
+};
+template <int V>
+using ic = std::integral_constant<int, V>;
+template <bool V>
+using bc = std::integral_constant<bool, V>;
+template <int H, int J, int ST>
+struct JobT {  // word 2 H + (J & 1) of slab (J >> 1) -> weight stage ST
+  static constexpr bool has = true;
+  static constexpr int h = H, j = J, st = ST;
+};
+struct NoJob {
+  static constexpr bool has = false;
+  static constexpr int h = 0, j = 0, st = 0;
+};
+}  // namespace
+
+// LDS accesses outside hipcc's s_waitcnt bookkeeping and scheduling (the "memory" clobber keeps their mutual order)
+#define V4_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define V4_WRITE(addr, val, off) asm volatile("ds_write_b128 %0, %1 offset:%2\n\ts_nop 1" : : "v"(addr), "v"(val), "n"(off) : "memory")
+#define V4_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+template <int PROBE>  // experiments (timing only, wrong results): 1 = the x DMA always fetches K-tile 0 (cache hits), 2 = no x DMA
+__global__ __launch_bounds__(512) void gemm_cdna4_v4_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
+                                                            const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
+                                                            uint16_t* __restrict__ out, int M, int N, int K, int tiles_m,
+                                                            int tiles_n, int n_begin, int n_end) {
+  constexpr int kEpiRow = 2 * WN + 16;  // bytes per staged output row (+16 pad)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int l32 = lane & 31, hk = lane >> 5;
+  const int wm = wv >> 2, wn = wv & 3;
+
+  // XCD-aware, two-row-band tile order: as v3 (awq_gemm_v3.hip)
+  const int T = tiles_m * tiles_n;
+  int tile;
+  {
+    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    const int q = T >> 3, r = T & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tm, tn;
+  {
+    const int full = (tiles_m >> 1) * 2 * tiles_n;
+    if (tile < full) {
+      const int band = tile / (2 * tiles_n), rem = tile - band * 2 * tiles_n;
+      tn = rem >> 1;
+      tm = 2 * band + (rem & 1);
+    } else {
+      tn = tile - full;
+      tm = tiles_m - 1;
+    }
+  }
+  const int m0 = min(tm * TM, M - TM), n0 = n_begin + tn * TN;
+  const int nit = K >> 7;
+
+  // ---- x tile: LDS-DMA, 4 x 16 B per thread per K-tile; swizzle applied to the SOURCE granule ----
+  u32 a_off0;
+  {
+    const int row = tid >> 3, gcp = tid & 7;
+    const int gc = gcp ^ ((row >> 1) & 7);
+    a_off0 = (u32)(m0 + row) * (u32)K + gc * 8;
+  }
+  auto issue_a = [&](int kt, int stage) {
+    if (PROBE == 2) return;
+    if (PROBE == 1) kt = 0;
+    char* dst = smem + stage * kTileX + wv * 1024;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint16_t* xq = x + (size_t)kt * TK + (size_t)q * 64 * K;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xq + a_off0),
+                                       (__attribute__((address_space(3))) void*)(dst + q * 8192), 16, 0, 0);
+    }
+  };
+
+  // ---- weight tile: wave wv owns slabs 2 wv, 2 wv + 1 of the 256-row tile ----
+  const int nslab = N >> 4;
+  u32 b_off[2], sz_off[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int sl = min((n0 >> 4) + 2 * wv + s, min(nslab, n_end >> 4) - 1);
+    b_off[s] = (u32)sl * nit * 256 + lane * 4;
+    sz_off[s] = (u32)sl * nit * 16 + i;
+  }
+  const int nl = 32 * wv + i;  // tile row of slab 0's lane row; slab 1 = + 16
+  Cdna4Dequant cd;
+  cd.init(lane);
+
+  auto load_group = [&](int grp) {
+    Raw r;
+    const u32* qg = qw + (size_t)grp * 256;
+    const u32* sg = szp + (size_t)grp * 16;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      r.w[s] = *reinterpret_cast<const u32x4*>(qg + b_off[s]);
+      r.sz[s] = sg[sz_off[s]];
+    }
+    return r;
+  };
+  auto prep = [&](const Raw& r) {
+    Group gq;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      gq.w[s] = r.w[s];
+      const u32 sd = (r.sz[s] & 0xFFFFu) * 0x00010001u;
+      gq.b01[s] = sd & cd.m01;
+      gq.b23[s] = sd & cd.m23;
+      gq.c[s] = __builtin_fmaf(-128.0f, __builtin_bit_cast(float, r.sz[s] << 16), __builtin_bit_cast(float, r.sz[s] & 0xFFFF0000u));
+    }
+    return gq;
+  };
+
+  // ---- LDS byte addresses (the dynamic segment starts at LDS offset of `smem`) ----
+  const u32 lds0 = (u32)(size_t)(__attribute__((address_space(3))) char*)smem;
+  u32 xa[4], wa[4], ja[2];  // per k-step fragment addresses (stage 0, fragment 0); job destinations (word parity)
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    xa[ks] = lds0 + tile_off(wm * 128 + l32, 2 * ks + hk);
+    wa[ks] = lds0 + kWBase + tile_off(wn * WN + l32, 2 * ks + hk);
+  }
+#pragma unroll
+  for (int b = 0; b < 2; ++b) ja[b] = lds0 + kWBase + tile_off(nl, 4 * b + g);
+
+  u32x4 w0, w1, x0, x1, x2, x3;  // fragments (single set)
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  auto mf = [](const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  };
+
+  Group gc;
+  // one k-step (header comment).  SN / KN: stage and k-step whose fragments are read for the next step; RD: read them;
+  // BAR: the block barrier of the K-tile sits behind cluster A; job: the weight word produced in this step.
+  auto step = [&](auto sn_, auto kn_, auto rd_, auto bar_, auto job_) {
+    constexpr int SN = decltype(sn_)::value, KN = decltype(kn_)::value;
+    constexpr bool RD = decltype(rd_)::value, BAR = decltype(bar_)::value;
+    using J = decltype(job_);
+    // cluster A behind its wait ladder; the fences keep each MFMA between "its" wait and the next one (without them
+    // hipcc bunches the four waits in front of A1, i.e. waits for x3' -- the read issued last -- before any MFMA)
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(w0), "+v"(x0));
+    acc[0][0] = mf(w0, x0, acc[0][0]);
+    V4_FENCE();
+    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(x1));
+    acc[0][1] = mf(w0, x1, acc[0][1]);
+    V4_FENCE();
+    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(x2));
+    acc[0][2] = mf(w0, x2, acc[0][2]);
+    V4_FENCE();
+    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(x3));
+    acc[0][3] = mf(w0, x3, acc[0][3]);
+    Cdna4Dequant::Pending pj;
+    if constexpr (J::has) {  // the two dequant MFMAs of this step's weight word queue behind A4
+      constexpr int widx = 2 * J::h + (J::j & 1), s = J::j >> 1;
+      const u32 word = widx == 0 ? gc.w[s].x : (widx == 1 ? gc.w[s].y : (widx == 2 ? gc.w[s].z : gc.w[s].w));
+      pj = cd.word_issue(word, gc.b01[s], gc.b23[s], gc.c[s]);
+    }
+    if constexpr (BAR) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w1));
+      __syncthreads();  // + vmcnt(0): the next tile's x DMA and packed words have landed; every read of the other stage retired
+    }
+    V4_FENCE();
+    if constexpr (RD) V4_READ(w0, wa[KN], SN * kTileW);
+    if constexpr (!BAR) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(w1) : "n"(RD ? 1 : 0));
+    V4_FENCE();
+    acc[1][0] = mf(w1, x0, acc[1][0]);
+    if constexpr (J::has) {
+      const bf16x8 v = Cdna4Dequant::word_finish(pj);
+      V4_WRITE(ja[J::j & 1], __builtin_bit_cast(u32x4, v), J::st * kTileW + (J::j >> 1) * 2048);
+    }
+    V4_FENCE();
+    if constexpr (RD) V4_READ(x0, xa[KN], SN * kTileX);
+    acc[1][1] = mf(w1, x1, acc[1][1]);
+    V4_FENCE();
+    if constexpr (RD) V4_READ(x1, xa[KN], SN * kTileX + 4096);
+    acc[1][2] = mf(w1, x2, acc[1][2]);
+    V4_FENCE();
+    if constexpr (RD) V4_READ(x2, xa[KN], SN * kTileX + 8192);
+    acc[1][3] = mf(w1, x3, acc[1][3]);
+    V4_FENCE();
+    if constexpr (RD) {
+      V4_READ(x3, xa[KN], SN * kTileX + 12288);
+      V4_READ(w1, wa[KN], SN * kTileW + 4096);
+    }
+    V4_FENCE();
+  };
+
+  // ---------------- prologue: tile 0 complete in stage 0, tile 1's x tile in flight, its first weight word written ----
+  issue_a(0, 0);
+  gc = prep(load_group(0));
+  Raw rn = load_group(nit > 1 ? 1 : 0);
+  {
+    char* Bs = smem + kWBase;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int s = j >> 1;
+      const u32 word = (j & 1) ? gc.w[s].y : gc.w[s].x;
+      *reinterpret_cast<bf16x8*>(Bs + tile_off(nl + 16 * s, 4 * (j & 1) + g)) = cd.word(word, gc.b01[s], gc.b23[s], gc.c[s]);
+    }
+  }
+  __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and the ds_writes
+#pragma unroll
+  for (int s = 0; s < 2; ++s) asm volatile("" : "+v"(rn.w[s]), "+v"(rn.sz[s]));  // as v3: no pending ordinary load enters the loop
+  issue_a(1, 1);
+  V4_FENCE();
+  // first word of tile 1 = (group 0, half 1) -> stage 1, then the fragments of k-step 0 in the order the ladder expects
+  {
+    const bf16x8 v = cd.word(gc.w[0].z, gc.b01[0], gc.b23[0], gc.c[0]);
+    V4_WRITE(ja[0], __builtin_bit_cast(u32x4, v), kTileW);
+  }
+  V4_READ(w0, wa[0], 0);
+  V4_READ(x0, xa[0], 0);
+  V4_READ(x1, xa[0], 4096);
+  V4_READ(x2, xa[0], 8192);
+  V4_READ(x3, xa[0], 12288);
+  V4_READ(w1, wa[0], 4096);
+  V4_FENCE();
+
+  // One iteration = one quantisation group = two K-tiles (2q in stage 0, 2q + 1 in stage 1); the last group is peeled.
+  auto group_iter = [&](int q, auto more_tag) {
+    constexpr bool more = decltype(more_tag)::value;
+    using T = bc<true>;
+    using F = bc<false>;
+    // ---------- K-tile 2q (stage 0); writes words 1..3 of tile 2q+1 = (group q, half 1) into stage 1 ----------
+    step(ic<0>{}, ic<1>{}, T{}, F{}, JobT<1, 1, 1>{});
+    step(ic<0>{}, ic<2>{}, T{}, F{}, JobT<1, 2, 1>{});
+    step(ic<0>{}, ic<3>{}, T{}, F{}, JobT<1, 3, 1>{});
+    if constexpr (more) {
+      gc = prep(rn);  // group q+1: loaded one iteration ago, retired by the previous barrier's vmcnt(0)
+      step(ic<1>{}, ic<0>{}, T{}, T{}, JobT<0, 0, 0>{});  // barrier inside; first word of tile 2q+2 -> stage 0
+      rn = load_group(min(q + 2, nit - 1));
+      issue_a(2 * q + 2, 0);
+      V4_FENCE();
+      step(ic<1>{}, ic<1>{}, T{}, F{}, JobT<0, 1, 0>{});
+      step(ic<1>{}, ic<2>{}, T{}, F{}, JobT<0, 2, 0>{});
+      step(ic<1>{}, ic<3>{}, T{}, F{}, JobT<0, 3, 0>{});
+      step(ic<0>{}, ic<0>{}, T{}, T{}, JobT<1, 0, 1>{});  // barrier inside; first word of tile 2q+3 -> stage 1
+      issue_a(2 * q + 3, 1);
+      V4_FENCE();
+    } else {
+      step(ic<1>{}, ic<0>{}, T{}, T{}, NoJob{});
+      step(ic<1>{}, ic<1>{}, T{}, F{}, NoJob{});
+      step(ic<1>{}, ic<2>{}, T{}, F{}, NoJob{});
+      step(ic<1>{}, ic<3>{}, T{}, F{}, NoJob{});
+      step(ic<0>{}, ic<0>{}, F{}, T{}, NoJob{});
+    }
+  };
+  for (int q = 0; q + 1 < nit; ++q) group_iter(q, std::true_type{});
+  group_iter(nit - 1, std::false_type{});
+
+  // ---------------- epilogue through LDS: acc[a][b][r] = C[n = wn*64 + a*32 + (r&3) + 8 (r>>2) + 4 hk][m = wm*128 + b*32 + l32] ----
+  __syncthreads();
+  char* eb = smem + wv * (128 * kEpiRow);
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        u32x2 v;
+        v.x = (u32)BF16::from_float(acc[a][b][4 * j + 0]) | ((u32)BF16::from_float(acc[a][b][4 * j + 1]) << 16);
+        v.y = (u32)BF16::from_float(acc[a][b][4 * j + 2]) | ((u32)BF16::from_float(acc[a][b][4 * j + 3]) << 16);
+        *reinterpret_cast<u32x2*>(eb + (b * 32 + l32) * kEpiRow + (a * 32 + 8 * j + 4 * hk) * 2) = v;
+      }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's own LDS writes (region is wave-private)
+  __builtin_amdgcn_wave_barrier();
+  constexpr int GR = WN / 8, RP = 64 / GR;
+#pragma unroll
+  for (int ps = 0; ps < 128 / RP; ++ps) {
+    const int row = ps * RP + lane / GR, gc2 = lane % GR;
+    const int m = m0 + wm * 128 + row, nn = n0 + wn * WN + gc2 * 8;
+    u32x4 v = *reinterpret_cast<const u32x4*>(eb + row * kEpiRow + gc2 * 16);
+    if (nn < n_end) {
+      if (bias != nullptr) {  // `out + self.bias` in T (qmodule.py:221)
+        const u32x4 bv = *reinterpret_cast<const u32x4*>(bias + nn);
+        auto add2 = [](u32 a, u32 b) {
+          const float lo = __builtin_bit_cast(float, a << 16) + __builtin_bit_cast(float, b << 16);
+          const float hi = __builtin_bit_cast(float, a & 0xFFFF0000u) + __builtin_bit_cast(float, b & 0xFFFF0000u);
+          return (u32)BF16::from_float(lo) | ((u32)BF16::from_float(hi) << 16);
+        };
+        v = u32x4{add2(v.x, bv.x), add2(v.y, bv.y), add2(v.z, bv.z), add2(v.w, bv.w)};
+      }
+      *reinterpret_cast<u32x4*>(out + (size_t)m * N + nn) = v;
+    }
+  }
+}
+
+namespace {
+int g_v4_probe = 0;
+}
+// weight rows [n_begin, n_end) of the matrix with 256 x 256 tiles (m >= 256); same contract as v3's launch_v3<2>
+void launch_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
+                          int n_begin, int n_end, hipStream_t st) {
+  constexpr int smem_main = 2 * kTileX + 2 * kTileW;
+  constexpr int smem_epi = 8 * 128 * (2 * WN + 16);
+  constexpr int smem = smem_main > smem_epi ? smem_main : smem_epi;
+  const int tiles_m = (m + TM - 1) / TM, tiles_n = (n_end - n_begin + TN - 1) / TN;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cdna4_v4_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cdna4_v4_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cdna4_v4_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr = true;
+  }
+  auto kern = g_v4_probe == 1 ? gemm_cdna4_v4_kernel<1> : (g_v4_probe == 2 ? gemm_cdna4_v4_kernel<2> : gemm_cdna4_v4_kernel<0>);
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw,
+                     (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end);
+}
+void gemm_v4_set_probe(int v) { g_v4_probe = v; }
+
+}  // namespace awq

@@ -44,6 +44,11 @@ int launch_moe_gemm(const void* x, const void* qw, const void* s, const void* z,
                     int experts, int n, int k, int gpad, int dtype, int layout, hipStream_t st);
 int gemv_tune_set(const char* key, int value);
 int gemm_tune_set(const char* key, int value);
+int gemm_v3_tune_set(const char* key, int value);  // gemm_v4, gemm_v4_probe
+void gemm_v4_set_probe(int v);
+// 256 x 256-tile prefill GEMM with the hand-scheduled K loop (awq_gemm_v4.hip): weight rows [n_begin, n_end), m >= 256
+void launch_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
+                          int n_begin, int n_end, hipStream_t st);
 int launch_bias_add(void* out, const void* bias, int m, int n, int dtype, hipStream_t st);
 int launch_unpack_v2(const void* qw, void* out_u8, int n, int k, hipStream_t st);
 int launch_dequant_v2(const void* qw, const void* s, const void* z, void* out, int n, int k, int dtype, hipStream_t st);

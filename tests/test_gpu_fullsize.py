@@ -96,6 +96,28 @@ def test_gemm_v3_tile_widths_identical(env, variant):
         assert torch.equal(y, ref), M  # same K order, same numerics: bit-identical to the 128 x 128 kernel
 
 
+@pytest.mark.parametrize("bias", [False, True])
+def test_gemm_v4_identical_to_v3(env, bias):
+    """The hand-scheduled K loop (awq_gemm_v4.hip, default for 256-wide tiles) and v3's compiler-scheduled loop (knob gemm_v4=0)
+    issue the same products in the same order: bit-identical outputs, ragged M and ragged N-tile edges included."""
+    ops, synth = env
+    for (K, N) in ((4096, 6144), (1024, 1296), (14336, 4096)):
+        w = synth.random_wq(K, N, dtype=torch.bfloat16, seed=K + N, keep_q=False)
+        c4 = ops.repack_v2_to_cdna4(w["qweight"])
+        szp = ops.pack_sz_cdna4(w["scales"], w["scaled_zeros"], K)
+        b = (torch.randn(N, device="cuda") * 0.02).bfloat16() if bias else None
+        for M in (256, 300, 1000, 2048):
+            x = torch.randn(M, K, device="cuda").bfloat16()
+            ops._capi.tune(gemm_variant=4, gemm_v4=0)
+            try:
+                ref = ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], b, szp)
+                ops._capi.tune(gemm_v4=1)
+                y = ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], b, szp)
+            finally:
+                ops._capi.tune(gemm_variant=0, gemm_v4=1)
+            assert torch.equal(y, ref), (K, N, M)
+
+
 def test_fused_mlp_fullsize(env):
     """Llama-3-8B gate/up (2 x 14336 x 4096) in one launch == two GEMVs + F.silu + mul on the same buffers."""
     ops, synth = env
