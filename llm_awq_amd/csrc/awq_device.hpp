@@ -150,13 +150,16 @@ __device__ __forceinline__ u32x4 ldg_nt_u32x4(const u32* p) {
 // =============================================================================================
 // "cdna4" interleave (this repository's MI355X-native layout; emitted by the rewritten repacker).
 // Same bytes/shape as v2, nibbles permuted so that a 1-KiB tile = 16 rows x 128 k is ONE contiguous
-// wave-load and every extraction (word >> 4i) & 0x000F000F | 0x43004300 is directly the A-operand
-// register of a v_mfma_f32_16x16x16_bf16 that dequantises ON THE MATRIX CORE:
+// wave-load and every extraction (word >> 4i) & 0x000F000F | 0x43004300 is directly an A-operand
+// register of a v_mfma_f32_4x4x4_16B_bf16 (16 independent 4 x 4 x 4 blocks, block = lane / 4) that dequantises
+// ON THE MATRIX CORE -- per block (k octet g, row quad nq), rows = 4 k, inner = the quad's 4 rows n':
 //      D[k][n] = sum_n' (128 + Q[n'][k]) * (s_n [n'==n])  +  (sz_n - 128 s_n)  =  Q[n][k] s_n + sz_n   (exact in fp32)
-// lane l = 16 g + kl, word a, nibble p (i = p & 3, hi = p >> 2):
-//      n = 16 nb + 4 g + 2 (i & 1) + hi,   k = 128 kg + 32 a + 8 (kl / 4) + 4 (i >> 1) + kl % 4
+// lane l = 16 g + 4 nq + r, word a, nibble p (i = p & 3, hi = p >> 2):
+//      n = 16 nb + 4 nq + 2 (i & 1) + hi,   k = 128 kg + 32 a + 8 g + 4 (i >> 1) + r
 // D comes out with lane (n = l % 16, g = l / 16) holding k = 32 a + 8 g + {0..3} (first MFMA) and
 // + {4..7} (second): after v_cvt_pk_bf16_f32 that IS the operand of the matmul MFMA 16x16x32.
+// (The 4x4x4 form issues at twice the rate of a 16x16x16 with a diagonal B operand -- measured 3.9 vs 7.5 ns per
+// instruction per SIMD, tools/ubench/mfma4x4_probe.hip -- and wastes 3/4 instead of 15/16 of its products.)
 // =============================================================================================
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -166,7 +169,7 @@ struct Cdna4Dequant {
   u32 m01, m23;  // lane masks selecting where s_n sits in the diagonal B operand
   u32 kMagic, kMask;
   __device__ __forceinline__ void init(int lane, u32 nibble_mask = 0x000F000Fu) {
-    const int pos = (lane & 15) - 4 * (lane >> 4);
+    const int pos = lane & 3;  // B operand of block lane / 4: column lane % 4 = this lane's row n, nonzero at inner index pos
     m01 = pos == 0 ? 0x0000FFFFu : (pos == 1 ? 0xFFFF0000u : 0u);
     m23 = pos == 2 ? 0x0000FFFFu : (pos == 3 ? 0xFFFF0000u : 0u);
     // gfx950 VOP3 takes no 32-bit literal: park the magic in a VGPR and the mask in an SGPR so that
@@ -176,14 +179,14 @@ struct Cdna4Dequant {
     asm volatile("" : "+v"(kMagic));
     asm volatile("" : "+s"(kMask));
   }
-  // one word (two 16x16x16 MFMAs) -> one bf16x8 operand: W[n = lane%16][k = 32a + 8g + 0..7]
+  // one word (two 4x4x4 16-block MFMAs) -> one bf16x8 operand: W[n = lane%16][k = 32a + 8g + 0..7]
   __device__ __forceinline__ bf16x8 word(u32 w, u32 b01, u32 b23, float cv) const {
     const u32x2 a0 = {(w & kMask) | kMagic, ((w >> 4) & kMask) | kMagic};
     const u32x2 a1 = {((w >> 8) & kMask) | kMagic, ((w >> 12) & kMask) | kMagic};
     const u32x2 b = {b01, b23};
     const f32x4 c = {cv, cv, cv, cv};
-    const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a0), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
-    const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a1), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+    const f32x4 d0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, a0), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+    const f32x4 d1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, a1), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
     bf16x8 r = {(__bf16)d0[0], (__bf16)d0[1], (__bf16)d0[2], (__bf16)d0[3],
                 (__bf16)d1[0], (__bf16)d1[1], (__bf16)d1[2], (__bf16)d1[3]};
     return r;
@@ -198,8 +201,8 @@ struct Cdna4Dequant {
     const u32x2 b = {b01, b23};
     const f32x4 c = {cv, cv, cv, cv};
     Pending p;
-    p.d0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a0), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
-    p.d1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a1), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+    p.d0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, a0), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+    p.d1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, a1), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
     return p;
   }
   static __device__ __forceinline__ bf16x8 word_finish(const Pending& p) {

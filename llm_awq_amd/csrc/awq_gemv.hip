@@ -13,7 +13,7 @@
 //       LAYOUT 0  reference v2 interleave: 16 B per lane = 32 k of one row; unpack + dequant on the VALU
 //                 (round_T(q*s+sz), bit-exact with the reference's __hfma2), fp16 and bf16.
 //       LAYOUT 1  "cdna4" interleave (bf16): one contiguous 1-KiB tile per wave-load, dequantised ON THE
-//                 MATRIX CORE by two v_mfma_f32_16x16x16_bf16 per word (awq_device.hpp) -- ~2.5x fewer
+//                 MATRIX CORE by two v_mfma_f32_4x4x4_16B_bf16 per word (awq_device.hpp) -- ~2.5x fewer
 //                 VALU instructions per weight.
 //   * the dequantised weights are the A operand of v_mfma_f32_16x16x32, the activation rows the B
 //     operand: one MFMA per 512 weights whatever M is.  Split-K partials are reduced through LDS in fp32;

@@ -139,7 +139,7 @@ __device__ __forceinline__ u32 cdna4_read_nibble(const u32* qw, int n, int k, in
   const int nb = n >> 4, c = n & 15, g = c >> 2, j = c & 3;
   const int kg = k >> 7, kk = k & 127, a = kk >> 5, r32 = kk & 31;
   const int b8 = r32 >> 3, e = r32 & 7, th = e >> 2, rr = e & 3;
-  const int lane = 16 * g + 4 * b8 + rr;
+  const int lane = 16 * b8 + 4 * g + rr;  // k octet | row quad | k within the quartet
   const int p = (2 * th + (j >> 1)) + 4 * (j & 1);
   return (qw[cdna4_tile_word(nb, kg, K >> 7) + lane * 4 + a] >> (4 * p)) & 0xFu;
 }
@@ -151,13 +151,13 @@ __global__ void repack_v2_to_cdna4_kernel(const u32* __restrict__ src, u32* __re
   const size_t tile = t >> 8;
   const int nit = K >> 7;
   const int nb = (int)(tile / nit), kg = (int)(tile % nit);
-  const int g = lane >> 4, kl = lane & 15;
+  const int g = lane >> 4, nq = (lane >> 2) & 3, r = lane & 3;
   u32 w = 0;
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
     const int i = p & 3, hi = p >> 2;
-    const int n = 16 * nb + 4 * g + 2 * (i & 1) + hi;
-    const int k = 128 * kg + 32 * a + 8 * (kl >> 2) + 4 * (i >> 1) + (kl & 3);
+    const int n = 16 * nb + 4 * nq + 2 * (i & 1) + hi;
+    const int k = 128 * kg + 32 * a + 8 * g + 4 * (i >> 1) + r;
     w |= v2_read_nibble(src, n, k, K) << (4 * p);
   }
   dst[t] = w;

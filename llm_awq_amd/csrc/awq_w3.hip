@@ -9,9 +9,9 @@ namespace awq {
 
 // logical (n, k) held by nibble p of logical word a of lane `lane` of a cdna4 tile (see awq_device.hpp)
 __device__ __forceinline__ void cdna4_nibble_nk(int lane, int a, int p, int& n_in_slab, int& k_in_group) {
-  const int g = lane >> 4, kl = lane & 15, i = p & 3, hi = p >> 2;
-  n_in_slab = 4 * g + 2 * (i & 1) + hi;
-  k_in_group = 32 * a + 8 * (kl >> 2) + 4 * (i >> 1) + (kl & 3);
+  const int g = lane >> 4, nq = (lane >> 2) & 3, r = lane & 3, i = p & 3, hi = p >> 2;
+  n_in_slab = 4 * nq + 2 * (i & 1) + hi;
+  k_in_group = 32 * a + 8 * g + 4 * (i >> 1) + r;
 }
 
 // one thread per (tile, lane): gather the 32 integers of the lane's four logical words, fold, store 3 words

@@ -76,9 +76,9 @@ def _cdna4_gather_index(N: int, K: int, device) -> torch.Tensor:
     (nb, kg) -> int64 [N/16, K/128, 64, 4, 8] (the interleave defined in include/awq_cdna4.h / DESIGN.md)."""
     ar = lambda n, pos: torch.arange(n, device=device).view([n if d == pos else 1 for d in range(5)])
     nb, kg, lane, a, p = ar(N // 16, 0), ar(K // 128, 1), ar(64, 2), ar(4, 3), ar(8, 4)
-    g, kl, i, hi = lane // 16, lane % 16, p & 3, p >> 2
-    n = 16 * nb + 4 * g + 2 * (i & 1) + hi
-    k = 128 * kg + 32 * a + 8 * (kl // 4) + 4 * (i >> 1) + kl % 4
+    g, nq, r, i, hi = lane // 16, (lane // 4) % 4, lane % 4, p & 3, p >> 2
+    n = 16 * nb + 4 * nq + 2 * (i & 1) + hi
+    k = 128 * kg + 32 * a + 8 * g + 4 * (i >> 1) + r
     return n * K + k
 
 

@@ -255,10 +255,11 @@ def pseudo_quant_linear(w: torch.Tensor, n_bit=4, group_size=128, dtype=torch.bf
 # what the rewritten repacker emits, see DESIGN.md "cdna4 interleave").  Same size/dtype as v2
 # (int16 [N/4, K]), a pure permutation of nibbles:
 #   u32 words [N/16][K/128][64 lanes][4 words]; one 1-KiB tile = 16 rows x 128 k (one group).
-#   lane = 16*g + kl, word a, nibble p  (i = p & 3, hi = p >> 2)  holds
-#       Q[n = 16*nb + 4*g + 2*(i & 1) + hi][k = 128*kg + 32*a + 8*(kl // 4) + 4*(i >> 1) + kl % 4]
-# so that (word >> 4*i) & 0x000F000F | 0x43004300 is directly an MFMA 16x16x16 bf16 A-operand register
-# (rows = k, inner = n) of the "dequantise on the matrix core" step  W^T = (128+Q)^T . diag(s) + (sz-128 s).
+#   lane = 16*g + 4*nq + r, word a, nibble p  (i = p & 3, hi = p >> 2)  holds
+#       Q[n = 16*nb + 4*nq + 2*(i & 1) + hi][k = 128*kg + 32*a + 8*g + 4*(i >> 1) + r]
+# so that (word >> 4*i) & 0x000F000F | 0x43004300 is directly an A-operand register of the 16-block MFMA 4x4x4 bf16
+# (block = lane // 4 = (k octet g, row quad nq), rows = k, inner = the quad's four n) of the "dequantise on the matrix
+# core" step  W^T = (128+Q)^T . diag(s) + (sz-128 s), whose result lands with lane 16*g + n holding k = 32a + 8g + 0..7.
 # --------------------------------------------------------------------------------------
 
 
@@ -272,8 +273,7 @@ def cdna4_position(n, k, K):
     a, r32 = kk // 32, kk % 32
     b8, e = r32 // 8, r32 % 8
     th, rr = e // 4, e % 4
-    kl = 4 * b8 + rr
-    lane = 16 * g + kl
+    lane = 16 * b8 + 4 * g + rr  # g = row quad of the slab, b8 = k octet of the 32-k word range
     i = 2 * th + (j >> 1)
     p = i + 4 * (j & 1)
     word = ((nb * (K // 128) + kg) * 64 + lane) * 4 + a
