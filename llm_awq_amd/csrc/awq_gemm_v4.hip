@@ -61,7 +61,11 @@ struct NoJob {
 #define V4_WRITE(addr, val, off) asm volatile("ds_write_b128 %0, %1 offset:%2\n\ts_nop 1" : : "v"(addr), "v"(val), "n"(off) : "memory")
 #define V4_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-template <int PROBE>  // experiments (timing only, wrong results): 1 = the x DMA always fetches K-tile 0 (cache hits), 2 = no x DMA
+// (A variant with double-buffered x fragments -- the reads of k-step s+1 issued in cluster A of k-step s, 248 VGPRs -- measured
+// 5-8 % SLOWER, profiles/r01_gemm_v4.txt: read-to-use distance is not what limits this loop.)
+// PROBE: experiments (timing only, wrong results): 1 = the x DMA always fetches K-tile 0 (cache hits), 2 = no x DMA,
+// 3 = no epilogue (one dword per lane is stored so that the accumulators stay live)
+template <int PROBE>
 __global__ __launch_bounds__(512) void gemm_cdna4_v4_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                             const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
                                                             uint16_t* __restrict__ out, int M, int N, int K, int tiles_m,
@@ -231,6 +235,8 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v4_kernel(const uint16_t* __re
     V4_FENCE();
   };
 
+  auto kstep = [&](auto, auto sn_, auto kn_, auto rd_, auto bar_, auto job_) { step(sn_, kn_, rd_, bar_, job_); };
+
   // ---------------- prologue: tile 0 complete in stage 0, tile 1's x tile in flight, its first weight word written ----
   issue_a(0, 0);
   gc = prep(load_group(0));
@@ -268,32 +274,43 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v4_kernel(const uint16_t* __re
     using T = bc<true>;
     using F = bc<false>;
     // ---------- K-tile 2q (stage 0); writes words 1..3 of tile 2q+1 = (group q, half 1) into stage 1 ----------
-    step(ic<0>{}, ic<1>{}, T{}, F{}, JobT<1, 1, 1>{});
-    step(ic<0>{}, ic<2>{}, T{}, F{}, JobT<1, 2, 1>{});
-    step(ic<0>{}, ic<3>{}, T{}, F{}, JobT<1, 3, 1>{});
+    kstep(ic<0>{}, ic<0>{}, ic<1>{}, T{}, F{}, JobT<1, 1, 1>{});
+    kstep(ic<1>{}, ic<0>{}, ic<2>{}, T{}, F{}, JobT<1, 2, 1>{});
+    kstep(ic<0>{}, ic<0>{}, ic<3>{}, T{}, F{}, JobT<1, 3, 1>{});
     if constexpr (more) {
       gc = prep(rn);  // group q+1: loaded one iteration ago, retired by the previous barrier's vmcnt(0)
-      step(ic<1>{}, ic<0>{}, T{}, T{}, JobT<0, 0, 0>{});  // barrier inside; first word of tile 2q+2 -> stage 0
+      kstep(ic<1>{}, ic<1>{}, ic<0>{}, T{}, T{}, JobT<0, 0, 0>{});  // barrier inside; first word of tile 2q+2 -> stage 0
       rn = load_group(min(q + 2, nit - 1));
       issue_a(2 * q + 2, 0);
       V4_FENCE();
-      step(ic<1>{}, ic<1>{}, T{}, F{}, JobT<0, 1, 0>{});
-      step(ic<1>{}, ic<2>{}, T{}, F{}, JobT<0, 2, 0>{});
-      step(ic<1>{}, ic<3>{}, T{}, F{}, JobT<0, 3, 0>{});
-      step(ic<0>{}, ic<0>{}, T{}, T{}, JobT<1, 0, 1>{});  // barrier inside; first word of tile 2q+3 -> stage 1
+      kstep(ic<0>{}, ic<1>{}, ic<1>{}, T{}, F{}, JobT<0, 1, 0>{});
+      kstep(ic<1>{}, ic<1>{}, ic<2>{}, T{}, F{}, JobT<0, 2, 0>{});
+      kstep(ic<0>{}, ic<1>{}, ic<3>{}, T{}, F{}, JobT<0, 3, 0>{});
+      kstep(ic<1>{}, ic<0>{}, ic<0>{}, T{}, T{}, JobT<1, 0, 1>{});  // barrier inside; first word of tile 2q+3 -> stage 1
       issue_a(2 * q + 3, 1);
       V4_FENCE();
     } else {
-      step(ic<1>{}, ic<0>{}, T{}, T{}, NoJob{});
-      step(ic<1>{}, ic<1>{}, T{}, F{}, NoJob{});
-      step(ic<1>{}, ic<2>{}, T{}, F{}, NoJob{});
-      step(ic<1>{}, ic<3>{}, T{}, F{}, NoJob{});
-      step(ic<0>{}, ic<0>{}, F{}, T{}, NoJob{});
+      kstep(ic<1>{}, ic<1>{}, ic<0>{}, T{}, T{}, NoJob{});
+      kstep(ic<0>{}, ic<1>{}, ic<1>{}, T{}, F{}, NoJob{});
+      kstep(ic<1>{}, ic<1>{}, ic<2>{}, T{}, F{}, NoJob{});
+      kstep(ic<0>{}, ic<1>{}, ic<3>{}, T{}, F{}, NoJob{});
+      kstep(ic<1>{}, ic<0>{}, ic<0>{}, F{}, T{}, NoJob{});
     }
   };
   for (int q = 0; q + 1 < nit; ++q) group_iter(q, std::true_type{});
   group_iter(nit - 1, std::false_type{});
 
+  if (PROBE == 3) {
+    float t = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[a][b][r];
+    if (t == 12345.678f) out[tid] = 1;
+    return;
+  }
   // ---------------- epilogue through LDS: acc[a][b][r] = C[n = wn*64 + a*32 + (r&3) + 8 (r>>2) + 4 hk][m = wm*128 + b*32 + l32] ----
   __syncthreads();
   char* eb = smem + wv * (128 * kEpiRow);
@@ -341,14 +358,14 @@ void launch_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const 
   constexpr int smem_epi = 8 * 128 * (2 * WN + 16);
   constexpr int smem = smem_main > smem_epi ? smem_main : smem_epi;
   const int tiles_m = (m + TM - 1) / TM, tiles_n = (n_end - n_begin + TN - 1) / TN;
+  using Kern = void (*)(const uint16_t*, const u32*, const u32*, const uint16_t*, uint16_t*, int, int, int, int, int, int, int);
+  static const Kern kerns[4] = {gemm_cdna4_v4_kernel<0>, gemm_cdna4_v4_kernel<1>, gemm_cdna4_v4_kernel<2>, gemm_cdna4_v4_kernel<3>};
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cdna4_v4_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cdna4_v4_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cdna4_v4_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    for (Kern kf : kerns) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr = true;
   }
-  auto kern = g_v4_probe == 1 ? gemm_cdna4_v4_kernel<1> : (g_v4_probe == 2 ? gemm_cdna4_v4_kernel<2> : gemm_cdna4_v4_kernel<0>);
+  const Kern kern = kerns[g_v4_probe >= 0 && g_v4_probe <= 3 ? g_v4_probe : 0];
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw,
                      (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end);
 }

@@ -95,7 +95,7 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e1));
     for (int v : variants) {
       AQ(awq_tune_set("gemm_v4_probe", v / 1000));  // Nxxx: timing-only probes of the v4 kernel (results are wrong by design)
-      AQ(awq_tune_set("gemm_v4", (v % 1000) >= 100));  // 1xx: wide tiles run the hand-scheduled K loop (awq_gemm_v4.hip)
+      AQ(awq_tune_set("gemm_v4", (v % 1000) >= 100));  // 1xx: wide tiles run the hand-scheduled K loop (awq_gemm_v4.hip)  // 1xx: wide tiles run the hand-scheduled K loop (awq_gemm_v4.hip)
       AQ(awq_tune_set("gemm_variant", v % 100));
       CK(hipMemset(dout, 0xFF, (size_t)M * N * 2));
       AQ(awq_w4a16_gemm_cdna4(dx, qw4, ds, dz, dszp, dout, M, N, K, 128, AWQ_BF16, nullptr, 0, nullptr));
@@ -129,7 +129,7 @@ int main(int argc, char** argv) {
       fflush(stdout);
     }
     AQ(awq_tune_set("gemm_variant", 0));
-    AQ(awq_tune_set("gemm_v4", 0));
+    AQ(awq_tune_set("gemm_v4", 1));
     AQ(awq_tune_set("gemm_v4_probe", 0));
     hipFree(dq); hipFree(qw2); hipFree(qw4); hipFree(ds); hipFree(dz); hipFree(dszp); hipFree(dx); hipFree(dout); hipFree(dref);
   }
