@@ -329,9 +329,15 @@ void launch_wide(const void* x, const void* qw, const void* szp, const void* bia
 }
 }  // namespace
 
+namespace {
+int g_moe_v4 = 1;  // grouped prefill GEMM on 256 x 256 tiles (awq_gemm_v4.hip); 0: the 128 x 128 grouped kernel
+}
+bool moe_v4_enabled() { return g_moe_v4 != 0; }
+
 int gemm_v3_tune_set(const char* key, int value) {
   if (!strcmp(key, "gemm_v4")) g_v4 = value;
   else if (!strcmp(key, "gemm_v4_probe")) gemm_v4_set_probe(value);
+  else if (!strcmp(key, "moe_v4")) g_moe_v4 = value;
   else return -1;
   return 0;
 }

@@ -65,39 +65,18 @@ struct NoJob {
 // 5-8 % SLOWER, profiles/r01_gemm_v4.txt: read-to-use distance is not what limits this loop.)
 // PROBE: experiments (timing only, wrong results): 1 = the x DMA always fetches K-tile 0 (cache hits), 2 = no x DMA,
 // 3 = no epilogue (one dword per lane is stored so that the accumulators stay live)
+// one 256 x 256 output tile: rows [m0, m0 + 256) of x (all of them must exist), weight rows [n0, n0 + 256) clipped to n_end;
+// stores are masked to rows [row_lo, row_hi) (dense: every row of the tile; grouped: the expert's rows inside it)
 template <int PROBE>
-__global__ __launch_bounds__(512) void gemm_cdna4_v4_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
-                                                            const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
-                                                            uint16_t* __restrict__ out, int M, int N, int K, int tiles_m,
-                                                            int tiles_n, int n_begin, int n_end) {
+__device__ __forceinline__ void v4_tile(char* smem, const uint16_t* __restrict__ x, const u32* __restrict__ qw,
+                                        const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
+                                        uint16_t* __restrict__ out, int N, int K, int m0, int n0, int n_end, int row_lo,
+                                        int row_hi) {
   constexpr int kEpiRow = 2 * WN + 16;  // bytes per staged output row (+16 pad)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
   const int l32 = lane & 31, hk = lane >> 5;
   const int wm = wv >> 2, wn = wv & 3;
-
-  // XCD-aware, two-row-band tile order: as v3 (awq_gemm_v3.hip)
-  const int T = tiles_m * tiles_n;
-  int tile;
-  {
-    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
-    const int q = T >> 3, r = T & 7;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  int tm, tn;
-  {
-    const int full = (tiles_m >> 1) * 2 * tiles_n;
-    if (tile < full) {
-      const int band = tile / (2 * tiles_n), rem = tile - band * 2 * tiles_n;
-      tn = rem >> 1;
-      tm = 2 * band + (rem & 1);
-    } else {
-      tn = tile - full;
-      tm = tiles_m - 1;
-    }
-  }
-  const int m0 = min(tm * TM, M - TM), n0 = n_begin + tn * TN;
   const int nit = K >> 7;
 
   // ---- x tile: LDS-DMA, 4 x 16 B per thread per K-tile; swizzle applied to the SOURCE granule ----
@@ -333,7 +312,7 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v4_kernel(const uint16_t* __re
     const int row = ps * RP + lane / GR, gc2 = lane % GR;
     const int m = m0 + wm * 128 + row, nn = n0 + wn * WN + gc2 * 8;
     u32x4 v = *reinterpret_cast<const u32x4*>(eb + row * kEpiRow + gc2 * 16);
-    if (nn < n_end) {
+    if (nn < n_end && m >= row_lo && m < row_hi) {
       if (bias != nullptr) {  // `out + self.bias` in T (qmodule.py:221)
         const u32x4 bv = *reinterpret_cast<const u32x4*>(bias + nn);
         auto add2 = [](u32 a, u32 b) {
@@ -346,6 +325,68 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v4_kernel(const uint16_t* __re
       *reinterpret_cast<u32x4*>(out + (size_t)m * N + nn) = v;
     }
   }
+}
+
+// dense: XCD-aware, two-row-band tile order as v3 (awq_gemm_v3.hip); the last row tile is shifted up to end at row M - 1
+template <int PROBE>
+__global__ __launch_bounds__(512) void gemm_cdna4_v4_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
+                                                            const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
+                                                            uint16_t* __restrict__ out, int M, int N, int K, int tiles_m,
+                                                            int tiles_n, int n_begin, int n_end) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int T = tiles_m * tiles_n;
+  int tile;
+  {
+    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    const int q = T >> 3, r = T & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tm, tn;
+  {
+    const int full = (tiles_m >> 1) * 2 * tiles_n;
+    if (tile < full) {
+      const int band = tile / (2 * tiles_n), rem = tile - band * 2 * tiles_n;
+      tn = rem >> 1;
+      tm = 2 * band + (rem & 1);
+    } else {
+      tn = tile - full;
+      tm = tiles_m - 1;
+    }
+  }
+  v4_tile<PROBE>(smem, x, qw, szp, bias, out, N, K, min(tm * TM, M - TM), n_begin + tn * TN, n_end, 0, M);
+}
+
+// grouped (MoE): expert e owns rows [offsets[e], offsets[e+1]) of the sorted x / out and the e-th slice of the stacked
+// cdna4 weights / packed scales.  The grid is an upper bound (total / 256 + experts row tiles); a block finds its
+// (expert, row tile) by walking the offsets and exits if there is none.  A tile always reads 256 existing rows of x
+// (shifted up at the end of the buffer); rows of other experts inside it are computed and not stored.
+__global__ __launch_bounds__(512) void moe_gemm_cdna4_v4_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
+                                                                const u32* __restrict__ szp, const int* __restrict__ offsets,
+                                                                uint16_t* __restrict__ out, int total, int experts, int N,
+                                                                int K, int row_tiles, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int T = row_tiles * tiles_n;
+  int tile;
+  {
+    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    const int q = T >> 3, r = T & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int rt = tile / tiles_n;
+  const int tn = tile - rt * tiles_n;
+  int e = 0, lo = 0, hi = 0;
+  for (; e < experts; ++e) {
+    lo = offsets[e];
+    hi = offsets[e + 1];
+    const int cnt = (hi - lo + TM - 1) / TM;
+    if (rt < cnt) break;
+    rt -= cnt;
+  }
+  if (e == experts) return;  // wave-uniform: no tile for this block
+  const int r_lo = lo + rt * TM, r_hi = min(r_lo + TM, hi);
+  const size_t ew = (size_t)(N >> 4) * (K >> 7);  // tiles per expert
+  v4_tile<0>(smem, x, qw + (size_t)e * ew * 256, szp + (size_t)e * ew * 16, nullptr, out, N, K, min(r_lo, total - TM), tn * TN, N,
+             r_lo, r_hi);
 }
 
 namespace {
@@ -370,5 +411,25 @@ void launch_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const 
                      (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end);
 }
 void gemm_v4_set_probe(int v) { g_v4_probe = v; }
+
+// grouped GEMM over sorted tokens, 256 x 256 tiles; needs total >= 256.  Returns -1 if unsupported.
+int launch_moe_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total, int experts,
+                             int n, int k, hipStream_t st) {
+  if (total < TM || experts < 1 || (n % 16) != 0 || (k % 128) != 0 || (size_t)total * (size_t)k >= (1ull << 31) ||
+      (size_t)n * (size_t)k / 8 >= (1ull << 31))
+    return -1;
+  constexpr int smem_main = 2 * kTileX + 2 * kTileW;
+  constexpr int smem_epi = 8 * 128 * (2 * WN + 16);
+  constexpr int smem = smem_main > smem_epi ? smem_main : smem_epi;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(moe_gemm_cdna4_v4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr = true;
+  }
+  const int row_tiles = total / TM + experts, tiles_n = (n + TN - 1) / TN;
+  hipLaunchKernelGGL(moe_gemm_cdna4_v4_kernel, dim3(row_tiles * tiles_n), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw,
+                     (const u32*)szp, (const int*)offsets, (uint16_t*)out, total, experts, n, k, row_tiles, tiles_n);
+  return 0;
+}
 
 }  // namespace awq

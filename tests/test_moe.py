@@ -137,3 +137,31 @@ def test_gpu_grouped_decode_and_module(counts):
         lo, hi = int(off[e]), int(off[e + 1])
         if hi > lo:
             check_forward(y[lo:hi], x[lo:hi], cases[e]["q"], cases[e]["scales"], cases[e]["scaled_zeros"], dtype)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("counts", [[300, 0, 1, 255], [256, 256], [1, 700, 3, 40], [0, 0, 0, 256], [511, 2, 257, 0, 90]])
+def test_gpu_grouped_prefill_v4(counts):
+    """>= 256 sorted rows: the grouped 256 x 256 kernel (awq_gemm_v4.hip; tiles straddling expert boundaries, the shifted
+    last tile, empty experts) is bit-identical to the 128 x 128 grouped kernel (knob moe_v4=0) and meets the oracle."""
+    from llm_awq_amd import ops
+    dtype = torch.bfloat16
+    E, N, K = len(counts), 400, 512
+    mods, cases = _experts(E, N, K, dtype, seed=sum(counts) + 11)
+    grp = MOE.GroupedWQLinear(mods).cuda().to_cdna4()
+    T = sum(counts)
+    g = torch.Generator().manual_seed(T + 5)
+    x = torch.randn(T, K, generator=g).to(dtype).cuda()
+    off = torch.tensor([0] + list(np.cumsum(counts)), dtype=torch.int32).cuda()
+    y = grp(x, off)
+    ops._capi.tune(moe_v4=0)
+    try:
+        y_ref = grp(x, off)
+    finally:
+        ops._capi.tune(moe_v4=1)
+    assert torch.equal(y, y_ref)
+    y, x = y.cpu(), x.cpu()
+    for e in range(E):
+        lo, hi = int(off[e]), int(off[e + 1])
+        if hi > lo:
+            check_forward(y[lo:hi], x[lo:hi], cases[e]["q"], cases[e]["scales"], cases[e]["scaled_zeros"], dtype)

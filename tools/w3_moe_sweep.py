@@ -79,9 +79,13 @@ def main():
         ids = torch.stack([torch.randperm(E, device="cuda")[:2] for _ in range(T)])
         order, off = sort_by_expert(ids, E)
         xs = torch.randn(2 * T, K, device="cuda").to(dt)
-        us = graph_time(lambda _c: ops.moe_gemm(xs, qw, s, z, off, layout="cdna4"), [0, 1, 2, 3])
-        tf = 2.0 * 2 * T * N * K / us / 1e6
-        print(f"{name:6s} K={K:6d} N={N:6d} rows={2 * T}  {us:8.1f} us  {tf:7.1f} TFLOP/s  {tf / 25:5.1f}% of 2.5 PF", flush=True)
+        szp = torch.stack([ops.pack_sz_cdna4(ss[e], zs[e], K) for e in range(E)])
+        for label, fn in (("128x128 grouped kernel", lambda _c: ops.moe_gemm(xs, qw, s, z, off, layout="cdna4")),
+                          ("256x256 grouped v4    ", lambda _c: ops.moe_forward_cdna4(xs, qw, s, z, szp, off))):
+            us = graph_time(fn, [0, 1, 2, 3])
+            tf = 2.0 * 2 * T * N * K / us / 1e6
+            print(f"{name:6s} K={K:6d} N={N:6d} rows={2 * T} {label} {us:8.1f} us  {tf:7.1f} TFLOP/s  {tf / 25:5.1f}% of 2.5 PF",
+                  flush=True)
         del qw, s, z, qws, ss, zs
         torch.cuda.empty_cache()
 
