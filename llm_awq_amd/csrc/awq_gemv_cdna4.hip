@@ -212,7 +212,7 @@ Cfg pick_cfg(int m, int n_rows, int k, int ns, int force_waves, int force_s) {
   // only adds clamped loads
   const int nit = k / kGroup, slabs = n_rows / 16 / ns;
   int waves = slabs >= 768 ? 4 : (slabs >= 384 ? 8 : (nit >= 64 ? 8 : 16));
-  if (ns == 2 && waves > 4) waves >>= 1;  // two slabs per block: half the waves give the same bytes in flight
+  if (ns == 2 && waves > 4 && slabs >= 256) waves >>= 1;  // two slabs per block: half the waves give the same bytes in flight
   while (waves > 4 && waves * 2 > nit) waves >>= 1;
   if (force_waves) waves = force_waves;
   const int per = (nit + waves - 1) / waves;
@@ -261,7 +261,11 @@ static int launch_mb(const void* x, const void* qw, const void* szp, const void*
   const int pipe = g_pipe < 0 ? 2 : g_pipe;
   if (pipe >= 2) {  // software-pipelined variant: ring of `pipe` chunks of `ps` steps
     const int per = (k / kGroup + c.waves - 1) / c.waves;
-    const int ps = g_pipe_s ? g_pipe_s : ((EPI == 1 || per >= 8) ? 2 : 1);
+    // steps per chunk: about 16-28 KiB of weight tiles in flight per CU (measured optimum, profiles/r01_gemvc_ring_sweep.txt
+    // and r01_gemvc_ring2.txt: deeper rings and longer chunks only lengthen the queue in front of the last waves' first
+    // data -- a CU does not pull more than ~25 GB/s whatever is outstanding, profiles/r01_gemv_trace.txt)
+    const double waves_per_cu = (double)(n / 16 / (EPI == 1 ? 2 : 1)) * c.waves / 256.0;
+    const int ps = g_pipe_s ? g_pipe_s : ((per >= 2 && waves_per_cu * (EPI == 1 ? 2 : 1) <= 10.0) ? 2 : 1);
 #define AWQ_PCASE(W_, S_, D_)                                                  \
   if (c.waves == W_ && ps == S_ && pipe == D_ && (size_t)W_ * S_ * m * 256 <= 96 * 1024) { \
     launch_cfg<W_, S_, MB, EPI, BITS, D_>(x, qw, szp, bias, out, m, n, k, st); \
