@@ -87,6 +87,10 @@ int awq_w4a16_forward(const void* x, const void* qweight, const void* scales, co
       check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype) == AWQ_OK && awq::gemv_v2fast_enabled() &&
       awq::launch_gemv_v2fast(x, qweight, scales, scaled_zeros, bias, out, m, n, k, k / 128, dtype, (hipStream_t)stream) == 0)
     return finish_launch();  // bias fused into the decode kernel's epilogue
+  if (m > 8 && m <= 255 && bias && group_size == 128 && awq::gemm_variant_get() == 0 &&
+      check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype) == AWQ_OK &&
+      awq::launch_skinny_v2(x, qweight, scales, scaled_zeros, bias, out, m, n, k, k / 128, dtype, (hipStream_t)stream) == 0)
+    return finish_launch();  // bias fused into the skinny kernel's epilogue
   if (m < 8)
     st = awq_w4a16_gemv(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype, stream);
   else

@@ -420,6 +420,9 @@ static int launch_gemm_t(const void* x, const void* qw, const void* s, const voi
 
 int launch_gemm(const void* x, const void* qw, const void* s, const void* z, const void* szp, void* out, int m, int n,
                 int k, int dtype, int layout, void*, size_t, hipStream_t st) {
+  if (layout == 0 && g_gemm_variant == 0 && m > 8 && m <= 255 &&
+      launch_skinny_v2(x, qw, s, z, nullptr, out, m, n, k, k / kGroup, dtype, st) == 0)
+    return 0;  // short prompts / batched decode on un-repacked (fp16) checkpoints
   if (m <= 16) return launch_gemv(x, qw, s, z, szp, out, m, n, k, dtype, layout, st);
   if (layout == 1) {
     // variant 3 / auto: v3 kernel with the tile width picked by chip fill; 4 = force 256 x 256; 5 = force 256 x 128

@@ -18,6 +18,9 @@ int launch_gemv_cdna4(const void* x, const void* qw, const void* szp, const void
 bool gemv_v2fast_enabled();  // false while a knob of the older kernel (awq_tune_set gemv_*) is active
 int launch_gemv_v2fast(const void* x, const void* qw, const void* s, const void* z, const void* bias, void* out, int m, int n, int k,
                        int gpad, int dtype, hipStream_t st);
+// reference (v2) layout skinny GEMM (awq_skinny_v2.hip): 9 <= m <= 255, n % 16 == 0, fp16 / bf16, bias fused.  -1 if unsupported.
+int launch_skinny_v2(const void* x, const void* qw, const void* s, const void* z, const void* bias, void* out, int m, int n, int k,
+                     int gpad, int dtype, hipStream_t st);
 // W3 ("w3c") format helpers (awq_w3.hip)
 int launch_pack_w3(const void* q_u8, void* qw3, int n, int k, hipStream_t st);
 int launch_unpack_w3(const void* qw3, void* out_u8, int n, int k, hipStream_t st);

@@ -96,6 +96,21 @@ def test_gemv_reference_layout_kernels_agree(ops, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [9, 16, 17, 33, 48, 64, 65, 130, 255])
+@pytest.mark.parametrize("N,K", [(768, 768), (1040, 1280), (64, 11008), (8192, 512)])
+def test_skinny_reference_layout_vs_oracle(ops, dtype, M, N, K):
+    """9 <= M <= 255 on un-repacked buffers (fp16 and bf16): the v2-layout skinny kernel behind gemm_forward_cuda_new / forward,
+    every column-block count, slab counts that do not divide the slabs-per-block, ragged K splits, row chunks, fused bias."""
+    c = make_case(N, K, dtype, seed=M * 5 + N + K, M=M, bias=(M % 2 == 1))
+    args = (c["x"].cuda(), c["qweight"].cuda(), c["scales"].cuda(), c["scaled_zeros"].cuda())
+    if c["bias"] is not None:
+        y = ops.forward(*args, c["bias"].cuda()).cpu()
+    else:
+        y = ops.gemm(*args).cpu()
+    check_forward(y, c["x"], c["q"], c["scales"], c["scaled_zeros"], dtype, bias=c["bias"])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("variant", [0, 1, 2])  # auto / force 128x128 / force 256x256
 @pytest.mark.parametrize("M", [8, 17, 64, 100, 128, 129, 200, 512, 777])
 @pytest.mark.parametrize("N,K", [(768, 768), (3072, 768), (768, 3072), (136, 1280)])

@@ -202,6 +202,6 @@ def test_gpu_loader_end_to_end(tmp_path):
         assert int(o[p + ".qweight_layout"]) == 1 and o[p + ".qweight"].is_cuda
         k0, k1 = P.shard_bounds(F, world, r, 128)
         szp = ops.pack_sz_cdna4(o[p + ".scales"], o[p + ".scaled_zeros"], k1 - k0)
-        y = ops.forward_cdna4(c["x"][:, k0:k1].contiguous().cuda(), o[p + ".qweight"], o[p + ".scales"], o[p + ".scaled_zeros"], szp, None)
+        y = ops.gemm_cdna4(c["x"][:, k0:k1].contiguous().cuda(), o[p + ".qweight"], o[p + ".scales"], o[p + ".scaled_zeros"], None, szp)
         acc = acc + y.float().cpu()
     assert ((acc - full).norm() / full.norm()).item() < 6e-3
