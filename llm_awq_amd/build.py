@@ -54,7 +54,11 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
                "-Wno-unused-function",
                # keep MFMA results in VGPRs: the matrix-core dequant feeds v_cvt_pk_bf16_f32 directly
                # (the AGPR form costs one v_accvgpr_read per value)
-               "-mllvm", "-amdgpu-mfma-vgpr-form", *srcs, "-o", LIB_PATH]
+               "-mllvm", "-amdgpu-mfma-vgpr-form",
+               # AWQ_PROBES=1: compile the timing-only probes (linear-read / null kernels, GEMM v4 no-DMA / no-epilogue)
+               # behind the gemv_probe / gemm_v4_probe knobs; a default build has no knob that changes results
+               *(["-DAWQ_ENABLE_PROBES"] if os.environ.get("AWQ_PROBES") == "1" else []),
+               *srcs, "-o", LIB_PATH]
         dt = _run(cmd, "libawq_cdna4.so")
         if verbose:
             print(f"[llm_awq_amd.build] libawq_cdna4.so built in {dt:.1f}s")

@@ -336,7 +336,9 @@ bool moe_v4_enabled() { return g_moe_v4 != 0; }
 
 int gemm_v3_tune_set(const char* key, int value) {
   if (!strcmp(key, "gemm_v4")) g_v4 = value;
+#ifdef AWQ_ENABLE_PROBES
   else if (!strcmp(key, "gemm_v4_probe")) gemm_v4_set_probe(value);
+#endif
   else if (!strcmp(key, "moe_v4")) g_moe_v4 = value;
   else return -1;
   return 0;

@@ -63,7 +63,7 @@ struct NoJob {
 
 // (A variant with double-buffered x fragments -- the reads of k-step s+1 issued in cluster A of k-step s, 248 VGPRs -- measured
 // 5-8 % SLOWER, profiles/r01_gemm_v4.txt: read-to-use distance is not what limits this loop.)
-// PROBE: experiments (timing only, wrong results): 1 = the x DMA always fetches K-tile 0 (cache hits), 2 = no x DMA,
+// PROBE (only with -DAWQ_ENABLE_PROBES): experiments (timing only, wrong results): 1 = the x DMA always fetches K-tile 0 (cache hits), 2 = no x DMA,
 // 3 = no epilogue (one dword per lane is stored so that the accumulators stay live)
 // one 256 x 256 output tile: rows [m0, m0 + 256) of x (all of them must exist), weight rows [n0, n0 + 256) clipped to n_end;
 // stores are masked to rows [row_lo, row_hi) (dense: every row of the tile; grouped: the expert's rows inside it)
@@ -400,7 +400,11 @@ void launch_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const 
   constexpr int smem = smem_main > smem_epi ? smem_main : smem_epi;
   const int tiles_m = (m + TM - 1) / TM, tiles_n = (n_end - n_begin + TN - 1) / TN;
   using Kern = void (*)(const uint16_t*, const u32*, const u32*, const uint16_t*, uint16_t*, int, int, int, int, int, int, int);
+#ifdef AWQ_ENABLE_PROBES
   static const Kern kerns[4] = {gemm_cdna4_v4_kernel<0>, gemm_cdna4_v4_kernel<1>, gemm_cdna4_v4_kernel<2>, gemm_cdna4_v4_kernel<3>};
+#else  // a default build has no knob that changes results
+  static const Kern kerns[4] = {gemm_cdna4_v4_kernel<0>, gemm_cdna4_v4_kernel<0>, gemm_cdna4_v4_kernel<0>, gemm_cdna4_v4_kernel<0>};
+#endif
   static bool attr = false;
   if (!attr) {
     for (Kern kf : kerns) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, smem);

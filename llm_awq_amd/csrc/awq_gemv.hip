@@ -191,7 +191,13 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_w4a16_kernel(const uint16_t* 
   }
 }
 
-// ---- calibration probes (experiments only): ideal linear 16-byte streaming read, and an empty kernel ----
+// ---- calibration probes (experiments only; compiled with -DAWQ_ENABLE_PROBES = AWQ_PROBES=1 python -m llm_awq_amd.build):
+//      ideal linear 16-byte streaming read, and an empty kernel.  A default build has no knob that changes results ----
+#ifdef AWQ_ENABLE_PROBES
+constexpr bool kProbes = true;
+#else
+constexpr bool kProbes = false;
+#endif
 __global__ __launch_bounds__(256) void probe_linear_read_kernel(const u32x4* __restrict__ p, size_t n16, u32* out) {
   u32 acc = 0;
   size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -225,8 +231,8 @@ struct GemvTune {
 int gemv_tune_set(const char* key, int value) {
   if (!strcmp(key, "gemv_waves")) g_tune.waves = value;
   else if (!strcmp(key, "gemv_pf")) g_tune.pf = value;
-  else if (!strcmp(key, "gemv_probe")) g_tune.probe = value;
-  else if (!strcmp(key, "gemv_probe_blocks")) g_tune.probe_blocks = value;
+  else if (kProbes && !strcmp(key, "gemv_probe")) g_tune.probe = value;
+  else if (kProbes && !strcmp(key, "gemv_probe_blocks")) g_tune.probe_blocks = value;
   else if (!strcmp(key, "gemv_x_budget_kib")) g_tune.x_budget_kib = value;
   else if (!strcmp(key, "gemv_v2fast")) g_tune.v2fast = value;
   else return -1;
@@ -264,12 +270,12 @@ static int launch_gemv_t(const void* x, const void* qw, const void* s, const voi
                          int n, int k, hipStream_t st) {
   const int nit = k / kGroup;
   const int slabs = (n + 15) / 16;
-  if (g_tune.probe == 2) {
+  if (kProbes && g_tune.probe == 2) {
     hipLaunchKernelGGL(probe_linear_read_kernel, dim3(g_tune.probe_blocks), dim3(256), 0, st, (const u32x4*)qw,
                        (size_t)n * k / 32, (u32*)out);
     return 0;
   }
-  if (g_tune.probe == 3) {
+  if (kProbes && g_tune.probe == 3) {
     hipLaunchKernelGGL(probe_null_kernel, dim3(256), dim3(256), 0, st, (u32*)out);
     return 0;
   }
@@ -281,10 +287,10 @@ static int launch_gemv_t(const void* x, const void* qw, const void* s, const voi
     const int per = nit / waves;
     pf = per >= 8 ? 8 : (per >= 4 ? 4 : 2);
   }
-  const bool probe = g_tune.probe == 1;
+  const bool probe = kProbes && g_tune.probe == 1;
 #define AWQ_GEMV_CASE(W_, P_)                                                                 \
   if (waves == W_ && pf == P_) {                                                              \
-    if (probe) launch_one<DT, P_, W_, LAYOUT, false, 1>(x, qw, s, z, szp, out, m, n, k, st);  \
+    if (probe) launch_one<DT, P_, W_, LAYOUT, false, kProbes ? 1 : 0>(x, qw, s, z, szp, out, m, n, k, st);  \
     else if (LAYOUT == 1 && szp) launch_one<DT, P_, W_, LAYOUT, LAYOUT == 1, 0>(x, qw, s, z, szp, out, m, n, k, st); \
     else launch_one<DT, P_, W_, LAYOUT, false, 0>(x, qw, s, z, szp, out, m, n, k, st);        \
     return 0;                                                                                 \

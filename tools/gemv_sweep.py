@@ -12,7 +12,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from llm_awq_amd import _capi, ops, synth  # noqa: E402
 
-DEFAULT = dict(gemv_waves=0, gemv_pf=0, gemv_probe=0, gemv_probe_blocks=2048, gemv_v2fast=1)
+PROBES = os.environ.get("AWQ_PROBES") == "1"  # the library must have been built with AWQ_PROBES=1 too
+DEFAULT = dict(gemv_waves=0, gemv_pf=0, gemv_v2fast=1, **(dict(gemv_probe=0, gemv_probe_blocks=2048) if PROBES else {}))
 
 
 def algo_bytes(M, K, N):
@@ -87,7 +88,7 @@ def main():
             layouts = (0, 1) if dtype == torch.bfloat16 else (0,)
             cfgs = [dict(DEFAULT, layout=l) for l in (layouts + ((2,) if dtype == torch.bfloat16 else ()))]
             cfgs.insert(1, dict(DEFAULT, gemv_v2fast=0, layout=0))  # the older v2-layout kernel
-            if not args.defaults_only:
+            if not args.defaults_only and PROBES:
                 cfgs.append(dict(DEFAULT, gemv_probe=3, layout=0))
                 cfgs.append(dict(DEFAULT, gemv_probe=2, gemv_probe_blocks=4096, layout=0))
                 for layout in layouts:
@@ -106,7 +107,7 @@ def main():
                     print("   cfg failed", cfg, e)
                     continue
                 print(f"K={K:6d} N={N:6d} M={M:2d} layout={cur['layout']} waves={cfg['gemv_waves']:2d} pf={cfg['gemv_pf']} "
-                      f"probe={cfg['gemv_probe']} v2fast={cfg['gemv_v2fast']}  {us:8.2f} us  {ab / us / 1e3:8.1f} GB/s  {ab / us / 1e3 / 80:5.1f}%", flush=True)
+                      f"probe={cfg.get('gemv_probe', 0)} v2fast={cfg['gemv_v2fast']}  {us:8.2f} us  {ab / us / 1e3:8.1f} GB/s  {ab / us / 1e3 / 80:5.1f}%", flush=True)
             _capi.tune(**DEFAULT)
         del copies
         torch.cuda.empty_cache()

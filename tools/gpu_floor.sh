@@ -1,5 +1,6 @@
 #!/bin/bash
 set -u
+# needs the probe build: AWQ_PROBES=1 python -c 'from llm_awq_amd import build; build.build_lib(force=True)' before gpurun
 cd "${GRAFT_REPO_ROOT:-.}"
 O=gpurun_out; mkdir -p $O
 for blocks in 2048 4096 8192; do
