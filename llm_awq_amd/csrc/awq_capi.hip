@@ -162,10 +162,10 @@ int awq_unpack_cdna4(const void* qweight, void* out_u8, int n, int k, void* stre
 int awq_dequant_cdna4(const void* qweight, const void* scales, const void* scaled_zeros, void* out, int n, int k,
                       int group_size, int dtype, void* stream) {
   if (!qweight || !scales || !scaled_zeros || !out) return AWQ_ERR_NULL;
-  if (dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
+  if (dtype != AWQ_F16 && dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
   if (group_size != 128) return AWQ_ERR_GROUP;
   if (n < 16 || (n % 16) != 0 || k < 128 || (k % 128) != 0) return AWQ_ERR_SHAPE;
-  awq::launch_dequant_cdna4(qweight, scales, scaled_zeros, out, n, k, (hipStream_t)stream);
+  awq::launch_dequant_cdna4(qweight, scales, scaled_zeros, out, n, k, dtype, (hipStream_t)stream);
   return finish_launch();
 }
 
@@ -180,11 +180,10 @@ int awq_w4a16_gemv_cdna4(const void* x, const void* qweight, const void* scales,
                          const void* sz_packed, void* out, int m, int n, int k, int group_size, int dtype, void* stream) {
   if (group_size != 128) return AWQ_ERR_GROUP;
   if (m < 1 || m > 16) return AWQ_ERR_BATCH;
-  if (dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
   int st = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
   if (st != AWQ_OK) return st;
   if ((n % 16) != 0) return AWQ_ERR_SHAPE;
-  if (!(sz_packed && m <= 8 && awq::launch_gemv_cdna4(x, qweight, sz_packed, nullptr, out, m, n, k, 0, 4, (hipStream_t)stream) == 0))
+  if (!(sz_packed && m <= 8 && awq::launch_gemv_cdna4(x, qweight, sz_packed, nullptr, out, m, n, k, 0, 4, dtype, (hipStream_t)stream) == 0))
     awq::launch_gemv(x, qweight, scales, scaled_zeros, sz_packed, out, m, n, k, dtype, 1, (hipStream_t)stream);
   return finish_launch();
 }
@@ -193,11 +192,11 @@ int awq_w4a16_mlp_gate_up_cdna4(const void* x, const void* qweight_gate_up, cons
                                 int n2, int k, int group_size, int dtype, void* stream) {
   if (!x || !qweight_gate_up || !sz_packed || !out) return AWQ_ERR_NULL;
   if (group_size != 128) return AWQ_ERR_GROUP;
-  if (dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
+  if (dtype != AWQ_F16 && dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
   if (m < 1 || m > 8) return AWQ_ERR_BATCH;
   if (n2 < 32 || (n2 % 32) != 0 || k < 128 || (k % 128) != 0) return AWQ_ERR_SHAPE;
   if (!aligned16(x) || !aligned16(qweight_gate_up) || !aligned16(out) || !aligned16(sz_packed)) return AWQ_ERR_ALIGN;
-  if (awq::launch_gemv_cdna4(x, qweight_gate_up, sz_packed, nullptr, out, m, n2, k, 1, 4, (hipStream_t)stream) != 0)
+  if (awq::launch_gemv_cdna4(x, qweight_gate_up, sz_packed, nullptr, out, m, n2, k, 1, 4, dtype, (hipStream_t)stream) != 0)
     return AWQ_ERR_SHAPE;
   return finish_launch();
 }
@@ -205,13 +204,12 @@ int awq_w4a16_mlp_gate_up_cdna4(const void* x, const void* qweight_gate_up, cons
 int awq_w4a16_gemm_cdna4(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
                          const void* sz_packed, void* out, int m, int n, int k, int group_size, int dtype, void* workspace,
                          size_t workspace_bytes, void* stream) {
-  if (dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
   int st = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
   if (st != AWQ_OK) return st;
   if ((n % 16) != 0) return AWQ_ERR_SHAPE;
   const bool skinny = sz_packed && m > 8 && m < 256 && awq::gemm_variant_get() == 0 &&
-                      awq::launch_skinny_cdna4(x, qweight, sz_packed, nullptr, out, m, n, k, (hipStream_t)stream) == 0;
-  if (!skinny && !(sz_packed && m <= 8 && awq::launch_gemv_cdna4(x, qweight, sz_packed, nullptr, out, m, n, k, 0, 4, (hipStream_t)stream) == 0))
+                      awq::launch_skinny_cdna4(x, qweight, sz_packed, nullptr, out, m, n, k, dtype, (hipStream_t)stream) == 0;
+  if (!skinny && !(sz_packed && m <= 8 && awq::launch_gemv_cdna4(x, qweight, sz_packed, nullptr, out, m, n, k, 0, 4, dtype, (hipStream_t)stream) == 0))
     awq::launch_gemm(x, qweight, scales, scaled_zeros, sz_packed, out, m, n, k, dtype, 1, workspace, workspace_bytes, (hipStream_t)stream);
   return finish_launch();
 }
@@ -219,25 +217,25 @@ int awq_w4a16_gemm_cdna4(const void* x, const void* qweight, const void* scales,
 int awq_w4a16_forward_cdna4(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
                             const void* sz_packed, const void* bias, void* out, int m, int n, int k, int group_size,
                             int dtype, void* workspace, size_t workspace_bytes, void* stream) {
-  if (m <= 8 && sz_packed && dtype == AWQ_BF16 && group_size == 128) {  // decode: bias fused into the GEMV epilogue
+  if (m <= 8 && sz_packed && group_size == 128) {  // decode: bias fused into the GEMV epilogue
     int st0 = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
     if (st0 != AWQ_OK) return st0;
     if ((n % 16) != 0) return AWQ_ERR_SHAPE;
-    if (awq::launch_gemv_cdna4(x, qweight, sz_packed, bias, out, m, n, k, 0, 4, (hipStream_t)stream) == 0) return finish_launch();
+    if (awq::launch_gemv_cdna4(x, qweight, sz_packed, bias, out, m, n, k, 0, 4, dtype, (hipStream_t)stream) == 0) return finish_launch();
   }
-  if (m > 8 && m < 256 && sz_packed && dtype == AWQ_BF16 && group_size == 128 && awq::gemm_variant_get() == 0) {
+  if (m > 8 && m < 256 && sz_packed && group_size == 128 && awq::gemm_variant_get() == 0) {
     // short prompts / batched decode: skinny kernel, bias fused
     int st0 = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
     if (st0 != AWQ_OK) return st0;
     if ((n % 16) != 0) return AWQ_ERR_SHAPE;
-    if (awq::launch_skinny_cdna4(x, qweight, sz_packed, bias, out, m, n, k, (hipStream_t)stream) == 0) return finish_launch();
+    if (awq::launch_skinny_cdna4(x, qweight, sz_packed, bias, out, m, n, k, dtype, (hipStream_t)stream) == 0) return finish_launch();
   }
-  if (bias && m > 128 && sz_packed && dtype == AWQ_BF16 && group_size == 128 && awq::gemm_variant_get() == 0) {
+  if (bias && m > 128 && sz_packed && group_size == 128 && awq::gemm_variant_get() == 0) {
     // prefill: bias fused into the GEMM v3 epilogue (no second kernel)
     int st0 = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
     if (st0 != AWQ_OK) return st0;
     if ((n % 16) != 0 || !aligned16(bias)) return (n % 16) ? AWQ_ERR_SHAPE : AWQ_ERR_ALIGN;
-    if (awq::launch_gemm_cdna4_v3(x, qweight, sz_packed, bias, out, m, n, k, 0, (hipStream_t)stream) == 0) return finish_launch();
+    if (awq::launch_gemm_cdna4_v3(x, qweight, sz_packed, bias, out, m, n, k, 0, dtype, (hipStream_t)stream) == 0) return finish_launch();
   }
   int st = awq_w4a16_gemm_cdna4(x, qweight, scales, scaled_zeros, sz_packed, out, m, n, k, group_size, dtype, workspace,
                                 workspace_bytes, stream);  // m <= 16 is routed to the GEMV inside
@@ -252,7 +250,7 @@ int awq_w4a16_moe_gemm(const void* x_sorted, const void* qweight, const void* sc
   if (!expert_offsets) return AWQ_ERR_NULL;
   if (num_experts < 1 || gpad * 128 < k || total_tokens < 0) return AWQ_ERR_SHAPE;
   if (layout != 0 && layout != 1) return AWQ_ERR_SHAPE;
-  if (layout == 1 && (dtype != AWQ_BF16 || (n % 16) != 0)) return AWQ_ERR_DTYPE;
+  if (layout == 1 && (n % 16) != 0) return AWQ_ERR_SHAPE;
   if (total_tokens == 0) return AWQ_OK;
   int st = check_common(x_sorted, qweight, scales, scaled_zeros, out, total_tokens, n, k, group_size, dtype);
   if (st != AWQ_OK) return st;
@@ -265,16 +263,16 @@ int awq_w4a16_moe_forward_cdna4(const void* x_sorted, const void* qweight, const
                                 const void* sz_packed, const void* expert_offsets, void* out, int total_tokens,
                                 int num_experts, int n, int k, int gpad, int group_size, int dtype, void* stream) {
   if (!expert_offsets || !sz_packed) return AWQ_ERR_NULL;
-  if (dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
+  if (dtype != AWQ_F16 && dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
   if (num_experts < 1 || gpad * 128 < k || total_tokens < 0 || (n % 16) != 0) return AWQ_ERR_SHAPE;
   if (total_tokens == 0) return AWQ_OK;
   int st = check_common(x_sorted, qweight, scales, scaled_zeros, out, total_tokens, n, k, group_size, dtype);
   if (st != AWQ_OK) return st;
   if (total_tokens <= 8 && awq::launch_moe_gemv_cdna4(x_sorted, qweight, sz_packed, expert_offsets, out, total_tokens, num_experts, n,
-                                                      k, (hipStream_t)stream) == 0)
+                                                      k, dtype, (hipStream_t)stream) == 0)
     return finish_launch();
   if (total_tokens >= 256 && awq::moe_v4_enabled() &&
-      awq::launch_moe_gemm_cdna4_v4(x_sorted, qweight, sz_packed, expert_offsets, out, total_tokens, num_experts, n, k,
+      awq::launch_moe_gemm_cdna4_v4(x_sorted, qweight, sz_packed, expert_offsets, out, total_tokens, num_experts, n, k, dtype,
                                     (hipStream_t)stream) == 0)
     return finish_launch();
   awq::launch_moe_gemm(x_sorted, qweight, scales, scaled_zeros, expert_offsets, out, total_tokens, num_experts, n, k, gpad, dtype, 1,
@@ -320,7 +318,7 @@ int awq_w3a16_forward(const void* x, const void* qweight_w3, const void* scales,
   if (st != AWQ_OK) return st;
   if (check_w3_shape(n, k)) return AWQ_ERR_SHAPE;
   if (m <= 8) {
-    if (awq::launch_gemv_cdna4(x, qweight_w3, sz_packed, bias, out, m, n, k, 0, 3, (hipStream_t)stream) != 0) return AWQ_ERR_SHAPE;
+    if (awq::launch_gemv_cdna4(x, qweight_w3, sz_packed, bias, out, m, n, k, 0, 3, dtype, (hipStream_t)stream) != 0) return AWQ_ERR_SHAPE;
     return finish_launch();
   }
   // prefill: expand the 3-bit tiles to W4 cdna4 tiles in the workspace, then the W4 GEMM runs unchanged

@@ -75,6 +75,26 @@ struct F16 {
   static __device__ __forceinline__ uint16_t from_float(float f) {
     return __builtin_bit_cast(uint16_t, (_Float16)f);
   }
+  static __device__ __forceinline__ float to_float(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+  // ---- matrix-core dequant (cdna4 interleave): A operand = 1024 + q (0x6400 | q), C = sz - 1024 s ----
+  static constexpr u32 kDqMagic = 0x64006400u;
+  static __device__ __forceinline__ f32x4 mfma4(u32x2 a, u32x2 b, const f32x4& c) {
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    return __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
+  }
+  // {s | sz << 16} -> sz - 1024 s: both products are exact in fp32 and so is their sum (|sz| = s z, z <= 15: 22 bits)
+  static __device__ __forceinline__ float dq_offset(u32 sz) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, sz), __builtin_bit_cast(f16x2, 0x3C00E400u), 0.0f, false);
+  }
+  static __device__ __forceinline__ vec8 pack8(const f32x4& d0, const f32x4& d1) {
+    vec8 r = {(_Float16)d0[0], (_Float16)d0[1], (_Float16)d0[2], (_Float16)d0[3],
+              (_Float16)d1[0], (_Float16)d1[1], (_Float16)d1[2], (_Float16)d1[3]};
+    return r;
+  }
+  typedef float f32x16_t __attribute__((ext_vector_type(16)));
+  static __device__ __forceinline__ f32x16_t mfma32(const vec8& a, const vec8& b, const f32x16_t& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
 };
 
 struct BF16 {
@@ -115,6 +135,27 @@ struct BF16 {
   static __device__ __forceinline__ uint16_t from_float(float f) {
     return __builtin_bit_cast(uint16_t, (__bf16)f);
   }
+  static __device__ __forceinline__ float to_float(uint16_t b) { return __builtin_bit_cast(float, (u32)b << 16); }
+  // ---- matrix-core dequant (cdna4 interleave): A operand = 128 + q (0x4300 | q), C = sz - 128 s ----
+  static constexpr u32 kDqMagic = 0x43004300u;
+  static __device__ __forceinline__ f32x4 mfma4(u32x2 a, u32x2 b, const f32x4& c) {
+    typedef short s16x4_t __attribute__((ext_vector_type(4)));
+    return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4_t, a), __builtin_bit_cast(s16x4_t, b), c, 0, 0, 0);
+  }
+  // {s | sz << 16} -> sz - 128 s (s * -128 and sz * 1 are exact products and their sum is exactly representable:
+  // |sz| = s * z, z <= 15)
+  static __device__ __forceinline__ float dq_offset(u32 sz) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, sz), __builtin_bit_cast(bf16x2, 0x3F80C300u), 0.0f, false);
+  }
+  static __device__ __forceinline__ vec8 pack8(const f32x4& d0, const f32x4& d1) {
+    vec8 r = {(__bf16)d0[0], (__bf16)d0[1], (__bf16)d0[2], (__bf16)d0[3],
+              (__bf16)d1[0], (__bf16)d1[1], (__bf16)d1[2], (__bf16)d1[3]};
+    return r;
+  }
+  typedef float f32x16_t __attribute__((ext_vector_type(16)));
+  static __device__ __forceinline__ f32x16_t mfma32(const vec8& a, const vec8& b, const f32x16_t& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
 };
 
 // Dequantise one 16-byte chunk (4 words = 32 k of one row) into four MFMA operands:
@@ -151,9 +192,10 @@ __device__ __forceinline__ u32x4 ldg_nt_u32x4(const u32* p) {
 // "cdna4" interleave (this repository's MI355X-native layout; emitted by the rewritten repacker).
 // Same bytes/shape as v2, nibbles permuted so that a 1-KiB tile = 16 rows x 128 k is ONE contiguous
 // wave-load and every extraction (word >> 4i) & 0x000F000F | 0x43004300 is directly an A-operand
-// register of a v_mfma_f32_4x4x4_16B_bf16 (16 independent 4 x 4 x 4 blocks, block = lane / 4) that dequantises
+// register of a v_mfma_f32_4x4x4_16B_bf16 / _f16 (16 independent 4 x 4 x 4 blocks, block = lane / 4) that dequantises
 // ON THE MATRIX CORE -- per block (k octet g, row quad nq), rows = 4 k, inner = the quad's 4 rows n':
-//      D[k][n] = sum_n' (128 + Q[n'][k]) * (s_n [n'==n])  +  (sz_n - 128 s_n)  =  Q[n][k] s_n + sz_n   (exact in fp32)
+//      D[k][n] = sum_n' (128 + Q[n'][k]) * (s_n [n'==n])  +  (sz_n - 128 s_n)  =  Q[n][k] s_n + sz_n   (exact in fp32;
+//      fp16: magic 0x6400 = 1024 + q and offset 1024 -- 11 x 11 significant bits, still exact)
 // lane l = 16 g + 4 nq + r, word a, nibble p (i = p & 3, hi = p >> 2):
 //      n = 16 nb + 4 nq + 2 (i & 1) + hi,   k = 128 kg + 32 a + 8 g + 4 (i >> 1) + r
 // D comes out with lane (n = l % 16, g = l / 16) holding k = 32 a + 8 g + {0..3} (first MFMA) and
@@ -165,7 +207,9 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ size_t cdna4_tile_word(int nb, int kg, int nit) { return ((size_t)nb * nit + kg) * 256; }
 
-struct Cdna4Dequant {
+template <typename DT>
+struct Cdna4DequantT {
+  using vec8 = typename DT::vec8;
   u32 m01, m23;  // lane masks selecting where s_n sits in the diagonal B operand
   u32 kMagic, kMask;
   __device__ __forceinline__ void init(int lane, u32 nibble_mask = 0x000F000Fu) {
@@ -174,24 +218,13 @@ struct Cdna4Dequant {
     m23 = pos == 2 ? 0x0000FFFFu : (pos == 3 ? 0xFFFF0000u : 0u);
     // gfx950 VOP3 takes no 32-bit literal: park the magic in a VGPR and the mask in an SGPR so that
     // (w & mask) | magic is ONE v_and_or_b32 instead of v_and_b32 + v_or_b32 with literals
-    kMagic = 0x43004300u;
+    kMagic = DT::kDqMagic;
     kMask = nibble_mask;  // 0x00070007 for W3 tiles (bit 3 of every nibble carries the folded fourth word)
     asm volatile("" : "+v"(kMagic));
     asm volatile("" : "+s"(kMask));
   }
-  // one word (two 4x4x4 16-block MFMAs) -> one bf16x8 operand: W[n = lane%16][k = 32a + 8g + 0..7]
-  __device__ __forceinline__ bf16x8 word(u32 w, u32 b01, u32 b23, float cv) const {
-    const u32x2 a0 = {(w & kMask) | kMagic, ((w >> 4) & kMask) | kMagic};
-    const u32x2 a1 = {((w >> 8) & kMask) | kMagic, ((w >> 12) & kMask) | kMagic};
-    const u32x2 b = {b01, b23};
-    const f32x4 c = {cv, cv, cv, cv};
-    const f32x4 d0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, a0), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
-    const f32x4 d1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, a1), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
-    bf16x8 r = {(__bf16)d0[0], (__bf16)d0[1], (__bf16)d0[2], (__bf16)d0[3],
-                (__bf16)d1[0], (__bf16)d1[1], (__bf16)d1[2], (__bf16)d1[3]};
-    return r;
-  }
-  // the same in two halves, for kernels that put other work between the dequant MFMAs and the use of their results
+  // the two dequant MFMAs of one word, and the rounding of their results, as separate halves for kernels that put other
+  // work in between
   struct Pending {
     f32x4 d0, d1;
   };
@@ -201,31 +234,29 @@ struct Cdna4Dequant {
     const u32x2 b = {b01, b23};
     const f32x4 c = {cv, cv, cv, cv};
     Pending p;
-    p.d0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, a0), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
-    p.d1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, a1), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+    p.d0 = DT::mfma4(a0, b, c);
+    p.d1 = DT::mfma4(a1, b, c);
     return p;
   }
-  static __device__ __forceinline__ bf16x8 word_finish(const Pending& p) {
-    bf16x8 r = {(__bf16)p.d0[0], (__bf16)p.d0[1], (__bf16)p.d0[2], (__bf16)p.d0[3],
-                (__bf16)p.d1[0], (__bf16)p.d1[1], (__bf16)p.d1[2], (__bf16)p.d1[3]};
-    return r;
-  }
+  static __device__ __forceinline__ vec8 word_finish(const Pending& p) { return DT::pack8(p.d0, p.d1); }
+  // one word (two 4x4x4 16-block MFMAs) -> one 8-element operand: W[n = lane%16][k = 32a + 8g + 0..7]
+  __device__ __forceinline__ vec8 word(u32 w, u32 b01, u32 b23, float cv) const { return word_finish(word_issue(w, b01, b23, cv)); }
   // whole 1-KiB tile -> 4 operands (op[a] covers k = 32a + 8g + 0..7 of the tile's 128 k)
-  __device__ __forceinline__ void tile(const u32x4& w, uint16_t s_bits, uint16_t z_bits, bf16x8 (&op)[4]) const {
+  __device__ __forceinline__ void tile(const u32x4& w, uint16_t s_bits, uint16_t z_bits, vec8 (&op)[4]) const {
     tile_packed(w, (u32)s_bits | ((u32)z_bits << 16), op);
   }
-  // same, from the packed {scale | scaled_zero << 16} dword: one v_perm for the splat, one v_dot2 for sz - 128 s
-  // (s * -128 and sz * 1 are exact products and their sum is exactly representable: |sz| = s*z, z <= 15)
-  __device__ __forceinline__ void tile_packed(const u32x4& w, u32 sz, bf16x8 (&op)[4]) const {
+  // same, from the packed {scale | scaled_zero << 16} dword: one v_perm for the splat, one v_dot2 for sz - offset * s
+  __device__ __forceinline__ void tile_packed(const u32x4& w, u32 sz, vec8 (&op)[4]) const {
     const u32 sdup = __builtin_amdgcn_perm(sz, sz, 0x01000100u);  // {s, s}
     const u32 b01 = sdup & m01, b23 = sdup & m23;
-    const float cv = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, sz), __builtin_bit_cast(bf16x2, 0x3F80C300u), 0.0f, false);
+    const float cv = DT::dq_offset(sz);
     op[0] = word(w.x, b01, b23, cv);
     op[1] = word(w.y, b01, b23, cv);
     op[2] = word(w.z, b01, b23, cv);
     op[3] = word(w.w, b01, b23, cv);
   }
 };
+using Cdna4Dequant = Cdna4DequantT<BF16>;
 
 
 // =============================================================================================

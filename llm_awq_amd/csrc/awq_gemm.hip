@@ -61,7 +61,7 @@ __device__ __forceinline__ void gemm128_tile(char* smem, const uint16_t* __restr
   const u32* b_src1 = qw + cdna4_tile_word(sl1, 0, nit) + lane * 4;
   const uint16_t* s_src = scales + nrow;
   const uint16_t* z_src = zeros + nrow;
-  Cdna4Dequant cd;
+  Cdna4DequantT<DT> cd;
   if (LAYOUT == 1) cd.init(lane);
 
   f32x4 acc[4][4];
@@ -103,12 +103,11 @@ __device__ __forceinline__ void gemm128_tile(char* smem, const uint16_t* __restr
     } else {
       // lane (row i of the slab, octet g): word w covers k = 32w + 8g + 0..7 -> granule 4w + g
       const u32 sd0 = (u32)rs * 0x00010001u, sd1 = (u32)rs1 * 0x00010001u;
-      const float c0 = __builtin_fmaf(-128.0f, __builtin_bit_cast(float, (u32)rs << 16), __builtin_bit_cast(float, (u32)rz << 16));
-      const float c1 = __builtin_fmaf(-128.0f, __builtin_bit_cast(float, (u32)rs1 << 16), __builtin_bit_cast(float, (u32)rz1 << 16));
-      *reinterpret_cast<bf16x8*>(Bs + tile_off(nl, 0 + g)) = cd.word(rb.x, sd0 & cd.m01, sd0 & cd.m23, c0);
-      *reinterpret_cast<bf16x8*>(Bs + tile_off(nl, 4 + g)) = cd.word(rb.y, sd0 & cd.m01, sd0 & cd.m23, c0);
-      *reinterpret_cast<bf16x8*>(Bs + tile_off(nl + 16, 0 + g)) = cd.word(rb.z, sd1 & cd.m01, sd1 & cd.m23, c1);
-      *reinterpret_cast<bf16x8*>(Bs + tile_off(nl + 16, 4 + g)) = cd.word(rb.w, sd1 & cd.m01, sd1 & cd.m23, c1);
+      const float c0 = DT::dq_offset((u32)rs | ((u32)rz << 16)), c1 = DT::dq_offset((u32)rs1 | ((u32)rz1 << 16));
+      *reinterpret_cast<vec8*>(Bs + tile_off(nl, 0 + g)) = cd.word(rb.x, sd0 & cd.m01, sd0 & cd.m23, c0);
+      *reinterpret_cast<vec8*>(Bs + tile_off(nl, 4 + g)) = cd.word(rb.y, sd0 & cd.m01, sd0 & cd.m23, c0);
+      *reinterpret_cast<vec8*>(Bs + tile_off(nl + 16, 0 + g)) = cd.word(rb.z, sd1 & cd.m01, sd1 & cd.m23, c1);
+      *reinterpret_cast<vec8*>(Bs + tile_off(nl + 16, 4 + g)) = cd.word(rb.w, sd1 & cd.m01, sd1 & cd.m23, c1);
     }
     __syncthreads();
     if (kt + 1 < nk) load_tile(kt + 1);
@@ -253,7 +252,7 @@ __global__ __launch_bounds__(512) void gemm_w4a16_256x256_kernel(const uint16_t*
   const u32* b_src1 = qw + cdna4_tile_word(sl1, 0, nit) + lane * 4;
   const uint16_t* s_src = scales + nrow;
   const uint16_t* z_src = zeros + nrow;
-  Cdna4Dequant cd;
+  Cdna4DequantT<DT> cd;
   if (LAYOUT == 1) cd.init(lane);
 
   auto issue_a = [&](int kt, int buf) {
@@ -276,12 +275,11 @@ __global__ __launch_bounds__(512) void gemm_w4a16_256x256_kernel(const uint16_t*
       for (int j = 0; j < 4; ++j) *reinterpret_cast<vec8*>(Bs + tile_off(nl, c * 4 + j)) = wop[j];
     } else {
       const u32 sd0 = (u32)r.s * 0x00010001u, sd1 = (u32)r.s1 * 0x00010001u;
-      const float c0 = __builtin_fmaf(-128.0f, __builtin_bit_cast(float, (u32)r.s << 16), __builtin_bit_cast(float, (u32)r.z << 16));
-      const float c1 = __builtin_fmaf(-128.0f, __builtin_bit_cast(float, (u32)r.s1 << 16), __builtin_bit_cast(float, (u32)r.z1 << 16));
-      *reinterpret_cast<bf16x8*>(Bs + tile_off(nl, 0 + g)) = cd.word(r.w.x, sd0 & cd.m01, sd0 & cd.m23, c0);
-      *reinterpret_cast<bf16x8*>(Bs + tile_off(nl, 4 + g)) = cd.word(r.w.y, sd0 & cd.m01, sd0 & cd.m23, c0);
-      *reinterpret_cast<bf16x8*>(Bs + tile_off(nl + 16, 0 + g)) = cd.word(r.w.z, sd1 & cd.m01, sd1 & cd.m23, c1);
-      *reinterpret_cast<bf16x8*>(Bs + tile_off(nl + 16, 4 + g)) = cd.word(r.w.w, sd1 & cd.m01, sd1 & cd.m23, c1);
+      const float c0 = DT::dq_offset((u32)r.s | ((u32)r.z << 16)), c1 = DT::dq_offset((u32)r.s1 | ((u32)r.z1 << 16));
+      *reinterpret_cast<vec8*>(Bs + tile_off(nl, 0 + g)) = cd.word(r.w.x, sd0 & cd.m01, sd0 & cd.m23, c0);
+      *reinterpret_cast<vec8*>(Bs + tile_off(nl, 4 + g)) = cd.word(r.w.y, sd0 & cd.m01, sd0 & cd.m23, c0);
+      *reinterpret_cast<vec8*>(Bs + tile_off(nl + 16, 0 + g)) = cd.word(r.w.z, sd1 & cd.m01, sd1 & cd.m23, c1);
+      *reinterpret_cast<vec8*>(Bs + tile_off(nl + 16, 4 + g)) = cd.word(r.w.w, sd1 & cd.m01, sd1 & cd.m23, c1);
     }
   };
 
@@ -376,7 +374,8 @@ int launch_moe_gemm(const void* x, const void* qw, const void* s, const void* z,
   hipLaunchKernelGGL((moe_gemm_w4a16_kernel<DT_, L_>), grid, block, 0, st, (const uint16_t*)x, (const u32*)qw,      \
                      (const uint16_t*)s, (const uint16_t*)z, (const int*)offsets, (uint16_t*)out, experts, n, k, gpad, \
                      tiles_n)
-  if (layout == 1) AWQ_MOE(BF16, 1);
+  if (layout == 1 && dtype == 0) AWQ_MOE(F16, 1);
+  else if (layout == 1) AWQ_MOE(BF16, 1);
   else if (dtype == 0) AWQ_MOE(F16, 0);
   else AWQ_MOE(BF16, 0);
 #undef AWQ_MOE
@@ -427,9 +426,9 @@ int launch_gemm(const void* x, const void* qw, const void* s, const void* z, con
   if (layout == 1) {
     // variant 3 / auto: v3 kernel with the tile width picked by chip fill; 4 = force 256 x 256; 5 = force 256 x 128
     if ((g_gemm_variant >= 3 || (g_gemm_variant == 0 && m > 128)) &&
-        launch_gemm_cdna4_v3(x, qw, szp, nullptr, out, m, n, k, g_gemm_variant == 4 ? 256 : (g_gemm_variant == 5 ? 128 : 0), st) == 0)
+        launch_gemm_cdna4_v3(x, qw, szp, nullptr, out, m, n, k, g_gemm_variant == 4 ? 256 : (g_gemm_variant == 5 ? 128 : 0), dtype, st) == 0)
       return 0;
-    return launch_gemm_t<BF16, 1>(x, qw, s, z, out, m, n, k, st);
+    return dtype == 0 ? launch_gemm_t<F16, 1>(x, qw, s, z, out, m, n, k, st) : launch_gemm_t<BF16, 1>(x, qw, s, z, out, m, n, k, st);
   }
   return dtype == 0 ? launch_gemm_t<F16, 0>(x, qw, s, z, out, m, n, k, st)
                     : launch_gemm_t<BF16, 0>(x, qw, s, z, out, m, n, k, st);

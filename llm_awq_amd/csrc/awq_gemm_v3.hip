@@ -1,4 +1,4 @@
-// Prefill GEMM v3 on cdna4-interleaved weights (bf16, gfx950): 256 x (128 * NSL) x 64 tile, 8 waves (2 along M x 4
+// Prefill GEMM v3 on cdna4-interleaved weights (bf16 and fp16, gfx950): 256 x (128 * NSL) x 64 tile, 8 waves (2 along M x 4
 // along N, 128 x (32 * NSL) each), v_mfma_f32_32x32x16_bf16, double-buffered LDS.
 //
 // Replaces gemm_w4a16_T1 / gemm_w4a16_T2 (reference awq/kernels/csrc/quantization_new/gemm/gemm_cuda.cu:312-1124) for
@@ -11,7 +11,7 @@
 //   * no ordinary load is ever consumed while an LDS-DMA is in flight (hipcc would drain the DMA queue there);
 //   * 32x32x16 MFMAs: half the matrix instructions per flop and the higher measured ceiling of the two shapes;
 //   * NSL = 1 (256 x 128 tiles) doubles the tile count for shapes that would fill only half the chip with 256 x 256.
-// Numerics are those of every other kernel here: W = round_bf16(q*s + sz) exactly (matrix-core dequant), fp32
+// Numerics are those of every other kernel here: W = round_T(q*s + sz) exactly (matrix-core dequant), fp32
 // accumulation in K order, one rounding of the result -- bit-identical to the 128x128 kernel.
 #include <string.h>
 
@@ -43,7 +43,7 @@ struct Raw {
 };
 }  // namespace
 
-template <int NSL>
+template <typename DT, int NSL>
 __global__ __launch_bounds__(512) void gemm_cdna4_v3_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                             const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
                                                             uint16_t* __restrict__ out, int M, int N, int K, int tiles_m,
@@ -113,7 +113,8 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v3_kernel(const uint16_t* __re
     sz_off[s] = (u32)sl * nit * 16 + i;  // packed {scale | scaled_zero << 16}
   }
   const int nl = 16 * NSL * wv + i;  // tile row of slab 0's lane row; slab s = + 16 s
-  Cdna4Dequant cd;
+  using vec8 = typename DT::vec8;
+  Cdna4DequantT<DT> cd;
   cd.init(lane);
 
   auto load_group = [&](int grp) {
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v3_kernel(const uint16_t* __re
       const u32 sd = (r.sz[s] & 0xFFFFu) * 0x00010001u;
       gq.b01[s] = sd & cd.m01;
       gq.b23[s] = sd & cd.m23;
-      gq.c[s] = __builtin_fmaf(-128.0f, __builtin_bit_cast(float, r.sz[s] << 16), __builtin_bit_cast(float, r.sz[s] & 0xFFFF0000u));
+      gq.c[s] = DT::dq_offset(r.sz[s]);
     }
     return gq;
   };
@@ -144,8 +145,8 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v3_kernel(const uint16_t* __re
     char* Bs = smem + kWBase + stage * kTileW;
     const int widx = 2 * h + (j & 1), s = j >> 1;
     const u32 word = widx == 0 ? gq.w[s].x : (widx == 1 ? gq.w[s].y : (widx == 2 ? gq.w[s].z : gq.w[s].w));
-    const bf16x8 v = cd.word(word, gq.b01[s], gq.b23[s], gq.c[s]);
-    *reinterpret_cast<bf16x8*>(Bs + tile_off(nl + 16 * s, 4 * (j & 1) + g)) = v;
+    const vec8 v = cd.word(word, gq.b01[s], gq.b23[s], gq.c[s]);
+    *reinterpret_cast<vec8*>(Bs + tile_off(nl + 16 * s, 4 * (j & 1) + g)) = v;
   };
   // the 2 NSL word jobs of a K-tile are spread over its four production slots (slot 0 = right after the barrier of
   // the previous tile, slots 1..3 = its own first three k-steps)
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v3_kernel(const uint16_t* __re
 
   // fragments (single set): each one is re-read for the NEXT k-step right after the last MFMA of this k-step that
   // consumes it, so every ds_read has several MFMAs (plus the other wave of the SIMD) to land
-  bf16x8 wf[NSL], xf[4];
+  vec8 wf[NSL], xf[4];
   f32x16 acc[NSL][4];
 #pragma unroll
   for (int a = 0; a < NSL; ++a)
@@ -175,37 +176,37 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v3_kernel(const uint16_t* __re
   auto step = [&](int stage_n, int ks_n, bool rd, bool bar = false) {
     if (NSL == 2) {
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[b], acc[0][b], 0, 0, 0);
+      for (int b = 0; b < 4; ++b) acc[0][b] = DT::mfma32(wf[0], xf[b], acc[0][b]);
       if (bar) {
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
         __syncthreads();
       }
-      if (rd) wf[0] = *reinterpret_cast<const bf16x8*>(w_addr(stage_n, ks_n, 0));
+      if (rd) wf[0] = *reinterpret_cast<const vec8*>(w_addr(stage_n, ks_n, 0));
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        acc[NSL - 1][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[NSL - 1], xf[b], acc[NSL - 1][b], 0, 0, 0);
-        if (rd) xf[b] = *reinterpret_cast<const bf16x8*>(x_addr(stage_n, ks_n, b));
+        acc[NSL - 1][b] = DT::mfma32(wf[NSL - 1], xf[b], acc[NSL - 1][b]);
+        if (rd) xf[b] = *reinterpret_cast<const vec8*>(x_addr(stage_n, ks_n, b));
       }
-      if (rd) wf[NSL - 1] = *reinterpret_cast<const bf16x8*>(w_addr(stage_n, ks_n, NSL - 1));
+      if (rd) wf[NSL - 1] = *reinterpret_cast<const vec8*>(w_addr(stage_n, ks_n, NSL - 1));
     } else {
       // one weight fragment: the first two MFMAs run in front of the barrier, x fragments are re-read behind it
-      bf16x8 xn[2];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[0], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[1], acc[0][1], 0, 0, 0);
+      vec8 xn[2];
+      acc[0][0] = DT::mfma32(wf[0], xf[0], acc[0][0]);
+      acc[0][1] = DT::mfma32(wf[0], xf[1], acc[0][1]);
       if (bar) {
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __syncthreads();
       }
       if (rd) {
-        xn[0] = *reinterpret_cast<const bf16x8*>(x_addr(stage_n, ks_n, 0));
-        xn[1] = *reinterpret_cast<const bf16x8*>(x_addr(stage_n, ks_n, 1));
+        xn[0] = *reinterpret_cast<const vec8*>(x_addr(stage_n, ks_n, 0));
+        xn[1] = *reinterpret_cast<const vec8*>(x_addr(stage_n, ks_n, 1));
       }
-      acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[2], acc[0][2], 0, 0, 0);
-      if (rd) xf[2] = *reinterpret_cast<const bf16x8*>(x_addr(stage_n, ks_n, 2));
-      acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[3], acc[0][3], 0, 0, 0);
+      acc[0][2] = DT::mfma32(wf[0], xf[2], acc[0][2]);
+      if (rd) xf[2] = *reinterpret_cast<const vec8*>(x_addr(stage_n, ks_n, 2));
+      acc[0][3] = DT::mfma32(wf[0], xf[3], acc[0][3]);
       if (rd) {
-        xf[3] = *reinterpret_cast<const bf16x8*>(x_addr(stage_n, ks_n, 3));
-        wf[0] = *reinterpret_cast<const bf16x8*>(w_addr(stage_n, ks_n, 0));
+        xf[3] = *reinterpret_cast<const vec8*>(x_addr(stage_n, ks_n, 3));
+        wf[0] = *reinterpret_cast<const vec8*>(w_addr(stage_n, ks_n, 0));
         xf[0] = xn[0];
         xf[1] = xn[1];
       }
@@ -220,9 +221,9 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v3_kernel(const uint16_t* __re
   for (int j = 0; j < 2 * NSL; ++j) job(gc, 0, j, 0);
   __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and the ds_writes
 #pragma unroll
-  for (int t = 0; t < NSL; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(w_addr(0, 0, t));
+  for (int t = 0; t < NSL; ++t) wf[t] = *reinterpret_cast<const vec8*>(w_addr(0, 0, t));
 #pragma unroll
-  for (int t = 0; t < 4; ++t) xf[t] = *reinterpret_cast<const bf16x8*>(x_addr(0, 0, t));
+  for (int t = 0; t < 4; ++t) xf[t] = *reinterpret_cast<const vec8*>(x_addr(0, 0, t));
   // pin the prefetched group into registers BEFORE the next LDS-DMA goes out: otherwise the loop header inherits a
   // pending ordinary load from this path and hipcc drains the DMA queue (vmcnt(0)) at the top of every iteration
 #pragma unroll
@@ -275,8 +276,8 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v3_kernel(const uint16_t* __re
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         u32x2 v;
-        v.x = (u32)BF16::from_float(acc[a][b][4 * j + 0]) | ((u32)BF16::from_float(acc[a][b][4 * j + 1]) << 16);
-        v.y = (u32)BF16::from_float(acc[a][b][4 * j + 2]) | ((u32)BF16::from_float(acc[a][b][4 * j + 3]) << 16);
+        v.x = (u32)DT::from_float(acc[a][b][4 * j + 0]) | ((u32)DT::from_float(acc[a][b][4 * j + 1]) << 16);
+        v.y = (u32)DT::from_float(acc[a][b][4 * j + 2]) | ((u32)DT::from_float(acc[a][b][4 * j + 3]) << 16);
         *reinterpret_cast<u32x2*>(eb + (b * 32 + l32) * kEpiRow + (a * 32 + 8 * j + 4 * hk) * 2) = v;
       }
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's own LDS writes (region is wave-private)
@@ -292,9 +293,9 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v3_kernel(const uint16_t* __re
       if (bias != nullptr) {  // `out + self.bias` in T (qmodule.py:221): the matmul result was already rounded to bf16
         const u32x4 bv = *reinterpret_cast<const u32x4*>(bias + nn);
         auto add2 = [](u32 a, u32 b) {
-          const float lo = __builtin_bit_cast(float, a << 16) + __builtin_bit_cast(float, b << 16);
-          const float hi = __builtin_bit_cast(float, a & 0xFFFF0000u) + __builtin_bit_cast(float, b & 0xFFFF0000u);
-          return (u32)BF16::from_float(lo) | ((u32)BF16::from_float(hi) << 16);
+          const float lo = DT::to_float((uint16_t)(a & 0xFFFFu)) + DT::to_float((uint16_t)(b & 0xFFFFu));
+          const float hi = DT::to_float((uint16_t)(a >> 16)) + DT::to_float((uint16_t)(b >> 16));
+          return (u32)DT::from_float(lo) | ((u32)DT::from_float(hi) << 16);
         };
         v = u32x4{add2(v.x, bv.x), add2(v.y, bv.y), add2(v.z, bv.z), add2(v.w, bv.w)};
       }
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v3_kernel(const uint16_t* __re
 }
 
 namespace {
-template <int NSL>
+template <typename DT, int NSL>
 void launch_v3(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
                int n_end, hipStream_t st) {
   constexpr int TN = 128 * NSL;
@@ -314,18 +315,24 @@ void launch_v3(const void* x, const void* qw, const void* szp, const void* bias,
   const int tiles_m = (m + TM - 1) / TM, tiles_n = (n_end - n_begin + TN - 1) / TN;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cdna4_v3_kernel<NSL>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cdna4_v3_kernel<DT, NSL>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr = true;
   }
-  hipLaunchKernelGGL(gemm_cdna4_v3_kernel<NSL>, dim3(tiles_m * tiles_n), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw,
+  hipLaunchKernelGGL((gemm_cdna4_v3_kernel<DT, NSL>), dim3(tiles_m * tiles_n), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw,
                      (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end);
 }
 constexpr double kNarrowRate = 0.77;  // 256 x 128 tiles (v3 K loop) vs 256 x 256 (v4 K loop) at equal chip fill (profiles/r01_gemm_v4.txt)
 int g_v4 = 1;  // 1 (default): 256-wide tiles run the hand-scheduled K loop of awq_gemm_v4.hip; 0: v3's compiler-scheduled loop
 void launch_wide(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
-                 int n_end, hipStream_t st) {
-  if (g_v4) launch_gemm_cdna4_v4(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
-  else launch_v3<2>(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
+                 int n_end, int dtype, hipStream_t st) {
+  if (g_v4) launch_gemm_cdna4_v4(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st);
+  else if (dtype == 0) launch_v3<F16, 2>(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
+  else launch_v3<BF16, 2>(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
+}
+void launch_narrow(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
+                   int n_end, int dtype, hipStream_t st) {
+  if (dtype == 0) launch_v3<F16, 1>(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
+  else launch_v3<BF16, 1>(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
 }
 }  // namespace
 
@@ -348,14 +355,14 @@ int gemm_v3_tune_set(const char* key, int value) {
 // In auto mode a matrix whose 256-wide tile count is k full rounds plus a partial one runs the full rounds with 256-wide
 // tiles and the remaining weight rows with 128-wide tiles in a second launch when that is faster.
 int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                         int tile_n, hipStream_t st) {
+                         int tile_n, int dtype, hipStream_t st) {
   if (!szp || m < TM || (n % 16) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return -1;
   if (tile_n == 128) {
-    launch_v3<1>(x, qw, szp, bias, out, m, n, k, 0, n, st);
+    launch_narrow(x, qw, szp, bias, out, m, n, k, 0, n, dtype, st);
     return 0;
   }
   if (tile_n == 256) {
-    launch_wide(x, qw, szp, bias, out, m, n, k, 0, n, st);
+    launch_wide(x, qw, szp, bias, out, m, n, k, 0, n, dtype, st);
     return 0;
   }
   const long tiles_m = (m + TM - 1) / TM;
@@ -371,12 +378,12 @@ int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, const v
     cost_mixed = rounds(tiles_m * cols_main) + rounds(tiles_m * ((n_rest + 127) / 128)) * 0.5 / kNarrowRate + 0.02;
   }
   if (cost_mixed < cost_wide && cost_mixed < cost_narrow) {
-    launch_wide(x, qw, szp, bias, out, m, n, k, 0, (int)(cols_main * 256), st);
-    launch_v3<1>(x, qw, szp, bias, out, m, n, k, (int)(cols_main * 256), n, st);
+    launch_wide(x, qw, szp, bias, out, m, n, k, 0, (int)(cols_main * 256), dtype, st);
+    launch_narrow(x, qw, szp, bias, out, m, n, k, (int)(cols_main * 256), n, dtype, st);
   } else if (cost_narrow < cost_wide) {
-    launch_v3<1>(x, qw, szp, bias, out, m, n, k, 0, n, st);
+    launch_narrow(x, qw, szp, bias, out, m, n, k, 0, n, dtype, st);
   } else {
-    launch_wide(x, qw, szp, bias, out, m, n, k, 0, n, st);
+    launch_wide(x, qw, szp, bias, out, m, n, k, 0, n, dtype, st);
   }
   return 0;
 }

@@ -1,4 +1,4 @@
-// Prefill GEMM v4 on cdna4-interleaved weights (bf16, gfx950): the tiling and data flow of awq_gemm_v3.hip's 256 x 256 x 64
+// Prefill GEMM v4 on cdna4-interleaved weights (bf16 and fp16, gfx950): the tiling and data flow of awq_gemm_v3.hip's 256 x 256 x 64
 // kernel (8 waves = 2 along M x 4 along N, 128 x 64 each, v_mfma_f32_32x32x16_bf16, x tile by LDS-DMA, weight tile
 // dequantised on the matrix core one word per k-step, double-buffered LDS) with every LDS access of the K loop placed by
 // hand.
@@ -67,7 +67,7 @@ struct NoJob {
 // 3 = no epilogue (one dword per lane is stored so that the accumulators stay live)
 // one 256 x 256 output tile: rows [m0, m0 + 256) of x (all of them must exist), weight rows [n0, n0 + 256) clipped to n_end;
 // stores are masked to rows [row_lo, row_hi) (dense: every row of the tile; grouped: the expert's rows inside it)
-template <int PROBE>
+template <typename DT, int PROBE>
 __device__ __forceinline__ void v4_tile(char* smem, const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                         const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
                                         uint16_t* __restrict__ out, int N, int K, int m0, int n0, int n_end, int row_lo,
@@ -108,7 +108,8 @@ __device__ __forceinline__ void v4_tile(char* smem, const uint16_t* __restrict__
     sz_off[s] = (u32)sl * nit * 16 + i;
   }
   const int nl = 32 * wv + i;  // tile row of slab 0's lane row; slab 1 = + 16
-  Cdna4Dequant cd;
+  using vec8 = typename DT::vec8;
+  Cdna4DequantT<DT> cd;
   cd.init(lane);
 
   auto load_group = [&](int grp) {
@@ -130,7 +131,7 @@ __device__ __forceinline__ void v4_tile(char* smem, const uint16_t* __restrict__
       const u32 sd = (r.sz[s] & 0xFFFFu) * 0x00010001u;
       gq.b01[s] = sd & cd.m01;
       gq.b23[s] = sd & cd.m23;
-      gq.c[s] = __builtin_fmaf(-128.0f, __builtin_bit_cast(float, r.sz[s] << 16), __builtin_bit_cast(float, r.sz[s] & 0xFFFF0000u));
+      gq.c[s] = DT::dq_offset(r.sz[s]);
     }
     return gq;
   };
@@ -155,7 +156,7 @@ __device__ __forceinline__ void v4_tile(char* smem, const uint16_t* __restrict__
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   auto mf = [](const u32x4& a, const u32x4& b, const f32x16& c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    return DT::mfma32(__builtin_bit_cast(vec8, a), __builtin_bit_cast(vec8, b), c);
   };
 
   Group gc;
@@ -178,7 +179,7 @@ __device__ __forceinline__ void v4_tile(char* smem, const uint16_t* __restrict__
     V4_FENCE();
     asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(x3));
     acc[0][3] = mf(w0, x3, acc[0][3]);
-    Cdna4Dequant::Pending pj;
+    typename Cdna4DequantT<DT>::Pending pj;
     if constexpr (J::has) {  // the two dequant MFMAs of this step's weight word queue behind A4
       constexpr int widx = 2 * J::h + (J::j & 1), s = J::j >> 1;
       const u32 word = widx == 0 ? gc.w[s].x : (widx == 1 ? gc.w[s].y : (widx == 2 ? gc.w[s].z : gc.w[s].w));
@@ -194,7 +195,7 @@ __device__ __forceinline__ void v4_tile(char* smem, const uint16_t* __restrict__
     V4_FENCE();
     acc[1][0] = mf(w1, x0, acc[1][0]);
     if constexpr (J::has) {
-      const bf16x8 v = Cdna4Dequant::word_finish(pj);
+      const vec8 v = Cdna4DequantT<DT>::word_finish(pj);
       V4_WRITE(ja[J::j & 1], __builtin_bit_cast(u32x4, v), J::st * kTileW + (J::j >> 1) * 2048);
     }
     V4_FENCE();
@@ -226,7 +227,7 @@ __device__ __forceinline__ void v4_tile(char* smem, const uint16_t* __restrict__
     for (int j = 0; j < 4; ++j) {
       const int s = j >> 1;
       const u32 word = (j & 1) ? gc.w[s].y : gc.w[s].x;
-      *reinterpret_cast<bf16x8*>(Bs + tile_off(nl + 16 * s, 4 * (j & 1) + g)) = cd.word(word, gc.b01[s], gc.b23[s], gc.c[s]);
+      *reinterpret_cast<vec8*>(Bs + tile_off(nl + 16 * s, 4 * (j & 1) + g)) = cd.word(word, gc.b01[s], gc.b23[s], gc.c[s]);
     }
   }
   __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and the ds_writes
@@ -236,7 +237,7 @@ __device__ __forceinline__ void v4_tile(char* smem, const uint16_t* __restrict__
   V4_FENCE();
   // first word of tile 1 = (group 0, half 1) -> stage 1, then the fragments of k-step 0 in the order the ladder expects
   {
-    const bf16x8 v = cd.word(gc.w[0].z, gc.b01[0], gc.b23[0], gc.c[0]);
+    const vec8 v = cd.word(gc.w[0].z, gc.b01[0], gc.b23[0], gc.c[0]);
     V4_WRITE(ja[0], __builtin_bit_cast(u32x4, v), kTileW);
   }
   V4_READ(w0, wa[0], 0);
@@ -300,8 +301,8 @@ __device__ __forceinline__ void v4_tile(char* smem, const uint16_t* __restrict__
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         u32x2 v;
-        v.x = (u32)BF16::from_float(acc[a][b][4 * j + 0]) | ((u32)BF16::from_float(acc[a][b][4 * j + 1]) << 16);
-        v.y = (u32)BF16::from_float(acc[a][b][4 * j + 2]) | ((u32)BF16::from_float(acc[a][b][4 * j + 3]) << 16);
+        v.x = (u32)DT::from_float(acc[a][b][4 * j + 0]) | ((u32)DT::from_float(acc[a][b][4 * j + 1]) << 16);
+        v.y = (u32)DT::from_float(acc[a][b][4 * j + 2]) | ((u32)DT::from_float(acc[a][b][4 * j + 3]) << 16);
         *reinterpret_cast<u32x2*>(eb + (b * 32 + l32) * kEpiRow + (a * 32 + 8 * j + 4 * hk) * 2) = v;
       }
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's own LDS writes (region is wave-private)
@@ -316,9 +317,9 @@ __device__ __forceinline__ void v4_tile(char* smem, const uint16_t* __restrict__
       if (bias != nullptr) {  // `out + self.bias` in T (qmodule.py:221)
         const u32x4 bv = *reinterpret_cast<const u32x4*>(bias + nn);
         auto add2 = [](u32 a, u32 b) {
-          const float lo = __builtin_bit_cast(float, a << 16) + __builtin_bit_cast(float, b << 16);
-          const float hi = __builtin_bit_cast(float, a & 0xFFFF0000u) + __builtin_bit_cast(float, b & 0xFFFF0000u);
-          return (u32)BF16::from_float(lo) | ((u32)BF16::from_float(hi) << 16);
+          const float lo = DT::to_float((uint16_t)(a & 0xFFFFu)) + DT::to_float((uint16_t)(b & 0xFFFFu));
+          const float hi = DT::to_float((uint16_t)(a >> 16)) + DT::to_float((uint16_t)(b >> 16));
+          return (u32)DT::from_float(lo) | ((u32)DT::from_float(hi) << 16);
         };
         v = u32x4{add2(v.x, bv.x), add2(v.y, bv.y), add2(v.z, bv.z), add2(v.w, bv.w)};
       }
@@ -328,7 +329,7 @@ __device__ __forceinline__ void v4_tile(char* smem, const uint16_t* __restrict__
 }
 
 // dense: XCD-aware, two-row-band tile order as v3 (awq_gemm_v3.hip); the last row tile is shifted up to end at row M - 1
-template <int PROBE>
+template <typename DT, int PROBE>
 __global__ __launch_bounds__(512) void gemm_cdna4_v4_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                             const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
                                                             uint16_t* __restrict__ out, int M, int N, int K, int tiles_m,
@@ -353,13 +354,14 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v4_kernel(const uint16_t* __re
       tm = tiles_m - 1;
     }
   }
-  v4_tile<PROBE>(smem, x, qw, szp, bias, out, N, K, min(tm * TM, M - TM), n_begin + tn * TN, n_end, 0, M);
+  v4_tile<DT, PROBE>(smem, x, qw, szp, bias, out, N, K, min(tm * TM, M - TM), n_begin + tn * TN, n_end, 0, M);
 }
 
 // grouped (MoE): expert e owns rows [offsets[e], offsets[e+1]) of the sorted x / out and the e-th slice of the stacked
 // cdna4 weights / packed scales.  The grid is an upper bound (total / 256 + experts row tiles); a block finds its
 // (expert, row tile) by walking the offsets and exits if there is none.  A tile always reads 256 existing rows of x
 // (shifted up at the end of the buffer); rows of other experts inside it are computed and not stored.
+template <typename DT>
 __global__ __launch_bounds__(512) void moe_gemm_cdna4_v4_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                                 const u32* __restrict__ szp, const int* __restrict__ offsets,
                                                                 uint16_t* __restrict__ out, int total, int experts, int N,
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(512) void moe_gemm_cdna4_v4_kernel(const uint16_t* 
   if (e == experts) return;  // wave-uniform: no tile for this block
   const int r_lo = lo + rt * TM, r_hi = min(r_lo + TM, hi);
   const size_t ew = (size_t)(N >> 4) * (K >> 7);  // tiles per expert
-  v4_tile<0>(smem, x, qw + (size_t)e * ew * 256, szp + (size_t)e * ew * 16, nullptr, out, N, K, min(r_lo, total - TM), tn * TN, N,
+  v4_tile<DT, 0>(smem, x, qw + (size_t)e * ew * 256, szp + (size_t)e * ew * 16, nullptr, out, N, K, min(r_lo, total - TM), tn * TN, N,
              r_lo, r_hi);
 }
 
@@ -394,23 +396,28 @@ int g_v4_probe = 0;
 }
 // weight rows [n_begin, n_end) of the matrix with 256 x 256 tiles (m >= 256); same contract as v3's launch_v3<2>
 void launch_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                          int n_begin, int n_end, hipStream_t st) {
+                          int n_begin, int n_end, int dtype, hipStream_t st) {
   constexpr int smem_main = 2 * kTileX + 2 * kTileW;
   constexpr int smem_epi = 8 * 128 * (2 * WN + 16);
   constexpr int smem = smem_main > smem_epi ? smem_main : smem_epi;
   const int tiles_m = (m + TM - 1) / TM, tiles_n = (n_end - n_begin + TN - 1) / TN;
   using Kern = void (*)(const uint16_t*, const u32*, const u32*, const uint16_t*, uint16_t*, int, int, int, int, int, int, int);
 #ifdef AWQ_ENABLE_PROBES
-  static const Kern kerns[4] = {gemm_cdna4_v4_kernel<0>, gemm_cdna4_v4_kernel<1>, gemm_cdna4_v4_kernel<2>, gemm_cdna4_v4_kernel<3>};
+  static const Kern kerns[2][4] = {
+      {gemm_cdna4_v4_kernel<F16, 0>, gemm_cdna4_v4_kernel<F16, 1>, gemm_cdna4_v4_kernel<F16, 2>, gemm_cdna4_v4_kernel<F16, 3>},
+      {gemm_cdna4_v4_kernel<BF16, 0>, gemm_cdna4_v4_kernel<BF16, 1>, gemm_cdna4_v4_kernel<BF16, 2>, gemm_cdna4_v4_kernel<BF16, 3>}};
 #else  // a default build has no knob that changes results
-  static const Kern kerns[4] = {gemm_cdna4_v4_kernel<0>, gemm_cdna4_v4_kernel<0>, gemm_cdna4_v4_kernel<0>, gemm_cdna4_v4_kernel<0>};
+  static const Kern kerns[2][4] = {
+      {gemm_cdna4_v4_kernel<F16, 0>, gemm_cdna4_v4_kernel<F16, 0>, gemm_cdna4_v4_kernel<F16, 0>, gemm_cdna4_v4_kernel<F16, 0>},
+      {gemm_cdna4_v4_kernel<BF16, 0>, gemm_cdna4_v4_kernel<BF16, 0>, gemm_cdna4_v4_kernel<BF16, 0>, gemm_cdna4_v4_kernel<BF16, 0>}};
 #endif
   static bool attr = false;
   if (!attr) {
-    for (Kern kf : kerns) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    for (auto& row : kerns)
+      for (Kern kf : row) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr = true;
   }
-  const Kern kern = kerns[g_v4_probe >= 0 && g_v4_probe <= 3 ? g_v4_probe : 0];
+  const Kern kern = kerns[dtype == 0 ? 0 : 1][g_v4_probe >= 0 && g_v4_probe <= 3 ? g_v4_probe : 0];
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw,
                      (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end);
 }
@@ -418,7 +425,7 @@ void gemm_v4_set_probe(int v) { g_v4_probe = v; }
 
 // grouped GEMM over sorted tokens, 256 x 256 tiles; needs total >= 256.  Returns -1 if unsupported.
 int launch_moe_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total, int experts,
-                             int n, int k, hipStream_t st) {
+                             int n, int k, int dtype, hipStream_t st) {
   if (total < TM || experts < 1 || (n % 16) != 0 || (k % 128) != 0 || (size_t)total * (size_t)k >= (1ull << 31) ||
       (size_t)n * (size_t)k / 8 >= (1ull << 31))
     return -1;
@@ -427,11 +434,13 @@ int launch_moe_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, con
   constexpr int smem = smem_main > smem_epi ? smem_main : smem_epi;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(moe_gemm_cdna4_v4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(moe_gemm_cdna4_v4_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(moe_gemm_cdna4_v4_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr = true;
   }
   const int row_tiles = total / TM + experts, tiles_n = (n + TN - 1) / TN;
-  hipLaunchKernelGGL(moe_gemm_cdna4_v4_kernel, dim3(row_tiles * tiles_n), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw,
+  auto mkern = dtype == 0 ? moe_gemm_cdna4_v4_kernel<F16> : moe_gemm_cdna4_v4_kernel<BF16>;
+  hipLaunchKernelGGL(mkern, dim3(row_tiles * tiles_n), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw,
                      (const u32*)szp, (const int*)offsets, (uint16_t*)out, total, experts, n, k, row_tiles, tiles_n);
   return 0;
 }

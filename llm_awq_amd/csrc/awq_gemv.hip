@@ -41,7 +41,6 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_w4a16_kernel(const uint16_t* 
                                                                  uint16_t* __restrict__ out, int M, int N, int K,
                                                                  int seg_steps) {
   using vec8 = typename DT::vec8;
-  static_assert(LAYOUT == 0 || DT::id == 1, "the cdna4 interleave is defined for bf16");
   constexpr int NT = 64 * WAVES;
   constexpr int XS = 8;  // x granules (16 B) a thread can stage through registers ahead of the weight stream
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -68,7 +67,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_w4a16_kernel(const uint16_t* 
   char* xs = smem + WAVES * 1024;
   const int xrow_bytes = 2 * seg_steps * kGroup + 16;
 
-  Cdna4Dequant cd;
+  Cdna4DequantT<DT> cd;
   if (LAYOUT == 1) cd.init(lane);
 
   auto load_slot = [&](int it) {
@@ -102,11 +101,11 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_w4a16_kernel(const uint16_t* 
     } else {
       // operand a covers k = 32a + 8g + 0..7 of the step: x granule index 4a + g
       const u32x4* xr = reinterpret_cast<const u32x4*>(xs + mrow * xrow_bytes + (it - seg0) * 256);
-      bf16x8 op[4];
+      vec8 op[4];
       cd.tile(sl.w, sb, zb, op);
 #pragma unroll
       for (int a = 0; a < 4; ++a)
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(op[a], __builtin_bit_cast(bf16x8, xr[4 * a + g]), acc, 0, 0, 0);
+        acc = DT::mfma(op[a], __builtin_bit_cast(vec8, xr[4 * a + g]), acc);
     }
   };
 
@@ -304,7 +303,8 @@ static int launch_gemv_t(const void* x, const void* qw, const void* s, const voi
 
 int launch_gemv(const void* x, const void* qw, const void* s, const void* z, const void* szp, void* out, int m, int n,
                 int k, int dtype, int layout, hipStream_t st) {
-  if (layout == 1) return launch_gemv_t<BF16, 1>(x, qw, s, z, szp, out, m, n, k, st);
+  if (layout == 1)
+    return dtype == 0 ? launch_gemv_t<F16, 1>(x, qw, s, z, szp, out, m, n, k, st) : launch_gemv_t<BF16, 1>(x, qw, s, z, szp, out, m, n, k, st);
   // reference layout, m <= 8: the pipelined kernel of awq_gemv_v2fast.hip unless a knob of this file's kernel is set
   if (gemv_v2fast_enabled() && launch_gemv_v2fast(x, qw, s, z, nullptr, out, m, n, k, k / kGroup, dtype, st) == 0)
     return 0;

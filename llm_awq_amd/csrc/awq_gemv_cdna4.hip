@@ -1,4 +1,4 @@
-// Decode GEMV on cdna4-interleaved weights, 1 <= M <= 8, bf16 (gfx950).  The fast path of
+// Decode GEMV on cdna4-interleaved weights, 1 <= M <= 8, bf16 and fp16 (gfx950).  The fast path of
 // WQLinear.forward for decode (replaces gemv_kernel, awq/kernels/csrc/quantization_new/gemv/gemv_cuda.cu:74-229)
 // and, with EPI = 1, of QuantLlamaMLP's gate/up pair + SiLU*mul (tinychat/modules/fused_mlp.py:36-83).
 //
@@ -21,7 +21,7 @@
 namespace awq {
 
 // the whole block's work for slab `nb`: shared by the plain kernel and the grouped (per-expert) kernel
-template <int WAVES, int S, int MB, int EPI, int BITS, int PIPE>
+template <typename DT, int WAVES, int S, int MB, int EPI, int BITS, int PIPE>
 __device__ __forceinline__ void gemv_cdna4_body(char* smem, const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                 const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
                                                 uint16_t* __restrict__ out, int M, int N, int K, int nb) {
@@ -47,7 +47,8 @@ __device__ __forceinline__ void gemv_cdna4_body(char* smem, const uint16_t* __re
   for (int s = 0; s < NS; ++s) slab_tile[s] = ((u32)nb + (u32)s * (u32)(N >> 5)) * (u32)nit;  // EPI 1: up slab = gate slab + (N/2)/16
   const u32 wlane_b = BITS == 4 ? lane * 16u : lane * 12u;
   const u32 ilane_b = (u32)i * 4u;
-  Cdna4Dequant cd;
+  using vec8 = typename DT::vec8;
+  Cdna4DequantT<DT> cd;
   cd.init(lane, BITS == 4 ? 0x000F000Fu : 0x00070007u);
   const int mrow = min(i, M - 1);
   const int cnt = (nit - wv + WAVES - 1) / WAVES;  // this wave's steps: kg = wv + WAVES * t
@@ -104,17 +105,17 @@ __device__ __forceinline__ void gemv_cdna4_body(char* smem, const uint16_t* __re
     for (int t = 0; t < S; ++t) {
       if (wv + WAVES * (c0 + t) >= nit) continue;  // ragged tail: wave-uniform skip (the loads were clamped)
       const u32x4* xrow = reinterpret_cast<const u32x4*>(xs + t * xstep + mrow * 256);
-      bf16x8 xop[4];
+      vec8 xop[4];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) xop[a] = __builtin_bit_cast(bf16x8, xrow[(4 * a + g) ^ (mrow & 15)]);
+      for (int a = 0; a < 4; ++a) xop[a] = __builtin_bit_cast(vec8, xrow[(4 * a + g) ^ (mrow & 15)]);
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         const u32 szv = R.sz[s][t];
-        bf16x8 op[4];
+        vec8 op[4];
         const u32x4 wt = BITS == 4 ? R.w[s][t] : w3_expand(R.w[s][t].x, R.w[s][t].y, R.w[s][t].z);
         cd.tile_packed(wt, szv, op);
 #pragma unroll
-        for (int a = 0; a < 4; ++a) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(op[a], xop[a], acc[s], 0, 0, 0);
+        for (int a = 0; a < 4; ++a) acc[s] = DT::mfma(op[a], xop[a], acc[s]);
       }
     }
   };
@@ -160,34 +161,34 @@ __device__ __forceinline__ void gemv_cdna4_body(char* smem, const uint16_t* __re
       v[s] = t;
     }
     const int nn = nb * 16 + 4 * g + r;
-    auto to_f = [](uint16_t b) { return __builtin_bit_cast(float, (u32)b << 16); };
+    auto to_f = [](uint16_t b) { return DT::to_float(b); };
     if (EPI == 0) {
-      uint16_t o = BF16::from_float(v[0]);
-      if (bias != nullptr) o = BF16::from_float(to_f(o) + to_f(bias[nn]));  // `out + self.bias` in T (qmodule.py:221)
+      uint16_t o = DT::from_float(v[0]);
+      if (bias != nullptr) o = DT::from_float(to_f(o) + to_f(bias[nn]));  // `out + self.bias` in T (qmodule.py:221)
       out[(size_t)i * N + nn] = o;
     } else {
       // fused_mlp.py:79-82: c = F.silu(gate_output) * up_output, every op rounded to T
-      const float gt = to_f(BF16::from_float(v[0])), up = to_f(BF16::from_float(v[NS - 1]));
-      const float sl = to_f(BF16::from_float(gt / (1.0f + __expf(-gt))));
-      out[(size_t)i * (N >> 1) + nn] = BF16::from_float(sl * up);
+      const float gt = to_f(DT::from_float(v[0])), up = to_f(DT::from_float(v[NS - 1]));
+      const float sl = to_f(DT::from_float(gt / (1.0f + __expf(-gt))));
+      out[(size_t)i * (N >> 1) + nn] = DT::from_float(sl * up);
     }
   }
 }
 
-template <int WAVES, int S, int MB, int EPI, int BITS, int PIPE>
+template <typename DT, int WAVES, int S, int MB, int EPI, int BITS, int PIPE>
 __global__ __launch_bounds__(64 * WAVES) void gemv_cdna4_kernel(const uint16_t* __restrict__ x,
                                                                  const u32* __restrict__ qw,
                                                                  const u32* __restrict__ szp,
                                                                  const uint16_t* __restrict__ bias,
                                                                  uint16_t* __restrict__ out, int M, int N, int K) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemv_cdna4_body<WAVES, S, MB, EPI, BITS, PIPE>(smem, x, qw, szp, bias, out, M, N, K, blockIdx.x);
+  gemv_cdna4_body<DT, WAVES, S, MB, EPI, BITS, PIPE>(smem, x, qw, szp, bias, out, M, N, K, blockIdx.x);
 }
 
 // Grouped (per-expert) decode GEMV for MoE layers: block = (expert, slab); expert e owns rows [offsets[e], offsets[e+1]) of
 // the sorted x / out (at most 4 MB rows: the host only routes here when the TOTAL row count is that small) and the
 // e-th slice of the stacked cdna4 weights / packed scales.  Experts without tokens cost one offsets read per block.
-template <int WAVES, int S, int MB>
+template <typename DT, int WAVES, int S, int MB>
 __global__ __launch_bounds__(64 * WAVES) void moe_gemv_cdna4_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                                      const u32* __restrict__ szp,
                                                                      const int* __restrict__ offsets,
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(64 * WAVES) void moe_gemv_cdna4_kernel(const uint16
   const int e = blockIdx.x / nslab, nb = blockIdx.x - e * nslab;
   const int row0 = offsets[e], m_e = offsets[e + 1] - row0;
   if (m_e <= 0) return;
-  gemv_cdna4_body<WAVES, S, MB, 0, 4, 0>(smem, x + (size_t)row0 * K, qw + (size_t)e * nslab * nit * 256,
+  gemv_cdna4_body<DT, WAVES, S, MB, 0, 4, 0>(smem, x + (size_t)row0 * K, qw + (size_t)e * nslab * nit * 256,
                                       szp + (size_t)e * nslab * nit * 16, nullptr, out + (size_t)row0 * N, min(m_e, 4 * MB), N, K, nb);
 }
 
@@ -237,12 +238,12 @@ int gemv_cdna4_tune_set(const char* key, int value) {
   return 0;
 }
 
-template <int WAVES, int S, int MB, int EPI, int BITS, int PIPE>
+template <typename DT, int WAVES, int S, int MB, int EPI, int BITS, int PIPE>
 static void launch_cfg(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                        hipStream_t st) {
   constexpr int NS = EPI == 1 ? 2 : 1;
   const size_t smem = (size_t)NS * WAVES * 1024 + (size_t)WAVES * S * m * 256;
-  auto kern = gemv_cdna4_kernel<WAVES, S, MB, EPI, BITS, PIPE>;
+  auto kern = gemv_cdna4_kernel<DT, WAVES, S, MB, EPI, BITS, PIPE>;
   if (smem > 64 * 1024) {
     static bool done = false;
     if (!done) {
@@ -254,7 +255,7 @@ static void launch_cfg(const void* x, const void* qw, const void* szp, const voi
                      (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k);
 }
 
-template <int MB, int EPI, int BITS>
+template <typename DT, int MB, int EPI, int BITS>
 static int launch_mb(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                      hipStream_t st) {
   const Cfg c = pick_cfg(m, n, k, EPI == 1 ? 2 : 1, g_force_waves, g_force_s);
@@ -268,22 +269,25 @@ static int launch_mb(const void* x, const void* qw, const void* szp, const void*
     const int ps = g_pipe_s ? g_pipe_s : ((per >= 2 && waves_per_cu * (EPI == 1 ? 2 : 1) <= 10.0) ? 2 : 1);
 #define AWQ_PCASE(W_, S_, D_)                                                  \
   if (c.waves == W_ && ps == S_ && pipe == D_ && (size_t)W_ * S_ * m * 256 <= 96 * 1024) { \
-    launch_cfg<W_, S_, MB, EPI, BITS, D_>(x, qw, szp, bias, out, m, n, k, st); \
+    launch_cfg<DT, W_, S_, MB, EPI, BITS, D_>(x, qw, szp, bias, out, m, n, k, st); \
     return 0;                                                                  \
   }
     AWQ_PCASE(4, 1, 2) AWQ_PCASE(4, 2, 2) AWQ_PCASE(8, 1, 2) AWQ_PCASE(8, 2, 2) AWQ_PCASE(16, 1, 2) AWQ_PCASE(16, 2, 2)
-    if (BITS == 4 && EPI == 0) {
+    if constexpr (BITS == 4 && EPI == 0 && DT::id == 1) {
       AWQ_PCASE(4, 1, 3) AWQ_PCASE(8, 1, 3) AWQ_PCASE(16, 1, 3)
     }
 #undef AWQ_PCASE
   }
+  if constexpr (DT::id != 1) return -1;  // the chunk-mode variants below exist for the knob experiments: bf16 only
 #define AWQ_CASE(W_, S_)                                                      \
   if (c.waves == W_ && c.s == S_) {                                           \
-    launch_cfg<W_, S_, MB, EPI, BITS, 0>(x, qw, szp, bias, out, m, n, k, st); \
+    launch_cfg<DT, W_, S_, MB, EPI, BITS, 0>(x, qw, szp, bias, out, m, n, k, st); \
     return 0;                                                                 \
   }
-  AWQ_CASE(4, 2) AWQ_CASE(4, 4) AWQ_CASE(4, 7) AWQ_CASE(4, 8) AWQ_CASE(8, 2) AWQ_CASE(8, 4) AWQ_CASE(8, 7) AWQ_CASE(8, 8)
-  AWQ_CASE(16, 2) AWQ_CASE(16, 4) AWQ_CASE(16, 7) AWQ_CASE(16, 8)
+  if constexpr (DT::id == 1) {
+    AWQ_CASE(4, 2) AWQ_CASE(4, 4) AWQ_CASE(4, 7) AWQ_CASE(4, 8) AWQ_CASE(8, 2) AWQ_CASE(8, 4) AWQ_CASE(8, 7) AWQ_CASE(8, 8)
+    AWQ_CASE(16, 2) AWQ_CASE(16, 4) AWQ_CASE(16, 7) AWQ_CASE(16, 8)
+  }
 #undef AWQ_CASE
   return -1;
 }
@@ -291,20 +295,26 @@ static int launch_mb(const void* x, const void* qw, const void* szp, const void*
 // epi 0: out[m, n] (+ bias);  epi 1: qw holds [gate; up] stacked along N (n = 2 * ffn rows), out[m, n/2] = silu(gate) * up
 // bits 4: cdna4 W4 tiles; bits 3: w3c tiles (epi 0 only)
 int launch_gemv_cdna4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                      int epi, int bits, hipStream_t st) {
+                      int epi, int bits, int dtype, hipStream_t st) {
   if (m < 1 || m > 8) return -1;
   if (bits == 3) {
-    if (epi != 0) return -1;
-    return m <= 4 ? launch_mb<1, 0, 3>(x, qw, szp, bias, out, m, n, k, st) : launch_mb<2, 0, 3>(x, qw, szp, bias, out, m, n, k, st);
+    if (epi != 0 || dtype != 1) return -1;
+    return m <= 4 ? launch_mb<BF16, 1, 0, 3>(x, qw, szp, bias, out, m, n, k, st) : launch_mb<BF16, 2, 0, 3>(x, qw, szp, bias, out, m, n, k, st);
   }
-  if (epi == 1)
-    return m <= 4 ? launch_mb<1, 1, 4>(x, qw, szp, bias, out, m, n, k, st) : launch_mb<2, 1, 4>(x, qw, szp, bias, out, m, n, k, st);
-  return m <= 4 ? launch_mb<1, 0, 4>(x, qw, szp, bias, out, m, n, k, st) : launch_mb<2, 0, 4>(x, qw, szp, bias, out, m, n, k, st);
+#define AWQ_DT(DT_)                                                                                                     \
+  if (epi == 1)                                                                                                         \
+    return m <= 4 ? launch_mb<DT_, 1, 1, 4>(x, qw, szp, bias, out, m, n, k, st) : launch_mb<DT_, 2, 1, 4>(x, qw, szp, bias, out, m, n, k, st); \
+  return m <= 4 ? launch_mb<DT_, 1, 0, 4>(x, qw, szp, bias, out, m, n, k, st) : launch_mb<DT_, 2, 0, 4>(x, qw, szp, bias, out, m, n, k, st);
+  if (dtype == 0) {
+    AWQ_DT(F16)
+  }
+  AWQ_DT(BF16)
+#undef AWQ_DT
 }
 
 // grouped decode GEMV: total_rows <= 8 (so every expert has <= 8 rows), cdna4 layout, stacked packed sz [E][N/16][K/128][16]
 int launch_moe_gemv_cdna4(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total_rows,
-                          int experts, int n, int k, hipStream_t st) {
+                          int experts, int n, int k, int dtype, hipStream_t st) {
   if (total_rows < 1 || total_rows > 8 || (n % 16) != 0 || (k % 128) != 0) return -1;
   const int nit = k / kGroup;
   constexpr int WAVES = 8, S = 2;
@@ -312,11 +322,13 @@ int launch_moe_gemv_cdna4(const void* x, const void* qw, const void* szp, const 
   const int grid = experts * (n / 16);
   if (total_rows <= 4) {
     const size_t smem = (size_t)WAVES * 1024 + (size_t)WAVES * S * 4 * 256;
-    hipLaunchKernelGGL((moe_gemv_cdna4_kernel<WAVES, S, 1>), dim3(grid), dim3(64 * WAVES), smem, st, (const uint16_t*)x,
+    auto kern = dtype == 0 ? moe_gemv_cdna4_kernel<F16, WAVES, S, 1> : moe_gemv_cdna4_kernel<BF16, WAVES, S, 1>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), smem, st, (const uint16_t*)x,
                        (const u32*)qw, (const u32*)szp, (const int*)offsets, (uint16_t*)out, n, k);
   } else {
     const size_t smem = (size_t)WAVES * 1024 + (size_t)WAVES * S * 8 * 256;
-    hipLaunchKernelGGL((moe_gemv_cdna4_kernel<WAVES, S, 2>), dim3(grid), dim3(64 * WAVES), smem, st, (const uint16_t*)x,
+    auto kern = dtype == 0 ? moe_gemv_cdna4_kernel<F16, WAVES, S, 2> : moe_gemv_cdna4_kernel<BF16, WAVES, S, 2>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), smem, st, (const uint16_t*)x,
                        (const u32*)qw, (const u32*)szp, (const int*)offsets, (uint16_t*)out, n, k);
   }
   return 0;

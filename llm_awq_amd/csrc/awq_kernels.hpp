@@ -9,10 +9,10 @@ namespace awq {
 // szp: optional packed {scale | scaled_zero << 16} u32 [N/16][K/128][16] (cdna4 layout only), else nullptr
 int launch_gemv(const void* x, const void* qw, const void* s, const void* z, const void* szp, void* out, int m, int n,
                 int k, int dtype, int layout, hipStream_t st);
-// fast decode path on cdna4 buffers (1 <= m <= 8, bf16, packed sz required).  epi 0: out[m,n] (+bias);
+// fast decode path on cdna4 buffers (1 <= m <= 8, bf16 / fp16 (W3: bf16), packed sz required).  epi 0: out[m,n] (+bias);
 // epi 1: qw = [gate; up] stacked (n = 2*ffn rows), out[m, n/2] = silu(gate) * up.  Returns -1 if unsupported.
 int launch_gemv_cdna4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                      int epi, int bits, hipStream_t st);
+                      int epi, int bits, int dtype, hipStream_t st);
 // reference (v2) layout fast decode path (awq_gemv_v2fast.hip): 1 <= m <= 8, n % 16 == 0, fp16 / bf16, bias fused.
 // gpad = rows of scales / zeros that may be read (>= k / 128).  Returns -1 if unsupported.
 bool gemv_v2fast_enabled();  // false while a knob of the older kernel (awq_tune_set gemv_*) is active
@@ -28,21 +28,21 @@ int launch_dequant_w3(const void* qw3, const void* s, const void* z, void* out, 
 int launch_expand_w3_to_cdna4(const void* qw3, void* qw4, int n, int k, hipStream_t st);
 int gemv_cdna4_tune_set(const char* key, int value);
 int launch_moe_gemv_cdna4(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total_rows,
-                          int experts, int n, int k, hipStream_t st);
+                          int experts, int n, int k, int dtype, hipStream_t st);
 int launch_pack_sz_cdna4(const void* s, const void* z, void* szp, int n, int k, hipStream_t st);
 int launch_gemm(const void* x, const void* qw, const void* s, const void* z, const void* szp, void* out, int m, int n,
                 int k, int dtype, int layout, void* ws, size_t ws_bytes, hipStream_t st);
 int launch_repack_v2_cdna4(const void* src, void* dst, int n, int k, int to_cdna4, hipStream_t st);
 int launch_unpack_cdna4(const void* qw, void* out_u8, int n, int k, hipStream_t st);
-int launch_dequant_cdna4(const void* qw, const void* s, const void* z, void* out, int n, int k, hipStream_t st);
+int launch_dequant_cdna4(const void* qw, const void* s, const void* z, void* out, int n, int k, int dtype, hipStream_t st);
 size_t gemm_workspace_bytes(int m, int n, int k);
 // bias may be nullptr; when given it is added in the epilogue (`out + bias` in T)
 int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                         int tile_n, hipStream_t st);
+                         int tile_n, int dtype, hipStream_t st);
 int gemm_variant_get();
 // skinny GEMM, 9 <= m <= 255 (row chunks of <= 64), cdna4 layout + packed sz (awq_skinny_cdna4.hip); bias may be nullptr; -1 if unsupported
 int launch_skinny_cdna4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                        hipStream_t st);
+                        int dtype, hipStream_t st);
 int launch_moe_gemm(const void* x, const void* qw, const void* s, const void* z, const void* offsets, void* out, int total_m,
                     int experts, int n, int k, int gpad, int dtype, int layout, hipStream_t st);
 int gemv_tune_set(const char* key, int value);
@@ -51,11 +51,11 @@ int gemm_v3_tune_set(const char* key, int value);  // gemm_v4, gemm_v4_probe
 void gemm_v4_set_probe(int v);
 // grouped (MoE) GEMM with the same K loop: sorted rows, device expert offsets, stacked cdna4 weights + packed scales; total >= 256
 int launch_moe_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total, int experts,
-                             int n, int k, hipStream_t st);
+                             int n, int k, int dtype, hipStream_t st);
 bool moe_v4_enabled();
 // 256 x 256-tile prefill GEMM with the hand-scheduled K loop (awq_gemm_v4.hip): weight rows [n_begin, n_end), m >= 256
 void launch_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                          int n_begin, int n_end, hipStream_t st);
+                          int n_begin, int n_end, int dtype, hipStream_t st);
 int launch_bias_add(void* out, const void* bias, int m, int n, int dtype, hipStream_t st);
 int launch_unpack_v2(const void* qw, void* out_u8, int n, int k, hipStream_t st);
 int launch_dequant_v2(const void* qw, const void* s, const void* z, void* out, int n, int k, int dtype, hipStream_t st);

@@ -1,4 +1,4 @@
-// Skinny GEMM on cdna4-interleaved weights, 9 <= M <= 64, bf16 (gfx950): short prompts / chunk prefill / batched decode --
+// Skinny GEMM on cdna4-interleaved weights, 9 <= M <= 64 per pass, bf16 and fp16 (gfx950): short prompts / chunk prefill / batched decode --
 // the M range between the decode GEMV (awq_gemv_cdna4.hip) and the tiled prefill GEMM (awq_gemm_v3.hip), which the
 // reference serves with gemm_w4a16_T1's 16/32-row tiles + split-K (gemm_cuda.cu:1155-1193).
 //
@@ -14,11 +14,12 @@
 
 namespace awq {
 
-template <int WAVES, int NS, int CB>
+template <typename DT, int WAVES, int NS, int CB>
 __global__ __launch_bounds__(64 * WAVES) void skinny_cdna4_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                                    const u32* __restrict__ szp,
                                                                    const uint16_t* __restrict__ bias,
                                                                    uint16_t* __restrict__ out, int M, int N, int K) {
+  using vec8 = typename DT::vec8;
   constexpr int XB = 4 * CB;            // staging pieces per step: 4 x rows (1 KiB) each
   constexpr int XBYTES = 16 * CB * 256; // wave-private x region: 16 CB rows x 256 B
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(64 * WAVES) void skinny_cdna4_kernel(const uint16_t
     xsrc_b[b] = ((u32)min(r, M - 1) * (u32)K + (u32)((i ^ (r & 15)) * 8)) * 2u;
   }
 
-  Cdna4Dequant cd;
+  Cdna4DequantT<DT> cd;
   cd.init(lane);
   const int cnt = (nit - wv + WAVES - 1) / WAVES;  // this wave's steps: kg = wv + WAVES * t
 
@@ -79,21 +80,21 @@ __global__ __launch_bounds__(64 * WAVES) void skinny_cdna4_kernel(const uint16_t
     }
     if (t + 1 < cnt) load_step(t + 1);  // next step's packed words and x slice stream in under this step's math
     // x operands of the step, shared by the block's NS slabs: xo[c][a] = rows 16c .. 16c+15, k = 32a + 8g .. +8
-    bf16x8 xo[CB][4];
+    vec8 xo[CB][4];
 #pragma unroll
     for (int c = 0; c < CB; ++c) {
       const char* xrow = xs + (c * 16 + i) * 256;
 #pragma unroll
-      for (int a = 0; a < 4; ++a) xo[c][a] = *reinterpret_cast<const bf16x8*>(xrow + (((4 * a + g) ^ i) << 4));
+      for (int a = 0; a < 4; ++a) xo[c][a] = *reinterpret_cast<const vec8*>(xrow + (((4 * a + g) ^ i) << 4));
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      bf16x8 op[4];
+      vec8 op[4];
       cd.tile_packed(wc[s], szc[s], op);
 #pragma unroll
       for (int a = 0; a < 4; ++a)  // a outer: consecutive MFMAs hit different accumulators
 #pragma unroll
-        for (int c = 0; c < CB; ++c) acc[s][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(op[a], xo[c][a], acc[s][c], 0, 0, 0);
+        for (int c = 0; c < CB; ++c) acc[s][c] = DT::mfma(op[a], xo[c][a], acc[s][c]);
     }
   }
 
@@ -121,24 +122,24 @@ __global__ __launch_bounds__(64 * WAVES) void skinny_cdna4_kernel(const uint16_t
     }
     if (slab < nslab && m < M) {
       const int nn = slab * 16 + 4 * g;
-      auto to_f = [](uint16_t b) { return __builtin_bit_cast(float, (u32)b << 16); };
+      auto to_f = [](uint16_t b) { return DT::to_float(b); };
       uint16_t o[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        o[r] = BF16::from_float(v[r]);
-        if (bias != nullptr) o[r] = BF16::from_float(to_f(o[r]) + to_f(bias[nn + r]));  // `out + self.bias` in T
+        o[r] = DT::from_float(v[r]);
+        if (bias != nullptr) o[r] = DT::from_float(to_f(o[r]) + to_f(bias[nn + r]));  // `out + self.bias` in T
       }
       *reinterpret_cast<u32x2*>(out + (size_t)m * N + nn) = u32x2{(u32)o[0] | ((u32)o[1] << 16), (u32)o[2] | ((u32)o[3] << 16)};
     }
   }
 }
 
-template <int WAVES, int NS, int CB>
+template <typename DT, int WAVES, int NS, int CB>
 static void launch_skinny(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                           hipStream_t st) {
   const size_t xbytes = (size_t)WAVES * 16 * CB * 256, rbytes = (size_t)WAVES * NS * CB * 1024;
   const size_t smem = xbytes > rbytes ? xbytes : rbytes;
-  auto kern = skinny_cdna4_kernel<WAVES, NS, CB>;
+  auto kern = skinny_cdna4_kernel<DT, WAVES, NS, CB>;
   if (smem > 64 * 1024) {
     static bool done = false;
     if (!done) {
@@ -151,6 +152,7 @@ static void launch_skinny(const void* x, const void* qw, const void* szp, const 
                      (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k);
 }
 
+template <typename DT>
 static int launch_skinny_64(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                             hipStream_t st);
 
@@ -158,33 +160,36 @@ static int launch_skinny_64(const void* x, const void* qw, const void* szp, cons
 // the prefill GEMM) runs as row chunks of <= 64: the weights are re-streamed per chunk, which still beats the 128 x 128
 // kernel's long serial K loop on one wave of tiles (measured: profiles/r01_skinny_sweep.txt) except for very wide N.
 int launch_skinny_cdna4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                        hipStream_t st) {
+                        int dtype, hipStream_t st) {
   if (!szp || m < 1 || m > 255 || (n % 16) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return -1;
   if (m > 128 && n >= 16384) return -1;
   const int chunks = (m + 63) / 64, rows = (m + chunks - 1) / chunks;
   for (int r0 = 0; r0 < m; r0 += rows) {
     const int mr = m - r0 < rows ? m - r0 : rows;
-    launch_skinny_64(static_cast<const uint16_t*>(x) + (size_t)r0 * k, qw, szp, bias, static_cast<uint16_t*>(out) + (size_t)r0 * n, mr, n,
-                     k, st);
+    const uint16_t* xr = static_cast<const uint16_t*>(x) + (size_t)r0 * k;
+    uint16_t* orow = static_cast<uint16_t*>(out) + (size_t)r0 * n;
+    if (dtype == 0) launch_skinny_64<F16>(xr, qw, szp, bias, orow, mr, n, k, st);
+    else launch_skinny_64<BF16>(xr, qw, szp, bias, orow, mr, n, k, st);
   }
   return 0;
 }
 
+template <typename DT>
 static int launch_skinny_64(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                             hipStream_t st) {
   const int nslab = n / 16;
   if (m <= 16) {
-    if (nslab >= 1024) launch_skinny<8, 2, 1>(x, qw, szp, bias, out, m, n, k, st);
-    else launch_skinny<8, 1, 1>(x, qw, szp, bias, out, m, n, k, st);
+    if (nslab >= 1024) launch_skinny<DT, 8, 2, 1>(x, qw, szp, bias, out, m, n, k, st);
+    else launch_skinny<DT, 8, 1, 1>(x, qw, szp, bias, out, m, n, k, st);
   } else if (m <= 32) {
-    if (nslab >= 512) launch_skinny<8, 2, 2>(x, qw, szp, bias, out, m, n, k, st);
-    else launch_skinny<8, 1, 2>(x, qw, szp, bias, out, m, n, k, st);
+    if (nslab >= 512) launch_skinny<DT, 8, 2, 2>(x, qw, szp, bias, out, m, n, k, st);
+    else launch_skinny<DT, 8, 1, 2>(x, qw, szp, bias, out, m, n, k, st);
   } else if (m <= 48) {
-    if (nslab >= 512) launch_skinny<4, 4, 3>(x, qw, szp, bias, out, m, n, k, st);
-    else launch_skinny<8, 2, 3>(x, qw, szp, bias, out, m, n, k, st);
+    if (nslab >= 512) launch_skinny<DT, 4, 4, 3>(x, qw, szp, bias, out, m, n, k, st);
+    else launch_skinny<DT, 8, 2, 3>(x, qw, szp, bias, out, m, n, k, st);
   } else {
-    if (nslab >= 512) launch_skinny<4, 4, 4>(x, qw, szp, bias, out, m, n, k, st);
-    else launch_skinny<8, 2, 4>(x, qw, szp, bias, out, m, n, k, st);
+    if (nslab >= 512) launch_skinny<DT, 4, 4, 4>(x, qw, szp, bias, out, m, n, k, st);
+    else launch_skinny<DT, 8, 2, 4>(x, qw, szp, bias, out, m, n, k, st);
   }
   return 0;
 }

@@ -186,21 +186,23 @@ __global__ void unpack_cdna4_kernel(const u32* __restrict__ qw, uint8_t* __restr
 }
 
 // one wave per 1-KiB tile, through the SAME matrix-core dequant as the cdna4 GEMV / GEMM
+template <typename DT>
 __global__ __launch_bounds__(64) void dequant_cdna4_kernel(const u32* __restrict__ qw, const uint16_t* __restrict__ scales,
                                                             const uint16_t* __restrict__ zeros, uint16_t* __restrict__ out,
                                                             int N, int K) {
+  using vec8 = typename DT::vec8;
   const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
   const int nit = K >> 7;
   const int nb = blockIdx.x / nit, kg = blockIdx.x % nit;
-  Cdna4Dequant cd;
+  Cdna4DequantT<DT> cd;
   cd.init(lane);
   const u32x4 w = *reinterpret_cast<const u32x4*>(qw + cdna4_tile_word(nb, kg, nit) + lane * 4);
   const int n = nb * 16 + c;
-  bf16x8 op[4];
+  vec8 op[4];
   cd.tile(w, scales[(size_t)kg * N + n], zeros[(size_t)kg * N + n], op);
 #pragma unroll
   for (int a = 0; a < 4; ++a)
-    *reinterpret_cast<bf16x8*>(out + (size_t)n * K + (size_t)kg * 128 + 32 * a + 8 * g) = op[a];
+    *reinterpret_cast<vec8*>(out + (size_t)n * K + (size_t)kg * 128 + 32 * a + 8 * g) = op[a];
 }
 
 // packed {scale | scaled_zero << 16} per (16-row slab, group, row): one dword load per lane per step
@@ -276,8 +278,9 @@ int launch_unpack_cdna4(const void* qw, void* out_u8, int n, int k, hipStream_t 
   return 0;
 }
 
-int launch_dequant_cdna4(const void* qw, const void* s, const void* z, void* out, int n, int k, hipStream_t st) {
-  hipLaunchKernelGGL(dequant_cdna4_kernel, dim3((n / 16) * (k / 128)), dim3(64), 0, st, (const u32*)qw, (const uint16_t*)s,
+int launch_dequant_cdna4(const void* qw, const void* s, const void* z, void* out, int n, int k, int dtype, hipStream_t st) {
+  auto kern = dtype == 0 ? dequant_cdna4_kernel<F16> : dequant_cdna4_kernel<BF16>;
+  hipLaunchKernelGGL(kern, dim3((n / 16) * (k / 128)), dim3(64), 0, st, (const u32*)qw, (const uint16_t*)s,
                      (const uint16_t*)z, (uint16_t*)out, n, k);
   return 0;
 }

@@ -50,7 +50,7 @@ void check_inputs(const torch::Tensor& x, const torch::Tensor& kernel, const tor
 // ---------------------------------------------------------------------------------------------------------------
 // Lazy v2 -> cdna4 cache.  tinychat hands the extension RAW reference-layout buffers (fused_mlp.py:40-77 passes
 // gate_proj_qweight etc. directly, make_quant_attn concatenates v2 buffers after load), so the drop-in entry points
-// cannot assume the repacker ran.  For bf16 weights the first call with a given (qweight, scales, zeros) triple repacks
+// cannot assume the repacker ran.  The first call with a given (qweight, scales, zeros) triple repacks
 // them once on the GPU (awq_repack_v2_to_cdna4 + awq_pack_sz_cdna4, tens of microseconds) and later calls run the
 // cdna4 kernels.  An entry is tied to the IDENTITY of the three tensors (weak TensorImpl references, so a freed
 // tensor whose address is re-used can never hit) and to their version counters (an in-place update re-packs).
@@ -81,7 +81,9 @@ bool cache_enabled() {
 // returns true and fills (c4, szp) when the cdna4 kernels can serve this call
 bool cdna4_view(const torch::Tensor& kernel, const torch::Tensor& scales, const torch::Tensor& zeros, int64_t n, int64_t k,
                 hipStream_t stream, at::Tensor& c4, at::Tensor& szp) {
-  if (!cache_enabled() || kernel.scalar_type() != at::kShort || scales.scalar_type() != at::kBFloat16) return false;
+  if (!cache_enabled() || kernel.scalar_type() != at::kShort ||
+      (scales.scalar_type() != at::kBFloat16 && scales.scalar_type() != at::kHalf))
+    return false;
   if (n % 16 != 0 || k % 128 != 0 || kernel.numel() != n / 4 * k) return false;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
@@ -133,7 +135,7 @@ torch::Tensor gemv_forward_cuda_new(torch::Tensor in_feats, torch::Tensor kernel
   at::Tensor c4, szp;
   if (cdna4_view(kernel, scaling_factors, zeros, n, k, stream, c4, szp)) {
     raise_on(awq_w4a16_forward_cdna4(in_feats.data_ptr(), c4.data_ptr(), scaling_factors.data_ptr(), zeros.data_ptr(), szp.data_ptr(),
-                                     nullptr, out.data_ptr(), m, n, k, group_size, AWQ_BF16, nullptr, 0, (void*)stream));
+                                     nullptr, out.data_ptr(), m, n, k, group_size, dtype_code(in_feats), nullptr, 0, (void*)stream));
     return out;
   }
   raise_on(awq_w4a16_gemv(in_feats.data_ptr(), kernel.data_ptr(), scaling_factors.data_ptr(), zeros.data_ptr(),
@@ -161,7 +163,7 @@ torch::Tensor gemm_forward_cuda_new(torch::Tensor in_feats, torch::Tensor kernel
     at::Tensor c4, szp;
     if (cdna4_view(kernel, scales, zeros, n, k, stream, c4, szp)) {
       raise_on(awq_w4a16_forward_cdna4(in_feats.data_ptr(), c4.data_ptr(), scales.data_ptr(), zeros.data_ptr(), szp.data_ptr(), nullptr,
-                                       out.data_ptr(), (int)m, (int)n, (int)k, 128, AWQ_BF16, nullptr, 0, (void*)stream));
+                                       out.data_ptr(), (int)m, (int)n, (int)k, 128, dtype_code(in_feats), nullptr, 0, (void*)stream));
       return out;
     }
   }
@@ -212,7 +214,8 @@ torch::Tensor pack_sz_cdna4(torch::Tensor scales, torch::Tensor zeros, int k) {
 torch::Tensor forward_cdna4(torch::Tensor in_feats, torch::Tensor kernel, torch::Tensor scales, torch::Tensor zeros,
                             torch::Tensor sz_packed, c10::optional<torch::Tensor> bias) {
   check_inputs(in_feats, kernel, scales, zeros);
-  TORCH_CHECK(in_feats.scalar_type() == at::kBFloat16, "the cdna4 interleave is defined for bfloat16");
+  TORCH_CHECK(in_feats.scalar_type() == at::kBFloat16 || in_feats.scalar_type() == at::kHalf,
+              "the cdna4 interleave is defined for bfloat16 / float16");
   TORCH_CHECK(sz_packed.is_cuda() && sz_packed.is_contiguous() && sz_packed.scalar_type() == at::kInt);
   const int64_t n = kernel.size(0) * 4, k = in_feats.size(-1);
   TORCH_CHECK(k > 0 && in_feats.numel() % k == 0 && kernel.numel() == n / 4 * k);
@@ -229,7 +232,7 @@ torch::Tensor forward_cdna4(torch::Tensor in_feats, torch::Tensor kernel, torch:
     bp = bias->data_ptr();
   }
   raise_on(awq_w4a16_forward_cdna4(in_feats.data_ptr(), kernel.data_ptr(), scales.data_ptr(), zeros.data_ptr(),
-                                   sz_packed.data_ptr(), bp, out.data_ptr(), (int)m, (int)n, (int)k, 128, AWQ_BF16, nullptr,
+                                   sz_packed.data_ptr(), bp, out.data_ptr(), (int)m, (int)n, (int)k, 128, dtype_code(in_feats), nullptr,
                                    0, (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()));
   return out;
 }
@@ -255,7 +258,8 @@ torch::Tensor moe_gemm_forward(torch::Tensor x_sorted, torch::Tensor kernel, tor
 torch::Tensor moe_forward_cdna4(torch::Tensor x_sorted, torch::Tensor kernel, torch::Tensor scales, torch::Tensor zeros,
                                 torch::Tensor sz_packed, torch::Tensor expert_offsets) {
   check_inputs(x_sorted, kernel, scales, zeros);
-  TORCH_CHECK(x_sorted.scalar_type() == at::kBFloat16, "the cdna4 interleave is defined for bfloat16");
+  TORCH_CHECK(x_sorted.scalar_type() == at::kBFloat16 || x_sorted.scalar_type() == at::kHalf,
+              "the cdna4 interleave is defined for bfloat16 / float16");
   TORCH_CHECK(expert_offsets.is_cuda() && expert_offsets.is_contiguous() && expert_offsets.scalar_type() == at::kInt);
   TORCH_CHECK(sz_packed.is_cuda() && sz_packed.is_contiguous() && sz_packed.scalar_type() == at::kInt);
   TORCH_CHECK(kernel.dim() == 3 && scales.dim() == 3 && zeros.dim() == 3 && x_sorted.dim() == 2);
@@ -266,7 +270,7 @@ torch::Tensor moe_forward_cdna4(torch::Tensor x_sorted, torch::Tensor kernel, to
   at::Tensor out = torch::empty({t, n}, x_sorted.options());
   raise_on(awq_w4a16_moe_forward_cdna4(x_sorted.data_ptr(), kernel.data_ptr(), scales.data_ptr(), zeros.data_ptr(),
                                        sz_packed.data_ptr(), expert_offsets.data_ptr(), out.data_ptr(), (int)t, (int)e, (int)n,
-                                       (int)k, (int)scales.size(1), 128, AWQ_BF16,
+                                       (int)k, (int)scales.size(1), 128, dtype_code(x_sorted),
                                        (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()));
   return out;
 }
@@ -315,8 +319,8 @@ torch::Tensor forward_w3(torch::Tensor in_feats, torch::Tensor kernel, torch::Te
 torch::Tensor mlp_gate_up_cdna4(torch::Tensor in_feats, torch::Tensor kernel_gate_up, torch::Tensor sz_packed) {
   TORCH_CHECK(in_feats.is_cuda() && kernel_gate_up.is_cuda() && sz_packed.is_cuda());
   TORCH_CHECK(in_feats.is_contiguous() && kernel_gate_up.is_contiguous() && sz_packed.is_contiguous());
-  TORCH_CHECK(in_feats.scalar_type() == at::kBFloat16 && kernel_gate_up.scalar_type() == at::kShort &&
-              sz_packed.scalar_type() == at::kInt);
+  TORCH_CHECK((in_feats.scalar_type() == at::kBFloat16 || in_feats.scalar_type() == at::kHalf) &&
+              kernel_gate_up.scalar_type() == at::kShort && sz_packed.scalar_type() == at::kInt);
   const int64_t n2 = kernel_gate_up.size(0) * 4, k = in_feats.size(-1);
   TORCH_CHECK(k > 0 && in_feats.numel() % k == 0 && kernel_gate_up.numel() == n2 / 4 * k);
   TORCH_CHECK(sz_packed.numel() == n2 * (k / 128), "sz_packed must be int32 [n2/16, k/128, 16]");
@@ -326,7 +330,7 @@ torch::Tensor mlp_gate_up_cdna4(torch::Tensor in_feats, torch::Tensor kernel_gat
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(in_feats.device());
   at::Tensor out = torch::empty(shape, in_feats.options());
   raise_on(awq_w4a16_mlp_gate_up_cdna4(in_feats.data_ptr(), kernel_gate_up.data_ptr(), sz_packed.data_ptr(), out.data_ptr(),
-                                       (int)m, (int)n2, (int)k, 128, AWQ_BF16,
+                                       (int)m, (int)n2, (int)k, 128, dtype_code(in_feats),
                                        (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()));
   return out;
 }

@@ -12,7 +12,7 @@ Per packed linear (`<p>.qweight` + `<p>.scales` + `<p>.qzeros` | `<p>.scaled_zer
   1. converts v1 -> v2 when the checkpoint is v1 (HIP kernel, bit-exact against the reference's golden vectors),
   2. cuts the rank's tensor-parallel shard out of the v2 buffers (`tp_plan`: module prefix -> "column" | "row" |
      "stacked:<parts>" | "replicate"; cuts are whole 16-row slabs / whole 128-k groups, llm_awq_amd/parallel.py),
-  3. interleaves the shard to the cdna4 layout when it is eligible (bf16, N % 16 == 0, K % 128 == 0) and the target asks
+  3. interleaves the shard to the cdna4 layout when it is eligible (N % 16 == 0, K % 128 == 0) and the target asks
      for it, and emits the same keys / shapes / dtypes as a v2 checkpoint plus the one-byte `<p>.qweight_layout` marker
      `WQLinear` reads at load time.
 Only one linear's tensors are resident on the host at a time (safetensors and `torch.load(mmap=True)` map the file).

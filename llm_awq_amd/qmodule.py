@@ -178,12 +178,12 @@ class WQLinear(nn.Module):
     @torch.no_grad()
     def to_cdna4(self):
         """Permute `qweight` (same shape / dtype, so the checkpoint contract is unchanged) into the cdna4
-        interleave and build the packed {scale | scaled_zero} side buffer.  bf16, out_features % 16 == 0,
+        interleave and build the packed {scale | scaled_zero} side buffer.  bf16 / fp16, out_features % 16 == 0,
         group_size 128; buffers must live on the GPU.  Idempotent."""
         if self.layout in ("cdna4", "w3c"):
             return self
-        if self.scales.dtype != torch.bfloat16:
-            raise TypeError("the cdna4 interleave (matrix-core dequant) is defined for bfloat16 WQLinear only")
+        if self.scales.dtype not in (torch.bfloat16, torch.float16):
+            raise TypeError("the cdna4 interleave (matrix-core dequant) is defined for bfloat16 / float16 WQLinear only")
         if self.out_features % 16 or self.group_size != 128:
             raise ValueError("cdna4 interleave needs out_features % 16 == 0 and group_size == 128")
         eng = load_engine()

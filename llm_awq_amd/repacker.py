@@ -16,7 +16,7 @@ whose nibbles feed the matrix-core dequant, plus a one-byte marker `<p>.qweight_
 
 Same key rules as the reference: a tensor is a packed weight if "qweight" is in its key, a scale if "scales" is,
 "qzeros" keys are consumed with their scales; v2 inputs ("scaled_zeros" present) skip the v1 step.
-Layers the cdna4 interleave cannot hold (N % 16 != 0, K % 128 != 0, or fp16 scales) stay v2.
+Layers the cdna4 interleave cannot hold (N % 16 != 0 or K % 128 != 0) stay v2.
 """
 from __future__ import annotations
 
@@ -47,7 +47,7 @@ class GpuKernels:
 
 def cdna4_eligible(qweight_v2: torch.Tensor, scales_v2: torch.Tensor) -> bool:
     n, k = qweight_v2.shape[0] * 4, qweight_v2.shape[1]
-    return n % 16 == 0 and k % 128 == 0 and scales_v2.dtype == torch.bfloat16
+    return n % 16 == 0 and k % 128 == 0 and scales_v2.dtype in (torch.bfloat16, torch.float16)
 
 
 def repack_state_dict(sd: Dict[str, torch.Tensor], target: str = "cdna4", device: str = "cuda",

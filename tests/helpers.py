@@ -46,5 +46,6 @@ def check_forward(y_gpu: torch.Tensor, x, q, scales, scaled_zeros, dtype, bias=N
     rel = ((yg - y_or).norm() / y_or.norm()).item()
     assert rel <= 1e-3, rel
     mism = (y_or != yg).double().mean().item()
-    assert mism <= 0.02, f"{mism*100:.2f}% of elements differ from the fp32-accumulate oracle"
+    # (two elements are always allowed: tiny outputs -- 64 values -- would otherwise fail on a pair of 1-ulp flips)
+    assert mism <= max(0.02, 2.5 / y_or.numel()), f"{mism*100:.2f}% of elements differ from the fp32-accumulate oracle"
     return worst, rel, mism

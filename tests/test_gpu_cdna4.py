@@ -36,34 +36,38 @@ def test_structured_tile_is_transpose_detecting(ops):
     assert (c4.cpu().numpy() == O.pack_cdna4(q)).all()
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,K", [(16, 128), (64, 768), (256, 1280), (512, 4096)])
-def test_matrix_core_dequant_bit_exact(ops, N, K):
-    c = make_case(N, K, torch.bfloat16, seed=N + K)
+def test_matrix_core_dequant_bit_exact(ops, dtype, N, K):
+    c = make_case(N, K, dtype, seed=N + K)
     W = O.dequant_weight(c["q"], c["scales"], c["scaled_zeros"], 128)
     c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
     got = ops.dequant_cdna4(c4, c["scales"].cuda(), c["scaled_zeros"].cuda()).cpu()
     assert torch.equal(got.view(torch.int16), W.view(torch.int16))
 
 
-def test_matrix_core_dequant_adversarial_scales(ops):
+@pytest.mark.parametrize("dtype,emin,emax", [(torch.bfloat16, -30, 8), (torch.float16, -12, 3)])
+def test_matrix_core_dequant_adversarial_scales(ops, dtype, emin, emax):
+    """scales over the dtype's exponent range, every zero point 0..15: (offset + q) * s + (sz - offset * s) stays exact in
+    fp32 (bf16: offset 128, 8 x 8 significant bits; fp16: offset 1024, 11 x 11), so the single rounding is the reference's"""
     g = torch.Generator().manual_seed(9)
     N, K = 64, 512
     q = torch.randint(0, 16, (N, K), generator=g).numpy().astype(np.uint8)
-    scales = torch.zeros(8, N, dtype=torch.bfloat16)
-    scales[:4] = (torch.rand(4, N, generator=g) * 2 + 0.5) * torch.pow(2.0, torch.randint(-30, 8, (4, N), generator=g).float())
+    scales = torch.zeros(8, N, dtype=dtype)
+    scales[:4] = ((torch.rand(4, N, generator=g) * 2 + 0.5) * torch.pow(2.0, torch.randint(emin, emax, (4, N), generator=g).float())).to(dtype)
     zeros = torch.randint(0, 16, (4, N), generator=g)
-    sz = torch.zeros(8, N, dtype=torch.bfloat16)
-    sz[:4] = -(scales[:4] * zeros.float()).to(torch.bfloat16)
+    sz = torch.zeros(8, N, dtype=dtype)
+    sz[:4] = -(scales[:4].float() * zeros.float()).to(dtype)
     W = O.dequant_weight(q, scales, sz, 128)
     c4 = ops.repack_v2_to_cdna4(torch.from_numpy(O.pack_v2(q)).cuda())
     got = ops.dequant_cdna4(c4, scales.cuda(), sz.cuda()).cpu()
     assert torch.equal(got.view(torch.int16), W.view(torch.int16))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 7, 8, 13, 16])
 @pytest.mark.parametrize("N,K", [(768, 768), (3072, 768), (768, 3072), (256, 4096), (1040, 1280), (64, 11008)])
-def test_gemv_cdna4_vs_oracle(ops, M, N, K):
-    dtype = torch.bfloat16
+def test_gemv_cdna4_vs_oracle(ops, dtype, M, N, K):
     c = make_case(N, K, dtype, seed=M * 131 + N + K, M=M)
     c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
     y = ops.gemv_cdna4(c["x"].cuda(), c4, c["scales"].cuda(), c["scaled_zeros"].cuda()).cpu()
@@ -106,11 +110,11 @@ def test_gemv_knobs_do_not_change_results(ops, knobs):
         ops._capi.tune(gemv_waves=0, gemv_pf=0, gemv_x_budget_kib=64)
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("M", [17, 64, 128, 200, 512, 777])
 @pytest.mark.parametrize("N,K", [(768, 768), (3072, 768), (768, 3072), (144, 1280)])
-def test_gemm_cdna4_vs_oracle(ops, variant, M, N, K):
-    dtype = torch.bfloat16
+def test_gemm_cdna4_vs_oracle(ops, dtype, variant, M, N, K):
     c = make_case(N, K, dtype, seed=M * 17 + N + K, M=M, bias=(M == 64))
     c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
     ops._capi.tune(gemm_variant=variant)
@@ -142,11 +146,11 @@ def test_fast_gemv_knobs(ops, knobs):
         ops._capi.tune(gemvc_waves=0, gemvc_s=0, gemvc_pipe=-1, gemvc_pipe_s=0)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M", [1, 2, 4, 7, 8])
 @pytest.mark.parametrize("F,K", [(256, 768), (1376, 512), (64, 4096)])
-def test_fused_gate_up_silu_mul(ops, M, F, K):
+def test_fused_gate_up_silu_mul(ops, dtype, M, F, K):
     """one launch == the reference's QuantLlamaMLP sequence (fused_mlp.py:36-83): two GEMVs, F.silu, multiply, all in T."""
-    dtype = torch.bfloat16
     cg = make_case(F, K, dtype, seed=F + K + M, M=M)
     cu = make_case(F, K, dtype, seed=F + K + M + 1, M=M)
     x = cg["x"]
@@ -164,12 +168,12 @@ def test_fused_gate_up_silu_mul(ops, M, F, K):
     assert (y == ref).float().mean() > 0.95
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M", [9, 16, 17, 31, 32, 33, 48, 49, 63, 64, 65, 100, 129, 200, 255])
 @pytest.mark.parametrize("N,K", [(768, 768), (1040, 1280), (64, 11008), (8192, 512), (16400, 256)])
-def test_skinny_gemm_vs_oracle(ops, M, N, K):
+def test_skinny_gemm_vs_oracle(ops, dtype, M, N, K):
     """9 <= M <= 255 (short prompts / batched decode; above 64 rows in chunks): the skinny kernel, every column-block count, slab counts that do not
     divide the slabs-per-block, ragged K splits, wide N (both slab groupings), bias fused."""
-    dtype = torch.bfloat16
     c = make_case(N, K, dtype, seed=M * 7 + N + K, M=M, bias=(M % 2 == 1))
     c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
     szp = ops.pack_sz_cdna4(c["scales"].cuda(), c["scaled_zeros"].cuda(), K)

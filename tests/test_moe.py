@@ -72,8 +72,6 @@ def test_sparse_moe_block_with_oracle_matmul():
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("counts", [[5, 0, 130, 1], [0, 0, 0, 7], [128, 128, 1, 300], [0, 0, 0, 0]])
 def test_gpu_grouped_gemm_vs_oracle(layout, dtype, counts):
-    if layout == "cdna4" and dtype != torch.bfloat16:
-        pytest.skip("cdna4 interleave is bf16 only")
     from llm_awq_amd import ops
     E, N, K = len(counts), 384, 512
     mods, cases = _experts(E, N, K, dtype, seed=sum(counts) + 7)
