@@ -91,7 +91,7 @@ int awq_repack_v1_to_v2(const void* qweight_v1, const void* scales_v1, const voi
 /* ---- "cdna4" interleave: this repository's MI355X-native int4 layout (what the rewritten
  * tinychat/offline-weight-repacker.py equivalent emits; DESIGN.md "cdna4 interleave").  Same bytes and
  * shape as v2 (int16 [N/4, K]); a pure nibble permutation that makes one 16-row x 128-k tile a contiguous
- * 1-KiB wave-load and lets the weights be dequantised on the matrix core.  bf16 only; n % 16 == 0.
+ * 1-KiB wave-load and lets the weights be dequantised on the matrix core.  bf16 and fp16; n % 16 == 0.
  * scales / scaled_zeros keep the v2 contract. ---- */
 int awq_repack_v2_to_cdna4(const void* qweight_v2, void* qweight_cdna4, int n, int k, void* stream);
 int awq_repack_cdna4_to_v2(const void* qweight_cdna4, void* qweight_v2, int n, int k, void* stream);
@@ -109,7 +109,7 @@ int awq_w4a16_gemv_cdna4(const void* x, const void* qweight_cdna4, const void* s
  * gemv_forward_cuda_new calls, F.silu and a multiply): qweight_gate_up = the gate and up projections' cdna4 buffers
  * stacked along N (n2 = 2 * intermediate rows, exactly what torch.cat([gate.qweight, up.qweight], 0) gives),
  * sz_packed built from the equally concatenated scales / scaled_zeros; out[m, n2/2] = silu(x.Wg^T) * (x.Wu^T), every
- * intermediate rounded to T like the reference's separate ops.  1 <= m <= 8, bf16. */
+ * intermediate rounded to T like the reference's separate ops.  1 <= m <= 8, bf16 / fp16. */
 int awq_w4a16_mlp_gate_up_cdna4(const void* x, const void* qweight_gate_up, const void* sz_packed, void* out, int m,
                                 int n2, int k, int group_size, int dtype, void* stream);
 
@@ -132,7 +132,7 @@ int awq_w4a16_moe_gemm(const void* x_sorted, const void* qweight, const void* sc
 
 /* the same on cdna4 buffers with the stacked packed scales (int32 [E, n/16, k/128, 16]): decode batches (total_tokens <= 8,
  * hence at most 8 rows per expert) stream each expert's tiles once with the GEMV structure (block = (expert, slab));
- * larger batches run the grouped GEMM.  bf16 only. */
+ * larger batches run the grouped GEMM.  bf16 and fp16. */
 int awq_w4a16_moe_forward_cdna4(const void* x_sorted, const void* qweight, const void* scales, const void* scaled_zeros,
                                 const void* sz_packed, const void* expert_offsets, void* out, int total_tokens,
                                 int num_experts, int n, int k, int gpad, int group_size, int dtype, void* stream);
