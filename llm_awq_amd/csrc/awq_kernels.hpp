@@ -29,6 +29,9 @@ int launch_expand_w3_to_cdna4(const void* qw3, void* qw4, int n, int k, hipStrea
 int gemv_cdna4_tune_set(const char* key, int value);
 int launch_moe_gemv_cdna4(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total_rows,
                           int experts, int n, int k, int dtype, hipStream_t st);
+// grouped skinny kernel for 9..255 sorted rows (awq_skinny_cdna4.hip)
+int launch_moe_skinny_cdna4(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total_rows,
+                            int experts, int n, int k, int dtype, hipStream_t st);
 int launch_pack_sz_cdna4(const void* s, const void* z, void* szp, int n, int k, hipStream_t st);
 int launch_gemm(const void* x, const void* qw, const void* s, const void* z, const void* szp, void* out, int m, int n,
                 int k, int dtype, int layout, void* ws, size_t ws_bytes, hipStream_t st);

@@ -14,18 +14,17 @@
 
 namespace awq {
 
+// the block's work for slab group `nb` on M <= 16 CB rows: shared by the plain kernel and the grouped (per-expert) kernel
 template <typename DT, int WAVES, int NS, int CB>
-__global__ __launch_bounds__(64 * WAVES) void skinny_cdna4_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
-                                                                   const u32* __restrict__ szp,
-                                                                   const uint16_t* __restrict__ bias,
-                                                                   uint16_t* __restrict__ out, int M, int N, int K) {
+__device__ __forceinline__ void skinny_cdna4_body(char* smem, const uint16_t* __restrict__ x, const u32* __restrict__ qw,
+                                                  const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
+                                                  uint16_t* __restrict__ out, int M, int N, int K, int nb) {
   using vec8 = typename DT::vec8;
   constexpr int XB = 4 * CB;            // staging pieces per step: 4 x rows (1 KiB) each
   constexpr int XBYTES = 16 * CB * 256; // wave-private x region: 16 CB rows x 256 B
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, g = lane >> 4;
-  const int nb = blockIdx.x, nit = K >> 7, nslab = N >> 4;
+  const int nit = K >> 7, nslab = N >> 4;
   char* xs = smem + wv * XBYTES;
 
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(qw), 0, nslab * nit * 1024, 0x00020000);
@@ -135,6 +134,34 @@ __global__ __launch_bounds__(64 * WAVES) void skinny_cdna4_kernel(const uint16_t
 }
 
 template <typename DT, int WAVES, int NS, int CB>
+__global__ __launch_bounds__(64 * WAVES) void skinny_cdna4_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
+                                                                   const u32* __restrict__ szp,
+                                                                   const uint16_t* __restrict__ bias,
+                                                                   uint16_t* __restrict__ out, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  skinny_cdna4_body<DT, WAVES, NS, CB>(smem, x, qw, szp, bias, out, M, N, K, blockIdx.x);
+}
+
+// Grouped (per-expert) form for MoE batches between the grouped GEMV (<= 8 sorted rows) and the grouped prefill GEMM
+// (>= 256): block = (expert, slab group); expert e owns rows [offsets[e], offsets[e+1]) of the sorted x / out and the e-th
+// slice of the stacked cdna4 weights / packed scales; more than 16 CB rows run as further passes over the expert's slabs.
+template <typename DT, int WAVES, int NS, int CB>
+__global__ __launch_bounds__(64 * WAVES) void moe_skinny_cdna4_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
+                                                                       const u32* __restrict__ szp,
+                                                                       const int* __restrict__ offsets,
+                                                                       uint16_t* __restrict__ out, int N, int K, int groups) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int e = blockIdx.x / groups, nb = blockIdx.x - e * groups;
+  const int row0 = offsets[e], m_e = offsets[e + 1] - row0;  // block-uniform
+  const size_t et = (size_t)(N >> 4) * (K >> 7);             // tiles per expert
+  for (int r0 = 0; r0 < m_e; r0 += 16 * CB) {
+    if (r0 > 0) __syncthreads();  // the previous pass's reduction reads of the LDS region are done
+    skinny_cdna4_body<DT, WAVES, NS, CB>(smem, x + (size_t)(row0 + r0) * K, qw + (size_t)e * et * 256, szp + (size_t)e * et * 16, nullptr,
+                                         out + (size_t)(row0 + r0) * N, min(m_e - r0, 16 * CB), N, K, nb);
+  }
+}
+
+template <typename DT, int WAVES, int NS, int CB>
 static void launch_skinny(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                           hipStream_t st) {
   const size_t xbytes = (size_t)WAVES * 16 * CB * 256, rbytes = (size_t)WAVES * NS * CB * 1024;
@@ -191,6 +218,54 @@ static int launch_skinny_64(const void* x, const void* qw, const void* szp, cons
     if (nslab >= 512) launch_skinny<DT, 4, 4, 4>(x, qw, szp, bias, out, m, n, k, st);
     else launch_skinny<DT, 8, 2, 4>(x, qw, szp, bias, out, m, n, k, st);
   }
+  return 0;
+}
+
+template <typename DT, int WAVES, int NS, int CB>
+static void launch_moe_skinny(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int experts, int n, int k,
+                              hipStream_t st) {
+  const size_t xbytes = (size_t)WAVES * 16 * CB * 256, rbytes = (size_t)WAVES * NS * CB * 1024;
+  const size_t smem = xbytes > rbytes ? xbytes : rbytes;
+  auto kern = moe_skinny_cdna4_kernel<DT, WAVES, NS, CB>;
+  if (smem > 64 * 1024) {
+    static bool done = false;
+    if (!done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      done = true;
+    }
+  }
+  const int groups = (n / 16 + NS - 1) / NS;
+  hipLaunchKernelGGL(kern, dim3(experts * groups), dim3(64 * WAVES), smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp,
+                     (const int*)offsets, (uint16_t*)out, n, k, groups);
+}
+
+// 9 <= total_rows <= 255 sorted rows over `experts` experts (stacked cdna4 weights + packed sz).  The column-block count is
+// sized for 1.5x the mean rows per expert; an expert with more rows takes extra passes.  Returns -1 if unsupported.
+int launch_moe_skinny_cdna4(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total_rows,
+                            int experts, int n, int k, int dtype, hipStream_t st) {
+  if (!szp || total_rows < 1 || total_rows > 255 || experts < 1 || (n % 16) != 0 || (k % 128) != 0) return -1;
+  if ((size_t)n * (size_t)k / 8 >= (1ull << 31) || (size_t)total_rows * (size_t)k >= (1ull << 31)) return -1;
+  const int want = (3 * total_rows + 2 * experts - 1) / (2 * experts);  // 1.5 x mean
+  const int cb = want <= 16 ? 1 : (want <= 32 ? 2 : (want <= 48 ? 3 : 4));
+  const bool wide = n / 16 >= 512;
+#define AWQ_MS(DT_)                                                                                             \
+  if (cb == 1) {                                                                                                \
+    if (wide) launch_moe_skinny<DT_, 8, 2, 1>(x, qw, szp, offsets, out, experts, n, k, st);                     \
+    else launch_moe_skinny<DT_, 8, 1, 1>(x, qw, szp, offsets, out, experts, n, k, st);                          \
+  } else if (cb == 2) {                                                                                         \
+    if (wide) launch_moe_skinny<DT_, 8, 2, 2>(x, qw, szp, offsets, out, experts, n, k, st);                     \
+    else launch_moe_skinny<DT_, 8, 1, 2>(x, qw, szp, offsets, out, experts, n, k, st);                          \
+  } else if (cb == 3) {                                                                                         \
+    launch_moe_skinny<DT_, 8, 2, 3>(x, qw, szp, offsets, out, experts, n, k, st);                               \
+  } else {                                                                                                      \
+    launch_moe_skinny<DT_, 8, 2, 4>(x, qw, szp, offsets, out, experts, n, k, st);                               \
+  }
+  if (dtype == 0) {
+    AWQ_MS(F16)
+  } else {
+    AWQ_MS(BF16)
+  }
+#undef AWQ_MS
   return 0;
 }
 

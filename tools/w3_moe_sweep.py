@@ -86,6 +86,18 @@ def main():
             tf = 2.0 * 2 * T * N * K / us / 1e6
             print(f"{name:6s} K={K:6d} N={N:6d} rows={2 * T} {label} {us:8.1f} us  {tf:7.1f} TFLOP/s  {tf / 25:5.1f}% of 2.5 PF",
                   flush=True)
+        for tokens in (8, 32, 96):  # batched decode: top-2 -> 2 x tokens sorted rows
+            idd = torch.stack([torch.randperm(E, device="cuda")[:2] for _ in range(tokens)])
+            _o, offd = sort_by_expert(idd, E)
+            xd = torch.randn(2 * tokens, K, device="cuda").to(dt)
+            res = []
+            for knob in (1, 0):
+                _capi.tune(moe_v4=knob)
+                res.append(graph_time(lambda _c: ops.moe_forward_cdna4(xd, qw, s, z, szp, offd), [0, 1, 2, 3]))
+            _capi.tune(moe_v4=1)
+            by = E * N * K // 2
+            print(f"{name:6s} K={K:6d} N={N:6d} rows={2 * tokens:4d} grouped skinny {res[0]:8.1f} us ({by / res[0] / 1e3:6.0f} GB/s if every expert is hit)"
+                  f"   128x128 grouped {res[1]:8.1f} us", flush=True)
         del qw, s, z, qws, ss, zs
         torch.cuda.empty_cache()
 
