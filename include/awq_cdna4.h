@@ -114,6 +114,17 @@ int awq_w4a16_mlp_gate_up_cdna4(const void* x, const void* qweight_gate_up, cons
                                 int n2, int k, int group_size, int dtype, void* stream);
 
 /* gemm / WQLinear.forward dispatch on cdna4-interleaved weights (any m >= 1; m <= 16 runs the GEMV) */
+/* RMSNorm fused in front of the quantised linear: replaces the FTLlamaRMSNorm launch
+ * (tinychat/modules/fused_norm.py:7-21 -> awq/kernels/csrc/layernorm/layernorm.cu:39-61, layernorm_forward_cuda) followed by
+ * WQLinear.forward / QuantLlamaMLP's gate/up pair.  x is the UN-normalised activation [m, k], gamma the norm weight [k]:
+ *   xn = T((float(x) * rsqrtf(mean(x^2) + eps)) * float(gamma))          (layernorm.cu:55,60)
+ *   fused_gate_up == 0: out[m, n]   = xn . W^T (+ bias)                  (qmodule.py:201-224)
+ *   fused_gate_up != 0: out[m, n/2] = silu(xn . Wg^T) * (xn . Wu^T)      (fused_mlp.py:36-83; qweight = [gate; up], n = 2 * ffn)
+ * Decode rows only: 1 <= m <= 4, k <= 16384; returns AWQ_ERR_BATCH / AWQ_ERR_SHAPE otherwise (run norm and linear separately). */
+int awq_w4a16_rmsnorm_forward_cdna4(const void* x, const void* gamma, float eps, const void* qweight, const void* sz_packed,
+                                    const void* bias, void* out, int m, int n, int k, int group_size, int dtype,
+                                    int fused_gate_up, void* stream);
+
 int awq_w4a16_gemm_cdna4(const void* x, const void* qweight_cdna4, const void* scales, const void* scaled_zeros,
                          const void* sz_packed, void* out, int m, int n, int k, int group_size, int dtype,
                          void* workspace, size_t workspace_bytes, void* stream);

@@ -201,6 +201,22 @@ int awq_w4a16_mlp_gate_up_cdna4(const void* x, const void* qweight_gate_up, cons
   return finish_launch();
 }
 
+int awq_w4a16_rmsnorm_forward_cdna4(const void* x, const void* gamma, float eps, const void* qweight, const void* sz_packed,
+                                    const void* bias, void* out, int m, int n, int k, int group_size, int dtype,
+                                    int fused_gate_up, void* stream) {
+  if (!x || !gamma || !qweight || !sz_packed || !out) return AWQ_ERR_NULL;
+  if (group_size != 128) return AWQ_ERR_GROUP;
+  if (dtype != AWQ_F16 && dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
+  if (m < 1 || m > 4) return AWQ_ERR_BATCH;
+  const int mult = fused_gate_up ? 32 : 16;
+  if (n < mult || (n % mult) != 0 || k < 128 || (k % 128) != 0 || (fused_gate_up && bias)) return AWQ_ERR_SHAPE;
+  if (!aligned16(x) || !aligned16(gamma) || !aligned16(qweight) || !aligned16(out) || !aligned16(sz_packed)) return AWQ_ERR_ALIGN;
+  if (awq::launch_gemv_cdna4_norm(x, gamma, eps, qweight, sz_packed, bias, out, m, n, k, fused_gate_up ? 1 : 0, dtype,
+                                  (hipStream_t)stream) != 0)
+    return AWQ_ERR_SHAPE;
+  return finish_launch();
+}
+
 int awq_w4a16_gemm_cdna4(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
                          const void* sz_packed, void* out, int m, int n, int k, int group_size, int dtype, void* workspace,
                          size_t workspace_bytes, void* stream) {

@@ -13,6 +13,11 @@
 //     against the activation rows; fp32 accumulation; split-K partials reduced through LDS; one rounding.
 //   * the kernel is instruction-issue bound next to the HBM stream (about one wave instruction per 4.5 cycles
 //     per SIMD whatever the pipe), so everything per-step is kept to the minimum instruction count.
+// NORM = 1 fuses the RMSNorm in front of the linear (FTLlamaRMSNorm -> WQLinear, tinychat/modules/fused_norm.py:7-21 +
+// awq/kernels/csrc/layernorm/layernorm.cu:39-61): out = W . T((x * rsqrt(mean(x^2) + eps)) * gamma).
+// The block's waves already load disjoint k-slices of x, so each wave sums the squares of its own slices, the partials
+// meet in LDS (one barrier, while the first weight tiles are in flight), and the slices are normalised into the same
+// wave-private staging region the plain kernel uses -- the 8 KiB activation row never makes a round trip through HBM.
 #include <string.h>
 
 #include "awq_device.hpp"
@@ -21,10 +26,13 @@
 namespace awq {
 
 // the whole block's work for slab `nb`: shared by the plain kernel and the grouped (per-expert) kernel
-template <typename DT, int WAVES, int S, int MB, int EPI, int BITS, int PIPE>
+constexpr int kNormSteps = 8;  // NORM: k-steps of x a wave may own (K <= 128 * 8 * WAVES)
+
+template <typename DT, int WAVES, int S, int MB, int EPI, int BITS, int PIPE, int NORM = 0>
 __device__ __forceinline__ void gemv_cdna4_body(char* smem, const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                 const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
-                                                uint16_t* __restrict__ out, int M, int N, int K, int nb) {
+                                                uint16_t* __restrict__ out, int M, int N, int K, int nb,
+                                                const uint16_t* __restrict__ gamma = nullptr, float eps = 0.f) {
   constexpr int NS = EPI == 1 ? 2 : 1;  // slabs per block
   // the wave index is wave-uniform: taking it through readfirstlane puts every tile / step address computation on
   // the scalar unit (the kernel is VALU-issue bound: ~5 cycles per VALU instruction per SIMD, DESIGN.md "gemv")
@@ -33,7 +41,9 @@ __device__ __forceinline__ void gemv_cdna4_body(char* smem, const uint16_t* __re
   const int nit = K >> 7;
   const int xstep = M * 256;  // bytes of x per 128-k step (M rows)
   float(*red)[4][64] = reinterpret_cast<float(*)[4][64]>(smem);  // [NS * WAVES][4][64]
-  char* xs = smem + NS * WAVES * 1024 + wv * (S * xstep);
+  // x staging: S steps per wave (re-written chunk by chunk); NORM: every step the wave owns, normalised once up front
+  const int xsteps = NORM ? (nit + WAVES - 1) / WAVES : S;
+  char* xs = smem + NS * WAVES * 1024 + wv * (xsteps * xstep);
 
   // Every global load is a raw buffer load: SGPR descriptor + loop-invariant VGPR lane offset + SGPR tile offset, so
   // the per-step address arithmetic runs on the scalar unit and costs no VALU issue slot (out-of-range reads, which
@@ -65,7 +75,7 @@ __device__ __forceinline__ void gemv_cdna4_body(char* smem, const uint16_t* __re
   auto load_chunk = [&](int c0, Regs& R) {
     // x slices first (vmcnt retires in order: their wait must not sit behind the weight stream)
 #pragma unroll
-    for (int t = 0; t < S; ++t) {
+    for (int t = 0; t < (NORM ? 0 : S); ++t) {
       const int kg = min(wv + WAVES * (c0 + t), nit - 1);
 #pragma unroll
       for (int b = 0; b < MB; ++b) {
@@ -95,7 +105,7 @@ __device__ __forceinline__ void gemv_cdna4_body(char* smem, const uint16_t* __re
   };
   auto compute_chunk = [&](int c0, const Regs& R) {
 #pragma unroll
-    for (int t = 0; t < S; ++t)
+    for (int t = 0; t < (NORM ? 0 : S); ++t)
 #pragma unroll
       for (int b = 0; b < MB; ++b)
         // unconditional: lanes past the last row hold a copy of row M - 1 and write it to that row's slot (same bytes).
@@ -104,7 +114,7 @@ __device__ __forceinline__ void gemv_cdna4_body(char* smem, const uint16_t* __re
 #pragma unroll
     for (int t = 0; t < S; ++t) {
       if (wv + WAVES * (c0 + t) >= nit) continue;  // ragged tail: wave-uniform skip (the loads were clamped)
-      const u32x4* xrow = reinterpret_cast<const u32x4*>(xs + t * xstep + mrow * 256);
+      const u32x4* xrow = reinterpret_cast<const u32x4*>(xs + (NORM ? c0 + t : t) * xstep + mrow * 256);
       vec8 xop[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) xop[a] = __builtin_bit_cast(vec8, xrow[(4 * a + g) ^ (mrow & 15)]);
@@ -116,6 +126,61 @@ __device__ __forceinline__ void gemv_cdna4_body(char* smem, const uint16_t* __re
         cd.tile_packed(wt, szv, op);
 #pragma unroll
         for (int a = 0; a < 4; ++a) acc[s] = DT::mfma(op[a], xop[a], acc[s]);
+      }
+    }
+  };
+  // NORM: every x / gamma slice the wave owns goes to registers FIRST (vmcnt retires in order: these small L2-resident loads
+  // must not queue behind the weight stream), then the ring's first weight chunk is requested, then the norm is finished
+  static_assert(!NORM || MB == 1, "the fused RMSNorm path serves M <= 4");
+  u32x4 xv[NORM ? kNormSteps : 1], gv[NORM ? kNormSteps : 1];
+  const int nr = min(g, M - 1);                        // (MB == 1) row of this lane group, clamped
+  const u32 ngran_b = (u32)((i ^ (nr & 15)) * 8) * 2u;  // the granule that lands in LDS slot i of row nr
+  auto norm_issue = [&]() {
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(gamma), 0, K * 2, 0x00020000);
+    const u32 xoff_b = (u32)nr * (u32)K * 2u + ngran_b;
+#pragma unroll
+    for (int t = 0; t < kNormSteps; ++t) {
+      const int kg = min(wv + WAVES * t, nit - 1);  // clamped: no load in a branch; steps past the end are masked below
+      xv[t] = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff_b, (u32)kg * 256u, 0);
+      gv[t] = __builtin_amdgcn_raw_buffer_load_b128(rg, ngran_b, (u32)kg * 256u, 0);
+    }
+  };
+  auto norm_finish = [&]() {
+    float ss = 0.f;
+#pragma unroll
+    for (int t = 0; t < kNormSteps; ++t) {
+      if (t < cnt) {
+        const u32 w4[4] = {xv[t].x, xv[t].y, xv[t].z, xv[t].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = DT::to_float((uint16_t)(w4[e] & 0xFFFFu)), hi = DT::to_float((uint16_t)(w4[e] >> 16));
+          ss = __builtin_fmaf(lo, lo, ss);
+          ss = __builtin_fmaf(hi, hi, ss);
+        }
+      }
+    }
+    // the 16 lanes of a row group hold different granules of the same row
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) ss += __shfl_xor(ss, d, 64);
+    float* psum = reinterpret_cast<float*>(smem + NS * WAVES * 1024 + WAVES * (xsteps * xstep));  // [WAVES][4]
+    if (i == 0) psum[wv * 4 + g] = ss;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < WAVES; ++q) tot += psum[q * 4 + g];
+    const float rstd = rsqrtf(tot / (float)K + eps);  // layernorm.cu:55: rsqrtf(variance / n + eps)
+#pragma unroll
+    for (int t = 0; t < kNormSteps; ++t) {
+      if (t < cnt) {
+        const u32 w4[4] = {xv[t].x, xv[t].y, xv[t].z, xv[t].w}, g4[4] = {gv[t].x, gv[t].y, gv[t].z, gv[t].w};
+        u32 o4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {  // layernorm.cu:60: T((float(x) * s_variance) * float(gamma))
+          const float lo = (DT::to_float((uint16_t)(w4[e] & 0xFFFFu)) * rstd) * DT::to_float((uint16_t)(g4[e] & 0xFFFFu));
+          const float hi = (DT::to_float((uint16_t)(w4[e] >> 16)) * rstd) * DT::to_float((uint16_t)(g4[e] >> 16));
+          o4[e] = (u32)DT::from_float(lo) | ((u32)DT::from_float(hi) << 16);
+        }
+        *reinterpret_cast<u32x4*>(xs + t * xstep + nr * 256 + i * 16) = u32x4{o4[0], o4[1], o4[2], o4[3]};
       }
     }
   };
@@ -133,9 +198,24 @@ __device__ __forceinline__ void gemv_cdna4_body(char* smem, const uint16_t* __re
     // (loads past the end are clamped: L2 hits on the slab's last tile)
     constexpr int D = PIPE > 0 ? PIPE : 1;  // (PIPE == 0 never gets here; keeps the array non-empty)
     Regs R[D];
+    int cbeg = 0;
+    if constexpr (NORM != 0) {
+      // both register sets are requested before the norm is finished (two chunks per wave keep the stream going through the
+      // reduce / barrier / normalise chain); the first ring iteration is peeled accordingly
+      static_assert(!NORM || D == 2, "");
+      norm_issue();
+      load_chunk(0, R[0]);
+      load_chunk(S, R[1]);
+      norm_finish();
+      compute_chunk(0, R[0]);
+      load_chunk(2 * S, R[0]);
+      compute_chunk(S, R[1]);
+      cbeg = 2 * S;
+    } else {
 #pragma unroll
-    for (int j = 0; j + 1 < D; ++j) load_chunk(j * S, R[j]);
-    for (int c0 = 0; c0 < cnt; c0 += D * S) {
+      for (int j = 0; j + 1 < D; ++j) load_chunk(j * S, R[j]);
+    }
+    for (int c0 = cbeg; c0 < cnt; c0 += D * S) {
 #pragma unroll
       for (int j = 0; j < D; ++j) {
         load_chunk(c0 + (j + D - 1) * S, R[(j + D - 1) % D]);
@@ -173,6 +253,15 @@ __device__ __forceinline__ void gemv_cdna4_body(char* smem, const uint16_t* __re
       out[(size_t)i * (N >> 1) + nn] = DT::from_float(sl * up);
     }
   }
+}
+
+template <typename DT, int WAVES, int S, int EPI>
+__global__ __launch_bounds__(64 * WAVES) void gemv_cdna4_norm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gamma,
+                                                                      const u32* __restrict__ qw, const u32* __restrict__ szp,
+                                                                      const uint16_t* __restrict__ bias, uint16_t* __restrict__ out,
+                                                                      int M, int N, int K, float eps) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemv_cdna4_body<DT, WAVES, S, 1, EPI, 4, 2, 1>(smem, x, qw, szp, bias, out, M, N, K, blockIdx.x, gamma, eps);
 }
 
 template <typename DT, int WAVES, int S, int MB, int EPI, int BITS, int PIPE>
@@ -310,6 +399,40 @@ int launch_gemv_cdna4(const void* x, const void* qw, const void* szp, const void
   }
   AWQ_DT(BF16)
 #undef AWQ_DT
+}
+
+// RMSNorm fused in front of the linear (see the header): x is the UN-normalised activation, gamma the norm weight [k].
+// 1 <= m <= 4, k <= 128 * 8 * waves; epi as above.  Returns -1 if unsupported (the caller runs norm and linear separately).
+int launch_gemv_cdna4_norm(const void* x, const void* gamma, float eps, const void* qw, const void* szp, const void* bias, void* out,
+                           int m, int n, int k, int epi, int dtype, hipStream_t st) {
+  if (m < 1 || m > 4 || !gamma || !szp || (n % (epi == 1 ? 32 : 16)) != 0 || (k % 128) != 0) return -1;
+  const int ns = epi == 1 ? 2 : 1;
+  const Cfg c = pick_cfg(m, n, k, ns, g_force_waves, 0);
+  const int nit = k / kGroup, per = (nit + c.waves - 1) / c.waves;
+  if (per > kNormSteps) return -1;
+  const double waves_per_cu = (double)(n / 16 / ns) * c.waves / 256.0;
+  const int ps = g_pipe_s ? g_pipe_s : ((per >= 2 && waves_per_cu * ns <= 10.0) ? 2 : 1);
+  const size_t smem = (size_t)ns * c.waves * 1024 + (size_t)c.waves * per * m * 256 + (size_t)c.waves * 16;
+  if (smem > 160 * 1024) return -1;
+#define AWQ_NCASE(DT_, W_, S_, E_)                                                                                       \
+  if (c.waves == W_ && ps == S_ && epi == E_) {                                                                          \
+    auto kern = gemv_cdna4_norm_kernel<DT_, W_, S_, E_>;                                                                 \
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL(kern, dim3(n / 16 / ns), dim3(64 * W_), smem, st, (const uint16_t*)x, (const uint16_t*)gamma, (const u32*)qw, \
+                       (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k, eps);                            \
+    return 0;                                                                                                            \
+  }
+#define AWQ_NDT(DT_)                                                                                                     \
+  AWQ_NCASE(DT_, 4, 1, 0) AWQ_NCASE(DT_, 4, 2, 0) AWQ_NCASE(DT_, 8, 1, 0) AWQ_NCASE(DT_, 8, 2, 0) AWQ_NCASE(DT_, 16, 1, 0)   \
+  AWQ_NCASE(DT_, 16, 2, 0) AWQ_NCASE(DT_, 4, 1, 1) AWQ_NCASE(DT_, 4, 2, 1) AWQ_NCASE(DT_, 8, 1, 1) AWQ_NCASE(DT_, 8, 2, 1)
+  if (dtype == 0) {
+    AWQ_NDT(F16)
+  } else {
+    AWQ_NDT(BF16)
+  }
+#undef AWQ_NDT
+#undef AWQ_NCASE
+  return -1;
 }
 
 // grouped decode GEMV: total_rows <= 8 (so every expert has <= 8 rows), cdna4 layout, stacked packed sz [E][N/16][K/128][16]

@@ -13,6 +13,9 @@ int launch_gemv(const void* x, const void* qw, const void* s, const void* z, con
 // epi 1: qw = [gate; up] stacked (n = 2*ffn rows), out[m, n/2] = silu(gate) * up.  Returns -1 if unsupported.
 int launch_gemv_cdna4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                       int epi, int bits, int dtype, hipStream_t st);
+// RMSNorm fused in front of the decode GEMV (awq_gemv_cdna4.hip, NORM = 1): 1 <= m <= 4.  Returns -1 if unsupported.
+int launch_gemv_cdna4_norm(const void* x, const void* gamma, float eps, const void* qw, const void* szp, const void* bias, void* out,
+                           int m, int n, int k, int epi, int dtype, hipStream_t st);
 // reference (v2) layout fast decode path (awq_gemv_v2fast.hip): 1 <= m <= 8, n % 16 == 0, fp16 / bf16, bias fused.
 // gpad = rows of scales / zeros that may be read (>= k / 128).  Returns -1 if unsupported.
 bool gemv_v2fast_enabled();  // false while a knob of the older kernel (awq_tune_set gemv_*) is active

@@ -217,6 +217,22 @@ def mlp_gate_up_cdna4(x, qweight_gate_up, sz_packed, group_size: int = 128):
     return out
 
 
+def rmsnorm_forward_cdna4(x, gamma, eps: float, qweight, sz_packed, bias=None, fused_gate_up: bool = False, group_size: int = 128):
+    """C-ABI awq_w4a16_rmsnorm_forward_cdna4: T5/Llama RMSNorm (FTLlamaRMSNorm, fused_norm.py:7-21) fused in front of the
+    quantised linear -- or, with fused_gate_up, of the gate/up pair + SiLU*mul.  x: un-normalised [.., K], 1 <= M <= 4."""
+    _need_gpu(x, gamma, qweight, sz_packed)
+    k = x.shape[-1]
+    m = x.numel() // k
+    n = qweight.shape[0] * 4
+    out = torch.empty(*x.shape[:-1], n // 2 if fused_gate_up else n, dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _capi.check(_capi.lib().awq_w4a16_rmsnorm_forward_cdna4(x.data_ptr(), gamma.data_ptr(), float(eps), qweight.data_ptr(),
+                                                                 sz_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                                                 out.data_ptr(), m, n, k, group_size, _dt(x), 1 if fused_gate_up else 0,
+                                                                 _stream(x)))
+    return out
+
+
 # ---- W3 ("w3c" tiles, bf16) ----
 
 def pack_w3(q_u8):

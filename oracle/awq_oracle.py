@@ -349,3 +349,17 @@ def quantize_linear_w3(w: torch.Tensor, dtype=torch.bfloat16, group_size: int = 
     sz[:, : s.shape[1]] = -(qs[:, : s.shape[1]] * z.to(torch.int32).to(torch.float32)).to(dtype)
     return dict(w_fake=fake, s=s, z=z, qweight=torch.from_numpy(pack_w3(iw.numpy())), scales=qs.t().contiguous(),
                 scaled_zeros=sz.t().contiguous(), intweight=iw)
+
+
+# --------------------------------------------------------------------------------------
+# RMSNorm in front of the linear: awq/kernels/csrc/layernorm/layernorm.cu:39-61
+# (generalT5LayerNorm: no mean subtraction, no bias), called by tinychat/modules/fused_norm.py:7-21.
+# --------------------------------------------------------------------------------------
+def rmsnorm(x: "torch.Tensor", gamma: "torch.Tensor", eps: float) -> "torch.Tensor":
+    """out = T((float(x) * rsqrt(mean(x^2) + eps)) * float(gamma)): fp32 sum of squares (layernorm.cu:48-52; the
+    reduction order is the kernel's business -- fp32 either way), rsqrtf(variance / n + eps) (:55), the two multiplies in
+    fp32 in that order and ONE rounding to T (:60)."""
+    xf = x.float()
+    var = (xf * xf).sum(-1, keepdim=True) / xf.shape[-1]
+    rstd = torch.rsqrt(var + eps)
+    return ((xf * rstd) * gamma.float()).to(x.dtype)

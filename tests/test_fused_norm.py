@@ -1,0 +1,83 @@
+"""RMSNorm fused in front of the quantised linear (awq/kernels/csrc/layernorm/layernorm.cu:39-61 +
+tinychat/modules/fused_norm.py:7-21 feeding WQLinear.forward / QuantLlamaMLP)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import awq_oracle as O
+from tests.helpers import make_case
+
+
+def test_oracle_rmsnorm_matches_llama_rmsnorm_formula():
+    """FTLlamaRMSNorm "is equivalent to T5LayerNorm" (fused_norm.py:10-13): the oracle restatement against the textbook
+    LlamaRMSNorm computation in fp64 -- at most one ulp of T apart (different rounding points)."""
+    g = torch.Generator().manual_seed(0)
+    for dtype, tol in ((torch.bfloat16, 2.0 ** -7), (torch.float16, 2.0 ** -10)):
+        x = (torch.randn(3, 512, generator=g) * 3).to(dtype)
+        gamma = (1 + 0.1 * torch.randn(512, generator=g)).to(dtype)
+        got = O.rmsnorm(x, gamma, 1e-6).double()
+        xd = x.double()
+        want = xd * torch.rsqrt((xd * xd).mean(-1, keepdim=True) + 1e-6) * gamma.double()
+        assert ((got - want).abs() <= tol * want.abs() + 1e-12).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [1, 2, 3, 4])
+@pytest.mark.parametrize("N,K", [(768, 768), (256, 4096), (1024, 2048), (64, 8192)])
+def test_gpu_rmsnorm_linear_vs_oracle(dtype, M, N, K):
+    from llm_awq_amd import ops
+    c = make_case(N, K, dtype, seed=M + N + K, M=M, bias=(M == 2))
+    g = torch.Generator().manual_seed(N + M)
+    x = (torch.randn(M, K, generator=g) * 2.5).to(dtype)
+    gamma = (1 + 0.2 * torch.randn(K, generator=g)).to(dtype)
+    eps = 1e-5
+    c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
+    szp = ops.pack_sz_cdna4(c["scales"].cuda(), c["scaled_zeros"].cuda(), K)
+    y = ops.rmsnorm_forward_cdna4(x.cuda(), gamma.cuda(), eps, c4, szp, c["bias"].cuda() if c["bias"] is not None else None).cpu()
+    xn = O.rmsnorm(x, gamma, eps)
+    ref = O.wqlinear_forward(xn, None, c["scales"], c["scaled_zeros"], c["bias"], 128, q_int=c["q"])
+    rel = ((y.float() - ref.float()).norm() / ref.float().norm()).item()
+    assert rel <= 1e-3, rel
+    # the normalised activations can differ in the last bit where the fp32 sum of squares is reduced in another order
+    assert (y == ref).float().mean() > 0.9
+    # and against the two-launch product path: oracle-normalised x through the plain kernel
+    y2 = ops.gemm_cdna4(xn.cuda(), c4, c["scales"].cuda(), c["scaled_zeros"].cuda(), c["bias"].cuda() if c["bias"] is not None else None, szp).cpu()
+    assert (y == y2).float().mean() > 0.9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [1, 4])
+def test_gpu_rmsnorm_gate_up_vs_oracle(dtype, M):
+    from llm_awq_amd import ops
+    F, K = 1376, 2048
+    cg = make_case(F, K, dtype, seed=F + M, M=M)
+    cu = make_case(F, K, dtype, seed=F + M + 1, M=M)
+    g = torch.Generator().manual_seed(M)
+    x = (torch.randn(M, K, generator=g) * 1.7).to(dtype)
+    gamma = (1 + 0.2 * torch.randn(K, generator=g)).to(dtype)
+    qgu = torch.cat([cg["qweight"], cu["qweight"]], 0).cuda()
+    s = torch.cat([cg["scales"], cu["scales"]], 1).cuda()
+    z = torch.cat([cg["scaled_zeros"], cu["scaled_zeros"]], 1).cuda()
+    c4 = ops.repack_v2_to_cdna4(qgu)
+    szp = ops.pack_sz_cdna4(s, z, K)
+    y = ops.rmsnorm_forward_cdna4(x.cuda(), gamma.cuda(), 1e-6, c4, szp, None, fused_gate_up=True).cpu()
+    xn = O.rmsnorm(x, gamma, 1e-6)
+    gt = O.wqlinear_forward(xn, None, cg["scales"], cg["scaled_zeros"], None, 128, q_int=cg["q"])
+    up = O.wqlinear_forward(xn, None, cu["scales"], cu["scaled_zeros"], None, 128, q_int=cu["q"])
+    ref = torch.nn.functional.silu(gt) * up
+    rel = ((y.float() - ref.float()).norm() / ref.float().norm()).item()
+    assert rel <= 3e-3, rel
+    assert (y == ref).float().mean() > 0.85
+
+
+@pytest.mark.gpu
+def test_gpu_rmsnorm_forward_rejects_what_it_cannot_serve():
+    from llm_awq_amd import ops, _capi
+    c = make_case(256, 512, torch.bfloat16, seed=1, M=5)
+    c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
+    szp = ops.pack_sz_cdna4(c["scales"].cuda(), c["scaled_zeros"].cuda(), 512)
+    gamma = torch.ones(512, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(_capi.AwqNativeError):
+        ops.rmsnorm_forward_cdna4(c["x"].cuda(), gamma, 1e-6, c4, szp)  # M = 5 > 4
