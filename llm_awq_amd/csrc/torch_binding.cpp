@@ -54,8 +54,8 @@ void check_inputs(const torch::Tensor& x, const torch::Tensor& kernel, const tor
 // them once on the GPU (awq_repack_v2_to_cdna4 + awq_pack_sz_cdna4, tens of microseconds) and later calls run the
 // cdna4 kernels.  An entry is tied to the IDENTITY of the three tensors (weak TensorImpl references, so a freed
 // tensor whose address is re-used can never hit) and to their version counters (an in-place update re-packs).
-// Cost: a second packed copy of the weights (N*K/2 + N*K/32 bytes).  AWQ_CDNA4_AUTOCACHE=0 disables it; it is also
-// bypassed while the stream is being captured into a hipGraph (no allocations inside a capture).
+// Cost: a second packed copy of the weights (N*K/2 + N*K/32 bytes).  AWQ_CDNA4_AUTOCACHE=0 disables it.  While the stream is
+// being captured into a hipGraph nothing is built (no allocations inside a capture): entries made by a warm-up call are used.
 // ---------------------------------------------------------------------------------------------------------------
 struct CacheEntry {
   c10::weak_intrusive_ptr<c10::TensorImpl> w, s, z;
@@ -85,8 +85,10 @@ bool cdna4_view(const torch::Tensor& kernel, const torch::Tensor& scales, const 
       (scales.scalar_type() != at::kBFloat16 && scales.scalar_type() != at::kHalf))
     return false;
   if (n % 16 != 0 || k % 128 != 0 || kernel.numel() != n / 4 * k) return false;
+  // inside a hipGraph capture nothing may be allocated or re-packed: an entry built by an earlier (warm-up) call is used,
+  // a first call falls back to the reference-layout kernels
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
+  const bool capturing = hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
   std::lock_guard<std::mutex> lock(g_cache_mu);
   const void* key = kernel.data_ptr();
   auto it = g_cache.find(key);
@@ -101,8 +103,10 @@ bool cdna4_view(const torch::Tensor& kernel, const torch::Tensor& scales, const 
       ++g_cache_hits;
       return true;
     }
+    if (capturing) return false;
     g_cache.erase(it);
   }
+  if (capturing) return false;
   // drop entries whose tensors died (keeps the map from growing when models are reloaded)
   for (auto i2 = g_cache.begin(); i2 != g_cache.end();) i2 = i2->second.w.expired() ? g_cache.erase(i2) : std::next(i2);
   CacheEntry e(kernel, scales, zeros);

@@ -83,3 +83,26 @@ def test_fp16_is_cached_too_and_disabled_and_capture_bypass_the_cache(eng):
     torch.cuda.synchronize()
     assert eng.cdna4_cache_info()["entries"] == 0
     check_forward(yg.cpu(), c["x"], c["q"], c["scales"], c["scaled_zeros"], torch.bfloat16)
+
+
+def test_warm_entry_is_used_inside_a_capture(eng):
+    """tinychat warms up, then captures decode into a graph: the capture must run the cdna4 kernels from the entry the warm-up
+    built (a lookup allocates nothing), not fall back to the reference-layout kernels."""
+    N, K = 256, 512
+    c = make_case(N, K, torch.bfloat16, seed=8, M=2)
+    qw, s, z = _dev(c)
+    x = c["x"].cuda()
+    eng.cdna4_cache_clear()
+    y0 = eng.gemv_forward_cuda_new(x, qw, s, z, 2, N, K, 128)  # warm-up: builds the entry
+    info0 = eng.cdna4_cache_info()
+    assert info0["entries"] == 1
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            yg = eng.gemv_forward_cuda_new(x, qw, s, z, 2, N, K, 128)
+        g.replay()
+    torch.cuda.synchronize()
+    info1 = eng.cdna4_cache_info()
+    assert info1["entries"] == 1 and info1["hits"] == info0["hits"] + 1 and info1["builds"] == info0["builds"]
+    assert torch.equal(yg, y0)

@@ -170,3 +170,20 @@ def test_repack_v1_to_v2_golden(ops, golden):
         assert (qw2.cpu().numpy() == g[f"qw2_{i}"]).all()
         assert (s2.cpu().view(torch.int16).numpy() == g[f"sc2_{i}"]).all()
         assert (sz2.cpu().view(torch.int16).numpy() == g[f"sz2_{i}"]).all()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [1, 7, 8, 9, 64, 255, 256, 257, 600])
+@pytest.mark.parametrize("N,K", [(16, 128), (32, 256), (48, 384), (272, 128)])
+def test_smallest_shapes_every_dispatch_boundary(ops, dtype, M, N, K):
+    """One or two quantisation groups, one to seventeen slabs, M on both sides of every kernel boundary (GEMV <= 8, skinny
+    9..255, tiled GEMM >= 256), reference layout and cdna4, with and without bias."""
+    c = make_case(N, K, dtype, seed=M + N + K, M=M, bias=(M % 2 == 0))
+    b = c["bias"].cuda() if c["bias"] is not None else None
+    qw, s, z, x = c["qweight"].cuda(), c["scales"].cuda(), c["scaled_zeros"].cuda(), c["x"].cuda()
+    y2 = ops.forward(x, qw, s, z, b).cpu() if b is not None else (ops.gemv(x, qw, s, z) if M < 8 else ops.gemm(x, qw, s, z)).cpu()
+    check_forward(y2, c["x"], c["q"], c["scales"], c["scaled_zeros"], dtype, bias=c["bias"])
+    c4 = ops.repack_v2_to_cdna4(qw)
+    szp = ops.pack_sz_cdna4(s, z, K)
+    y4 = ops.gemm_cdna4(x, c4, s, z, b, szp).cpu()
+    check_forward(y4, c["x"], c["q"], c["scales"], c["scaled_zeros"], dtype, bias=c["bias"])
