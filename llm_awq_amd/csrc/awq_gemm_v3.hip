@@ -321,7 +321,7 @@ void launch_v3(const void* x, const void* qw, const void* szp, const void* bias,
   hipLaunchKernelGGL((gemm_cdna4_v3_kernel<DT, NSL>), dim3(tiles_m * tiles_n), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw,
                      (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end);
 }
-constexpr double kNarrowRate = 0.77;  // 256 x 128 tiles (v3 K loop) vs 256 x 256 (v4 K loop) at equal chip fill (profiles/r01_gemm_v4.txt)
+constexpr double kNarrowRate = 0.83;  // 256 x 128 tiles (awq_gemm_v4n.hip) vs 256 x 256 (awq_gemm_v4.hip) at equal chip fill (profiles/r01_gemm_v4.txt)
 int g_v4 = 1;  // 1 (default): 256-wide tiles run the hand-scheduled K loop of awq_gemm_v4.hip; 0: v3's compiler-scheduled loop
 void launch_wide(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
                  int n_end, int dtype, hipStream_t st) {
@@ -331,7 +331,8 @@ void launch_wide(const void* x, const void* qw, const void* szp, const void* bia
 }
 void launch_narrow(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
                    int n_end, int dtype, hipStream_t st) {
-  if (dtype == 0) launch_v3<F16, 1>(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
+  if (g_v4) launch_gemm_cdna4_v4n(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st);
+  else if (dtype == 0) launch_v3<F16, 1>(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
   else launch_v3<BF16, 1>(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
 }
 }  // namespace

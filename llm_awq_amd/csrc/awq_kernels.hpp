@@ -55,6 +55,9 @@ int gemv_tune_set(const char* key, int value);
 int gemm_tune_set(const char* key, int value);
 int gemm_v3_tune_set(const char* key, int value);  // gemm_v4, gemm_v4_probe
 void gemm_v4_set_probe(int v);
+// 256 x 128 tiles with the same hand-scheduled K loop (awq_gemm_v4n.hip)
+void launch_gemm_cdna4_v4n(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
+                           int n_begin, int n_end, int dtype, hipStream_t st);
 // grouped (MoE) GEMM with the same K loop: sorted rows, device expert offsets, stacked cdna4 weights + packed scales; total >= 256
 int launch_moe_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total, int experts,
                              int n, int k, int dtype, hipStream_t st);

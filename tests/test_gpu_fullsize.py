@@ -108,14 +108,15 @@ def test_gemm_v4_identical_to_v3(env, bias):
         b = (torch.randn(N, device="cuda") * 0.02).bfloat16() if bias else None
         for M in (256, 300, 1000, 2048):
             x = torch.randn(M, K, device="cuda").bfloat16()
-            ops._capi.tune(gemm_variant=4, gemm_v4=0)
-            try:
-                ref = ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], b, szp)
-                ops._capi.tune(gemm_v4=1)
-                y = ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], b, szp)
-            finally:
-                ops._capi.tune(gemm_variant=0, gemm_v4=1)
-            assert torch.equal(y, ref), (K, N, M)
+            for variant in (4, 5):  # 256-wide (awq_gemm_v4.hip) and 128-wide (awq_gemm_v4n.hip) tiles
+                ops._capi.tune(gemm_variant=variant, gemm_v4=0)
+                try:
+                    ref = ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], b, szp)
+                    ops._capi.tune(gemm_v4=1)
+                    y = ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], b, szp)
+                finally:
+                    ops._capi.tune(gemm_variant=0, gemm_v4=1)
+                assert torch.equal(y, ref), (K, N, M, variant)
 
 
 def test_fused_mlp_fullsize(env):
