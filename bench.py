@@ -215,7 +215,7 @@ def main():
         flops = sum(2.0 * M * K * N for (_nm, K, N, *_r) in weights)
         tfl = flops / (pms * 1e-3) / 1e12
         return {"m": M, "ms_per_pass": round(pms, 3), "tok_s": round(M / (pms * 1e-3) * (LAYERS / L), 1),
-                "roofline": {"bound": "mfma", "kernel": "gemm_cdna4_v4_kernel (256-wide tiles) + gemm_cdna4_v3_kernel<1> (128-wide remainder)" if args.layout == "cdna4" else "gemm_w4a16_256x256_kernel",
+                "roofline": {"bound": "mfma", "kernel": "gemm_cdna4_v4_kernel (256-wide tiles) + gemm_cdna4_v4n_kernel (128-wide remainder)" if args.layout == "cdna4" else "gemm_w4a16_256x256_kernel",
                              "achieved": round(tfl, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(tfl / MFMA_PEAK_TFLOPS, 4), "traffic": None}}
 
