@@ -2,17 +2,17 @@
 // WQLinear.forward for decode (replaces gemv_kernel, awq/kernels/csrc/quantization_new/gemv/gemv_cuda.cu:74-229)
 // and, with EPI = 1, of QuantLlamaMLP's gate/up pair + SiLU*mul (tinychat/modules/fused_mlp.py:36-83).
 //
-// Structure (measured on MI355X with tools/ubench/gemv_ubench.hip, see DESIGN.md "gemv"):
-//   * block = one 16-row slab (EPI 1: the gate slab and the matching up slab), WAVES waves split K in
-//     interleaved 128-k steps; a wave issues ALL loads of a chunk of S steps up front (S x 1 KiB of packed
-//     weights + S dwords of packed {scale|scaled_zero} + its own x slices), so there is no conditional load
-//     and no register ring: hipcc emits counted vmcnt waits and the HBM queue is full from the first cycle.
+// Structure (DESIGN.md "Decode GEMV"; measurements under profiles/r01_gemv*):
+//   * block = one 16-row slab (EPI 1: the gate slab and the matching up slab), WAVES waves split K in interleaved
+//     128-k steps.  A wave walks its steps in chunks of S (1 or 2) through a ring of PIPE = 2 register sets: the loads of
+//     the next chunk (S x 1 KiB of packed weights, S dwords of packed {scale | scaled_zero}, its own x slices) are in
+//     flight while the current chunk is dequantised.  No load sits in a branch (indices past the end are clamped), so
+//     hipcc emits counted vmcnt waits.  (PIPE = 0, kept for the knob experiments: all loads of a chunk up front.)
 //   * x slices are staged through a WAVE-PRIVATE LDS region (no block barrier before the final reduction).
-//   * weights are dequantised on the matrix core (Cdna4Dequant, awq_device.hpp: exact q*s+sz in fp32, one
-//     v_cvt_pk_bf16_f32 = the reference's rounding) and fed as the A operand of v_mfma_f32_16x16x32_bf16
-//     against the activation rows; fp32 accumulation; split-K partials reduced through LDS; one rounding.
-//   * the kernel is instruction-issue bound next to the HBM stream (about one wave instruction per 4.5 cycles
-//     per SIMD whatever the pipe), so everything per-step is kept to the minimum instruction count.
+//   * weights are dequantised on the matrix core (Cdna4DequantT, awq_device.hpp: exact q*s+sz in fp32, one
+//     v_cvt_pk = the reference's rounding) and fed as the A operand of v_mfma_f32_16x16x32 against the activation rows;
+//     fp32 accumulation; split-K partials reduced through LDS; one rounding; bias / SiLU*mul in the epilogue.
+//   * every global load is a raw buffer load with a scalar tile offset: the per-step address arithmetic is on the SALU.
 // NORM = 1 fuses the RMSNorm in front of the linear (FTLlamaRMSNorm -> WQLinear, tinychat/modules/fused_norm.py:7-21 +
 // awq/kernels/csrc/layernorm/layernorm.cu:39-61): out = W . T((x * rsqrt(mean(x^2) + eps)) * gamma).
 // The block's waves already load disjoint k-slices of x, so each wave sums the squares of its own slices, the partials
@@ -25,8 +25,9 @@
 
 namespace awq {
 
-// the whole block's work for slab `nb`: shared by the plain kernel and the grouped (per-expert) kernel
 constexpr int kNormSteps = 8;  // NORM: k-steps of x a wave may own (K <= 128 * 8 * WAVES)
+
+// the whole block's work for slab `nb`: shared by the plain kernel, the norm-fused kernel and the grouped (per-expert) kernel
 
 template <typename DT, int WAVES, int S, int MB, int EPI, int BITS, int PIPE, int NORM = 0>
 __device__ __forceinline__ void gemv_cdna4_body(char* smem, const uint16_t* __restrict__ x, const u32* __restrict__ qw,
