@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--tune", action="append", default=[], help="experiments only: awq_tune_set knobs as key=value (e.g. gemv_probe=2 with --layout v2 turns every decode launch into a linear read of the same weight bytes: the streaming floor of this harness)")
     ap.add_argument("--layout", default="cdna4", choices=["cdna4", "v2"], help="cdna4 = what the rewritten repacker emits (default); v2 = reference checkpoint layout through gemv/gemm_forward_cuda_new")
     ap.add_argument("--unfused-mlp", action="store_true", help="run gate and up as two launches (160 launches per token instead of 128)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"], help="activation / scale dtype: bf16 is BASELINE.json's configuration (default); f16 is the reference's default WQLinear dtype (single-GPU leg only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -92,7 +93,7 @@ def main():
     import llm_awq_amd
     from llm_awq_amd import synth
     eng = llm_awq_amd.load_engine()
-    dtype = torch.bfloat16
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     if args.tune:
         from llm_awq_amd import _capi
         _capi.tune(**{kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tune})
@@ -192,8 +193,8 @@ def main():
            "value": round(tok_s, 2),
            "unit": "decode tok/s (the 160 quantised linears of one token: 32 x {qkv, o, gate, up, down}; attention/norm/lm_head off-path)",
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-           "config": {"workload": "Llama-3-8B W4A16 g128 bf16 activations on 1xMI355X (decode GEMV + prefill GEMM)",
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": "Llama-3-8B W4A16 g128 " + ("bf16" if args.dtype == "bf16" else "fp16") + " activations on 1xMI355X (decode GEMV + prefill GEMM)",
                       "layers": L, "decode_m": 1, "prefill_m": args.prefill_m, "graph": graph is not None,
                       "layout": args.layout, "fused_gate_up_silu_mul": fused and args.layout == "cdna4",
                       "launches_per_token": launches, "parallelism": "tp1", **({"tune": args.tune} if args.tune else {})},
