@@ -323,7 +323,7 @@ __device__ __forceinline__ void v4_tile(char* smem, const uint16_t* __restrict__
         };
         v = u32x4{add2(v.x, bv.x), add2(v.y, bv.y), add2(v.z, bv.z), add2(v.w, bv.w)};
       }
-      *reinterpret_cast<u32x4*>(out + (size_t)m * N + nn) = v;
+      __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(out + (size_t)m * N + nn));  // streamed: keep the x / weight panels in L2
     }
   }
 }

@@ -320,7 +320,7 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v4n_kernel(const uint16_t* __r
         };
         v = u32x4{add2(v.x, bv.x), add2(v.y, bv.y), add2(v.z, bv.z), add2(v.w, bv.w)};
       }
-      *reinterpret_cast<u32x4*>(out + (size_t)m * N + nn) = v;
+      __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(out + (size_t)m * N + nn));  // streamed: keep the x / weight panels in L2
     }
   }
 }
