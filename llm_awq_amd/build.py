@@ -46,22 +46,41 @@ def _run(cmd, what):
 
 
 def build_lib(force: bool = False, verbose: bool = True) -> str:
-    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [d if os.path.isabs(d) else os.path.join(CSRC, d) for d in HIP_DEPS]
-    if force or _newer(LIB_PATH, deps):
-        os.makedirs(LIB_DIR, exist_ok=True)
-        cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-               "-Wno-unused-function",
-               # keep MFMA results in VGPRs: the matrix-core dequant feeds v_cvt_pk_bf16_f32 directly
-               # (the AGPR form costs one v_accvgpr_read per value)
-               "-mllvm", "-amdgpu-mfma-vgpr-form",
-               # AWQ_PROBES=1: compile the timing-only probes (linear-read / null kernels, GEMM v4 no-DMA / no-epilogue)
-               # behind the gemv_probe / gemm_v4_probe knobs; a default build has no knob that changes results
-               *(["-DAWQ_ENABLE_PROBES"] if os.environ.get("AWQ_PROBES") == "1" else []),
-               *srcs, "-o", LIB_PATH]
-        dt = _run(cmd, "libawq_cdna4.so")
+    """Every .hip source is compiled to its own object (in parallel, only when older than its source or the shared headers),
+    then linked: an edit to one kernel file rebuilds one object."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    deps = [d if os.path.isabs(d) else os.path.join(CSRC, d) for d in HIP_DEPS]
+    probes = os.environ.get("AWQ_PROBES") == "1"
+    if not force and not probes and not _newer(LIB_PATH, [os.path.join(CSRC, n) for n in HIP_SOURCES] + deps):
+        return LIB_PATH  # up to date (the GPU box receives the linked library without the per-file objects)
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+             # keep MFMA results in VGPRs: the matrix-core dequant feeds v_cvt_pk_bf16_f32 directly
+             # (the AGPR form costs one v_accvgpr_read per value)
+             "-mllvm", "-amdgpu-mfma-vgpr-form",
+             # AWQ_PROBES=1: compile the timing-only probes (linear-read / null kernels, GEMM v4 no-DMA / no-epilogue)
+             # behind the gemv_probe / gemm_v4_probe knobs; a default build has no knob that changes results
+             *(["-DAWQ_ENABLE_PROBES"] if os.environ.get("AWQ_PROBES") == "1" else [])]
+    stamp = os.path.join(obj_dir, "flags.txt")
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
+        force = True
+    jobs = []
+    for name in HIP_SOURCES:
+        src, obj = os.path.join(CSRC, name), os.path.join(obj_dir, name + ".o")
+        if force or _newer(obj, [src] + deps):
+            jobs.append((name, [HIPCC, *flags, "-c", src, "-o", obj]))
+    t0 = time.time()
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            list(ex.map(lambda j: _run(j[1], j[0]), jobs))
+    objs = [os.path.join(obj_dir, n + ".o") for n in HIP_SOURCES]
+    if jobs or _newer(LIB_PATH, objs):
+        _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB_PATH], "libawq_cdna4.so")
+        open(stamp, "w").write(" ".join(flags))
         if verbose:
-            print(f"[llm_awq_amd.build] libawq_cdna4.so built in {dt:.1f}s")
+            print(f"[llm_awq_amd.build] libawq_cdna4.so built in {time.time() - t0:.1f}s ({len(jobs)} of {len(HIP_SOURCES)} objects recompiled)")
     return LIB_PATH
 
 
