@@ -51,11 +51,7 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
     from concurrent.futures import ThreadPoolExecutor
 
     deps = [d if os.path.isabs(d) else os.path.join(CSRC, d) for d in HIP_DEPS]
-    probes = os.environ.get("AWQ_PROBES") == "1"
-    if not force and not probes and not _newer(LIB_PATH, [os.path.join(CSRC, n) for n in HIP_SOURCES] + deps):
-        return LIB_PATH  # up to date (the GPU box receives the linked library without the per-file objects)
     obj_dir = os.path.join(LIB_DIR, "obj")
-    os.makedirs(obj_dir, exist_ok=True)
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
              # keep MFMA results in VGPRs: the matrix-core dequant feeds v_cvt_pk_bf16_f32 directly
              # (the AGPR form costs one v_accvgpr_read per value)
@@ -64,7 +60,11 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
              # behind the gemv_probe / gemm_v4_probe knobs; a default build has no knob that changes results
              *(["-DAWQ_ENABLE_PROBES"] if os.environ.get("AWQ_PROBES") == "1" else [])]
     stamp = os.path.join(obj_dir, "flags.txt")
-    if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
+    same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(flags)
+    if not force and not _newer(LIB_PATH, [os.path.join(CSRC, n) for n in HIP_SOURCES] + deps) and (same_flags or not os.path.exists(stamp)):
+        return LIB_PATH  # up to date (the GPU box receives the linked library without the per-file objects / the stamp)
+    os.makedirs(obj_dir, exist_ok=True)
+    if not same_flags:
         force = True
     jobs = []
     for name in HIP_SOURCES:
