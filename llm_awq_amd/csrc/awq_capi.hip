@@ -247,7 +247,7 @@ int awq_w4a16_forward_cdna4(const void* x, const void* qweight, const void* scal
     if (awq::launch_skinny_cdna4(x, qweight, sz_packed, bias, out, m, n, k, dtype, (hipStream_t)stream) == 0) return finish_launch();
   }
   if (bias && m > 128 && sz_packed && group_size == 128 && awq::gemm_variant_get() == 0) {
-    // prefill: bias fused into the GEMM v3 epilogue (no second kernel)
+    // prefill: bias fused into the prefill GEMM epilogue (awq_gemm_v4.hip / awq_gemm_v4n.hip) (no second kernel)
     int st0 = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
     if (st0 != AWQ_OK) return st0;
     if ((n % 16) != 0 || !aligned16(bias)) return (n % 16) ? AWQ_ERR_SHAPE : AWQ_ERR_ALIGN;
