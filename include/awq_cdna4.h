@@ -125,6 +125,11 @@ int awq_w4a16_rmsnorm_forward_cdna4(const void* x, const void* gamma, float eps,
                                     const void* bias, void* out, int m, int n, int k, int group_size, int dtype,
                                     int fused_gate_up, void* stream);
 
+/* OPTIONAL fp32 workspace of awq_w4a16_gemm_cdna4 / awq_w4a16_forward_cdna4 (0 = none useful).  Prompts of 256 .. ~1 k tokens
+ * against narrow projections produce too few output tiles to fill the 256 CUs; given this many bytes (16-byte aligned) the
+ * K loop is split over blocks and a second kernel adds the partial tiles in a fixed order -- the role of the reference's
+ * split_k_iters + semaphore (gemm_cuda.cu:546-619).  Without a workspace the call runs unsplit (slower, same contract). */
+size_t awq_w4a16_forward_cdna4_workspace_bytes(int m, int n, int k);
 int awq_w4a16_gemm_cdna4(const void* x, const void* qweight_cdna4, const void* scales, const void* scaled_zeros,
                          const void* sz_packed, void* out, int m, int n, int k, int group_size, int dtype,
                          void* workspace, size_t workspace_bytes, void* stream);

@@ -217,6 +217,8 @@ int awq_w4a16_rmsnorm_forward_cdna4(const void* x, const void* gamma, float eps,
   return finish_launch();
 }
 
+size_t awq_w4a16_forward_cdna4_workspace_bytes(int m, int n, int k) { return awq::gemm_cdna4_v3_workspace_bytes(m, n, k); }
+
 int awq_w4a16_gemm_cdna4(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
                          const void* sz_packed, void* out, int m, int n, int k, int group_size, int dtype, void* workspace,
                          size_t workspace_bytes, void* stream) {
@@ -251,7 +253,8 @@ int awq_w4a16_forward_cdna4(const void* x, const void* qweight, const void* scal
     int st0 = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
     if (st0 != AWQ_OK) return st0;
     if ((n % 16) != 0 || !aligned16(bias)) return (n % 16) ? AWQ_ERR_SHAPE : AWQ_ERR_ALIGN;
-    if (awq::launch_gemm_cdna4_v3(x, qweight, sz_packed, bias, out, m, n, k, 0, dtype, (hipStream_t)stream) == 0) return finish_launch();
+    if (awq::launch_gemm_cdna4_v3(x, qweight, sz_packed, bias, out, m, n, k, 0, dtype, workspace, workspace_bytes, (hipStream_t)stream) == 0)
+      return finish_launch();
   }
   int st = awq_w4a16_gemm_cdna4(x, qweight, scales, scaled_zeros, sz_packed, out, m, n, k, group_size, dtype, workspace,
                                 workspace_bytes, stream);  // m <= 16 is routed to the GEMV inside

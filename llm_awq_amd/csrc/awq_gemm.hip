@@ -418,7 +418,7 @@ static int launch_gemm_t(const void* x, const void* qw, const void* s, const voi
 }
 
 int launch_gemm(const void* x, const void* qw, const void* s, const void* z, const void* szp, void* out, int m, int n,
-                int k, int dtype, int layout, void*, size_t, hipStream_t st) {
+                int k, int dtype, int layout, void* ws, size_t ws_bytes, hipStream_t st) {
   if (layout == 0 && g_gemm_variant == 0 && m > 8 && m <= 255 &&
       launch_skinny_v2(x, qw, s, z, nullptr, out, m, n, k, k / kGroup, dtype, st) == 0)
     return 0;  // short prompts / batched decode on un-repacked (fp16) checkpoints
@@ -426,7 +426,7 @@ int launch_gemm(const void* x, const void* qw, const void* s, const void* z, con
   if (layout == 1) {
     // variant 3 / auto: v3 kernel with the tile width picked by chip fill; 4 = force 256 x 256; 5 = force 256 x 128
     if ((g_gemm_variant >= 3 || (g_gemm_variant == 0 && m > 128)) &&
-        launch_gemm_cdna4_v3(x, qw, szp, nullptr, out, m, n, k, g_gemm_variant == 4 ? 256 : (g_gemm_variant == 5 ? 128 : 0), dtype, st) == 0)
+        launch_gemm_cdna4_v3(x, qw, szp, nullptr, out, m, n, k, g_gemm_variant == 4 ? 256 : (g_gemm_variant == 5 ? 128 : 0), dtype, ws, ws_bytes, st) == 0)
       return 0;
     return dtype == 0 ? launch_gemm_t<F16, 1>(x, qw, s, z, out, m, n, k, st) : launch_gemm_t<BF16, 1>(x, qw, s, z, out, m, n, k, st);
   }

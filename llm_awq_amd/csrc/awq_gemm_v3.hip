@@ -322,6 +322,7 @@ void launch_v3(const void* x, const void* qw, const void* szp, const void* bias,
                      (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end);
 }
 constexpr double kNarrowRate = 0.83;  // 256 x 128 tiles (awq_gemm_v4n.hip) vs 256 x 256 (awq_gemm_v4.hip) at equal chip fill (profiles/r01_gemm_v4.txt)
+int g_splitk = 1;  // narrow tiles: split K over blocks when the tiles fill less than half of the chip and a workspace is given
 int g_v4 = 1;  // 1 (default): 256-wide tiles run the hand-scheduled K loop of awq_gemm_v4.hip; 0: v3's compiler-scheduled loop
 void launch_wide(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
                  int n_end, int dtype, hipStream_t st) {
@@ -330,8 +331,8 @@ void launch_wide(const void* x, const void* qw, const void* szp, const void* bia
   else launch_v3<BF16, 2>(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
 }
 void launch_narrow(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
-                   int n_end, int dtype, hipStream_t st) {
-  if (g_v4) launch_gemm_cdna4_v4n(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st);
+                   int n_end, int dtype, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (g_v4) launch_gemm_cdna4_v4n(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, g_splitk ? ws : nullptr, ws_bytes, st);
   else if (dtype == 0) launch_v3<F16, 1>(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
   else launch_v3<BF16, 1>(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
 }
@@ -348,6 +349,10 @@ int gemm_v3_tune_set(const char* key, int value) {
   else if (!strcmp(key, "gemm_v4_probe")) gemm_v4_set_probe(value);
 #endif
   else if (!strcmp(key, "moe_v4")) g_moe_v4 = value;
+  else if (!strcmp(key, "gemm_splitk")) {  // 0 = off, 1 = auto, n > 1 = force n K ranges
+    g_splitk = value;
+    g_v4n_ksplit_force = value > 1 ? value : 0;
+  }
   else return -1;
   return 0;
 }
@@ -355,17 +360,14 @@ int gemm_v3_tune_set(const char* key, int value) {
 // tile_n: 0 = pick by chip fill (256 CUs, one block per CU), 128 / 256 = force one width for the whole matrix.
 // In auto mode a matrix whose 256-wide tile count is k full rounds plus a partial one runs the full rounds with 256-wide
 // tiles and the remaining weight rows with 128-wide tiles in a second launch when that is faster.
-int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                         int tile_n, int dtype, hipStream_t st) {
-  if (!szp || m < TM || (n % 16) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return -1;
-  if (tile_n == 128) {
-    launch_narrow(x, qw, szp, bias, out, m, n, k, 0, n, dtype, st);
-    return 0;
-  }
-  if (tile_n == 256) {
-    launch_wide(x, qw, szp, bias, out, m, n, k, 0, n, dtype, st);
-    return 0;
-  }
+namespace {
+struct Plan {
+  int mode;        // 0 = all 256-wide, 1 = all 128-wide, 2 = 256-wide for [0, cols_main * 256) + 128-wide for the rest
+  long cols_main;
+};
+Plan plan_tiles(int m, int n, int tile_n) {
+  if (tile_n == 128) return {1, 0};
+  if (tile_n == 256) return {0, 0};
   const long tiles_m = (m + TM - 1) / TM;
   auto rounds = [](long t) { return (double)((t + 255) / 256); };
   const long cols256 = (n + 255) / 256, t256 = tiles_m * cols256;
@@ -378,11 +380,29 @@ int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, const v
     const long n_rest = n - cols_main * 256;
     cost_mixed = rounds(tiles_m * cols_main) + rounds(tiles_m * ((n_rest + 127) / 128)) * 0.5 / kNarrowRate + 0.02;
   }
-  if (cost_mixed < cost_wide && cost_mixed < cost_narrow) {
-    launch_wide(x, qw, szp, bias, out, m, n, k, 0, (int)(cols_main * 256), dtype, st);
-    launch_narrow(x, qw, szp, bias, out, m, n, k, (int)(cols_main * 256), n, dtype, st);
-  } else if (cost_narrow < cost_wide) {
-    launch_narrow(x, qw, szp, bias, out, m, n, k, 0, n, dtype, st);
+  if (cost_mixed < cost_wide && cost_mixed < cost_narrow) return {2, cols_main};
+  return {cost_narrow < cost_wide ? 1 : 0, 0};
+}
+}  // namespace
+
+// fp32 workspace the call below can use to split K when its tiles under-fill the chip (0 = none needed)
+size_t gemm_cdna4_v3_workspace_bytes(int m, int n, int k) {
+  if (m < TM || (n % 16) != 0 || (k % 128) != 0 || !g_v4 || !g_splitk) return 0;
+  const Plan p = plan_tiles(m, n, 0);
+  if (p.mode == 1) return gemm_v4n_workspace_bytes(m, n, k);
+  if (p.mode == 2) return gemm_v4n_workspace_bytes(m, n - (int)(p.cols_main * 256), k);
+  return 0;
+}
+
+int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
+                         int tile_n, int dtype, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!szp || m < TM || (n % 16) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return -1;
+  const Plan p = plan_tiles(m, n, tile_n);
+  if (p.mode == 2) {
+    launch_wide(x, qw, szp, bias, out, m, n, k, 0, (int)(p.cols_main * 256), dtype, st);
+    launch_narrow(x, qw, szp, bias, out, m, n, k, (int)(p.cols_main * 256), n, dtype, ws, ws_bytes, st);
+  } else if (p.mode == 1) {
+    launch_narrow(x, qw, szp, bias, out, m, n, k, 0, n, dtype, ws, ws_bytes, st);
   } else {
     launch_wide(x, qw, szp, bias, out, m, n, k, 0, n, dtype, st);
   }

@@ -4,6 +4,12 @@
 // replaces v3's NSL = 1 instantiation there, whose compiler-scheduled loop exposes the LDS latency of its five fragment
 // reads per four MFMAs.  bf16 and fp16; numerics and accumulation order are v3's: results are bit-identical.
 //
+// Split-K (KSPLIT = 1): when even the narrow tiles fill less than half of the chip (prompts of 256 .. ~1 k tokens against the
+// N = 4096 projections: 32 tiles on 256 CUs, a serial K loop of up to 224 K-tiles) every tile is cut into `ksplit` K ranges
+// of whole quantisation groups; the blocks store their fp32 partial tiles to a caller-provided workspace and
+// splitk_reduce_kernel adds them in split order (deterministic), rounds once, adds the bias.  This is the job of the reference's
+// split_k_iters + semaphore (gemm_cuda.cu:546-619, semaphore.h:44-103) without the in-kernel ordering.
+//
 // A wave has ONE weight fragment per k-step, so its successor cannot be re-read into the same registers before the
 // step's last MFMA: the weight fragment is double-buffered (wa / wb by step parity) and read at the START of the step
 // before; the four x fragments are single-buffered and re-read right after the MFMA that consumes them:
@@ -59,11 +65,12 @@ struct NoJob {
 #define V4N_WRITE(addr, val, off) asm volatile("ds_write_b128 %0, %1 offset:%2\n\ts_nop 1" : : "v"(addr), "v"(val), "n"(off) : "memory")
 #define V4N_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-template <typename DT>
+template <typename DT, int KSPLIT>
 __global__ __launch_bounds__(512) void gemm_cdna4_v4n_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                              const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
                                                              uint16_t* __restrict__ out, int M, int N, int K, int tiles_m,
-                                                             int tiles_n, int n_begin, int n_end) {
+                                                             int tiles_n, int n_begin, int n_end, int ksplit,
+                                                             float* __restrict__ partial) {
   using vec8 = typename DT::vec8;
   constexpr int kEpiRow = 2 * WN + 16;  // bytes per staged output row (+16 pad)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -74,9 +81,10 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v4n_kernel(const uint16_t* __r
 
   // XCD-aware, two-row-band tile order: as v3 (awq_gemm_v3.hip)
   const int T = tiles_m * tiles_n;
+  const int split = KSPLIT ? (int)(blockIdx.x % (unsigned)ksplit) : 0;
   int tile;
   {
-    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    const int b = KSPLIT ? (int)(blockIdx.x / (unsigned)ksplit) : (int)blockIdx.x, xcd = b & 7, idx = b >> 3;
     const int q = T >> 3, r = T & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
@@ -93,7 +101,9 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v4n_kernel(const uint16_t* __r
     }
   }
   const int m0 = min(tm * TM, M - TM), n0 = n_begin + tn * TN;
-  const int nit = K >> 7;
+  const int nit_all = K >> 7;                                 // quantisation groups of the matrix
+  const int g0 = KSPLIT ? split * nit_all / ksplit : 0;       // this block's K range: groups [g0, g0 + nit), ranges differ by <= 1
+  const int nit = KSPLIT ? (split + 1) * nit_all / ksplit - g0 : nit_all;
 
   // ---- x tile: LDS-DMA, 4 x 16 B per thread per K-tile; swizzle applied to the SOURCE granule ----
   u32 a_off0;
@@ -106,7 +116,7 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v4n_kernel(const uint16_t* __r
     char* dst = smem + stage * kTileX + wv * 1024;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const uint16_t* xq = x + (size_t)kt * TK + (size_t)q * 64 * K;
+      const uint16_t* xq = x + (size_t)(kt + 2 * g0) * TK + (size_t)q * 64 * K;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xq + a_off0),
                                        (__attribute__((address_space(3))) void*)(dst + q * 8192), 16, 0, 0);
     }
@@ -115,14 +125,14 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v4n_kernel(const uint16_t* __r
   // ---- weight tile: wave wv owns slab wv of the 128-row tile ----
   const int nslab = N >> 4;
   const int sl = min((n0 >> 4) + wv, min(nslab, n_end >> 4) - 1);
-  const u32 b_off = (u32)sl * nit * 256 + lane * 4, sz_off = (u32)sl * nit * 16 + i;
+  const u32 b_off = (u32)sl * nit_all * 256 + lane * 4, sz_off = (u32)sl * nit_all * 16 + i;
   const int nl = 16 * wv + i;  // tile row of the lane's weight row
   Cdna4DequantT<DT> cd;
   cd.init(lane);
   auto load_group = [&](int grp) {
     Raw r;
-    r.w = *reinterpret_cast<const u32x4*>(qw + (size_t)grp * 256 + b_off);
-    r.sz = szp[(size_t)grp * 16 + sz_off];
+    r.w = *reinterpret_cast<const u32x4*>(qw + (size_t)(g0 + grp) * 256 + b_off);
+    r.sz = szp[(size_t)(g0 + grp) * 16 + sz_off];
     return r;
   };
   auto prep = [&](const Raw& r) {
@@ -290,6 +300,18 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v4n_kernel(const uint16_t* __r
   for (int q = 0; q + 1 < nit; ++q) group_iter(q, std::true_type{});
   group_iter(nit - 1, std::false_type{});
 
+  if constexpr (KSPLIT != 0) {
+    // fp32 partial tile -> workspace, in register order: [tile][split][wave][b][j][lane] float4 (1 KiB per wave store);
+    // splitk_reduce_kernel reads it back with the same indexing
+    float* base = partial + (((size_t)tile * ksplit + split) * 8 + wv) * (4 * 4 * 64 * 4);
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(base + ((b * 4 + j) * 64 + lane) * 4) =
+            f32x4{acc[b][4 * j + 0], acc[b][4 * j + 1], acc[b][4 * j + 2], acc[b][4 * j + 3]};
+    return;
+  }
   // ---------------- epilogue through LDS: acc[b][r] = C[n = wn*32 + (r&3) + 8 (r>>2) + 4 hk][m = wm*128 + b*32 + l32] ----
   __syncthreads();
   char* eb = smem + wv * (128 * kEpiRow);
@@ -325,22 +347,134 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v4n_kernel(const uint16_t* __r
   }
 }
 
-// weight rows [n_begin, n_end) of the matrix with 256 x 128 tiles (m >= 256); same contract as v3's launch_v3<DT, 1>
+// out tile = T(sum over the K ranges of the fp32 partials, in range order) (+ bias in T).  One wave per (tile, wave, b):
+// a 32-row x 32-column piece of the output; the sums are staged through LDS so that the stores are 16 B per lane, four
+// lanes per output row, as in the unsplit epilogue.
+template <typename DT>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, const uint16_t* __restrict__ bias,
+                                                            uint16_t* __restrict__ out, int M, int N, int tiles_m, int tiles_n,
+                                                            int n_begin, int n_end, int ksplit) {
+  constexpr int kRow = 2 * WN + 16;  // bytes per staged row (+16 pad)
+  __shared__ __attribute__((aligned(16))) char stage[4][32 * kRow];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int piece = blockIdx.x * 4 + w;  // over tiles * 8 waves * 4 b
+  const int b = piece & 3, wv = (piece >> 2) & 7, tile = piece >> 5;
+  if (tile >= tiles_m * tiles_n) return;
+  const int l32 = lane & 31, hk = lane >> 5, wm = wv >> 2, wn = wv & 3;
+  int tm, tn;  // the tile walk of gemm_cdna4_v4n_kernel (the linear index is the one the partials were stored under)
+  {
+    const int full = (tiles_m >> 1) * 2 * tiles_n;
+    if (tile < full) {
+      const int band = tile / (2 * tiles_n), rem = tile - band * 2 * tiles_n;
+      tn = rem >> 1;
+      tm = 2 * band + (rem & 1);
+    } else {
+      tn = tile - full;
+      tm = tiles_m - 1;
+    }
+  }
+  constexpr size_t kWaveFloats = 4 * 4 * 64 * 4;  // one wave's accumulators
+  const float* p = partial + (((size_t)tile * ksplit) * 8 + wv) * kWaveFloats + ((size_t)(b * 4) * 64 + lane) * 4;
+  f32x4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s2 = 0; s2 < ksplit; ++s2) {
+    f32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(p + (size_t)s2 * 8 * kWaveFloats + j * 256);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] += v[j];
+  }
+  char* eb = stage[w];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    u32x2 v;
+    v.x = (u32)DT::from_float(acc[j][0]) | ((u32)DT::from_float(acc[j][1]) << 16);
+    v.y = (u32)DT::from_float(acc[j][2]) | ((u32)DT::from_float(acc[j][3]) << 16);
+    *reinterpret_cast<u32x2*>(eb + l32 * kRow + (8 * j + 4 * hk) * 2) = v;
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0); the staging region is wave-private
+  __builtin_amdgcn_wave_barrier();
+  const int m_base = min(tm * TM, M - TM) + wm * 128 + b * 32, n_base = n_begin + tn * TN + wn * WN;
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int row = ps * 16 + (lane >> 2), gc2 = lane & 3;
+    const int nn = n_base + gc2 * 8;
+    u32x4 v = *reinterpret_cast<const u32x4*>(eb + row * kRow + gc2 * 16);
+    if (nn < n_end) {
+      if (bias != nullptr) {  // `out + self.bias` in T (qmodule.py:221)
+        const u32x4 bv = *reinterpret_cast<const u32x4*>(bias + nn);
+        auto add2 = [](u32 a, u32 c) {
+          const float lo = DT::to_float((uint16_t)(a & 0xFFFFu)) + DT::to_float((uint16_t)(c & 0xFFFFu));
+          const float hi = DT::to_float((uint16_t)(a >> 16)) + DT::to_float((uint16_t)(c >> 16));
+          return (u32)DT::from_float(lo) | ((u32)DT::from_float(hi) << 16);
+        };
+        v = u32x4{add2(v.x, bv.x), add2(v.y, bv.y), add2(v.z, bv.z), add2(v.w, bv.w)};
+      }
+      *reinterpret_cast<u32x4*>(out + (size_t)(m_base + row) * N + nn) = v;
+    }
+  }
+}
+
+// How many K ranges a launch over n_cols weight rows should use (1 = none).  Costs in units of one K-group iteration of one
+// block (~1.6 us), fitted to profiles/r01_splitk_sweep.txt: an unsplit block pays its groups + ~2 (pipeline fill, epilogue);
+// a split block its groups + ~0.6; blocks run in rounds of 256 (one per CU); every (tile, range) costs 128 KiB of fp32
+// partials written and read back (~0.041 per block) and the second launch ~1.3.
+int g_v4n_ksplit_force = 0;  // > 1: use exactly this many ranges (knob gemm_splitk = n; experiments)
+int gemm_v4n_ksplit(int m, int n_cols, int k) {
+  const long tiles = (long)((m + TM - 1) / TM) * ((n_cols + TN - 1) / TN);
+  const int nit = k / 128;
+  if (g_v4n_ksplit_force > 1) return g_v4n_ksplit_force <= nit && tiles * g_v4n_ksplit_force <= 1024 ? g_v4n_ksplit_force : 1;
+  auto rounds = [](long blocks) { return (double)((blocks + 255) / 256); };
+  const double unsplit = rounds(tiles) * (nit + 2.0);
+  double best_cost = 0.9 * unsplit;  // a split has to be clearly better
+  int best = 1;
+  for (int d = 2; d <= 16 && nit / d >= 2; ++d) {
+    const double cost = rounds(tiles * d) * ((nit + d - 1) / d + 0.6) + 0.041 * (double)(tiles * d) + 1.3;
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = d;
+    }
+  }
+  return best;
+}
+size_t gemm_v4n_workspace_bytes(int m, int n_cols, int k) {
+  const int ks = gemm_v4n_ksplit(m, n_cols, k);
+  if (ks <= 1) return 0;
+  const size_t tiles = (size_t)((m + TM - 1) / TM) * ((n_cols + TN - 1) / TN);
+  return tiles * ks * (size_t)TM * TN * 4;
+}
+
+// weight rows [n_begin, n_end) of the matrix with 256 x 128 tiles (m >= 256); same contract as v3's launch_v3<DT, 1>.
+// ws / ws_bytes: optional fp32 workspace; when it holds gemm_v4n_workspace_bytes() the K loop is split (see the header)
 void launch_gemm_cdna4_v4n(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                           int n_begin, int n_end, int dtype, hipStream_t st) {
+                           int n_begin, int n_end, int dtype, void* ws, size_t ws_bytes, hipStream_t st) {
   constexpr int smem_main = 2 * kTileX + 2 * kTileW;
   constexpr int smem_epi = 8 * 128 * (2 * WN + 16);
   constexpr int smem = smem_main > smem_epi ? smem_main : smem_epi;
   const int tiles_m = (m + TM - 1) / TM, tiles_n = (n_end - n_begin + TN - 1) / TN;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cdna4_v4n_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cdna4_v4n_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cdna4_v4n_kernel<F16, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cdna4_v4n_kernel<BF16, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cdna4_v4n_kernel<F16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cdna4_v4n_kernel<BF16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr = true;
   }
-  auto kern = dtype == 0 ? gemm_cdna4_v4n_kernel<F16> : gemm_cdna4_v4n_kernel<BF16>;
+  const int ks = gemm_v4n_ksplit(m, n_end - n_begin, k);
+  const size_t need = ks > 1 ? (size_t)tiles_m * tiles_n * ks * TM * TN * 4 : 0;
+  if (ks > 1 && ws != nullptr && ws_bytes >= need && (reinterpret_cast<uintptr_t>(ws) & 15) == 0) {
+    auto kern = dtype == 0 ? gemm_cdna4_v4n_kernel<F16, 1> : gemm_cdna4_v4n_kernel<BF16, 1>;
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n * ks), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp,
+                       (const uint16_t*)nullptr, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end, ks, (float*)ws);
+    auto red = dtype == 0 ? splitk_reduce_kernel<F16> : splitk_reduce_kernel<BF16>;
+    hipLaunchKernelGGL(red, dim3((unsigned)(tiles_m * tiles_n * 8)), dim3(256), 0, st, (const float*)ws, (const uint16_t*)bias, (uint16_t*)out,
+                       m, n, tiles_m, tiles_n, n_begin, n_end, ks);
+    return;
+  }
+  auto kern = dtype == 0 ? gemm_cdna4_v4n_kernel<F16, 0> : gemm_cdna4_v4n_kernel<BF16, 0>;
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp,
-                     (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end);
+                     (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end, 1, (float*)nullptr);
 }
 
 }  // namespace awq

@@ -44,7 +44,7 @@ int launch_dequant_cdna4(const void* qw, const void* s, const void* z, void* out
 size_t gemm_workspace_bytes(int m, int n, int k);
 // bias may be nullptr; when given it is added in the epilogue (`out + bias` in T)
 int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                         int tile_n, int dtype, hipStream_t st);
+                         int tile_n, int dtype, void* ws, size_t ws_bytes, hipStream_t st);
 int gemm_variant_get();
 // skinny GEMM, 9 <= m <= 255 (row chunks of <= 64), cdna4 layout + packed sz (awq_skinny_cdna4.hip); bias may be nullptr; -1 if unsupported
 int launch_skinny_cdna4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
@@ -57,7 +57,10 @@ int gemm_v3_tune_set(const char* key, int value);  // gemm_v4, gemm_v4_probe
 void gemm_v4_set_probe(int v);
 // 256 x 128 tiles with the same hand-scheduled K loop (awq_gemm_v4n.hip)
 void launch_gemm_cdna4_v4n(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                           int n_begin, int n_end, int dtype, hipStream_t st);
+                           int n_begin, int n_end, int dtype, void* ws, size_t ws_bytes, hipStream_t st);
+size_t gemm_v4n_workspace_bytes(int m, int n_cols, int k);
+extern int g_v4n_ksplit_force;  // knob gemm_splitk > 1
+size_t gemm_cdna4_v3_workspace_bytes(int m, int n, int k);
 // grouped (MoE) GEMM with the same K loop: sorted rows, device expert offsets, stacked cdna4 weights + packed scales; total >= 256
 int launch_moe_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total, int experts,
                              int n, int k, int dtype, hipStream_t st);

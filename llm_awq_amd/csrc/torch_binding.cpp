@@ -121,6 +121,19 @@ bool cdna4_view(const torch::Tensor& kernel, const torch::Tensor& scales, const 
   return true;
 }
 
+// optional split-K workspace of the cdna4 prefill path (include/awq_cdna4.h); comes from torch's caching allocator, so it is
+// stream-ordered and legal inside a graph capture
+static at::Tensor cdna4_workspace(const at::Tensor& like, int64_t m, int64_t n, int64_t k, void*& ptr, size_t& bytes) {
+  at::Tensor ws;
+  ptr = nullptr;
+  bytes = awq_w4a16_forward_cdna4_workspace_bytes((int)m, (int)n, (int)k);
+  if (bytes) {
+    ws = torch::empty({(int64_t)bytes}, like.options().dtype(at::kByte));
+    ptr = ws.data_ptr();
+  }
+  return ws;
+}
+
 torch::Tensor gemv_forward_cuda_new(torch::Tensor in_feats, torch::Tensor kernel, torch::Tensor scaling_factors,
                                     torch::Tensor zeros, int m, int n, int k, int group_size) {
   check_inputs(in_feats, kernel, scaling_factors, zeros);
@@ -166,8 +179,11 @@ torch::Tensor gemm_forward_cuda_new(torch::Tensor in_feats, torch::Tensor kernel
   {
     at::Tensor c4, szp;
     if (cdna4_view(kernel, scales, zeros, n, k, stream, c4, szp)) {
+      void* wsp;
+      size_t wsb;
+      at::Tensor ws = cdna4_workspace(in_feats, m, n, k, wsp, wsb);
       raise_on(awq_w4a16_forward_cdna4(in_feats.data_ptr(), c4.data_ptr(), scales.data_ptr(), zeros.data_ptr(), szp.data_ptr(), nullptr,
-                                       out.data_ptr(), (int)m, (int)n, (int)k, 128, dtype_code(in_feats), nullptr, 0, (void*)stream));
+                                       out.data_ptr(), (int)m, (int)n, (int)k, 128, dtype_code(in_feats), wsp, wsb, (void*)stream));
       return out;
     }
   }
@@ -235,9 +251,12 @@ torch::Tensor forward_cdna4(torch::Tensor in_feats, torch::Tensor kernel, torch:
     TORCH_CHECK(bias->is_cuda() && bias->is_contiguous() && bias->scalar_type() == in_feats.scalar_type() && bias->numel() == n);
     bp = bias->data_ptr();
   }
+  void* wsp;
+  size_t wsb;
+  at::Tensor ws = cdna4_workspace(in_feats, m, n, k, wsp, wsb);
   raise_on(awq_w4a16_forward_cdna4(in_feats.data_ptr(), kernel.data_ptr(), scales.data_ptr(), zeros.data_ptr(),
-                                   sz_packed.data_ptr(), bp, out.data_ptr(), (int)m, (int)n, (int)k, 128, dtype_code(in_feats), nullptr,
-                                   0, (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()));
+                                   sz_packed.data_ptr(), bp, out.data_ptr(), (int)m, (int)n, (int)k, 128, dtype_code(in_feats), wsp,
+                                   wsb, (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()));
   return out;
 }
 

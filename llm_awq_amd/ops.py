@@ -194,12 +194,15 @@ def gemm_cdna4(x, qweight, scales, scaled_zeros, bias=None, sz_packed=None, grou
     m = x.numel() // k
     n = qweight.shape[0] * 4
     out = torch.empty(*x.shape[:-1], n, dtype=x.dtype, device=x.device)
+    ws_bytes = _capi.lib().awq_w4a16_forward_cdna4_workspace_bytes(m, n, k)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device) if ws_bytes else None
     with torch.cuda.device(x.device):
         _capi.check(_capi.lib().awq_w4a16_forward_cdna4(x.data_ptr(), qweight.data_ptr(), scales.data_ptr(),
                                                          scaled_zeros.data_ptr(),
                                                          sz_packed.data_ptr() if sz_packed is not None else None,
                                                          bias.data_ptr() if bias is not None else None,
-                                                         out.data_ptr(), m, n, k, group_size, _dt(x), None, 0, _stream(x)))
+                                                         out.data_ptr(), m, n, k, group_size, _dt(x),
+                                                         ws.data_ptr() if ws is not None else None, ws_bytes, _stream(x)))
     return out
 
 

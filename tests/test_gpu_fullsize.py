@@ -86,13 +86,13 @@ def test_gemm_v3_tile_widths_identical(env, variant):
     szp = ops.pack_sz_cdna4(w["scales"], w["scaled_zeros"], K)
     for M in (256, 257, 1000, 2048):
         x = torch.randn(M, K, device="cuda").bfloat16()
-        ops._capi.tune(gemm_variant=1)
+        ops._capi.tune(gemm_variant=1, gemm_splitk=0)  # (split-K re-associates the sum: tests/test_gpu_splitk.py)
         ref = ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], None, szp)
         ops._capi.tune(gemm_variant=variant)
         try:
             y = ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], None, szp)
         finally:
-            ops._capi.tune(gemm_variant=0)
+            ops._capi.tune(gemm_variant=0, gemm_splitk=1)
         assert torch.equal(y, ref), M  # same K order, same numerics: bit-identical to the 128 x 128 kernel
 
 
@@ -109,13 +109,13 @@ def test_gemm_v4_identical_to_v3(env, bias):
         for M in (256, 300, 1000, 2048):
             x = torch.randn(M, K, device="cuda").bfloat16()
             for variant in (4, 5):  # 256-wide (awq_gemm_v4.hip) and 128-wide (awq_gemm_v4n.hip) tiles
-                ops._capi.tune(gemm_variant=variant, gemm_v4=0)
+                ops._capi.tune(gemm_variant=variant, gemm_v4=0, gemm_splitk=0)
                 try:
                     ref = ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], b, szp)
                     ops._capi.tune(gemm_v4=1)
                     y = ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], b, szp)
                 finally:
-                    ops._capi.tune(gemm_variant=0, gemm_v4=1)
+                    ops._capi.tune(gemm_variant=0, gemm_v4=1, gemm_splitk=1)
                 assert torch.equal(y, ref), (K, N, M, variant)
 
 

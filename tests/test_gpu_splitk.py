@@ -1,0 +1,130 @@
+"""-m gpu: the split-K path of the narrow-tile prefill GEMM (awq_gemm_v4n.hip) -- prompts of 256 .. ~1 k tokens against
+projections whose output tiles fill less than half of the chip.  The K ranges are summed in fp32 in a fixed order, so the
+result is deterministic but not bit-identical to the unsplit kernel (a different association of the same fp32 products);
+both must sit within the reference tolerance of a torch fp32 matmul on the dequantised weights.  The reference's own
+split-K (gemm_cuda.cu:546-619) has the same property."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(4096, 4096), (14336, 4096), (1024, 1296), (4096, 6144), (8192, 1024)]
+
+
+@pytest.fixture(scope="module")
+def env():
+    from llm_awq_amd import ops, synth
+    ops._capi.lib()
+    return ops, synth
+
+
+def test_workspace_query(env):
+    ops, _ = env
+    L = ops._capi.lib()
+    q = L.awq_w4a16_forward_cdna4_workspace_bytes
+    assert q(1, 4096, 4096) == 0 and q(64, 4096, 4096) == 0        # GEMV / skinny: no workspace
+    assert q(4096, 14336, 4096) == 0 and q(2048, 4096, 4096) == 0  # enough tiles: no split
+    tile = 256 * 128 * 4                                            # one fp32 partial tile
+    for (m, n, k, tiles) in ((256, 4096, 14336, 32), (512, 4096, 4096, 64)):
+        b = q(m, n, k)
+        assert b > 0 and b % (tiles * tile) == 0 and 2 <= b // (tiles * tile) <= 16, (m, n, k, b)
+    ops._capi.tune(gemm_splitk=5)                                   # experiments: a forced number of K ranges
+    try:
+        assert q(256, 4096, 14336) == 32 * 5 * tile
+    finally:
+        ops._capi.tune(gemm_splitk=1)
+    assert q(256, 4096, 4096 + 64) == 0                            # K not a multiple of 128: not this path
+    ops._capi.tune(gemm_splitk=0)
+    try:
+        assert q(256, 4096, 14336) == 0
+    finally:
+        ops._capi.tune(gemm_splitk=1)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("K,N", SHAPES)
+def test_splitk_vs_unsplit_and_torch_fp32(env, dtype, K, N):
+    ops, synth = env
+    L = ops._capi.lib()
+    w = synth.random_wq(K, N, dtype=dtype, seed=K + 3 * N, keep_q=False)
+    c4 = ops.repack_v2_to_cdna4(w["qweight"])
+    szp = ops.pack_sz_cdna4(w["scales"], w["scaled_zeros"], K)
+    W = ops.dequant_cdna4(c4, w["scales"], w["scaled_zeros"]).float()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    bias = (torch.randn(N, device="cuda", generator=g) * 0.02).to(dtype)
+    split_seen = 0
+    for M in (256, 300, 512, 777, 1024):
+        x = torch.randn(M, K, device="cuda", generator=g).to(dtype)
+        for b in (None, bias):
+            ref = (x.float() @ W.t()).to(dtype)
+            if b is not None:
+                ref = ref + b
+            ops._capi.tune(gemm_splitk=0)
+            y0 = ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], b, szp)
+            for knob in (1, 3, 5):  # auto; forced 3 / 5 K ranges (uneven ranges when K/128 is not a multiple)
+                ops._capi.tune(gemm_splitk=knob)
+                try:
+                    split = L.awq_w4a16_forward_cdna4_workspace_bytes(M, N, K) > 0
+                    y = ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], b, szp)
+                    y2 = ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], b, szp)
+                finally:
+                    ops._capi.tune(gemm_splitk=1)
+                split_seen += split
+                assert torch.equal(y, y2), (M, knob, "split-K must be deterministic")
+                if not split:
+                    assert torch.equal(y, y0), (M, knob)
+                for name, v in (("split", y), ("unsplit", y0)):
+                    rel = ((v.float() - ref.float()).norm() / ref.float().norm()).item()
+                    assert rel < 1e-3, (name, M, knob, rel)
+                    assert (ref == v).float().mean().item() > 0.97, (name, M, knob)
+                assert (y == y0).float().mean().item() > 0.97, (M, knob)
+                assert ((y.float() - y0.float()).norm() / y0.float().norm()).item() < 1e-3, (M, knob)
+    assert split_seen >= 10, "the split path was not exercised"
+
+
+def test_splitk_without_workspace_runs_unsplit(env):
+    """The workspace is optional in the C ABI: a call without it gives the unsplit kernel's bits."""
+    ops, synth = env
+    L = ops._capi.lib()
+    K, N, M = 4096, 4096, 512
+    w = synth.random_wq(K, N, dtype=torch.bfloat16, seed=9, keep_q=False)
+    c4 = ops.repack_v2_to_cdna4(w["qweight"])
+    szp = ops.pack_sz_cdna4(w["scales"], w["scaled_zeros"], K)
+    x = torch.randn(M, K, device="cuda").bfloat16()
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops._capi.check(L.awq_w4a16_forward_cdna4(x.data_ptr(), c4.data_ptr(), w["scales"].data_ptr(), w["scaled_zeros"].data_ptr(),
+                                              szp.data_ptr(), None, out.data_ptr(), M, N, K, 128, 1, None, 0, None))
+    torch.cuda.synchronize()
+    ops._capi.tune(gemm_splitk=0)
+    try:
+        y0 = ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], None, szp)
+    finally:
+        ops._capi.tune(gemm_splitk=1)
+    assert torch.equal(out, y0)
+
+
+def test_splitk_through_the_engine_and_graph(env):
+    """awq_inference_engine.gemm_forward_cuda_new allocates the workspace itself; replaying it from a HIP graph works."""
+    ops, synth = env
+    import llm_awq_amd
+    eng = llm_awq_amd.load_engine()
+    eng.cdna4_cache_enable(True)
+    K, N, M = 4096, 4096, 512
+    w = synth.random_wq(K, N, dtype=torch.bfloat16, seed=21, keep_q=False)
+    x = torch.randn(M, K, device="cuda").bfloat16()
+    y = eng.gemm_forward_cuda_new(x, w["qweight"], w["scales"], w["scaled_zeros"])  # warms the repack cache
+    c4 = ops.repack_v2_to_cdna4(w["qweight"])
+    szp = ops.pack_sz_cdna4(w["scales"], w["scaled_zeros"], K)
+    assert torch.equal(y, ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], None, szp))
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        eng.gemm_forward_cuda_new(x, w["qweight"], w["scales"], w["scaled_zeros"])
+    torch.cuda.current_stream().wait_stream(s)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        yg = eng.gemm_forward_cuda_new(x, w["qweight"], w["scales"], w["scaled_zeros"])
+    x.copy_(torch.randn(M, K, device="cuda").bfloat16())
+    gr.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(yg, ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], None, szp))
