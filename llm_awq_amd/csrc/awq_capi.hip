@@ -225,7 +225,7 @@ int awq_w4a16_gemm_cdna4(const void* x, const void* qweight, const void* scales,
   int st = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
   if (st != AWQ_OK) return st;
   if ((n % 16) != 0) return AWQ_ERR_SHAPE;
-  const bool skinny = sz_packed && m > 8 && m < 256 && awq::gemm_variant_get() == 0 &&
+  const bool skinny = sz_packed && m > 8 && m < 256 && awq::gemm_variant_get() == 0 && !awq::gemm_cdna4_v3_takes(m, k) &&
                       awq::launch_skinny_cdna4(x, qweight, sz_packed, nullptr, out, m, n, k, dtype, (hipStream_t)stream) == 0;
   if (!skinny && !(sz_packed && m <= 8 && awq::launch_gemv_cdna4(x, qweight, sz_packed, nullptr, out, m, n, k, 0, 4, dtype, (hipStream_t)stream) == 0))
     awq::launch_gemm(x, qweight, scales, scaled_zeros, sz_packed, out, m, n, k, dtype, 1, workspace, workspace_bytes, (hipStream_t)stream);
@@ -241,14 +241,14 @@ int awq_w4a16_forward_cdna4(const void* x, const void* qweight, const void* scal
     if ((n % 16) != 0) return AWQ_ERR_SHAPE;
     if (awq::launch_gemv_cdna4(x, qweight, sz_packed, bias, out, m, n, k, 0, 4, dtype, (hipStream_t)stream) == 0) return finish_launch();
   }
-  if (m > 8 && m < 256 && sz_packed && group_size == 128 && awq::gemm_variant_get() == 0) {
+  if (m > 8 && m < 256 && sz_packed && group_size == 128 && awq::gemm_variant_get() == 0 && !awq::gemm_cdna4_v3_takes(m, k)) {
     // short prompts / batched decode: skinny kernel, bias fused
     int st0 = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
     if (st0 != AWQ_OK) return st0;
     if ((n % 16) != 0) return AWQ_ERR_SHAPE;
     if (awq::launch_skinny_cdna4(x, qweight, sz_packed, bias, out, m, n, k, dtype, (hipStream_t)stream) == 0) return finish_launch();
   }
-  if (bias && m > 128 && sz_packed && group_size == 128 && awq::gemm_variant_get() == 0) {
+  if (bias && awq::gemm_cdna4_v3_takes(m, k) && sz_packed && group_size == 128 && awq::gemm_variant_get() == 0) {
     // prefill: bias fused into the prefill GEMM epilogue (awq_gemm_v4.hip / awq_gemm_v4n.hip) (no second kernel)
     int st0 = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
     if (st0 != AWQ_OK) return st0;

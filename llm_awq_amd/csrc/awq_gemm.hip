@@ -425,7 +425,7 @@ int launch_gemm(const void* x, const void* qw, const void* s, const void* z, con
   if (m <= 16) return launch_gemv(x, qw, s, z, szp, out, m, n, k, dtype, layout, st);
   if (layout == 1) {
     // variant 3 / auto: v3 kernel with the tile width picked by chip fill; 4 = force 256 x 256; 5 = force 256 x 128
-    if ((g_gemm_variant >= 3 || (g_gemm_variant == 0 && m > 128)) &&
+    if ((g_gemm_variant >= 3 || (g_gemm_variant == 0 && gemm_cdna4_v3_takes(m, k))) &&
         launch_gemm_cdna4_v3(x, qw, szp, nullptr, out, m, n, k, g_gemm_variant == 4 ? 256 : (g_gemm_variant == 5 ? 128 : 0), dtype, ws, ws_bytes, st) == 0)
       return 0;
     return dtype == 0 ? launch_gemm_t<F16, 1>(x, qw, s, z, out, m, n, k, st) : launch_gemm_t<BF16, 1>(x, qw, s, z, out, m, n, k, st);

@@ -322,6 +322,7 @@ void launch_v3(const void* x, const void* qw, const void* szp, const void* bias,
                      (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end);
 }
 constexpr double kNarrowRate = 0.83;  // 256 x 128 tiles (awq_gemm_v4n.hip) vs 256 x 256 (awq_gemm_v4.hip) at equal chip fill (profiles/r01_gemm_v4.txt)
+int g_small_m = 1;  // knob gemm_small_m: 0 = the prefill GEMM only takes m >= 256 (see gemm_cdna4_v3_takes)
 int g_splitk = 1;  // narrow tiles: split K over blocks when the tiles fill less than half of the chip and a workspace is given
 int g_v4 = 1;  // 1 (default): 256-wide tiles run the hand-scheduled K loop of awq_gemm_v4.hip; 0: v3's compiler-scheduled loop
 void launch_wide(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
@@ -349,6 +350,7 @@ int gemm_v3_tune_set(const char* key, int value) {
   else if (!strcmp(key, "gemm_v4_probe")) gemm_v4_set_probe(value);
 #endif
   else if (!strcmp(key, "moe_v4")) g_moe_v4 = value;
+  else if (!strcmp(key, "gemm_small_m")) g_small_m = value;
   else if (!strcmp(key, "gemm_splitk")) {  // 0 = off, 1 = auto, n > 1 = force n K ranges
     g_splitk = value;
     g_v4n_ksplit_force = value > 1 ? value : 0;
@@ -385,9 +387,20 @@ Plan plan_tiles(int m, int n, int tile_n) {
 }
 }  // namespace
 
+// Which m the prefill GEMM takes.  m >= 256 always; below that the narrow-tile kernel runs ONE row tile whose missing rows are
+// not stored, at the cost of a 256-row tile whatever m is, while the skinny kernel (awq_skinny_cdna4.hip) re-streams and
+// re-dequantises the weights once per 64 rows: the crossover measured on the Llama shapes (profiles/r01_small_m_sweep.txt) sits
+// at m ~ 75 for K >= 8192 and ~150 for K = 4096, which m * K >= 0.6 M approximates; at m = 255 the GEMM is 1.6 - 3.1x faster.
+bool gemm_cdna4_v3_takes(int m, int k) {
+  if (m >= TM) return true;
+  if (g_small_m == 2) return g_v4 && m > 8;  // experiments: every m the skinny kernel would take
+  return g_small_m && g_v4 && m >= 72 && (long)m * k >= 600000;
+}
+
 // fp32 workspace the call below can use to split K when its tiles under-fill the chip (0 = none needed)
 size_t gemm_cdna4_v3_workspace_bytes(int m, int n, int k) {
-  if (m < TM || (n % 16) != 0 || (k % 128) != 0 || !g_v4 || !g_splitk) return 0;
+  if (!gemm_cdna4_v3_takes(m, k) || (n % 16) != 0 || (k % 128) != 0 || !g_v4 || !g_splitk) return 0;
+  if (m < TM) return gemm_v4n_workspace_bytes(m, n, k);
   const Plan p = plan_tiles(m, n, 0);
   if (p.mode == 1) return gemm_v4n_workspace_bytes(m, n, k);
   if (p.mode == 2) return gemm_v4n_workspace_bytes(m, n - (int)(p.cols_main * 256), k);
@@ -396,8 +409,8 @@ size_t gemm_cdna4_v3_workspace_bytes(int m, int n, int k) {
 
 int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                          int tile_n, int dtype, void* ws, size_t ws_bytes, hipStream_t st) {
-  if (!szp || m < TM || (n % 16) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return -1;
-  const Plan p = plan_tiles(m, n, tile_n);
+  if (!szp || !gemm_cdna4_v3_takes(m, k) || (n % 16) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return -1;
+  const Plan p = m < TM ? Plan{1, 0} : plan_tiles(m, n, tile_n);  // m < 256: only the narrow-tile kernel masks rows
   if (p.mode == 2) {
     launch_wide(x, qw, szp, bias, out, m, n, k, 0, (int)(p.cols_main * 256), dtype, st);
     launch_narrow(x, qw, szp, bias, out, m, n, k, (int)(p.cols_main * 256), n, dtype, ws, ws_bytes, st);

@@ -100,24 +100,25 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v4n_kernel(const uint16_t* __r
       tm = tiles_m - 1;
     }
   }
-  const int m0 = min(tm * TM, M - TM), n0 = n_begin + tn * TN;
+  const int m0 = max(min(tm * TM, M - TM), 0), n0 = n_begin + tn * TN;  // (M < 256: one row tile, rows >= M clamped / not stored)
   const int nit_all = K >> 7;                                 // quantisation groups of the matrix
   const int g0 = KSPLIT ? split * nit_all / ksplit : 0;       // this block's K range: groups [g0, g0 + nit), ranges differ by <= 1
   const int nit = KSPLIT ? (split + 1) * nit_all / ksplit - g0 : nit_all;
 
   // ---- x tile: LDS-DMA, 4 x 16 B per thread per K-tile; swizzle applied to the SOURCE granule ----
-  u32 a_off0;
+  u32 a_off[4];
   {
     const int row = tid >> 3, gcp = tid & 7;
     const int gc = gcp ^ ((row >> 1) & 7);
-    a_off0 = (u32)(m0 + row) * (u32)K + gc * 8;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a_off[q] = (u32)min(m0 + row + 64 * q, M - 1) * (u32)K + gc * 8;  // (64 q keeps (row >> 1) & 7)
   }
   auto issue_a = [&](int kt, int stage) {
     char* dst = smem + stage * kTileX + wv * 1024;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const uint16_t* xq = x + (size_t)(kt + 2 * g0) * TK + (size_t)q * 64 * K;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xq + a_off0),
+      const uint16_t* xq = x + (size_t)(kt + 2 * g0) * TK;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xq + a_off[q]),
                                        (__attribute__((address_space(3))) void*)(dst + q * 8192), 16, 0, 0);
     }
   };
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v4n_kernel(const uint16_t* __r
     const int row = ps * RP + lane / GR, gc2 = lane % GR;
     const int m = m0 + wm * 128 + row, nn = n0 + wn * WN + gc2 * 8;
     u32x4 v = *reinterpret_cast<const u32x4*>(eb + row * kEpiRow + gc2 * 16);
-    if (nn < n_end) {
+    if (nn < n_end && m < M) {
       if (bias != nullptr) {  // `out + self.bias` in T (qmodule.py:221)
         const u32x4 bv = *reinterpret_cast<const u32x4*>(bias + nn);
         auto add2 = [](u32 a, u32 b) {
@@ -395,13 +396,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0); the staging region is wave-private
   __builtin_amdgcn_wave_barrier();
-  const int m_base = min(tm * TM, M - TM) + wm * 128 + b * 32, n_base = n_begin + tn * TN + wn * WN;
+  const int m_base = max(min(tm * TM, M - TM), 0) + wm * 128 + b * 32, n_base = n_begin + tn * TN + wn * WN;
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
     const int row = ps * 16 + (lane >> 2), gc2 = lane & 3;
     const int nn = n_base + gc2 * 8;
     u32x4 v = *reinterpret_cast<const u32x4*>(eb + row * kRow + gc2 * 16);
-    if (nn < n_end) {
+    if (nn < n_end && m_base + row < M) {
       if (bias != nullptr) {  // `out + self.bias` in T (qmodule.py:221)
         const u32x4 bv = *reinterpret_cast<const u32x4*>(bias + nn);
         auto add2 = [](u32 a, u32 c) {
@@ -445,7 +446,8 @@ size_t gemm_v4n_workspace_bytes(int m, int n_cols, int k) {
   return tiles * ks * (size_t)TM * TN * 4;
 }
 
-// weight rows [n_begin, n_end) of the matrix with 256 x 128 tiles (m >= 256); same contract as v3's launch_v3<DT, 1>.
+// weight rows [n_begin, n_end) of the matrix with 256 x 128 tiles; same contract as v3's launch_v3<DT, 1>, and also m < 256
+// (one row tile whose missing rows are computed from row m - 1 and not stored).
 // ws / ws_bytes: optional fp32 workspace; when it holds gemm_v4n_workspace_bytes() the K loop is split (see the header)
 void launch_gemm_cdna4_v4n(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                            int n_begin, int n_end, int dtype, void* ws, size_t ws_bytes, hipStream_t st) {

@@ -177,6 +177,11 @@ def test_skinny_gemm_vs_oracle(ops, dtype, M, N, K):
     c = make_case(N, K, dtype, seed=M * 7 + N + K, M=M, bias=(M % 2 == 1))
     c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
     szp = ops.pack_sz_cdna4(c["scales"].cuda(), c["scaled_zeros"].cuda(), K)
-    y = ops.gemm_cdna4(c["x"].cuda(), c4, c["scales"].cuda(), c["scaled_zeros"].cuda(),
-                       c["bias"].cuda() if c["bias"] is not None else None, szp).cpu()
-    check_forward(y, c["x"], c["q"], c["scales"], c["scaled_zeros"], dtype, bias=c["bias"])
+    for small_m in (0, 1):  # 0: always the skinny kernel; 1 (default): rows >= 72 with m * K >= 0.6 M go to the prefill GEMM
+        ops._capi.tune(gemm_small_m=small_m)
+        try:
+            y = ops.gemm_cdna4(c["x"].cuda(), c4, c["scales"].cuda(), c["scaled_zeros"].cuda(),
+                               c["bias"].cuda() if c["bias"] is not None else None, szp).cpu()
+        finally:
+            ops._capi.tune(gemm_small_m=1)
+        check_forward(y, c["x"], c["q"], c["scales"], c["scaled_zeros"], dtype, bias=c["bias"])

@@ -128,3 +128,60 @@ def test_splitk_through_the_engine_and_graph(env):
     gr.replay()
     torch.cuda.synchronize()
     assert torch.equal(yg, ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], None, szp))
+
+
+# ---------------- prompts shorter than one 256-row tile on the prefill GEMM (masked rows) ----------------
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [9, 33, 100, 129, 255])
+@pytest.mark.parametrize("N,K", [(768, 3072), (144, 1280)])
+def test_small_m_gemm_vs_oracle(env, dtype, M, N, K):
+    """knob gemm_small_m=2 sends every 9 <= m <= 255 to awq_gemm_v4n.hip's single row tile: rows >= m are computed from
+    row m - 1 and not stored (the guard rows around `out` must stay untouched), split-K on or off."""
+    from tests.helpers import check_forward, make_case
+    ops, _ = env
+    c = make_case(N, K, dtype, seed=M + N + K, M=M, bias=(M % 2 == 1))
+    c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
+    bias = c["bias"].cuda() if c["bias"] is not None else None
+    for splitk in (1, 0, 3):
+        ops._capi.tune(gemm_small_m=2, gemm_splitk=splitk)
+        try:
+            y = ops.gemm_cdna4(c["x"].cuda(), c4, c["scales"].cuda(), c["scaled_zeros"].cuda(), bias).cpu()
+        finally:
+            ops._capi.tune(gemm_small_m=1, gemm_splitk=1)
+        check_forward(y, c["x"], c["q"], c["scales"], c["scaled_zeros"], dtype, bias=c["bias"])
+
+
+def test_small_m_gemm_writes_only_its_rows(env):
+    ops, synth = env
+    L = ops._capi.lib()
+    K, N = 4096, 4096
+    w = synth.random_wq(K, N, dtype=torch.bfloat16, seed=77, keep_q=False)
+    c4 = ops.repack_v2_to_cdna4(w["qweight"])
+    szp = ops.pack_sz_cdna4(w["scales"], w["scaled_zeros"], K)
+    W = ops.dequant_cdna4(c4, w["scales"], w["scaled_zeros"]).float()
+    for M in (96, 200):
+        for knob in (2, 1):
+            ops._capi.tune(gemm_small_m=knob)
+            try:
+                x = torch.randn(M, K, device="cuda").bfloat16()
+                buf = torch.full((M + 64, N), 7.0, device="cuda", dtype=torch.bfloat16)  # guard rows after the output
+                wsb = L.awq_w4a16_forward_cdna4_workspace_bytes(M, N, K)
+                ws = torch.empty(max(wsb, 16) // 4, dtype=torch.float32, device="cuda")
+                ops._capi.check(L.awq_w4a16_forward_cdna4(x.data_ptr(), c4.data_ptr(), w["scales"].data_ptr(), w["scaled_zeros"].data_ptr(),
+                                                          szp.data_ptr(), None, buf.data_ptr(), M, N, K, 128, 1,
+                                                          ws.data_ptr() if wsb else None, wsb, None))
+                torch.cuda.synchronize()
+            finally:
+                ops._capi.tune(gemm_small_m=1)
+            assert torch.all(buf[M:] == 7.0), (M, knob)
+            ref = (x.float() @ W.t()).bfloat16()
+            rel = ((buf[:M].float() - ref.float()).norm() / ref.float().norm()).item()
+            assert rel < 1e-3 and (ref == buf[:M]).float().mean().item() > 0.97, (M, knob, rel)
+
+
+def test_small_m_rule(env):
+    """The default rule: the GEMM takes m >= 256, and shorter prompts only where its 256-row tile beats the skinny kernel."""
+    ops, _ = env
+    q = ops._capi.lib().awq_w4a16_forward_cdna4_workspace_bytes
+    assert q(128, 4096, 14336) > 0 and q(71, 4096, 14336) == 0  # K = 14336: from 72 rows
+    assert q(128, 4096, 4096) == 0 and q(192, 4096, 4096) > 0   # K = 4096: from 147 rows
