@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--prefill-m", type=int, default=4096, help="prefill rows of the headline GEMM figure (the reference quotes TTFT up to 4096 tokens, tinychat/README.md:174-178)")
     ap.add_argument("--prefill-m2", type=int, default=2048, help="second prefill size reported beside it (0 = skip)")
+    ap.add_argument("--prefill-m3", type=int, default=512, help="a short prompt (split-K territory) reported beside them (0 = skip)")
     ap.add_argument("--prefill-iters", type=int, default=3)
     ap.add_argument("--no-prefill", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -224,6 +225,8 @@ def main():
         out["prefill"] = prefill(args.prefill_m)
         if args.prefill_m2 and args.prefill_m2 != args.prefill_m:
             out["prefill_m%d" % args.prefill_m2] = prefill(args.prefill_m2)
+        if args.prefill_m3 and args.prefill_m3 not in (args.prefill_m, args.prefill_m2):
+            out["prefill_m%d" % args.prefill_m3] = prefill(args.prefill_m3)
 
     # ---------------- CPU baseline (reference's pseudo-quant Linear on the host cores) ----------------
     if not args.no_cpu_baseline:
