@@ -65,7 +65,7 @@ struct NoJob {
 #define V4N_WRITE(addr, val, off) asm volatile("ds_write_b128 %0, %1 offset:%2\n\ts_nop 1" : : "v"(addr), "v"(val), "n"(off) : "memory")
 #define V4N_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-template <typename DT, int KSPLIT>
+template <typename DT, int KSPLIT, int PARTIAL>
 __global__ __launch_bounds__(512) void gemm_cdna4_v4n_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                              const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
                                                              uint16_t* __restrict__ out, int M, int N, int K, int tiles_m,
@@ -163,8 +163,12 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v4n_kernel(const uint16_t* __r
   for (int b = 0; b < 4; ++b)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-  auto mf = [](const u32x4& a, const u32x4& b, const f32x16& c) {
-    return DT::mfma32(__builtin_bit_cast(vec8, a), __builtin_bit_cast(vec8, b), c);
+  // PARTIAL (m < 256, one row tile): a wave's 32-row x fragment b has rows only if wm * 128 + 32 b < M; product MFMAs of the
+  // others are skipped behind a wave-uniform branch (their LDS reads stay: the lgkmcnt ladders count them)
+  const int nb = PARTIAL ? __builtin_amdgcn_readfirstlane(min(max((M - wm * 128 + 31) >> 5, 0), 4)) : 4;
+  auto mfb = [&](auto b_, const u32x4& a, const u32x4& b) {
+    constexpr int B = decltype(b_)::value;
+    if (!PARTIAL || nb > B) acc[B] = DT::mfma32(__builtin_bit_cast(vec8, a), __builtin_bit_cast(vec8, b), acc[B]);
   };
 
   Group gc;
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v4n_kernel(const uint16_t* __r
       }
       V4N_FENCE();
       asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(wc), "+v"(x0) : "n"(RD ? 4 : 3));
-      acc[0] = mf(wc, x0, acc[0]);
+      mfb(ic<0>{}, wc, x0);
       if constexpr (J::has) {
         const vec8 v = Cdna4DequantT<DT>::word_finish(pj);
         V4N_WRITE(ja[J::widx & 1], __builtin_bit_cast(u32x4, v), J::st * kTileW);
@@ -194,15 +198,15 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v4n_kernel(const uint16_t* __r
       V4N_FENCE();
       if constexpr (RD) V4N_READ(x0, xa[KN], SN * kTileX);
       asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x1) : "n"(RD ? 4 + JW : 2 + JW));
-      acc[1] = mf(wc, x1, acc[1]);
+      mfb(ic<1>{}, wc, x1);
       V4N_FENCE();
       if constexpr (RD) V4N_READ(x1, xa[KN], SN * kTileX + 4096);
       asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x2) : "n"(RD ? 4 + JW : 1 + JW));
-      acc[2] = mf(wc, x2, acc[2]);
+      mfb(ic<2>{}, wc, x2);
       V4N_FENCE();
       if constexpr (RD) V4N_READ(x2, xa[KN], SN * kTileX + 8192);
       asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x3) : "n"(RD ? 4 + JW : 0 + JW));
-      acc[3] = mf(wc, x3, acc[3]);
+      mfb(ic<3>{}, wc, x3);
       V4N_FENCE();
       if constexpr (RD) V4N_READ(x3, xa[KN], SN * kTileX + 12288);
       V4N_FENCE();
@@ -215,10 +219,10 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v4n_kernel(const uint16_t* __r
       }
       V4N_FENCE();
       asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(wc), "+v"(x0));
-      acc[0] = mf(wc, x0, acc[0]);
+      mfb(ic<0>{}, wc, x0);
       V4N_FENCE();
       asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(x1));
-      acc[1] = mf(wc, x1, acc[1]);
+      mfb(ic<1>{}, wc, x1);
       V4N_FENCE();
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x2), "+v"(x3));
       __syncthreads();  // + vmcnt(0): the next tile's x DMA and packed words have landed; every read of this tile's stages retired
@@ -233,10 +237,10 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v4n_kernel(const uint16_t* __r
         V4N_READ(x1, xa[KN], SN * kTileX + 4096);
       }
       V4N_FENCE();
-      acc[2] = mf(wc, x2, acc[2]);
+      mfb(ic<2>{}, wc, x2);
       V4N_FENCE();
       if constexpr (RD) V4N_READ(x2, xa[KN], SN * kTileX + 8192);
-      acc[3] = mf(wc, x3, acc[3]);
+      mfb(ic<3>{}, wc, x3);
       V4N_FENCE();
       if constexpr (RD) V4N_READ(x3, xa[KN], SN * kTileX + 12288);
       V4N_FENCE();
@@ -455,28 +459,29 @@ void launch_gemm_cdna4_v4n(const void* x, const void* qw, const void* szp, const
   constexpr int smem_epi = 8 * 128 * (2 * WN + 16);
   constexpr int smem = smem_main > smem_epi ? smem_main : smem_epi;
   const int tiles_m = (m + TM - 1) / TM, tiles_n = (n_end - n_begin + TN - 1) / TN;
+  using Kern = void (*)(const uint16_t*, const u32*, const u32*, const uint16_t*, uint16_t*, int, int, int, int, int, int, int, int, float*);
+  static const Kern kerns[2][2][2] = {  // [dtype][split][partial]
+      {{gemm_cdna4_v4n_kernel<F16, 0, 0>, gemm_cdna4_v4n_kernel<F16, 0, 1>}, {gemm_cdna4_v4n_kernel<F16, 1, 0>, gemm_cdna4_v4n_kernel<F16, 1, 1>}},
+      {{gemm_cdna4_v4n_kernel<BF16, 0, 0>, gemm_cdna4_v4n_kernel<BF16, 0, 1>}, {gemm_cdna4_v4n_kernel<BF16, 1, 0>, gemm_cdna4_v4n_kernel<BF16, 1, 1>}}};
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cdna4_v4n_kernel<F16, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cdna4_v4n_kernel<BF16, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cdna4_v4n_kernel<F16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cdna4_v4n_kernel<BF16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    for (int a = 0; a < 8; ++a)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[a >> 2][(a >> 1) & 1][a & 1]), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr = true;
   }
+  const int dt = dtype == 0 ? 0 : 1, partial = m <= TM - 32 ? 1 : 0;  // a whole 32-row fragment of the single row tile is empty
   const int ks = gemm_v4n_ksplit(m, n_end - n_begin, k);
   const size_t need = ks > 1 ? (size_t)tiles_m * tiles_n * ks * TM * TN * 4 : 0;
   if (ks > 1 && ws != nullptr && ws_bytes >= need && (reinterpret_cast<uintptr_t>(ws) & 15) == 0) {
-    auto kern = dtype == 0 ? gemm_cdna4_v4n_kernel<F16, 1> : gemm_cdna4_v4n_kernel<BF16, 1>;
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n * ks), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp,
-                       (const uint16_t*)nullptr, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end, ks, (float*)ws);
+    hipLaunchKernelGGL(kerns[dt][1][partial], dim3(tiles_m * tiles_n * ks), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw,
+                       (const u32*)szp, (const uint16_t*)nullptr, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end, ks, (float*)ws);
     auto red = dtype == 0 ? splitk_reduce_kernel<F16> : splitk_reduce_kernel<BF16>;
     hipLaunchKernelGGL(red, dim3((unsigned)(tiles_m * tiles_n * 8)), dim3(256), 0, st, (const float*)ws, (const uint16_t*)bias, (uint16_t*)out,
                        m, n, tiles_m, tiles_n, n_begin, n_end, ks);
     return;
   }
-  auto kern = dtype == 0 ? gemm_cdna4_v4n_kernel<F16, 0> : gemm_cdna4_v4n_kernel<BF16, 0>;
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp,
-                     (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end, 1, (float*)nullptr);
+  hipLaunchKernelGGL(kerns[dt][0][partial], dim3(tiles_m * tiles_n), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw,
+                     (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end, 1, (float*)nullptr);
 }
 
 }  // namespace awq
