@@ -113,12 +113,16 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v4n_kernel(const uint16_t* __r
 #pragma unroll
     for (int q = 0; q < 4; ++q) a_off[q] = (u32)min(m0 + row + 64 * q, M - 1) * (u32)K + gc * 8;  // (64 q keeps (row >> 1) & 7)
   }
+  // PARTIAL: rows >= M are not even fetched (their LDS rows keep stale bits; output rows depend on their own x row only and
+  // rows >= M are never stored)
+  const int a_rows = PARTIAL ? M - m0 - (tid >> 3) : 256;  // DMA q is live iff 64 q < a_rows
   auto issue_a = [&](int kt, int stage) {
     char* dst = smem + stage * kTileX + wv * 1024;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const uint16_t* xq = x + (size_t)(kt + 2 * g0) * TK;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xq + a_off[q]),
+      if (!PARTIAL || 64 * q < a_rows)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xq + a_off[q]),
                                        (__attribute__((address_space(3))) void*)(dst + q * 8192), 16, 0, 0);
     }
   };
