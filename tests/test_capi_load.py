@@ -53,3 +53,30 @@ def test_engine_module_exports():
     import sys
     llm_awq_amd.install_as_awq_inference_engine()
     assert sys.modules["awq_inference_engine"] is eng
+
+
+def test_prefill_routing_and_workspace_rule_without_gpu():
+    """awq_w4a16_forward_cdna4_workspace_bytes is pure host logic: which m the prefill GEMM takes (m >= 256, or a shorter prompt
+    with m >= 72 and m * K >= 0.6 M), and how many K ranges an under-filled launch is split into."""
+    L = _capi.lib()
+    q = L.awq_w4a16_forward_cdna4_workspace_bytes
+    tile = 256 * 128 * 4
+    # decode / skinny territory, and launches that fill the chip: no workspace
+    for (m, n, k) in ((1, 4096, 4096), (64, 4096, 14336), (71, 4096, 14336), (128, 4096, 4096), (2048, 4096, 4096), (4096, 28672, 4096)):
+        assert q(m, n, k) == 0, (m, n, k)
+    # under-filled launches: whole partial tiles, 2..16 K ranges, at least 2 quantisation groups per range
+    for (m, n, k) in ((72, 4096, 14336), (128, 4096, 14336), (147, 4096, 4096), (256, 4096, 4096), (512, 4096, 14336), (1024, 4096, 4096),
+                      (256, 1024, 8192), (300, 6144, 4096)):
+        b = q(m, n, k)
+        tiles = ((m + 255) // 256) * ((n + 127) // 128)
+        assert b > 0 and b % (tiles * tile) == 0, (m, n, k, b)
+        ks = b // (tiles * tile)
+        assert 2 <= ks <= 16 and (k // 128) // ks >= 2, (m, n, k, ks)
+    assert q(256, 4096, 4096 + 64) == 0 and q(256, 4100, 4096) == 0  # shapes the cdna4 GEMM does not take
+    try:
+        assert L.awq_tune_set(b"gemm_splitk", 0) == 0 and q(256, 4096, 4096) == 0
+        assert L.awq_tune_set(b"gemm_splitk", 5) == 0 and q(256, 4096, 14336) == 32 * 5 * tile
+        assert L.awq_tune_set(b"gemm_splitk", 1) == 0 and L.awq_tune_set(b"gemm_small_m", 0) == 0 and q(128, 4096, 14336) == 0
+    finally:
+        L.awq_tune_set(b"gemm_splitk", 1)
+        L.awq_tune_set(b"gemm_small_m", 1)
