@@ -10,6 +10,10 @@
 // splitk_reduce_kernel adds them in split order (deterministic), rounds once, adds the bias.  This is the job of the reference's
 // split_k_iters + semaphore (gemm_cuda.cu:546-619, semaphore.h:44-103) without the in-kernel ordering.
 //
+// PARTIAL = 1 (m < 256, a single row tile; launch_gemm_cdna4_v3 sends prompts of 72 .. 255 rows here when that beats the skinny
+// kernel): x rows >= m are not fetched, the product MFMAs of 32-row fragments without rows are skipped, stores are masked.
+// The PARTIAL = 0 instantiation is instruction-for-instruction the kernel without these paths.
+//
 // A wave has ONE weight fragment per k-step, so its successor cannot be re-read into the same registers before the
 // step's last MFMA: the weight fragment is double-buffered (wa / wb by step parity) and read at the START of the step
 // before; the four x fragments are single-buffered and re-read right after the MFMA that consumes them:
