@@ -9,6 +9,8 @@ export TMPDIR=/tmp
 ( timeout 600 python bench.py 2>&1 | tail -3 ) > $O/bench.log
 ( timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_bench -o bench -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-graph --prefill-iters 1 2>&1 | tail -3 ) > $O/rocprof_bench.log
 ( timeout 400 python tools/w3_moe_sweep.py 2>&1 | grep -v "^/opt" ) > $O/w3_moe_sweep.log
+( timeout 200 python tools/splitk_sweep.py 2>&1 | grep -v "^/opt" ) > $O/splitk_sweep.txt
+( timeout 200 python tools/small_m_sweep.py 2>&1 | grep -v "^/opt" ) > $O/small_m_sweep.txt
 ( timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o pmc -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph --prefill-iters 1 2>&1 | tail -3 ) > $O/rocprof_pmc_fetch.log
 ( timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o pmc -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph --prefill-iters 1 2>&1 | tail -3 ) > $O/rocprof_pmc_write.log
 python tools/rocpd_stats.py $O/prof_bench/bench_results.db $O/bench_kernel_stats.csv > $O/bench_kernel_stats.txt
