@@ -101,6 +101,21 @@ int awq_dequant_cdna4(const void* qweight_cdna4, const void* scales, const void*
 /* sz_packed u32 [n/16][k/128][16] = {scale | scaled_zero << 16}: the scales re-laid next to the tiles so a lane
  * fetches both with one dword load per step.  Optional for the matmul entry points (NULL = read scales/zeros). */
 int awq_pack_sz_cdna4(const void* scales, const void* scaled_zeros, void* sz_packed, int n, int k, void* stream);
+/* sz_half u32 [n/16][k/128][16] = {f16(s') | f16(scaled_zero) << 16}, s' = scale for rows n % 4 < 2 and scale / 16 for the
+ * others: the side buffer of the decode kernels' "f16-mantissa" dequant (csrc/awq_device.hpp Cdna4DequantH: two of the four
+ * nibble extractions of a word need no shift when the dequant MFMA runs in its f16 form; exact, same single rounding).
+ * *inexact_dev (device int, zeroed by the caller) is set when a scale or scaled zero is not exactly representable as a
+ * normal f16 number: such a layer must keep using sz_packed.  dtype = type of scales / scaled_zeros. */
+int awq_pack_szh_cdna4(const void* scales, const void* scaled_zeros, void* sz_half, int* inexact_dev, int n, int k, int dtype,
+                       void* stream);
+/* Decode (1 <= m <= 8) on cdna4 weights + sz_half: the fast path behind WQLinear.forward for m < 8 (replaces gemv_forward_cuda_new,
+ * awq/kernels/csrc/quantization_new/gemv/gemv_cuda.cu:245-338) and QuantLlamaMLP's gate/up pair (tinychat/modules/fused_mlp.py:36-83).
+ *   epilogue 0: out[m, n] = x . W^T (+ bias, in T)
+ *   epilogue 1: qweight = [gate; up] stacked along N (n = 2 ffn), out[m, n/2] = silu(x . Wg^T) * (x . Wu^T), bias must be NULL
+ *   epilogue 2: as 1 with gate / up rows interleaved 8 + 8 inside every 16-row slab (rows 16 j .. 16 j + 7 = gate rows 8 j ..,
+ *               rows 16 j + 8 .. = the matching up rows): twice the blocks, every block one tile stream */
+int awq_w4a16_decode_cdna4(const void* x, const void* qweight_cdna4, const void* sz_half, const void* bias, void* out, int m, int n,
+                           int k, int group_size, int dtype, int epilogue, void* stream);
 /* gemv on cdna4-interleaved weights (same contract as awq_w4a16_gemv otherwise) */
 int awq_w4a16_gemv_cdna4(const void* x, const void* qweight_cdna4, const void* scales, const void* scaled_zeros,
                          const void* sz_packed, void* out, int m, int n, int k, int group_size, int dtype, void* stream);

@@ -32,6 +32,8 @@ SIGNATURES = {
     "awq_unpack_cdna4": (_i, [_vp, _vp, _i, _i, _vp]),
     "awq_dequant_cdna4": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "awq_pack_sz_cdna4": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "awq_pack_szh_cdna4": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "awq_w4a16_decode_cdna4": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "awq_w4a16_gemv_cdna4": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "awq_w4a16_mlp_gate_up_cdna4": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "awq_w4a16_rmsnorm_forward_cdna4": (_i, [_vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -176,6 +176,29 @@ int awq_pack_sz_cdna4(const void* scales, const void* scaled_zeros, void* sz_pac
   return finish_launch();
 }
 
+int awq_pack_szh_cdna4(const void* scales, const void* scaled_zeros, void* sz_half, int* inexact_dev, int n, int k, int dtype,
+                       void* stream) {
+  if (!scales || !scaled_zeros || !sz_half || !inexact_dev) return AWQ_ERR_NULL;
+  if (dtype != AWQ_F16 && dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
+  if (n < 16 || (n % 16) != 0 || k < 128 || (k % 128) != 0) return AWQ_ERR_SHAPE;
+  awq::launch_pack_szh_cdna4(scales, scaled_zeros, sz_half, inexact_dev, n, k, dtype, (hipStream_t)stream);
+  return finish_launch();
+}
+
+int awq_w4a16_decode_cdna4(const void* x, const void* qweight, const void* sz_half, const void* bias, void* out, int m, int n, int k,
+                           int group_size, int dtype, int epilogue, void* stream) {
+  if (!x || !qweight || !sz_half || !out) return AWQ_ERR_NULL;
+  if (group_size != 128) return AWQ_ERR_GROUP;
+  if (dtype != AWQ_F16 && dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
+  if (m < 1 || m > 8) return AWQ_ERR_BATCH;
+  if (epilogue < 0 || epilogue > 2 || (epilogue != 0 && bias)) return AWQ_ERR_SHAPE;
+  const int mult = epilogue == 1 ? 32 : 16;
+  if (n < mult || (n % mult) != 0 || k < 128 || (k % 128) != 0) return AWQ_ERR_SHAPE;
+  if (!aligned16(x) || !aligned16(qweight) || !aligned16(out) || !aligned16(sz_half)) return AWQ_ERR_ALIGN;
+  if (awq::launch_gemv_dma(x, qweight, sz_half, bias, out, m, n, k, epilogue, dtype, 1, (hipStream_t)stream) != 0) return AWQ_ERR_SHAPE;
+  return finish_launch();
+}
+
 int awq_w4a16_gemv_cdna4(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
                          const void* sz_packed, void* out, int m, int n, int k, int group_size, int dtype, void* stream) {
   if (group_size != 128) return AWQ_ERR_GROUP;

@@ -258,6 +258,57 @@ struct Cdna4DequantT {
 };
 using Cdna4Dequant = Cdna4DequantT<BF16>;
 
+// ---------------------------------------------------------------------------------------------
+// "f16-mantissa" form of the matrix-core dequant (decode kernels; bf16 AND fp16 models).  The 4x4x4 dequant MFMA runs in
+// its f16 form whatever T is: a 10-bit mantissa takes a nibble at bits 3:0 (1024 + q) and one at bits 7:4 (1024 + 16 q) of
+// each half WITHOUT a shift, so a word costs 1 shift + 4 v_and_or instead of 3 + 4 (the decode kernel is issue bound:
+// profiles/r02_tile_ubench.txt, 142 -> 117 ns per tile per SIMD).  The x16 of the high nibbles is folded into the
+// diagonal operand: rows n % 4 >= 2 of a quad -- inner slots 2, 3 of the block, fed by the (w & 0x00F000F0) extractions --
+// carry s / 16.  Per (row, group) the side buffer "sz_half" holds {f16(s') | f16(sz) << 16}, s' = s or s / 16, and the
+// offset is C = sz - 1024 s' (one v_dot2_f32_f16), so D = (1024 + 16^e q) s' + sz - 1024 s' = q s + sz exactly in fp32
+// (11 x 11-bit products, |sz| = s z <= 15 s); one v_cvt_pk to T is the reference's single rounding.  Requires s' and sz to
+// be exactly representable as NORMAL f16 numbers (or 0): awq_pack_szh_cdna4 checks that per layer and the callers keep
+// the T-typed form (Cdna4DequantT) for layers that fail (bf16 scales below 2^-10).
+// ---------------------------------------------------------------------------------------------
+template <typename DT>
+struct Cdna4DequantH {
+  using vec8 = typename DT::vec8;
+  u32 sel01, sel23;  // v_perm selectors placing s' at inner index lane % 4 of the diagonal B operand
+  u32 kMagic, kMaskLo, kMaskHi, kDotC;
+  __device__ __forceinline__ void init(int lane) {
+    const int pos = lane & 3;
+    // v_perm_b32(S0, S1, sel): result byte i = byte sel[i] of {S0: 4..7, S1: 0..3}; selector 0x0C = constant 0x00
+    sel01 = pos == 0 ? 0x0C0C0100u : (pos == 1 ? 0x01000C0Cu : 0x0C0C0C0Cu);
+    sel23 = pos == 2 ? 0x0C0C0100u : (pos == 3 ? 0x01000C0Cu : 0x0C0C0C0Cu);
+    kMagic = 0x64006400u;
+    kMaskLo = 0x000F000Fu;
+    kMaskHi = 0x00F000F0u;
+    kDotC = 0x3C00E400u;  // f16 pair {-1024 (lo), 1 (hi)}
+    asm volatile("" : "+v"(kMagic));
+    asm volatile("" : "+s"(kMaskLo));
+    asm volatile("" : "+s"(kMaskHi));
+    asm volatile("" : "+v"(kDotC));
+  }
+  // whole 1-KiB tile -> 4 operands (op[a] covers k = 32a + 8g + 0..7 of the tile's 128 k), szh = this lane's sz_half dword
+  __device__ __forceinline__ void tile(const u32x4& w, u32 szh, vec8 (&op)[4]) const {
+    typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+    const u32 b01 = __builtin_amdgcn_perm(szh, szh, sel01), b23 = __builtin_amdgcn_perm(szh, szh, sel23);
+    const float cv = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, szh), __builtin_bit_cast(f16x2, kDotC), 0.0f, false);
+    const f32x4 c = {cv, cv, cv, cv};
+    const u32x2 b = {b01, b23};
+    const u32 ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const u32 w8 = ws[a] >> 8;
+      const u32x2 a0 = {(ws[a] & kMaskLo) | kMagic, (ws[a] & kMaskHi) | kMagic};
+      const u32x2 a1 = {(w8 & kMaskLo) | kMagic, (w8 & kMaskHi) | kMagic};
+      const f32x4 d0 = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(h16x4, a0), __builtin_bit_cast(h16x4, b), c, 0, 0, 0);
+      const f32x4 d1 = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(h16x4, a1), __builtin_bit_cast(h16x4, b), c, 0, 0, 0);
+      op[a] = DT::pack8(d0, d1);
+    }
+  }
+};
+
 
 // =============================================================================================
 // W3 ("w3c") tiles: the repository's 3-bit format (the reference has none: qmodule.py:82-83 raises for

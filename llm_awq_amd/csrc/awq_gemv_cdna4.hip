@@ -317,6 +317,7 @@ int g_force_waves = 0, g_force_s = 0;
 // g_pipe: -1 = default (ring of 2, the measured optimum: profiles/r01_gemvc_ring_sweep.txt), 0 = all-loads-up-front chunks,
 // >= 2 = ring depth of the software pipeline; g_pipe_s: steps per chunk (0 = by steps per wave)
 int g_pipe = -1, g_pipe_s = 0;
+int g_use_dma = 1;  // 1 = the LDS-DMA streaming kernel (awq_gemv_dma.hip) serves W4 decode; 0 = the register-ring kernel below
 }  // namespace
 
 int gemv_cdna4_tune_set(const char* key, int value) {
@@ -324,7 +325,8 @@ int gemv_cdna4_tune_set(const char* key, int value) {
   else if (!strcmp(key, "gemvc_s")) g_force_s = value;
   else if (!strcmp(key, "gemvc_pipe")) g_pipe = value;
   else if (!strcmp(key, "gemvc_pipe_s")) g_pipe_s = value;
-  else return -1;
+  else if (!strcmp(key, "gemv_dma")) g_use_dma = value;
+  else return gemv_dma_tune_set(key, value);
   return 0;
 }
 
@@ -387,6 +389,8 @@ static int launch_mb(const void* x, const void* qw, const void* szp, const void*
 int launch_gemv_cdna4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                       int epi, int bits, int dtype, hipStream_t st) {
   if (m < 1 || m > 8) return -1;
+  if (bits == 4 && g_use_dma && launch_gemv_dma(x, qw, szp, bias, out, m, n, k, epi, dtype, 0, st) == 0) return 0;
+  if (epi == 2) return -1;  // interleaved gate / up rows: only the streaming kernel pairs them
   if (bits == 3) {
     if (epi != 0 || dtype != 1) return -1;
     return m <= 4 ? launch_mb<BF16, 1, 0, 3>(x, qw, szp, bias, out, m, n, k, st) : launch_mb<BF16, 2, 0, 3>(x, qw, szp, bias, out, m, n, k, st);

@@ -1,0 +1,304 @@
+// Decode GEMV on cdna4-interleaved weights, LDS-DMA streaming form, 1 <= M <= 8, bf16 and fp16 (gfx950).
+// Replaces gemv_kernel (awq/kernels/csrc/quantization_new/gemv/gemv_cuda.cu:74-229) behind WQLinear.forward for decode and, with
+// EPI = 1 / 2, QuantLlamaMLP's gate/up pair + SiLU*mul (tinychat/modules/fused_mlp.py:36-83).
+//
+// Why this form (DESIGN.md "Decode GEMV"; profiles/r02_*): the register-ring kernel (awq_gemv_cdna4.hip) keeps ONE chunk per wave in
+// flight -- ~28 KiB per CU -- and its slowest waves receive their first bytes last and then pay one full queue round trip per
+// chunk (profiles/r01_gemv_trace.txt: the median wave of the gate/up launch ends at 9.8 us, the last at 15.7 us).  Here every wave
+// requests its weight tiles up front with `buffer_load_dwordx4 ... lds` (LDS-DMA: no VGPRs, one instruction per KiB), up to D tiles
+// deep into a wave-private LDS ring, so a CU has ~100 KiB in flight from the first microsecond and the memory system is never
+// waiting for a dependent request; the math trails the stream and reads the tiles back from LDS (one ds_read_b128 per tile).
+//   * block = one 16-row slab (EPI 1: the gate slab and its up slab, NS = 2), WAVES waves split K into CONTIGUOUS ranges of TX
+//     128-k steps (the slab's K extent is one contiguous stream in the cdna4 layout);
+//   * up front per wave: its x slices (M rows x TX x 256 B) and its packed {scale | zero} dwords (NS x TX x 64 B), also by LDS-DMA
+//     (older in the vmcnt order than every weight tile, so the first tile wait covers them);
+//   * ring of D steps (NS KiB each): step t waits with a COUNTED vmcnt ((D - 1) NS tiles may stay in flight), reads its tile(s), and
+//     re-issues the slot for step t + D; the last D steps count down.  All LDS reads of the loop are inline asm: hipcc would
+//     otherwise drain the DMA queue (vmcnt(0)) in front of every LDS read that may alias an in-flight DMA;
+//   * dequant on the matrix core (Cdna4DequantT: exact q*s+sz, one v_cvt_pk = the reference's rounding), product on
+//     v_mfma_f32_16x16x32, fp32 accumulate, split-K partials reduced through LDS, bias / SiLU*mul fused.
+#include <string.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "awq_device.hpp"
+#include "awq_kernels.hpp"
+
+namespace awq {
+
+#define DMA_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// `buffer_load_dword(x4) ... lds`: SIZE bytes per lane from rsrc[voff + soff] to LDS at (wave-uniform) dst + lane * SIZE; AUX 2 = nt.
+// (The builtin only exists in the device pass; un-guarded, the host pass silently drops the kernel's launch stub.)
+template <int SIZE, int AUX>
+__device__ __forceinline__ void dma_to_lds(const __amdgpu_buffer_rsrc_t& rsrc, char* dst, u32 voff, u32 soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (SIZE == 16 && AUX == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, DMA_LDS_PTR(dst), 16, voff, soff, 0, 2);
+  if constexpr (SIZE == 16 && AUX == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, DMA_LDS_PTR(dst), 16, voff, soff, 0, 0);
+  if constexpr (SIZE == 4 && AUX == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, DMA_LDS_PTR(dst), 4, voff, soff, 0, 0);
+#endif
+}
+template <int N_>
+__device__ __forceinline__ void dma_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N_) : "memory");
+}
+template <int J, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (J < E) {
+    f(std::integral_constant<int, J>{});
+    static_for<J + 1, E>(f);
+  }
+}
+
+// EPI 0: out[m, n] (+ bias);  EPI 1: qw = [gate; up] stacked along N, out[m, n/2] = silu(gate) * up (two slabs per block);
+// EPI 2: gate / up rows interleaved 8 + 8 inside every 16-row slab (fused_mlp.QuantLlamaMLP stacks them that way), out[m, n/2]
+template <typename DT, int WAVES, int D, int DQ, int EPI>
+__global__ __launch_bounds__(64 * WAVES) void gemv_dma_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
+                                                               const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
+                                                               uint16_t* __restrict__ out, int M, int N, int K, int TX) {
+  constexpr int NS = EPI == 1 ? 2 : 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int nit = K >> 7;
+  const int nb = blockIdx.x;
+  const int TXp = (TX + 3) & ~3;                 // steps covered by the 4-step DMA pieces of x / sz
+  const int xrow = TXp * 256 + 16;               // bytes per staged x row (+16: the M rows of an operand land in different banks)
+  const int wave_bytes = D * NS * 1024 + NS * TXp * 64 + M * xrow;
+  char* wbase = smem + wv * wave_bytes;
+  char* ring = wbase;                            // [D][NS] tiles of 1 KiB
+  char* szs = wbase + D * NS * 1024;             // [NS][TXp] x 64 B
+  char* xs = szs + NS * TXp * 64;                // [M][xrow]
+  const int s0 = wv * TX;                        // this wave's first k-step
+
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(qw), 0, (N >> 4) * nit * 1024, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(szp), 0, (N >> 4) * nit * 64, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(x), 0, M * K * 2, 0x00020000);
+  u32 slab_tile[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) slab_tile[s] = ((u32)nb + (u32)s * (u32)(N >> 5)) * (u32)nit;
+
+  // ---- up front: x slices and packed scales (out-of-range pieces read 0 through the buffer descriptor) ----
+  const u32 lane16 = lane * 16u, lane4 = lane * 4u;
+  for (int r = 0; r < M; ++r)
+    for (int q = 0; q < TXp; q += 4)
+      dma_to_lds<16, 0>(rx, xs + r * xrow + q * 256, lane16, ((u32)r * (u32)K + (u32)(s0 + q) * 128u) * 2u);
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+    for (int q = 0; q < TXp; q += 4)
+      dma_to_lds<4, 0>(rs, szs + (s * TXp + q) * 64, lane4, (slab_tile[s] + (u32)(s0 + q)) * 64u);
+
+  auto issue = [&](int t, int slot) {  // weight tile(s) of local step t into ring slot `slot`
+    const u32 kg = (u32)min(s0 + t, nit - 1);  // steps past the end (ragged K split) re-read the last tile; their math is skipped
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+      dma_to_lds<16, 2>(rw, ring + (slot * NS + s) * 1024, lane16, (slab_tile[s] + kg) * 1024u);
+  };
+#pragma unroll
+  for (int d = 0; d < D; ++d) issue(d, d);
+
+  using vec8 = typename DT::vec8;
+  Cdna4DequantT<DT> cd;   // DQ 0: sz_packed in T
+  Cdna4DequantH<DT> ch;   // DQ 1: sz_half, f16-mantissa extraction
+  if (DQ == 0) cd.init(lane);
+  else ch.init(lane);
+  const int mrow = min(i, M - 1);
+  const u32 lds0 = (u32)(size_t)(__attribute__((address_space(3))) char*)wbase;
+  const u32 ring_lane = lds0 + lane16;
+  const u32 sz_lane = lds0 + D * NS * 1024 + i * 4;
+  const u32 x_lane = lds0 + D * NS * 1024 + NS * TXp * 64 + mrow * xrow + g * 16;
+
+  f32x4 acc[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int slot = 0;
+  auto step = [&](int t, auto vm_, auto reissue_) {
+    constexpr int VM = decltype(vm_)::value;
+    constexpr bool REISSUE = decltype(reissue_)::value;
+    u32x4 w[NS], xo[4];
+    u32 sz[NS];
+    const u32 ra = ring_lane + slot * (NS * 1024), sa = sz_lane + t * 64, xa = x_lane + t * 256;
+    dma_wait_vm<VM>();
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      if (s == 0) asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(w[s]) : "v"(ra) : "memory");
+      else asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(w[s]) : "v"(ra) : "memory");
+      asm volatile("ds_read_b32 %0, %1" : "=v"(sz[s]) : "v"(sa + s * TXp * 64) : "memory");
+    }
+    asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(xo[0]) : "v"(xa) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(xo[1]) : "v"(xa) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:128" : "=v"(xo[2]) : "v"(xa) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:192" : "=v"(xo[3]) : "v"(xa) : "memory");
+    if (NS == 1)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(sz[0]), "+v"(xo[0]), "+v"(xo[1]), "+v"(xo[2]), "+v"(xo[3]) : : "memory");
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(w[0]), "+v"(w[NS - 1]), "+v"(sz[0]), "+v"(sz[NS - 1]), "+v"(xo[0]), "+v"(xo[1]), "+v"(xo[2]), "+v"(xo[3])
+                   :
+                   : "memory");
+    if (REISSUE) issue(t + D, slot);  // the slot's bytes are in registers: refill it for step t + D
+    if (s0 + t < nit) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        vec8 op[4];
+        if (DQ == 0) cd.tile_packed(w[s], sz[s], op);
+        else ch.tile(w[s], sz[s], op);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[s] = DT::mfma(op[a], __builtin_bit_cast(vec8, xo[a]), acc[s]);
+      }
+    }
+    slot = slot + 1 == D ? 0 : slot + 1;
+  };
+  int t = 0;
+  for (; t < TX - D; ++t) step(t, std::integral_constant<int, (D - 1) * NS>{}, std::true_type{});
+  // the last D steps: nothing left to issue, the waits count down
+  static_for<0, D>([&](auto j_) {
+    constexpr int J = decltype(j_)::value;
+    step(t + J, std::integral_constant<int, (D - 1 - J) * NS>{}, std::false_type{});
+  });
+
+  // ---- split-K reduction across the block's waves (fp32) through each wave's own (now idle) ring slots ----
+  // acc[r] = C[n = 4g + r][m = i];  wave q's partial of slab s lives at smem + q * wave_bytes + s * 1024
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) reinterpret_cast<float*>(wbase + s * 1024)[r * 64 + lane] = acc[s][r];
+  __syncthreads();
+  auto to_f = [](uint16_t b) { return DT::to_float(b); };
+  if (EPI != 2) {
+    if (wv < 4 && i < M) {
+      const int r = wv;
+      float v[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        float tsum = 0.f;
+#pragma unroll
+        for (int q = 0; q < WAVES; ++q) tsum += reinterpret_cast<const float*>(smem + q * wave_bytes + s * 1024)[r * 64 + lane];
+        v[s] = tsum;
+      }
+      const int nn = nb * 16 + 4 * g + r;
+      if (EPI == 0) {
+        uint16_t o = DT::from_float(v[0]);
+        if (bias != nullptr) o = DT::from_float(to_f(o) + to_f(bias[nn]));  // `out + self.bias` in T (qmodule.py:221)
+        out[(size_t)i * N + nn] = o;
+      } else {
+        // fused_mlp.py:79-82: c = F.silu(gate_output) * up_output, every op rounded to T
+        const float gt = to_f(DT::from_float(v[0])), up = to_f(DT::from_float(v[NS - 1]));
+        const float sl = to_f(DT::from_float(gt / (1.0f + __expf(-gt))));
+        out[(size_t)i * (N >> 1) + nn] = DT::from_float(sl * up);
+      }
+    }
+  } else {
+    // rows 0..7 of the slab are gate rows 8 nb .. 8 nb + 7, rows 8..15 the matching up rows: lane (g < 2) pairs with lane + 32
+    if (wv < 4 && i < M && g < 2) {
+      const int r = wv;
+      float gsum = 0.f, usum = 0.f;
+#pragma unroll
+      for (int q = 0; q < WAVES; ++q) {
+        const float* p = reinterpret_cast<const float*>(smem + q * wave_bytes);
+        gsum += p[r * 64 + lane];
+        usum += p[r * 64 + lane + 32];
+      }
+      const float gt = to_f(DT::from_float(gsum)), up = to_f(DT::from_float(usum));
+      const float sl = to_f(DT::from_float(gt / (1.0f + __expf(-gt))));
+      out[(size_t)i * (N >> 1) + nb * 8 + 4 * g + r] = DT::from_float(sl * up);
+    }
+  }
+}
+
+namespace {
+struct DmaCfg {
+  int waves, tx, d;
+  size_t smem;
+};
+int g_dma_waves = 0, g_dma_d = 0;
+
+size_t dma_smem(int waves, int d, int ns, int tx, int m) {
+  const int txp = (tx + 3) & ~3;
+  return (size_t)waves * ((size_t)d * ns * 1024 + (size_t)ns * txp * 64 + (size_t)m * (txp * 256 + 16));
+}
+
+// K split and ring depth: as many tiles in flight per CU as LDS allows (<= ~150 KiB per CU over the blocks that share it),
+// every wave at least 2 steps
+bool pick_dma(int m, int n_rows, int k, int ns, DmaCfg& c) {
+  const int nit = k / kGroup, slabs = n_rows / 16 / ns;
+  int waves = nit >= 112 ? 16 : 8;
+  if (slabs <= 256 && nit >= 32) waves = 16;  // one block per CU: more waves hide the per-tile chain
+  if (g_dma_waves) waves = g_dma_waves;
+  while (waves > 1 && waves > nit) waves >>= 1;
+  const int tx = (nit + waves - 1) / waves;
+  const double blocks_per_cu = (double)slabs / 256.0;
+  int d = tx < 8 ? tx : 8;
+  if (g_dma_d) d = g_dma_d < tx ? g_dma_d : tx;
+  // LDS: blocks that want to be co-resident on a CU must fit in 160 KiB
+  const int want = blocks_per_cu <= 1.0 ? 1 : (blocks_per_cu <= 2.0 ? 2 : (blocks_per_cu <= 3.0 ? 3 : 4));
+  while (d > 1 && dma_smem(waves, d, ns, tx, m) * want > 156 * 1024) --d;
+  // compiled ring depths: 1, 2, 4, 8 (7 with 16 waves: K = 14336)
+  if (d == 3) d = 2;
+  if (d == 5 || d == 6 || (d == 7 && waves != 16)) d = 4;
+  if (d == 8 && waves == 16) d = 7;
+  if (waves == 4 && d < 4) return false;
+  c = {waves, tx, d, dma_smem(waves, d, ns, tx, m)};
+  return c.smem <= 160 * 1024 && tx >= d;
+}
+}  // namespace
+
+int gemv_dma_tune_set(const char* key, int value) {
+  if (!strcmp(key, "gemvd_waves")) g_dma_waves = value;
+  else if (!strcmp(key, "gemvd_d")) g_dma_d = value;
+  else return -1;
+  return 0;
+}
+
+template <typename DT, int WAVES, int D, int DQ, int EPI>
+static void launch_dma_cfg(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
+                           const DmaCfg& c, hipStream_t st) {
+  constexpr int NS = EPI == 1 ? 2 : 1;
+  auto kern = gemv_dma_kernel<DT, WAVES, D, DQ, EPI>;
+  static LdsOptIn optin;
+  if (c.smem > 64 * 1024) optin.ensure(reinterpret_cast<const void*>(kern));
+  hipLaunchKernelGGL(kern, dim3(n / 16 / NS), dim3(64 * WAVES), c.smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp,
+                     (const uint16_t*)bias, (uint16_t*)out, m, n, k, c.tx);
+}
+
+template <typename DT, int EPI, int DQ>
+static int launch_dma_dt(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
+                         hipStream_t st) {
+  DmaCfg c;
+  if (!pick_dma(m, n, k, EPI == 1 ? 2 : 1, c)) return -1;
+#define AWQ_DCASE(W_, D_)                                                           \
+  if (c.waves == W_ && c.d == D_) {                                                 \
+    launch_dma_cfg<DT, W_, D_, DQ, EPI>(x, qw, szp, bias, out, m, n, k, c, st);      \
+    return 0;                                                                       \
+  }
+  AWQ_DCASE(8, 1) AWQ_DCASE(8, 2) AWQ_DCASE(8, 4) AWQ_DCASE(8, 8)
+  AWQ_DCASE(16, 1) AWQ_DCASE(16, 2) AWQ_DCASE(16, 4) AWQ_DCASE(16, 7)
+  AWQ_DCASE(4, 4) AWQ_DCASE(4, 8)
+#undef AWQ_DCASE
+  return -1;
+}
+
+// epi as in the kernel header; returns -1 if the shape is not served (the caller falls back to awq_gemv_cdna4.hip)
+int launch_gemv_dma(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int epi,
+                    int dtype, int szfmt, hipStream_t st) {
+  if (m < 1 || m > 8 || (k % 128) != 0 || (n % (epi == 1 ? 32 : 16)) != 0) return -1;
+#define AWQ_DDT(DT_, DQ_)                                                                   \
+  if (epi == 0) return launch_dma_dt<DT_, 0, DQ_>(x, qw, szp, bias, out, m, n, k, st);     \
+  if (epi == 1) return launch_dma_dt<DT_, 1, DQ_>(x, qw, szp, bias, out, m, n, k, st);     \
+  return launch_dma_dt<DT_, 2, DQ_>(x, qw, szp, bias, out, m, n, k, st);
+  if (szfmt == 1) {
+    if (dtype == 0) {
+      AWQ_DDT(F16, 1)
+    }
+    AWQ_DDT(BF16, 1)
+  }
+  if (dtype == 0) {
+    AWQ_DDT(F16, 0)
+  }
+  AWQ_DDT(BF16, 0)
+#undef AWQ_DDT
+}
+
+}  // namespace awq

@@ -4,7 +4,25 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace awq {
+// Kernels that use more than 64 KiB of dynamic LDS must be opted in with hipFuncSetAttribute, and the attribute belongs to the
+// (kernel, DEVICE) pair: a single-process multi-GPU caller (the reference's accelerate layer placement, awq/entry.py:167-186)
+// launches the same kernel on several devices.  One LdsOptIn per kernel instantiation remembers, per device ordinal, that the
+// opt-in has been made; racing threads may both make the (idempotent) call.
+struct LdsOptIn {
+  std::atomic<uint64_t> done[4] = {};  // device ordinals 0..255
+  void ensure(const void* kern, int bytes = 160 * 1024) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    std::atomic<uint64_t>& w = done[(dev >> 6) & 3];
+    if (w.load(std::memory_order_acquire) & bit) return;
+    (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    w.fetch_or(bit, std::memory_order_release);
+  }
+};
 // layout: 0 = reference v2 interleave, 1 = cdna4 interleave (bf16 only)
 // szp: optional packed {scale | scaled_zero << 16} u32 [N/16][K/128][16] (cdna4 layout only), else nullptr
 int launch_gemv(const void* x, const void* qw, const void* s, const void* z, const void* szp, void* out, int m, int n,
@@ -30,12 +48,20 @@ int launch_unpack_w3(const void* qw3, void* out_u8, int n, int k, hipStream_t st
 int launch_dequant_w3(const void* qw3, const void* s, const void* z, void* out, int n, int k, hipStream_t st);
 int launch_expand_w3_to_cdna4(const void* qw3, void* qw4, int n, int k, hipStream_t st);
 int gemv_cdna4_tune_set(const char* key, int value);
+// LDS-DMA streaming decode GEMV (awq_gemv_dma.hip): 1 <= m <= 8, cdna4 layout + packed sz.  epi 0: out[m,n] (+bias); epi 1: stacked
+// [gate; up]; epi 2: gate / up rows interleaved 8 + 8 per slab; both out[m, n/2] = silu(gate) * up.  -1 if the shape is not served.
+// szfmt 0: szp = sz_packed {s | sz << 16} in T;  szfmt 1: szp = sz_half (f16-mantissa dequant, awq_pack_szh_cdna4)
+int launch_gemv_dma(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int epi,
+                    int dtype, int szfmt, hipStream_t st);
+int gemv_dma_tune_set(const char* key, int value);
 int launch_moe_gemv_cdna4(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total_rows,
                           int experts, int n, int k, int dtype, hipStream_t st);
 // grouped skinny kernel for 9..255 sorted rows (awq_skinny_cdna4.hip)
 int launch_moe_skinny_cdna4(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total_rows,
                             int experts, int n, int k, int dtype, hipStream_t st);
 int launch_pack_sz_cdna4(const void* s, const void* z, void* szp, int n, int k, hipStream_t st);
+// "sz_half" form for the decode kernels: {f16(s') | f16(sz) << 16}; *inexact (device int, caller-zeroed) is set if a value is not exact
+int launch_pack_szh_cdna4(const void* s, const void* z, void* szh, int* inexact, int n, int k, int dtype, hipStream_t st);
 int launch_gemm(const void* x, const void* qw, const void* s, const void* z, const void* szp, void* out, int m, int n,
                 int k, int dtype, int layout, void* ws, size_t ws_bytes, hipStream_t st);
 int launch_repack_v2_cdna4(const void* src, void* dst, int n, int k, int to_cdna4, hipStream_t st);

@@ -217,6 +217,26 @@ __global__ void pack_sz_cdna4_kernel(const uint16_t* __restrict__ s, const uint1
   out[t] = (u32)s[src] | ((u32)z[src] << 16);
 }
 
+// "sz_half" side buffer of the decode kernels (Cdna4DequantH, awq_device.hpp): {f16(s') | f16(sz) << 16}, s' = s for rows
+// n % 4 < 2 and s / 16 for the others.  *inexact is set when a value is not exactly representable as a normal f16 number
+// (or 0): the caller then keeps the T-typed sz_packed form for this layer.
+template <typename DT>
+__global__ void pack_szh_cdna4_kernel(const uint16_t* __restrict__ s, const uint16_t* __restrict__ z, u32* __restrict__ out,
+                                      int* __restrict__ inexact, int N, int nit) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)N * nit) return;
+  const int c = (int)(t & 15);
+  const size_t tile = t >> 4;
+  const int nb = (int)(tile / nit), kg = (int)(tile % nit);
+  const size_t src = (size_t)kg * N + nb * 16 + c;
+  const float sf = DT::to_float(s[src]), zf = DT::to_float(z[src]);
+  const float sp = (c & 3) >= 2 ? sf * 0.0625f : sf;
+  const _Float16 sh = (_Float16)sp, zh = (_Float16)zf;
+  auto ok = [](float v, _Float16 h) { return (float)h == v && (v == 0.0f || fabsf(v) >= 6.103515625e-05f); };
+  if (!ok(sp, sh) || !ok(zf, zh)) atomicOr(inexact, 1);
+  out[t] = (u32)__builtin_bit_cast(uint16_t, sh) | ((u32)__builtin_bit_cast(uint16_t, zh) << 16);
+}
+
 static inline unsigned nblk(size_t n, unsigned b) { return (unsigned)((n + b - 1) / b); }
 
 int launch_unpack_v2(const void* qw, void* out_u8, int n, int k, hipStream_t st) {
@@ -270,6 +290,14 @@ int launch_pack_sz_cdna4(const void* s, const void* z, void* szp, int n, int k, 
   const size_t items = (size_t)n * (k / kGroup);
   hipLaunchKernelGGL(pack_sz_cdna4_kernel, dim3(nblk(items, 256)), dim3(256), 0, st, (const uint16_t*)s, (const uint16_t*)z,
                      (u32*)szp, n, k / kGroup);
+  return 0;
+}
+
+int launch_pack_szh_cdna4(const void* s, const void* z, void* szh, int* inexact, int n, int k, int dtype, hipStream_t st) {
+  const size_t items = (size_t)n * (k / kGroup);
+  auto kern = dtype == 0 ? pack_szh_cdna4_kernel<F16> : pack_szh_cdna4_kernel<BF16>;
+  hipLaunchKernelGGL(kern, dim3(nblk(items, 256)), dim3(256), 0, st, (const uint16_t*)s, (const uint16_t*)z, (u32*)szh, inexact, n,
+                     k / kGroup);
   return 0;
 }
 

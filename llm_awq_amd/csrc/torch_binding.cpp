@@ -12,6 +12,7 @@
 
 #include <cstdlib>
 #include <mutex>
+#include <tuple>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -358,6 +359,46 @@ torch::Tensor mlp_gate_up_cdna4(torch::Tensor in_feats, torch::Tensor kernel_gat
   return out;
 }
 
+// "sz_half" side buffer of the decode kernels; returns (int32 [n/16, k/128, 16], exact).  Synchronises once (reads the flag).
+std::tuple<torch::Tensor, bool> pack_szh_cdna4(torch::Tensor scales, torch::Tensor zeros, int k) {
+  TORCH_CHECK(scales.is_cuda() && zeros.is_cuda() && scales.is_contiguous() && zeros.is_contiguous());
+  TORCH_CHECK(scales.scalar_type() == zeros.scalar_type() && scales.sizes() == zeros.sizes() && scales.dim() == 2);
+  TORCH_CHECK(scales.scalar_type() == at::kBFloat16 || scales.scalar_type() == at::kHalf);
+  const int64_t n = scales.size(1);
+  TORCH_CHECK(n % 16 == 0 && k % 128 == 0 && scales.size(0) * 128 >= k);
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(scales.device());
+  at::Tensor out = torch::empty({n / 16, k / 128, 16}, scales.options().dtype(at::kInt));
+  at::Tensor flag = torch::zeros({1}, scales.options().dtype(at::kInt));
+  raise_on(awq_pack_szh_cdna4(scales.data_ptr(), zeros.data_ptr(), out.data_ptr(), (int*)flag.data_ptr(), (int)n, k, dtype_code(scales),
+                              (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()));
+  return {out, flag.item<int>() == 0};
+}
+
+// decode (<= 8 rows) on cdna4 weights + sz_half; epilogue 0: x.W^T (+bias), 1: stacked [gate; up] -> silu(gate)*up, 2: interleaved 8 + 8
+torch::Tensor decode_cdna4(torch::Tensor in_feats, torch::Tensor kernel, torch::Tensor sz_half, c10::optional<torch::Tensor> bias,
+                           int epilogue) {
+  TORCH_CHECK(in_feats.is_cuda() && kernel.is_cuda() && sz_half.is_cuda());
+  TORCH_CHECK(in_feats.is_contiguous() && kernel.is_contiguous() && sz_half.is_contiguous());
+  TORCH_CHECK((in_feats.scalar_type() == at::kBFloat16 || in_feats.scalar_type() == at::kHalf) && kernel.scalar_type() == at::kShort &&
+              sz_half.scalar_type() == at::kInt);
+  const int64_t n = kernel.size(0) * 4, k = in_feats.size(-1);
+  TORCH_CHECK(k > 0 && in_feats.numel() % k == 0 && kernel.numel() == n / 4 * k);
+  TORCH_CHECK(sz_half.numel() == n * (k / 128), "sz_half must be int32 [n/16, k/128, 16]");
+  const int64_t m = in_feats.numel() / k;
+  std::vector<int64_t> shape = in_feats.sizes().vec();
+  shape.back() = epilogue ? n / 2 : n;
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(in_feats.device());
+  at::Tensor out = torch::empty(shape, in_feats.options());
+  const void* bp = nullptr;
+  if (bias.has_value() && bias->defined()) {
+    TORCH_CHECK(bias->is_cuda() && bias->is_contiguous() && bias->scalar_type() == in_feats.scalar_type() && bias->numel() == n);
+    bp = bias->data_ptr();
+  }
+  raise_on(awq_w4a16_decode_cdna4(in_feats.data_ptr(), kernel.data_ptr(), sz_half.data_ptr(), bp, out.data_ptr(), (int)m, (int)n, (int)k,
+                                  128, dtype_code(in_feats), epilogue, (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()));
+  return out;
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -387,5 +428,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("pack_w3", &pack_w3, "logical uint8 [N, K] (0..7) -> w3c tiles int16 [N/4, 3K/4]");
   m.def("forward_w3", &forward_w3, "WQLinear forward for w_bit = 3 (w3c tiles)", py::arg("in_feats"), py::arg("kernel"),
         py::arg("scales"), py::arg("zeros"), py::arg("sz_packed"), py::arg("bias") = py::none());
+  m.def("pack_szh_cdna4", &pack_szh_cdna4, "scales/scaled_zeros [Gpad,N] -> (sz_half int32 [N/16, K/128, 16], exact)");
+  m.def("decode_cdna4", &decode_cdna4, "<= 8 rows on cdna4 weights + sz_half (LDS-DMA streaming kernel)", py::arg("in_feats"),
+        py::arg("kernel"), py::arg("sz_half"), py::arg("bias") = py::none(), py::arg("epilogue") = 0);
   m.def("mlp_gate_up_cdna4", &mlp_gate_up_cdna4, "silu(x Wg^T) * (x Wu^T) on stacked cdna4 gate/up buffers, <= 8 rows");
 }

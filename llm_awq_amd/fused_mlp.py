@@ -1,0 +1,108 @@
+"""QuantLlamaMLP / make_fused_mlp -- the MI355X build of tinychat/modules/fused_mlp.py:11-101.
+
+The reference module keeps gate_proj / up_proj as raw v2 buffers, issues two `gemv_forward_cuda_new` (or two
+`gemm_forward_cuda_new`) calls, `F.silu` and a multiply, then calls `down_proj`.  Here the pair is ONE weight stream:
+
+  * construction interleaves the gate and up rows 8 + 8 inside every 16-row slab (slab j = gate rows 8j..8j+7, then up rows
+    8j..8j+7; in the v2 buffers that is a permutation of whole packed rows, 4 logical rows each) and repacks the result to the
+    cdna4 interleave.  2 * ffn / 16 blocks of one tile stream each (1792 for Llama-3-8B: 7 per CU) instead of ffn / 16 blocks of
+    two streams (896: 3.5 per CU, so half the CUs carried 4 blocks and the rest 3);
+  * decode (< 8 rows): `decode_cdna4(..., epilogue=2)` -- gate, up, SiLU and the multiply in one launch, every intermediate
+    rounded to T exactly like the reference's separate ops (fused_mlp.py:39-61, :79-82);
+  * prefill (>= 8 rows): one GEMM over the interleaved weight (x is read once for both projections), then SiLU * up on the
+    de-interleaved halves.
+
+`scaled_zeros - 8 * scales` (fused_mlp.py:69,76): the reference's GEMM branch shifts the zero point by 8 while its GEMV
+branch, `WQLinear.forward` (qmodule.py:220, shift commented out), `from_linear` and the offline repacker (`zp_shift = 0`,
+offline-weight-repacker.py:142) all treat the stored nibbles as UNSIGNED 0..15 (dequantize.cuh:59-69 yields 0..15).  Both
+cannot be right for the same buffers; the unsigned convention is the checkpoint contract, so this module
+uses it for every row count -- decode and prefill agree with each other and with `WQLinear.forward`, which the reference's two
+branches do not.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import load_engine
+
+
+def interleave_gate_up(gq, uq, gs, us, gz, uz):
+    """v2 buffers of gate and up (qweight int16 [F/4, K], scales / scaled_zeros [Gpad, F]) -> the 8 + 8 row-interleaved
+    stack (qweight int16 [2F/4, K], scales / scaled_zeros [Gpad, 2F]).  F % 8 == 0."""
+    F4, K = gq.shape
+    assert uq.shape == gq.shape and F4 % 2 == 0, "intermediate size must be a multiple of 8"
+    q = torch.stack([gq.view(F4 // 2, 2, K), uq.view(F4 // 2, 2, K)], 1).reshape(2 * F4, K).contiguous()
+    Fo = gs.shape[1]
+
+    def cols(a, b):
+        return torch.stack([a.view(-1, Fo // 8, 8), b.view(-1, Fo // 8, 8)], 2).reshape(a.shape[0], 2 * Fo).contiguous()
+
+    return q, cols(gs, us), cols(gz, uz)
+
+
+class QuantLlamaMLP(nn.Module):
+    """Same constructor and attributes as the reference (gate_proj, down_proj, up_proj are WQLinear modules); the original
+    v2 buffers stay registered under the reference's names so state dicts are interchangeable."""
+
+    def __init__(self, gate_proj, down_proj, up_proj):
+        super().__init__()
+        self.register_buffer("gate_proj_qweight", gate_proj.qweight)
+        self.register_buffer("gate_proj_scales", gate_proj.scales)
+        self.register_buffer("gate_proj_scaled_zeros", gate_proj.scaled_zeros)
+        self.register_buffer("up_proj_qweight", up_proj.qweight)
+        self.register_buffer("up_proj_scales", up_proj.scales)
+        self.register_buffer("up_proj_scaled_zeros", up_proj.scaled_zeros)
+        if getattr(gate_proj, "layout", "v2") != "v2" or getattr(up_proj, "layout", "v2") != "v2":
+            raise ValueError("QuantLlamaMLP is built from v2 (reference layout) gate / up projections; it makes its own cdna4 stream")
+        self.in_features = gate_proj.in_features
+        self.intermediate_size = gate_proj.out_features
+        self.out_features = down_proj.out_features
+        self.w_bit = gate_proj.w_bit
+        self.down_proj = down_proj
+        self.split_k_iters = down_proj.split_k_iters
+        self._fused = None  # (qweight cdna4, scales, scaled_zeros, sz_packed, sz_half or None): built on the first GPU forward
+
+    @torch.no_grad()
+    def _build(self):
+        eng = load_engine()
+        q, s, z = interleave_gate_up(self.gate_proj_qweight, self.up_proj_qweight, self.gate_proj_scales, self.up_proj_scales,
+                                     self.gate_proj_scaled_zeros, self.up_proj_scaled_zeros)
+        c4 = eng.repack_v2_to_cdna4(q)
+        szp = eng.pack_sz_cdna4(s, z, self.in_features)
+        szh, exact = eng.pack_szh_cdna4(s, z, self.in_features)
+        self._fused = (c4, s, z, szp, szh if exact else None)
+        if getattr(self.down_proj, "layout", None) == "v2" and self.down_proj.out_features % 16 == 0:
+            self.down_proj.to_cdna4()
+
+    def forward(self, x):
+        return self.down_proj(self.our_llama_mlp(x))
+
+    @torch.no_grad()
+    def our_llama_mlp(self, x):
+        eng = load_engine()
+        if self._fused is None or self._fused[0].device != x.device:
+            self._build()
+        c4, s, z, szp, szh = self._fused
+        if not x.is_contiguous():
+            x = x.contiguous()
+        rows = x.numel() // x.shape[-1]
+        if rows < 8 and szh is not None:
+            return eng.decode_cdna4(x, c4, szh, None, 2)
+        # prefill (or a layer whose scales are not f16-exact): one GEMM over the interleaved pair, x read once
+        y = eng.forward_cdna4(x, c4, s, z, szp, None)
+        y = y.view(*y.shape[:-1], self.intermediate_size // 8, 2, 8)
+        gate, up = y[..., 0, :], y[..., 1, :]
+        return (F.silu(gate) * up).reshape(*x.shape[:-1], self.intermediate_size)
+
+
+def make_fused_mlp(m, parent_name=""):
+    """tinychat/modules/fused_mlp.py:86-101: replace every LlamaMLP whose projections are WQLinear modules."""
+    if m.__class__.__name__ in ["LlamaMLP"]:
+        return QuantLlamaMLP(m.gate_proj, m.down_proj, m.up_proj)
+    for name, child in m.named_children():
+        child = make_fused_mlp(child, parent_name=f"{parent_name}.{name}")
+        if isinstance(child, QuantLlamaMLP):
+            setattr(m, name, child)
+    return m

@@ -173,6 +173,34 @@ def pack_sz_cdna4(scales, scaled_zeros, in_features: int):
     return out
 
 
+def pack_szh_cdna4(scales, scaled_zeros, in_features: int):
+    """-> (int32 [N/16, K/128, 16] "sz_half" {f16(s') | f16(sz) << 16}, exact: bool).  `exact` False means a scale of this
+    layer is not representable as a normal f16 number: keep sz_packed (pack_sz_cdna4) for it.  Synchronises (reads the flag)."""
+    _need_gpu(scales, scaled_zeros)
+    n, k = scales.shape[1], in_features
+    out = torch.empty(n // 16, k // 128, 16, dtype=torch.int32, device=scales.device)
+    flag = torch.zeros(1, dtype=torch.int32, device=scales.device)
+    with torch.cuda.device(scales.device):
+        _capi.check(_capi.lib().awq_pack_szh_cdna4(scales.data_ptr(), scaled_zeros.data_ptr(), out.data_ptr(), flag.data_ptr(), n, k,
+                                                    _dt(scales), _stream(scales)))
+    return out, int(flag.item()) == 0
+
+
+def decode_cdna4(x, qweight, sz_half, bias=None, epilogue: int = 0, group_size: int = 128):
+    """C-ABI awq_w4a16_decode_cdna4: 1 <= M <= 8 on cdna4 weights + sz_half.  epilogue 0: x.W^T (+ bias); 1: stacked [gate; up]
+    -> silu(gate) * up; 2: the same with gate / up rows interleaved 8 + 8 per slab."""
+    _need_gpu(x, qweight, sz_half, bias)
+    k = x.shape[-1]
+    m = x.numel() // k
+    n = qweight.shape[0] * 4
+    out = torch.empty(*x.shape[:-1], n // 2 if epilogue else n, dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _capi.check(_capi.lib().awq_w4a16_decode_cdna4(x.data_ptr(), qweight.data_ptr(), sz_half.data_ptr(),
+                                                        bias.data_ptr() if bias is not None else None, out.data_ptr(), m, n, k,
+                                                        group_size, _dt(x), int(epilogue), _stream(x)))
+    return out
+
+
 def gemv_cdna4(x, qweight, scales, scaled_zeros, sz_packed=None, group_size: int = 128):
     _need_gpu(x, qweight, scales, scaled_zeros, sz_packed)
     k = x.shape[-1]

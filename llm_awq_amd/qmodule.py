@@ -128,6 +128,7 @@ class WQLinear(nn.Module):
         # dequant); "w3c" = the 3-bit tiles (w_bit == 3, always)
         self.layout = "v2" if w_bit == 4 else "w3c"
         self.sz_cdna4 = None
+        self.szh_cdna4 = None  # decode side buffer ("sz_half"): None = not built yet, False = this layer's scales are not f16-exact
         assert self.in_features % self.group_size == 0
         assert out_features % 8 == 0  # 32 // w_bit for the reference's w_bit = 4 (qmodule.py:93)
         assert out_features % self.interleave == 0
@@ -189,15 +190,20 @@ class WQLinear(nn.Module):
         eng = load_engine()
         self.qweight = eng.repack_v2_to_cdna4(self.qweight.contiguous())
         self.sz_cdna4 = eng.pack_sz_cdna4(self.scales.contiguous(), self.scaled_zeros.contiguous(), self.in_features)
+        self._build_szh(eng)
         self.layout = "cdna4"
         return self
+
+    def _build_szh(self, eng):
+        szh, exact = eng.pack_szh_cdna4(self.scales.contiguous(), self.scaled_zeros.contiguous(), self.in_features)
+        self.szh_cdna4 = szh if exact else False
 
     @torch.no_grad()
     def to_v2(self):
         if self.layout in ("v2", "w3c"):
             return self
         self.qweight = load_engine().repack_cdna4_to_v2(self.qweight)
-        self.sz_cdna4 = None
+        self.sz_cdna4 = self.szh_cdna4 = None
         self.layout = "v2"
         return self
 
@@ -209,9 +215,12 @@ class WQLinear(nn.Module):
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
         marker = state_dict.pop(prefix + "qweight_layout", None)
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+        self.szh_cdna4 = None
         if self.w_bit == 3:
             self.layout, self.sz_cdna4 = "w3c", None
         elif marker is not None and int(marker) == 1:
+            if self.group_size != 128 or self.out_features % 16:
+                raise ValueError("a cdna4-interleaved checkpoint needs group_size 128 and out_features % 16 == 0")
             self.layout = "cdna4"
             self.sz_cdna4 = None  # rebuilt lazily on the first forward
         else:
@@ -224,8 +233,20 @@ class WQLinear(nn.Module):
         if not x.is_contiguous():
             x = x.contiguous()
         if self.layout in ("cdna4", "w3c"):
-            if self.sz_cdna4 is None or self.sz_cdna4.device != self.scales.device:
+            if self.group_size != 128:
+                raise ValueError("the cdna4 / w3c kernels implement group_size 128 only")
+            # side buffers are derived from scales / scaled_zeros: rebuild when those moved, changed dtype or were edited in place
+            key = (self.scales.device, self.scales.dtype, self.scales.data_ptr(), self.scales._version, self.scaled_zeros.data_ptr(),
+                   self.scaled_zeros._version)
+            if self.sz_cdna4 is None or getattr(self, "_sz_key", None) != key:
                 self.sz_cdna4 = eng.pack_sz_cdna4(self.scales, self.scaled_zeros, self.in_features)
+                self.szh_cdna4 = None
+                self._sz_key = key
+            if self.layout == "cdna4" and x.numel() // x.shape[-1] <= 8:
+                if self.szh_cdna4 is None:
+                    self._build_szh(eng)
+                if self.szh_cdna4 is not False:
+                    return eng.decode_cdna4(x, self.qweight, self.szh_cdna4, self.bias, 0)
             fwd = eng.forward_cdna4 if self.layout == "cdna4" else eng.forward_w3
             return fwd(x, self.qweight, self.scales, self.scaled_zeros, self.sz_cdna4, self.bias)
         rows = x.numel() // x.shape[-1]

@@ -74,27 +74,46 @@ def v2_position(n, k):
     return row, kb * 64 + p // 4, p % 4
 
 
+_ROW_CHUNK = 512  # rows per pass of the index-map pack / unpack (a multiple of 16): bounds the index arrays at full model sizes
+
+
+def _row_chunks(N, step=_ROW_CHUNK):
+    for n0 in range(0, N, step):
+        yield n0, min(N, n0 + step)
+
+
 def pack_v2(q) -> np.ndarray:
-    """Logical ints ``[N, K]`` (0..15) -> v2 ``int16 [N/4, K]`` (qmodule.py:26-65)."""
-    q = np.asarray(q).astype(np.int64)
+    """Logical ints ``[N, K]`` (0..15) -> v2 ``int16 [N/4, K]`` (qmodule.py:26-65).  Row-chunked (a packed row only
+    holds nibbles of its own four logical rows), so Llama-3-70B-sized matrices stay within a few hundred MB."""
+    q = np.asarray(q)
     N, K = q.shape
     assert N % 4 == 0 and K % 64 == 0
-    nn, kk = np.meshgrid(np.arange(N), np.arange(K), indexing="ij")
-    row, col, nib = v2_position(nn, kk)
-    out = np.zeros((N // 4, K), dtype=np.int64)
-    np.add.at(out, (row, col), (q & 0xF) << (4 * nib))
-    return out.astype(np.uint16).view(np.int16)
+    out = np.zeros((N // 4, K), dtype=np.uint16)
+    kk1 = np.arange(K, dtype=np.int32)
+    for n0, n1 in _row_chunks(N):
+        nn, kk = np.meshgrid(np.arange(n0, n1, dtype=np.int32), kk1, indexing="ij")
+        row, col, nib = v2_position(nn, kk)
+        val = ((q[n0:n1].astype(np.uint16) & 0xF) << (4 * nib).astype(np.uint16)).astype(np.uint16)
+        # every (row, col) receives exactly four nibbles (nib = 0..3) with disjoint bits: OR == ADD, one pass per nibble
+        for j in range(4):
+            m = nib == j
+            out[row[m], col[m]] |= val[m]
+    return out.view(np.int16)
 
 
 def unpack_v2(qweight) -> np.ndarray:
     """v2 ``int16 [N/4, K]`` -> logical ``uint8 [N, K]``: inverse of :func:`pack_v2`; this is
     what dequantize.cuh:18-123 + the shuffle at gemv_cuda.cu:150-174 compute per thread."""
-    qw = np.asarray(qweight).view(np.uint16).astype(np.int64)
+    qw = np.asarray(qweight).view(np.uint16)
     R, K = qw.shape
     N = R * 4
-    nn, kk = np.meshgrid(np.arange(N), np.arange(K), indexing="ij")
-    row, col, nib = v2_position(nn, kk)
-    return ((qw[row, col] >> (4 * nib)) & 0xF).astype(np.uint8)
+    out = np.empty((N, K), dtype=np.uint8)
+    kk1 = np.arange(K, dtype=np.int32)
+    for n0, n1 in _row_chunks(N):
+        nn, kk = np.meshgrid(np.arange(n0, n1, dtype=np.int32), kk1, indexing="ij")
+        row, col, nib = v2_position(nn, kk)
+        out[n0:n1] = ((qw[row, col] >> (4 * nib).astype(np.uint16)) & 0xF).astype(np.uint8)
+    return out
 
 
 # --------------------------------------------------------------------------------------
@@ -282,26 +301,56 @@ def cdna4_position(n, k, K):
 
 def pack_cdna4(q) -> np.ndarray:
     """Logical ints [N, K] (0..15) -> cdna4 interleave, returned as int16 [N/4, K] (same shape as v2)."""
-    q = np.asarray(q).astype(np.int64)
+    q = np.asarray(q)
     N, K = q.shape
     assert N % 16 == 0 and K % 128 == 0
-    nn, kk = np.meshgrid(np.arange(N), np.arange(K), indexing="ij")
-    word, p = cdna4_position(nn, kk, K)
-    out = np.zeros(N * K // 8, dtype=np.int64)
-    np.add.at(out, word.reshape(-1), ((q & 0xF) << (4 * p)).reshape(-1))
-    return out.astype(np.uint32).view(np.int16).reshape(N // 4, K)
+    out = np.zeros(N * K // 8, dtype=np.uint32)
+    kk1 = np.arange(K, dtype=np.int64)
+    for n0, n1 in _row_chunks(N):  # a slab's tiles only hold nibbles of its own 16 rows
+        nn, kk = np.meshgrid(np.arange(n0, n1, dtype=np.int64), kk1, indexing="ij")
+        word, p = cdna4_position(nn, kk, K)
+        val = (q[n0:n1].astype(np.uint32) & 0xF) << (4 * p).astype(np.uint32)
+        for j in range(8):  # each word receives one nibble per p: disjoint bits, one pass per nibble index
+            m = p == j
+            out[word[m]] |= val[m]
+    return out.view(np.int16).reshape(N // 4, K)
 
 
 def unpack_cdna4(qweight) -> np.ndarray:
-    w = np.ascontiguousarray(np.asarray(qweight)).view(np.uint32).reshape(-1).astype(np.int64)
+    w = np.ascontiguousarray(np.asarray(qweight)).view(np.uint32).reshape(-1)
     N, K = qweight.shape[0] * 4, qweight.shape[1]
-    nn, kk = np.meshgrid(np.arange(N), np.arange(K), indexing="ij")
-    word, p = cdna4_position(nn, kk, K)
-    return ((w[word] >> (4 * p)) & 0xF).astype(np.uint8)
+    out = np.empty((N, K), dtype=np.uint8)
+    kk1 = np.arange(K, dtype=np.int64)
+    for n0, n1 in _row_chunks(N):
+        nn, kk = np.meshgrid(np.arange(n0, n1, dtype=np.int64), kk1, indexing="ij")
+        word, p = cdna4_position(nn, kk, K)
+        out[n0:n1] = ((w[word] >> (4 * p).astype(np.uint32)) & 0xF).astype(np.uint8)
+    return out
 
 
 def v2_to_cdna4(qweight_v2) -> np.ndarray:
     return pack_cdna4(unpack_v2(qweight_v2))
+
+
+def pack_sz_half(scales: torch.Tensor, scaled_zeros: torch.Tensor, K: int):
+    """THIS repository's "sz_half" side buffer of the decode kernels (no reference counterpart; DESIGN.md "f16-mantissa dequant"):
+    u32 [N/16][K/128][16] = {f16(s') | f16(sz) << 16} with s' = s for rows n % 4 < 2 and s / 16 for the others.
+    Returns (int32 array, exact) -- exact is False when a value is not representable as a normal f16 number (or 0)."""
+    G = K // 128
+    s = scales.float()[:G].t().contiguous()        # [N, G]
+    z = scaled_zeros.float()[:G].t().contiguous()
+    N = s.shape[0]
+    sp = torch.where((torch.arange(N) % 4 >= 2)[:, None], s * 0.0625, s)
+    sh, zh = sp.to(torch.float16), z.to(torch.float16)
+
+    def ok(v, h):
+        return bool(((h.float() == v) & ((v == 0) | (v.abs() >= 2.0 ** -14))).all())
+
+    exact = ok(sp, sh) and ok(z, zh)
+    lo = sh.view(torch.int16).numpy().view(np.uint16).astype(np.uint32)
+    hi = zh.view(torch.int16).numpy().view(np.uint16).astype(np.uint32)
+    packed = (lo | (hi << 16)).reshape(N // 16, 16, G).transpose(0, 2, 1)  # [slab][group][row in slab]
+    return np.ascontiguousarray(packed).view(np.int32), exact
 
 
 # --------------------------------------------------------------------------------------

@@ -1,0 +1,108 @@
+"""-m gpu: the decode entry point awq_w4a16_decode_cdna4 (LDS-DMA streaming kernel + f16-mantissa dequant, sz_half side buffer)
+against the oracle: every row count 1..8, ragged K splits (11008 = 86 groups), tiny and wide shapes, bias, the fused gate/up
+epilogues in both row arrangements, and the pack-time exactness check with its fallback."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import awq_oracle as O
+from tests.helpers import check_forward, make_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from llm_awq_amd import ops as o
+    o._capi.lib()
+    return o
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,K", [(16, 128), (48, 1280), (64, 11008), (256, 4096), (4096, 512), (6144, 4096), (4096, 14336)])
+def test_pack_szh_matches_oracle_and_decode_vs_oracle(ops, dtype, N, K):
+    c = make_case(N, K, dtype, seed=N + K, M=8, bias=True)
+    s, z = c["scales"].cuda(), c["scaled_zeros"].cuda()
+    szh, exact = ops.pack_szh_cdna4(s, z, K)
+    ref, ref_exact = O.pack_sz_half(c["scales"], c["scaled_zeros"], K)
+    assert exact and ref_exact
+    assert np.array_equal(szh.cpu().numpy(), ref)
+    c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
+    for M in (1, 2, 3, 4, 5, 7, 8):
+        x = c["x"][:M].contiguous()
+        for b in (None, c["bias"]):
+            y = ops.decode_cdna4(x.cuda(), c4, szh, b.cuda() if b is not None else None, 0)
+            check_forward(y.cpu(), x, c["q"], c["scales"], c["scaled_zeros"], dtype, bias=b)
+
+
+@pytest.mark.parametrize("knobs", [dict(gemvd_waves=4, gemvd_d=4), dict(gemvd_waves=8, gemvd_d=1), dict(gemvd_waves=8, gemvd_d=2),
+                                   dict(gemvd_waves=16, gemvd_d=1), dict(gemvd_waves=16, gemvd_d=2), dict(gemvd_waves=16, gemvd_d=4)])
+def test_decode_ring_configurations(ops, knobs):
+    """every compiled (waves, ring depth) incl. ragged step counts, waves with no steps, and the counted tail waits"""
+    try:
+        for (N, K) in [(64, 11008), (128, 4096), (48, 1280), (32, 128), (32, 14336)]:
+            for M in (1, 4, 8):
+                c = make_case(N, K, torch.bfloat16, seed=N + M, M=M, bias=True)
+                c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
+                szh, exact = ops.pack_szh_cdna4(c["scales"].cuda(), c["scaled_zeros"].cuda(), K)
+                assert exact
+                ops._capi.tune(**knobs)
+                y = ops.decode_cdna4(c["x"].cuda(), c4, szh, c["bias"].cuda(), 0)
+                check_forward(y.cpu(), c["x"], c["q"], c["scales"], c["scaled_zeros"], torch.bfloat16, bias=c["bias"])
+                # the same kernel on the T-typed sz_packed (the fallback for layers whose scales are not f16-exact)
+                szp = ops.pack_sz_cdna4(c["scales"].cuda(), c["scaled_zeros"].cuda(), K)
+                y2 = ops.gemm_cdna4(c["x"].cuda(), c4, c["scales"].cuda(), c["scaled_zeros"].cuda(), c["bias"].cuda(), szp)
+                check_forward(y2.cpu(), c["x"], c["q"], c["scales"], c["scaled_zeros"], torch.bfloat16, bias=c["bias"])
+                assert torch.equal(y, y2), "both dequant forms are exact: identical outputs"
+    finally:
+        ops._capi.tune(gemvd_waves=0, gemvd_d=0)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [1, 2, 4, 7, 8])
+@pytest.mark.parametrize("F,K", [(256, 768), (1376, 512), (64, 4096), (14336, 4096)])
+def test_fused_gate_up_both_arrangements(ops, dtype, M, F, K):
+    """epilogue 1 (stacked [gate; up]) and epilogue 2 (gate / up rows interleaved 8 + 8 per slab) == the reference's
+    QuantLlamaMLP sequence (fused_mlp.py:36-83): two GEMVs, F.silu, multiply, every op rounded to T."""
+    if F >= 4096 and M not in (1, 8):
+        pytest.skip("full-size case: M = 1 and 8 only")
+    cg = make_case(F, K, dtype, seed=F + K + M, M=M)
+    cu = make_case(F, K, dtype, seed=F + K + M + 1, M=M)
+    x = cg["x"]
+    g = O.wqlinear_forward(x, None, cg["scales"], cg["scaled_zeros"], None, 128, q_int=cg["q"])
+    u = O.wqlinear_forward(x, None, cu["scales"], cu["scaled_zeros"], None, 128, q_int=cu["q"])
+    ref = torch.nn.functional.silu(g) * u
+    # stacked
+    qgu = torch.cat([cg["qweight"], cu["qweight"]], 0).cuda()
+    s = torch.cat([cg["scales"], cu["scales"]], 1).cuda()
+    z = torch.cat([cg["scaled_zeros"], cu["scaled_zeros"]], 1).cuda()
+    szh, exact = ops.pack_szh_cdna4(s, z, K)
+    assert exact
+    y1 = ops.decode_cdna4(x.cuda(), ops.repack_v2_to_cdna4(qgu), szh, None, 1).cpu()
+    # interleaved: slab j = gate rows 8j..8j+7 then up rows 8j..8j+7 (packed v2 rows move in pairs: 4 logical rows each)
+    from llm_awq_amd.fused_mlp import interleave_gate_up
+    qi, si, zi = interleave_gate_up(cg["qweight"].cuda(), cu["qweight"].cuda(), cg["scales"].cuda(), cu["scales"].cuda(),
+                                    cg["scaled_zeros"].cuda(), cu["scaled_zeros"].cuda())
+    szh2, exact2 = ops.pack_szh_cdna4(si, zi, K)
+    assert exact2
+    y2 = ops.decode_cdna4(x.cuda(), ops.repack_v2_to_cdna4(qi), szh2, None, 2).cpu()
+    for y in (y1, y2):
+        rel = ((y.float() - ref.float()).norm() / ref.float().norm()).item()
+        assert rel <= 3e-3, rel   # three roundings to T deep; the exact-match fraction is the sharper check
+        assert (y == ref).float().mean() > 0.95
+    assert (y1 == y2).float().mean() > 0.99  # same math; only the split-K order inside a block differs
+
+
+def test_inexact_scales_are_flagged(ops):
+    """a bf16 scale below 2^-10 (s / 16 would be a subnormal f16) must be reported, and the T-typed path still serves it"""
+    c = make_case(32, 256, torch.bfloat16, seed=5, M=2)
+    s = c["scales"].clone()
+    s[0, 3] = 2.0 ** -12
+    sz = c["scaled_zeros"].clone()
+    sz[0, 3] = -(s[0, 3].float() * 7).to(torch.bfloat16)
+    szh, exact = ops.pack_szh_cdna4(s.cuda(), sz.cuda(), 256)
+    assert not exact and not O.pack_sz_half(s, sz, 256)[1]
+    c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
+    szp = ops.pack_sz_cdna4(s.cuda(), sz.cuda(), 256)
+    y = ops.gemm_cdna4(c["x"].cuda(), c4, s.cuda(), sz.cuda(), None, szp)
+    check_forward(y.cpu(), c["x"], c["q"], s, sz, torch.bfloat16)
