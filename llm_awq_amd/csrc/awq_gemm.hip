@@ -401,11 +401,8 @@ static int launch_gemm_t(const void* x, const void* qw, const void* s, const voi
   if (big) {
     const int tiles_m = (m + TM - 1) / TM, tiles_n = (n + TN - 1) / TN;
     auto kern = gemm_w4a16_256x256_kernel<DT, LAYOUT>;
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem256);
-      attr = true;
-    }
+    static LdsOptIn optin;  // per (kernel instantiation, device)
+    optin.ensure(reinterpret_cast<const void*>(kern), kSmem256);
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), kSmem256, st, (const uint16_t*)x, (const u32*)qw,
                        (const uint16_t*)s, (const uint16_t*)z, (uint16_t*)out, m, n, k, tiles_m, tiles_n);
     return 0;

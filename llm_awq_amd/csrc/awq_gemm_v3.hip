@@ -313,11 +313,8 @@ void launch_v3(const void* x, const void* qw, const void* szp, const void* bias,
   constexpr int smem_epi = 8 * 128 * (64 * NSL + 16);
   constexpr int smem = smem_main > smem_epi ? smem_main : smem_epi;
   const int tiles_m = (m + TM - 1) / TM, tiles_n = (n_end - n_begin + TN - 1) / TN;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cdna4_v3_kernel<DT, NSL>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr = true;
-  }
+  static LdsOptIn optin;  // per (kernel instantiation, device)
+  optin.ensure(reinterpret_cast<const void*>(gemm_cdna4_v3_kernel<DT, NSL>), smem);
   hipLaunchKernelGGL((gemm_cdna4_v3_kernel<DT, NSL>), dim3(tiles_m * tiles_n), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw,
                      (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end);
 }

@@ -411,13 +411,9 @@ void launch_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const 
       {gemm_cdna4_v4_kernel<F16, 0>, gemm_cdna4_v4_kernel<F16, 0>, gemm_cdna4_v4_kernel<F16, 0>, gemm_cdna4_v4_kernel<F16, 0>},
       {gemm_cdna4_v4_kernel<BF16, 0>, gemm_cdna4_v4_kernel<BF16, 0>, gemm_cdna4_v4_kernel<BF16, 0>, gemm_cdna4_v4_kernel<BF16, 0>}};
 #endif
-  static bool attr = false;
-  if (!attr) {
-    for (auto& row : kerns)
-      for (Kern kf : row) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr = true;
-  }
   const Kern kern = kerns[dtype == 0 ? 0 : 1][g_v4_probe >= 0 && g_v4_probe <= 3 ? g_v4_probe : 0];
+  static LdsOptIn optin[2][4];  // per (kernel, device)
+  optin[dtype == 0 ? 0 : 1][g_v4_probe >= 0 && g_v4_probe <= 3 ? g_v4_probe : 0].ensure(reinterpret_cast<const void*>(kern), smem);
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw,
                      (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end);
 }
@@ -432,12 +428,9 @@ int launch_moe_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, con
   constexpr int smem_main = 2 * kTileX + 2 * kTileW;
   constexpr int smem_epi = 8 * 128 * (2 * WN + 16);
   constexpr int smem = smem_main > smem_epi ? smem_main : smem_epi;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(moe_gemm_cdna4_v4_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(moe_gemm_cdna4_v4_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr = true;
-  }
+  static LdsOptIn optin[2];  // per (kernel, device)
+  optin[0].ensure(reinterpret_cast<const void*>(moe_gemm_cdna4_v4_kernel<F16>), smem);
+  optin[1].ensure(reinterpret_cast<const void*>(moe_gemm_cdna4_v4_kernel<BF16>), smem);
   const int row_tiles = total / TM + experts, tiles_n = (n + TN - 1) / TN;
   auto mkern = dtype == 0 ? moe_gemm_cdna4_v4_kernel<F16> : moe_gemm_cdna4_v4_kernel<BF16>;
   hipLaunchKernelGGL(mkern, dim3(row_tiles * tiles_n), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw,

@@ -471,12 +471,8 @@ void launch_gemm_cdna4_v4n(const void* x, const void* qw, const void* szp, const
   static const Kern kerns[2][2][2] = {  // [dtype][split][partial]
       {{gemm_cdna4_v4n_kernel<F16, 0, 0>, gemm_cdna4_v4n_kernel<F16, 0, 1>}, {gemm_cdna4_v4n_kernel<F16, 1, 0>, gemm_cdna4_v4n_kernel<F16, 1, 1>}},
       {{gemm_cdna4_v4n_kernel<BF16, 0, 0>, gemm_cdna4_v4n_kernel<BF16, 0, 1>}, {gemm_cdna4_v4n_kernel<BF16, 1, 0>, gemm_cdna4_v4n_kernel<BF16, 1, 1>}}};
-  static bool attr = false;
-  if (!attr) {
-    for (int a = 0; a < 8; ++a)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[a >> 2][(a >> 1) & 1][a & 1]), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr = true;
-  }
+  static LdsOptIn optin[8];  // per (kernel, device)
+  for (int a = 0; a < 8; ++a) optin[a].ensure(reinterpret_cast<const void*>(kerns[a >> 2][(a >> 1) & 1][a & 1]), smem);
   const int dt = dtype == 0 ? 0 : 1, partial = m <= TM - 32 ? 1 : 0;  // a whole 32-row fragment of the single row tile is empty
   const int ks = gemm_v4n_ksplit(m, n_end - n_begin, k);
   const size_t need = ks > 1 ? (size_t)tiles_m * tiles_n * ks * TM * TN * 4 : 0;

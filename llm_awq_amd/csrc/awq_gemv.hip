@@ -253,13 +253,8 @@ static void launch_one(const void* x, const void* qw, const void* s, const void*
   const size_t smem = (size_t)WAVES * 1024 + (size_t)m * (2 * seg * kGroup + 16);
   dim3 grid((n + 15) / 16), block(64 * WAVES);
   auto kern = gemv_w4a16_kernel<DT, PF, WAVES, LAYOUT, SZP, PROBE>;
-  if (smem > 64 * 1024) {
-    static bool done = false;  // per instantiation
-    if (!done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      done = true;
-    }
-  }
+  static LdsOptIn optin;  // per (kernel instantiation, device)
+  if (smem > 64 * 1024) optin.ensure(reinterpret_cast<const void*>(kern));
   hipLaunchKernelGGL(kern, grid, block, smem, st, (const uint16_t*)x, (const u32*)qw, (const uint16_t*)s,
                      (const uint16_t*)z, (const u32*)szp, (uint16_t*)out, m, n, k, (int)seg);
 }

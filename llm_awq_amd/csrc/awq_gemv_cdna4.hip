@@ -336,13 +336,8 @@ static void launch_cfg(const void* x, const void* qw, const void* szp, const voi
   constexpr int NS = EPI == 1 ? 2 : 1;
   const size_t smem = (size_t)NS * WAVES * 1024 + (size_t)WAVES * S * m * 256;
   auto kern = gemv_cdna4_kernel<DT, WAVES, S, MB, EPI, BITS, PIPE>;
-  if (smem > 64 * 1024) {
-    static bool done = false;
-    if (!done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      done = true;
-    }
-  }
+  static LdsOptIn optin;  // per (kernel instantiation, device)
+  if (smem > 64 * 1024) optin.ensure(reinterpret_cast<const void*>(kern));
   hipLaunchKernelGGL(kern, dim3(n / 16 / NS), dim3(64 * WAVES), smem, st, (const uint16_t*)x, (const u32*)qw,
                      (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k);
 }
@@ -422,7 +417,8 @@ int launch_gemv_cdna4_norm(const void* x, const void* gamma, float eps, const vo
 #define AWQ_NCASE(DT_, W_, S_, E_)                                                                                       \
   if (c.waves == W_ && ps == S_ && epi == E_) {                                                                          \
     auto kern = gemv_cdna4_norm_kernel<DT_, W_, S_, E_>;                                                                 \
-    if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    static LdsOptIn optin;                                                                                                \
+    if (smem > 64 * 1024) optin.ensure(reinterpret_cast<const void*>(kern));                                             \
     hipLaunchKernelGGL(kern, dim3(n / 16 / ns), dim3(64 * W_), smem, st, (const uint16_t*)x, (const uint16_t*)gamma, (const u32*)qw, \
                        (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k, eps);                            \
     return 0;                                                                                                            \

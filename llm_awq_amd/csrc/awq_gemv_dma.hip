@@ -39,6 +39,13 @@ __device__ __forceinline__ void dma_to_lds(const __amdgpu_buffer_rsrc_t& rsrc, c
   if constexpr (SIZE == 4 && AUX == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, DMA_LDS_PTR(dst), 4, voff, soff, 0, 0);
 #endif
 }
+// timing probes (builds with AWQ_PROBES=1 only; wrong results): bit 0 = no math (stream only), bit 1 = no weight DMA and no
+// waits for it (math only, on whatever the ring holds)
+#ifdef AWQ_ENABLE_PROBES
+#define DMA_PROBE(p) (p)
+#else
+#define DMA_PROBE(p) 0
+#endif
 template <int N_>
 __device__ __forceinline__ void dma_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N_) : "memory");
@@ -56,8 +63,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <typename DT, int WAVES, int D, int DQ, int EPI>
 __global__ __launch_bounds__(64 * WAVES) void gemv_dma_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                                const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
-                                                               uint16_t* __restrict__ out, int M, int N, int K, int TX) {
+                                                               uint16_t* __restrict__ out, int M, int N, int K, int TX, int probe_) {
   constexpr int NS = EPI == 1 ? 2 : 1;
+  const int probe = DMA_PROBE(probe_);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, g = lane >> 4;
@@ -91,6 +99,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_dma_kernel(const uint16_t* __
 
   auto issue = [&](int t, int slot) {  // weight tile(s) of local step t into ring slot `slot`
     const u32 kg = (u32)min(s0 + t, nit - 1);  // steps past the end (ragged K split) re-read the last tile; their math is skipped
+    if (probe & 2) return;
 #pragma unroll
     for (int s = 0; s < NS; ++s)
       dma_to_lds<16, 2>(rw, ring + (slot * NS + s) * 1024, lane16, (slab_tile[s] + kg) * 1024u);
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_dma_kernel(const uint16_t* __
     u32x4 w[NS], xo[4];
     u32 sz[NS];
     const u32 ra = ring_lane + slot * (NS * 1024), sa = sz_lane + t * 64, xa = x_lane + t * 256;
-    dma_wait_vm<VM>();
+    if (!(probe & 2)) dma_wait_vm<VM>();
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       if (s == 0) asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(w[s]) : "v"(ra) : "memory");
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_dma_kernel(const uint16_t* __
                    :
                    : "memory");
     if (REISSUE) issue(t + D, slot);  // the slot's bytes are in registers: refill it for step t + D
-    if (s0 + t < nit) {
+    if (s0 + t < nit && !(probe & 1)) {
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         vec8 op[4];
@@ -213,7 +222,7 @@ struct DmaCfg {
   int waves, tx, d;
   size_t smem;
 };
-int g_dma_waves = 0, g_dma_d = 0;
+int g_dma_waves = 0, g_dma_d = 0, g_dma_probe = 0;
 
 size_t dma_smem(int waves, int d, int ns, int tx, int m) {
   const int txp = (tx + 3) & ~3;
@@ -223,23 +232,28 @@ size_t dma_smem(int waves, int d, int ns, int tx, int m) {
 // K split and ring depth: as many tiles in flight per CU as LDS allows (<= ~150 KiB per CU over the blocks that share it),
 // every wave at least 2 steps
 bool pick_dma(int m, int n_rows, int k, int ns, DmaCfg& c) {
+  // measured on MI355X (tools/gemvd_sweep.py, tools/gemvd_probe.py; profiles/r02_gemvd_*): few waves with a deep ring when many
+  // slabs share a CU (gate/up: 4 waves x 8 tiles), 8 waves x 2..4 tiles for 1..2 slabs per CU, 16 waves x 1..2 for a long K
   const int nit = k / kGroup, slabs = n_rows / 16 / ns;
-  int waves = nit >= 112 ? 16 : 8;
-  if (slabs <= 256 && nit >= 32) waves = 16;  // one block per CU: more waves hide the per-tile chain
-  if (g_dma_waves) waves = g_dma_waves;
-  while (waves > 1 && waves > nit) waves >>= 1;
-  const int tx = (nit + waves - 1) / waves;
   const double blocks_per_cu = (double)slabs / 256.0;
+  int waves = nit >= 96 ? 16 : (blocks_per_cu > 3.0 ? 4 : 8);
+  if (g_dma_waves) waves = g_dma_waves;
+  while (waves > 4 && waves > nit) waves >>= 1;  // (waves beyond the step count idle: their steps are clamped and skipped)
+  int want = blocks_per_cu <= 1.0 ? 1 : (blocks_per_cu <= 2.0 ? 2 : (blocks_per_cu <= 3.0 ? 3 : 4));
+  if (waves == 4 && want > 3) want = 3;  // three deep-ring blocks per CU beat four shallow ones (gate/up: 14.8 vs 15.1 us)
+  // x staging is m * k * 2 bytes per block whatever the wave count: when it crowds out the ring, fewer, longer waves
+  while (waves > 4 && dma_smem(waves, 1, ns, (nit + waves - 1) / waves, m) > 150 * 1024) waves >>= 1;
+  const int tx = (nit + waves - 1) / waves;
   int d = tx < 8 ? tx : 8;
+  if (waves == 16 && !g_dma_d) d = 1;            // 16 waves per block already keep 16+ KiB per CU in flight (8.2 vs 8.7 us at d = 2)
+  if (waves == 8 && !g_dma_d && d > 2) d = 2;
   if (g_dma_d) d = g_dma_d < tx ? g_dma_d : tx;
   // LDS: blocks that want to be co-resident on a CU must fit in 160 KiB
-  const int want = blocks_per_cu <= 1.0 ? 1 : (blocks_per_cu <= 2.0 ? 2 : (blocks_per_cu <= 3.0 ? 3 : 4));
   while (d > 1 && dma_smem(waves, d, ns, tx, m) * want > 156 * 1024) --d;
   // compiled ring depths: 1, 2, 4, 8 (7 with 16 waves: K = 14336)
   if (d == 3) d = 2;
   if (d == 5 || d == 6 || (d == 7 && waves != 16)) d = 4;
   if (d == 8 && waves == 16) d = 7;
-  if (waves == 4 && d < 4) return false;
   c = {waves, tx, d, dma_smem(waves, d, ns, tx, m)};
   return c.smem <= 160 * 1024 && tx >= d;
 }
@@ -248,6 +262,7 @@ bool pick_dma(int m, int n_rows, int k, int ns, DmaCfg& c) {
 int gemv_dma_tune_set(const char* key, int value) {
   if (!strcmp(key, "gemvd_waves")) g_dma_waves = value;
   else if (!strcmp(key, "gemvd_d")) g_dma_d = value;
+  else if (!strcmp(key, "gemvd_probe")) g_dma_probe = value;
   else return -1;
   return 0;
 }
@@ -260,7 +275,7 @@ static void launch_dma_cfg(const void* x, const void* qw, const void* szp, const
   static LdsOptIn optin;
   if (c.smem > 64 * 1024) optin.ensure(reinterpret_cast<const void*>(kern));
   hipLaunchKernelGGL(kern, dim3(n / 16 / NS), dim3(64 * WAVES), c.smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp,
-                     (const uint16_t*)bias, (uint16_t*)out, m, n, k, c.tx);
+                     (const uint16_t*)bias, (uint16_t*)out, m, n, k, c.tx, g_dma_probe);
 }
 
 template <typename DT, int EPI, int DQ>
@@ -275,15 +290,32 @@ static int launch_dma_dt(const void* x, const void* qw, const void* szp, const v
   }
   AWQ_DCASE(8, 1) AWQ_DCASE(8, 2) AWQ_DCASE(8, 4) AWQ_DCASE(8, 8)
   AWQ_DCASE(16, 1) AWQ_DCASE(16, 2) AWQ_DCASE(16, 4) AWQ_DCASE(16, 7)
-  AWQ_DCASE(4, 4) AWQ_DCASE(4, 8)
+  AWQ_DCASE(4, 1) AWQ_DCASE(4, 2) AWQ_DCASE(4, 4) AWQ_DCASE(4, 8)
 #undef AWQ_DCASE
   return -1;
 }
 
-// epi as in the kernel header; returns -1 if the shape is not served (the caller falls back to awq_gemv_cdna4.hip)
+// epi as in the kernel header; returns -1 if the shape is not served.  The kernel stages every row's x slice in LDS up front
+// (m * k * 2 bytes per block): when m rows do not fit (m * k > ~50 k elements: batched decode against K >= 8 k) the rows are
+// served in chunks of as many rows as do fit, each chunk re-streaming the weights -- as the reference's GEMV does per row
+// (gemv_cuda.cu:187-208 loops over the batch inside one weight pass; here the LDS budget decides).
 int launch_gemv_dma(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int epi,
                     int dtype, int szfmt, hipStream_t st) {
   if (m < 1 || m > 8 || (k % 128) != 0 || (n % (epi == 1 ? 32 : 16)) != 0) return -1;
+  DmaCfg probe_cfg;
+  int mc = m;
+  while (mc > 1 && !pick_dma(mc, n, k, epi == 1 ? 2 : 1, probe_cfg)) --mc;
+  if (mc < m) {
+    if (!pick_dma(mc, n, k, epi == 1 ? 2 : 1, probe_cfg)) return -1;
+    const size_t ncols = epi ? (size_t)n / 2 : (size_t)n;
+    for (int r = 0; r < m; r += mc) {
+      const int rows = m - r < mc ? m - r : mc;
+      const int rc = launch_gemv_dma((const char*)x + (size_t)r * k * 2, qw, szp, bias, (char*)out + (size_t)r * ncols * 2, rows, n, k, epi,
+                                     dtype, szfmt, st);
+      if (rc != 0) return rc;
+    }
+    return 0;
+  }
 #define AWQ_DDT(DT_, DQ_)                                                                   \
   if (epi == 0) return launch_dma_dt<DT_, 0, DQ_>(x, qw, szp, bias, out, m, n, k, st);     \
   if (epi == 1) return launch_dma_dt<DT_, 1, DQ_>(x, qw, szp, bias, out, m, n, k, st);     \

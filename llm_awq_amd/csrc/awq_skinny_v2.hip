@@ -155,13 +155,8 @@ static void launch_skinny_v2(const void* x, const void* qw, const void* s, const
   const size_t xbytes = (size_t)WAVES * 16 * CB * 256, rbytes = (size_t)WAVES * NS * CB * 1024;
   const size_t smem = xbytes > rbytes ? xbytes : rbytes;
   auto kern = skinny_v2_kernel<DT, WAVES, NS, CB>;
-  if (smem > 64 * 1024) {
-    static bool done = false;
-    if (!done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      done = true;
-    }
-  }
+  static LdsOptIn optin;  // per (kernel instantiation, device)
+  if (smem > 64 * 1024) optin.ensure(reinterpret_cast<const void*>(kern));
   const int nslab = n / 16;
   hipLaunchKernelGGL(kern, dim3((nslab + NS - 1) / NS), dim3(64 * WAVES), smem, st, (const uint16_t*)x, (const u32*)qw,
                      (const uint16_t*)s, (const uint16_t*)z, (const uint16_t*)bias, (uint16_t*)out, m, n, k, gpad);

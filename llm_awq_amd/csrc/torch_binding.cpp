@@ -58,67 +58,135 @@ void check_inputs(const torch::Tensor& x, const torch::Tensor& kernel, const tor
 // Cost: a second packed copy of the weights (N*K/2 + N*K/32 bytes).  AWQ_CDNA4_AUTOCACHE=0 disables it.  While the stream is
 // being captured into a hipGraph nothing is built (no allocations inside a capture): entries made by a warm-up call are used.
 // ---------------------------------------------------------------------------------------------------------------
+// One entry per qweight tensor: the permuted weights (the expensive part: N*K/2 bytes) are tied to the qweight's identity and
+// version ONLY.  The packed scale buffers (3 % of that) hang off the entry in two slots keyed by the (scales, zeros) pair they
+// were built from: tinychat's QuantLlamaMLP passes the module's scaled_zeros on its decode branch and a FRESH temporary
+// (`scaled_zeros - 8 * scales`, fused_mlp.py:69,76) on every prefill call -- the temporary re-packs 1-2 MB of scales into the
+// least recently used slot, never the weights, and the decode pair keeps hitting its own slot.
+inline uint32_t tensor_version(const torch::Tensor& t) { return t.is_inference() ? 0u : (uint32_t)t._version(); }
+struct SzSlot {
+  c10::weak_intrusive_ptr<c10::TensorImpl> s, z;
+  uint32_t vs = 0, vz = 0;
+  at::Tensor szp, szh;  // sz_packed (T) and sz_half (decode; undefined when the layer's scales are not f16-exact)
+  uint64_t stamp = 0;
+  SzSlot() : s(c10::weak_intrusive_ptr<c10::TensorImpl>(c10::intrusive_ptr<c10::TensorImpl>())), z(s) {}
+};
 struct CacheEntry {
-  c10::weak_intrusive_ptr<c10::TensorImpl> w, s, z;
-  uint32_t vw, vs, vz;
-  at::Tensor c4, szp;
-  CacheEntry(const torch::Tensor& tw, const torch::Tensor& ts, const torch::Tensor& tz)
-      : w(tw.getIntrusivePtr()), s(ts.getIntrusivePtr()), z(tz.getIntrusivePtr()), vw(tw._version()), vs(ts._version()),
-        vz(tz._version()) {}
+  c10::weak_intrusive_ptr<c10::TensorImpl> w;
+  uint32_t vw;
+  at::Tensor c4;
+  SzSlot slot[2];
+  hipEvent_t built = nullptr;  // recorded on the building stream; other streams wait for it until it has completed
+  hipStream_t build_stream = nullptr;
+  bool settled = false;
+  explicit CacheEntry(const torch::Tensor& tw) : w(tw.getIntrusivePtr()), vw(tensor_version(tw)) {}
 };
 std::mutex g_cache_mu;
 std::unordered_map<const void*, CacheEntry> g_cache;
 int g_cache_enabled = -1;
-int64_t g_cache_hits = 0, g_cache_builds = 0;
+int64_t g_cache_hits = 0, g_cache_builds = 0, g_cache_sz_builds = 0, g_cache_bytes = 0, g_cache_max_bytes = -1;
+uint64_t g_cache_clock = 0;
 
 bool cache_enabled() {
   if (g_cache_enabled < 0) {
     const char* e = std::getenv("AWQ_CDNA4_AUTOCACHE");
     g_cache_enabled = (e && e[0] == '0') ? 0 : 1;
   }
+  if (g_cache_max_bytes < 0) {  // AWQ_CDNA4_AUTOCACHE_MAX_GB bounds the second copy of the weights (0 / unset = unbounded)
+    const char* e = std::getenv("AWQ_CDNA4_AUTOCACHE_MAX_GB");
+    g_cache_max_bytes = e ? (int64_t)(std::atof(e) * (double)(1ull << 30)) : 0;
+  }
   return g_cache_enabled == 1;
 }
 
-// returns true and fills (c4, szp) when the cdna4 kernels can serve this call
+void drop_entry(std::unordered_map<const void*, CacheEntry>::iterator it) {
+  if (it->second.c4.defined()) g_cache_bytes -= (int64_t)it->second.c4.nbytes();
+  if (it->second.built) (void)hipEventDestroy(it->second.built);
+  g_cache.erase(it);
+}
+
+// returns true and fills (c4, szp, szh) when the cdna4 kernels can serve this call (szh stays undefined if the scales are not f16-exact)
 bool cdna4_view(const torch::Tensor& kernel, const torch::Tensor& scales, const torch::Tensor& zeros, int64_t n, int64_t k,
-                hipStream_t stream, at::Tensor& c4, at::Tensor& szp) {
+                hipStream_t stream, at::Tensor& c4, at::Tensor& szp, at::Tensor* szh = nullptr) {
   if (!cache_enabled() || kernel.scalar_type() != at::kShort ||
       (scales.scalar_type() != at::kBFloat16 && scales.scalar_type() != at::kHalf))
     return false;
   if (n % 16 != 0 || k % 128 != 0 || kernel.numel() != n / 4 * k) return false;
-  // inside a hipGraph capture nothing may be allocated or re-packed: an entry built by an earlier (warm-up) call is used,
-  // a first call falls back to the reference-layout kernels
+  // inside a hipGraph capture the weights are never re-packed (an entry built by an earlier warm-up call is used, a first call
+  // falls back to the reference-layout kernels); the small scale buffers may be (torch's allocator is capture-safe)
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   const bool capturing = hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
   std::lock_guard<std::mutex> lock(g_cache_mu);
   const void* key = kernel.data_ptr();
   auto it = g_cache.find(key);
   if (it != g_cache.end()) {
-    CacheEntry& e = it->second;
-    auto lw = e.w.lock(), ls = e.s.lock(), lz = e.z.lock();
-    if (lw.get() == kernel.unsafeGetTensorImpl() && ls.get() == scales.unsafeGetTensorImpl() &&
-        lz.get() == zeros.unsafeGetTensorImpl() && e.vw == kernel._version() && e.vs == scales._version() &&
-        e.vz == zeros._version()) {
-      c4 = e.c4;
-      szp = e.szp;
-      ++g_cache_hits;
-      return true;
+    auto lw = it->second.w.lock();
+    if (lw.get() != kernel.unsafeGetTensorImpl() || it->second.vw != tensor_version(kernel)) {  // address re-used or edited in place
+      if (capturing) return false;
+      drop_entry(it);
+      it = g_cache.end();
     }
-    if (capturing) return false;
-    g_cache.erase(it);
   }
-  if (capturing) return false;
-  // drop entries whose tensors died (keeps the map from growing when models are reloaded)
-  for (auto i2 = g_cache.begin(); i2 != g_cache.end();) i2 = i2->second.w.expired() ? g_cache.erase(i2) : std::next(i2);
-  CacheEntry e(kernel, scales, zeros);
-  e.c4 = torch::empty_like(kernel);
-  e.szp = torch::empty({n / 16, k / 128, 16}, scales.options().dtype(at::kInt));
-  if (awq_repack_v2_to_cdna4(kernel.data_ptr(), e.c4.data_ptr(), (int)n, (int)k, (void*)stream) != AWQ_OK) return false;
-  if (awq_pack_sz_cdna4(scales.data_ptr(), zeros.data_ptr(), e.szp.data_ptr(), (int)n, (int)k, (void*)stream) != AWQ_OK) return false;
+  if (it == g_cache.end()) {
+    if (capturing) return false;
+    // drop entries whose qweight died or was re-pointed (keeps the map from growing when models are reloaded)
+    for (auto i2 = g_cache.begin(); i2 != g_cache.end();) {
+      auto cur = i2++;
+      auto lw = cur->second.w.lock();
+      if (!lw || lw->storage().data() != cur->first) drop_entry(cur);
+    }
+    const int64_t need = (int64_t)kernel.nbytes();
+    if (g_cache_max_bytes > 0 && g_cache_bytes + need > g_cache_max_bytes) return false;  // over budget: reference-layout kernels
+    CacheEntry e(kernel);
+    e.c4 = torch::empty_like(kernel);
+    if (awq_repack_v2_to_cdna4(kernel.data_ptr(), e.c4.data_ptr(), (int)n, (int)k, (void*)stream) != AWQ_OK) return false;
+    if (hipEventCreateWithFlags(&e.built, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(e.built, stream);
+    e.build_stream = stream;
+    g_cache_bytes += need;
+    ++g_cache_builds;
+    it = g_cache.emplace(key, std::move(e)).first;
+  }
+  CacheEntry& e = it->second;
+  if (!e.settled && e.built) {
+    if (stream != e.build_stream && !capturing) (void)hipStreamWaitEvent(stream, e.built, 0);  // the copy was made on another stream
+    if (!capturing && hipEventQuery(e.built) == hipSuccess) e.settled = true;
+  }
+  // ---- the scale side buffers ----
+  SzSlot* hit = nullptr;
+  for (SzSlot& sl : e.slot) {
+    auto ls = sl.s.lock(), lz = sl.z.lock();
+    if (sl.szp.defined() && ls.get() == scales.unsafeGetTensorImpl() && lz.get() == zeros.unsafeGetTensorImpl() &&
+        sl.vs == tensor_version(scales) && sl.vz == tensor_version(zeros))
+      hit = &sl;
+  }
+  if (hit == nullptr) {
+    SzSlot& sl = e.slot[0].stamp <= e.slot[1].stamp ? e.slot[0] : e.slot[1];
+    at::Tensor nszp = torch::empty({n / 16, k / 128, 16}, scales.options().dtype(at::kInt));
+    if (awq_pack_sz_cdna4(scales.data_ptr(), zeros.data_ptr(), nszp.data_ptr(), (int)n, (int)k, (void*)stream) != AWQ_OK) return false;
+    at::Tensor nszh;
+    if (!capturing) {  // the exactness flag is read back once: not inside a capture (decode then uses sz_packed)
+      at::Tensor h = torch::empty({n / 16, k / 128, 16}, scales.options().dtype(at::kInt));
+      at::Tensor flag = torch::zeros({1}, scales.options().dtype(at::kInt));
+      if (awq_pack_szh_cdna4(scales.data_ptr(), zeros.data_ptr(), h.data_ptr(), (int*)flag.data_ptr(), (int)n, (int)k,
+                             scales.scalar_type() == at::kHalf ? AWQ_F16 : AWQ_BF16, (void*)stream) == AWQ_OK &&
+          flag.item<int>() == 0)
+        nszh = h;
+    }
+    sl.s = c10::weak_intrusive_ptr<c10::TensorImpl>(scales.getIntrusivePtr());
+    sl.z = c10::weak_intrusive_ptr<c10::TensorImpl>(zeros.getIntrusivePtr());
+    sl.vs = tensor_version(scales);
+    sl.vz = tensor_version(zeros);
+    sl.szp = nszp;
+    sl.szh = nszh;
+    hit = &sl;
+    ++g_cache_sz_builds;
+  } else {
+    ++g_cache_hits;
+  }
+  hit->stamp = ++g_cache_clock;
   c4 = e.c4;
-  szp = e.szp;
-  g_cache.emplace(key, std::move(e));
-  ++g_cache_builds;
+  szp = hit->szp;
+  if (szh) *szh = hit->szh;
   return true;
 }
 
@@ -150,10 +218,14 @@ torch::Tensor gemv_forward_cuda_new(torch::Tensor in_feats, torch::Tensor kernel
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(in_feats.device());
   at::Tensor out = torch::empty(shape, in_feats.options());
   auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
-  at::Tensor c4, szp;
-  if (cdna4_view(kernel, scaling_factors, zeros, n, k, stream, c4, szp)) {
-    raise_on(awq_w4a16_forward_cdna4(in_feats.data_ptr(), c4.data_ptr(), scaling_factors.data_ptr(), zeros.data_ptr(), szp.data_ptr(),
-                                     nullptr, out.data_ptr(), m, n, k, group_size, dtype_code(in_feats), nullptr, 0, (void*)stream));
+  at::Tensor c4, szp, szh;
+  if (cdna4_view(kernel, scaling_factors, zeros, n, k, stream, c4, szp, &szh)) {
+    if (szh.defined())
+      raise_on(awq_w4a16_decode_cdna4(in_feats.data_ptr(), c4.data_ptr(), szh.data_ptr(), nullptr, out.data_ptr(), m, n, k, group_size,
+                                      dtype_code(in_feats), 0, (void*)stream));
+    else
+      raise_on(awq_w4a16_forward_cdna4(in_feats.data_ptr(), c4.data_ptr(), scaling_factors.data_ptr(), zeros.data_ptr(), szp.data_ptr(),
+                                       nullptr, out.data_ptr(), m, n, k, group_size, dtype_code(in_feats), nullptr, 0, (void*)stream));
     return out;
   }
   raise_on(awq_w4a16_gemv(in_feats.data_ptr(), kernel.data_ptr(), scaling_factors.data_ptr(), zeros.data_ptr(),
@@ -409,11 +481,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("cdna4_cache_info", []() {
     std::lock_guard<std::mutex> lock(g_cache_mu);
     return py::dict(py::arg("enabled") = cache_enabled(), py::arg("entries") = (int64_t)g_cache.size(), py::arg("hits") = g_cache_hits,
-                    py::arg("builds") = g_cache_builds);
+                    py::arg("builds") = g_cache_builds, py::arg("sz_builds") = g_cache_sz_builds, py::arg("bytes") = g_cache_bytes);
   }, "state of the lazy v2 -> cdna4 weight cache behind gemv/gemm_forward_cuda_new");
   m.def("cdna4_cache_clear", []() {
     std::lock_guard<std::mutex> lock(g_cache_mu);
-    g_cache.clear();
+    while (!g_cache.empty()) drop_entry(g_cache.begin());
   });
   m.def("cdna4_cache_enable", [](bool on) { g_cache_enabled = on ? 1 : 0; });
   // extras of the MI355X build (not part of the reference module)

@@ -106,3 +106,25 @@ def test_warm_entry_is_used_inside_a_capture(eng):
     info1 = eng.cdna4_cache_info()
     assert info1["entries"] == 1 and info1["hits"] == info0["hits"] + 1 and info1["builds"] == info0["builds"]
     assert torch.equal(yg, y0)
+
+
+def test_temporary_zeros_rebuild_only_the_scale_buffer(eng):
+    """tinychat's QuantLlamaMLP passes the module's scaled_zeros when decoding and a FRESH `scaled_zeros - 8 * scales` tensor on
+    every prefill call (fused_mlp.py:69,76): the weights must be re-packed once, only the 3 %-sized scale buffer per temporary,
+    and the decode pair must keep hitting its own slot."""
+    N, K = 512, 1024
+    c = make_case(N, K, torch.bfloat16, seed=11, M=64)
+    qw, s, z = _dev(c)
+    xd, xp = c["x"][:2].contiguous(), c["x"]
+    eng.cdna4_cache_clear()
+    b0 = eng.cdna4_cache_info()
+    for it in range(4):
+        yd = eng.gemv_forward_cuda_new(xd.cuda(), qw, s, z, 2, N, K, 128).cpu()
+        check_forward(yd, xd, c["q"], c["scales"], c["scaled_zeros"], torch.bfloat16)
+        ztmp = z - 8 * s  # a new tensor every call
+        yp = eng.gemm_forward_cuda_new(xp.cuda(), qw, s, ztmp).cpu()
+        check_forward(yp, xp, c["q"], c["scales"], ztmp.cpu(), torch.bfloat16)
+    info = eng.cdna4_cache_info()
+    assert info["builds"] == b0["builds"] + 1, info          # the weights: once
+    assert info["sz_builds"] == b0["sz_builds"] + 1 + 4, info  # the module's pair once, one per temporary
+    assert info["entries"] == 1
