@@ -93,12 +93,23 @@ class TPWQLinear(nn.Module):
         self.world = world if world is not None else dist.get_world_size(group)
         self.rank = rank if rank is not None else dist.get_rank(group)
         self.in_features, self.out_features = full.in_features, full.out_features
+        # the slicing below is defined on the REFERENCE (v2) interleave, where a K cut at a multiple of 64 / an N cut at a multiple
+        # of 4 is a plain column / row slice of the int16 buffer; the cdna4 and w3c tilings permute across those cuts
+        if getattr(full, "w_bit", 4) != 4:
+            raise NotImplementedError("tensor-parallel sharding is defined for w_bit = 4 (v2 buffers); shard before packing W3 tiles")
+        relayout = getattr(full, "layout", "v2") == "cdna4"
+        if relayout:
+            full.to_v2()
         fn = shard_row_parallel if mode == "row" else shard_column_parallel
         qw, s, z, self.bounds = fn(full.qweight, full.scales, full.scaled_zeros, self.world, self.rank)
         k_local = qw.shape[1]
         n_local = qw.shape[0] * 4
         self.shard = WQLinear(full.w_bit, full.group_size, k_local, n_local, False, qw.device, dtype=s.dtype)
         self.shard.qweight, self.shard.scales, self.shard.scaled_zeros = qw, s, z
+        if relayout:
+            full.to_cdna4()
+            if n_local % 16 == 0 and k_local % 128 == 0 and self.shard.group_size == 128:
+                self.shard.to_cdna4()  # the shard runs the same kernels the unsharded module did
         if full.bias is None:
             self.bias = None
         else:
