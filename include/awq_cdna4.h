@@ -185,9 +185,11 @@ int awq_w3a16_forward(const void* x, const void* qweight_w3, const void* scales,
                       const void* sz_packed, const void* bias, void* out, int m, int n, int k, int group_size, int dtype,
                       void* workspace, size_t workspace_bytes, void* stream);
 
-/* Tuning hook for experiments and benchmarks (not part of the reference surface): integer knobs such as
- * "gemv_waves", "gemv_unroll", "gemv_xmode", "gemv_stream_only", "gemm_variant"; 0 restores the default
- * heuristic.  Returns AWQ_OK or AWQ_ERR_SHAPE for an unknown key. Process-global, not thread-safe. */
+/* Tuning hook for tests, experiments and benchmarks (not part of the reference surface): integer knobs that force one of the
+ * shipped code paths ("gemm_variant", "gemm_splitk", "gemv_dma", "gemvd_waves", ...) so that tests can cover each of them; 0
+ * restores the default heuristic.  A default process cannot reach it: unless AWQ_TUNING=1 is set in the environment every
+ * call returns AWQ_ERR_SHAPE and changes nothing.  Timing probes and experiment-only kernel instantiations exist only in
+ * builds made with AWQ_PROBES=1.  Returns AWQ_OK, or AWQ_ERR_SHAPE for an unknown key.  Process-global, not thread-safe. */
 int awq_tune_set(const char* key, int value);
 
 #ifdef __cplusplus

@@ -82,6 +82,7 @@ def check(status: int) -> None:
 
 
 def tune(**knobs) -> None:
-    """awq_tune_set for each knob (experiments / benchmarks only)."""
+    """awq_tune_set for each knob (tests, experiments and benchmarks only: opts this process in with AWQ_TUNING=1)."""
+    os.environ["AWQ_TUNING"] = "1"
     for k, v in knobs.items():
         check(lib().awq_tune_set(k.encode(), int(v)))

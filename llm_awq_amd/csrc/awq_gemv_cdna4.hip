@@ -360,11 +360,16 @@ static int launch_mb(const void* x, const void* qw, const void* szp, const void*
     return 0;                                                                  \
   }
     AWQ_PCASE(4, 1, 2) AWQ_PCASE(4, 2, 2) AWQ_PCASE(8, 1, 2) AWQ_PCASE(8, 2, 2) AWQ_PCASE(16, 1, 2) AWQ_PCASE(16, 2, 2)
+#ifdef AWQ_ENABLE_PROBES
     if constexpr (BITS == 4 && EPI == 0 && DT::id == 1) {
       AWQ_PCASE(4, 1, 3) AWQ_PCASE(8, 1, 3) AWQ_PCASE(16, 1, 3)
     }
+#endif
 #undef AWQ_PCASE
   }
+#ifndef AWQ_ENABLE_PROBES
+  return -1;  // (the all-loads-up-front chunk variants, some of which spill, exist in AWQ_PROBES builds only)
+#else
   if constexpr (DT::id != 1) return -1;  // the chunk-mode variants below exist for the knob experiments: bf16 only
 #define AWQ_CASE(W_, S_)                                                      \
   if (c.waves == W_ && c.s == S_) {                                           \
@@ -377,6 +382,7 @@ static int launch_mb(const void* x, const void* qw, const void* szp, const void*
   }
 #undef AWQ_CASE
   return -1;
+#endif
 }
 
 // epi 0: out[m, n] (+ bias);  epi 1: qw holds [gate; up] stacked along N (n = 2 * ffn rows), out[m, n/2] = silu(gate) * up

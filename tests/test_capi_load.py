@@ -73,6 +73,11 @@ def test_prefill_routing_and_workspace_rule_without_gpu():
         ks = b // (tiles * tile)
         assert 2 <= ks <= 16 and (k // 128) // ks >= 2, (m, n, k, ks)
     assert q(256, 4096, 4096 + 64) == 0 and q(256, 4100, 4096) == 0  # shapes the cdna4 GEMM does not take
+    # a default process cannot reach the knobs (they re-order sums): AWQ_TUNING=1 opts in
+    import os
+    os.environ.pop("AWQ_TUNING", None)
+    assert L.awq_tune_set(b"gemm_splitk", 0) != 0 and q(256, 4096, 4096) > 0
+    os.environ["AWQ_TUNING"] = "1"
     try:
         assert L.awq_tune_set(b"gemm_splitk", 0) == 0 and q(256, 4096, 4096) == 0
         assert L.awq_tune_set(b"gemm_splitk", 5) == 0 and q(256, 4096, 14336) == 32 * 5 * tile

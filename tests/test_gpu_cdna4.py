@@ -126,14 +126,14 @@ def test_gemm_cdna4_vs_oracle(ops, dtype, variant, M, N, K):
     check_forward(y, c["x"], c["q"], c["scales"], c["scaled_zeros"], dtype, bias=c["bias"])
 
 
-@pytest.mark.parametrize("knobs", [dict(gemvc_pipe=0, gemvc_waves=4, gemvc_s=2), dict(gemvc_pipe=0, gemvc_waves=4, gemvc_s=8),
-                                   dict(gemvc_pipe=0, gemvc_waves=8, gemvc_s=7), dict(gemvc_pipe=0, gemvc_waves=16, gemvc_s=4),
-                                   dict(gemvc_pipe=0, gemvc_waves=16, gemvc_s=8), dict(gemvc_pipe=2, gemvc_pipe_s=1, gemvc_waves=4),
-                                   dict(gemvc_pipe=2, gemvc_pipe_s=2, gemvc_waves=8), dict(gemvc_pipe=2, gemvc_pipe_s=2, gemvc_waves=16),
-                                   dict(gemvc_pipe=3, gemvc_pipe_s=1, gemvc_waves=8), dict(gemvc_pipe=2, gemvc_pipe_s=1, gemvc_waves=16)])
+@pytest.mark.parametrize("knobs", [dict(gemvc_pipe=2, gemvc_pipe_s=1, gemvc_waves=4), dict(gemvc_pipe=2, gemvc_pipe_s=2, gemvc_waves=4),
+                                   dict(gemvc_pipe=2, gemvc_pipe_s=1, gemvc_waves=8), dict(gemvc_pipe=2, gemvc_pipe_s=2, gemvc_waves=8),
+                                   dict(gemvc_pipe=2, gemvc_pipe_s=2, gemvc_waves=16), dict(gemvc_pipe=2, gemvc_pipe_s=1, gemvc_waves=16)])
 def test_fast_gemv_knobs(ops, knobs):
-    """decode fast path: every (waves, chunk) configuration incl. ragged step counts and more waves than steps."""
+    """the register-ring decode kernel (awq_gemv_cdna4.hip: W3, fused norm, grouped decode and the fallback of the streaming kernel):
+    every shipped (waves, chunk) configuration incl. ragged step counts and more waves than steps."""
     try:
+        ops._capi.tune(gemv_dma=0)
         for (N, K) in [(64, 11008), (128, 4096), (48, 1280), (32, 128)]:
             for M in (1, 3, 4, 5, 8):
                 c = make_case(N, K, torch.bfloat16, seed=N + M, M=M, bias=True)
@@ -143,7 +143,7 @@ def test_fast_gemv_knobs(ops, knobs):
                 y = ops.gemm_cdna4(c["x"].cuda(), c4, c["scales"].cuda(), c["scaled_zeros"].cuda(), c["bias"].cuda(), szp)
                 check_forward(y.cpu(), c["x"], c["q"], c["scales"], c["scaled_zeros"], torch.bfloat16, bias=c["bias"])
     finally:
-        ops._capi.tune(gemvc_waves=0, gemvc_s=0, gemvc_pipe=-1, gemvc_pipe_s=0)
+        ops._capi.tune(gemvc_waves=0, gemvc_s=0, gemvc_pipe=-1, gemvc_pipe_s=0, gemv_dma=1)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
