@@ -173,13 +173,15 @@ int awq_w4a16_moe_forward_cdna4(const void* x_sorted, const void* qweight, const
  * awq/quantize/quantizer.py:61-103 with n_bit = 3), so the format is this repository's: per 16-row x 128-k tile
  * 64 lanes x 3 words (768 B) = the cdna4 W4 tile of the same integers (0..7) with its fourth word folded into the
  * free bit 3 of every nibble of the other three.  qweight_w3 is int16 [N/4, 3K/4] (N*K*3/8 bytes); scales /
- * scaled_zeros / sz_packed keep the W4 contract.  bf16 only, n % 16 == 0, k % 128 == 0. ---- */
+ * scaled_zeros / sz_packed keep the W4 contract.  bf16 and fp16, n % 16 == 0, k % 128 == 0. ---- */
 int awq_pack_w3(const void* q_u8 /* u8 [n, k], values 0..7 */, void* qweight_w3, int n, int k, void* stream);
 int awq_unpack_w3(const void* qweight_w3, void* out_u8, int n, int k, void* stream);
 int awq_dequant_w3(const void* qweight_w3, const void* scales, const void* scaled_zeros, void* out, int n, int k,
                    int group_size, int dtype, void* stream);
-/* WQLinear.forward for w_bit = 3: m <= 8 streams the 3-bit tiles directly (decode GEMV); larger m expands them to
- * W4 cdna4 tiles in `workspace` (awq_w3a16_forward_workspace_bytes = n*k/2) and runs the W4 GEMM. */
+/* WQLinear.forward for w_bit = 3.  Every kernel reads the 3-bit tiles natively: m <= 8 streams them through the decode GEMV;
+ * larger m runs the prefill tile kernels whose weight producer loads three words per lane and rebuilds the fourth (no expanded
+ * copy).  `workspace` is OPTIONAL (NULL / 0 is always accepted): awq_w3a16_forward_workspace_bytes is the fp32 split-K
+ * scratch that lets short prompts on narrow projections fill the chip, 0 for m <= 8 and for launches that already do. */
 size_t awq_w3a16_forward_workspace_bytes(int m, int n, int k);
 int awq_w3a16_forward(const void* x, const void* qweight_w3, const void* scales, const void* scaled_zeros,
                       const void* sz_packed, const void* bias, void* out, int m, int n, int k, int group_size, int dtype,

@@ -347,20 +347,20 @@ int awq_unpack_w3(const void* qweight_w3, void* out_u8, int n, int k, void* stre
 int awq_dequant_w3(const void* qweight_w3, const void* scales, const void* scaled_zeros, void* out, int n, int k,
                    int group_size, int dtype, void* stream) {
   if (!qweight_w3 || !scales || !scaled_zeros || !out) return AWQ_ERR_NULL;
-  if (dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
+  if (dtype != AWQ_BF16 && dtype != AWQ_F16) return AWQ_ERR_DTYPE;
   if (group_size != 128) return AWQ_ERR_GROUP;
   if (check_w3_shape(n, k)) return AWQ_ERR_SHAPE;
-  awq::launch_dequant_w3(qweight_w3, scales, scaled_zeros, out, n, k, (hipStream_t)stream);
+  awq::launch_dequant_w3(qweight_w3, scales, scaled_zeros, out, n, k, dtype, (hipStream_t)stream);
   return finish_launch();
 }
 
-size_t awq_w3a16_forward_workspace_bytes(int m, int n, int k) { return m <= 8 ? 0 : (size_t)n * (size_t)k / 2; }
+// w3c tiles are read natively by every kernel: the only workspace is the OPTIONAL split-K scratch of short prompts (as for W4)
+size_t awq_w3a16_forward_workspace_bytes(int m, int n, int k) { return m <= 8 ? 0 : awq::gemm_cdna4_v3_workspace_bytes_w3(m, n, k); }
 
 int awq_w3a16_forward(const void* x, const void* qweight_w3, const void* scales, const void* scaled_zeros,
                       const void* sz_packed, const void* bias, void* out, int m, int n, int k, int group_size, int dtype,
                       void* workspace, size_t workspace_bytes, void* stream) {
   if (!sz_packed) return AWQ_ERR_NULL;
-  if (dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
   int st = check_common(x, qweight_w3, scales, scaled_zeros, out, m, n, k, group_size, dtype);
   if (st != AWQ_OK) return st;
   if (check_w3_shape(n, k)) return AWQ_ERR_SHAPE;
@@ -368,12 +368,16 @@ int awq_w3a16_forward(const void* x, const void* qweight_w3, const void* scales,
     if (awq::launch_gemv_cdna4(x, qweight_w3, sz_packed, bias, out, m, n, k, 0, 3, dtype, (hipStream_t)stream) != 0) return AWQ_ERR_SHAPE;
     return finish_launch();
   }
-  // prefill: expand the 3-bit tiles to W4 cdna4 tiles in the workspace, then the W4 GEMM runs unchanged
-  const size_t need = awq_w3a16_forward_workspace_bytes(m, n, k);
-  if (!workspace || workspace_bytes < need || !aligned16(workspace)) return AWQ_ERR_WORKSPACE;
-  awq::launch_expand_w3_to_cdna4(qweight_w3, workspace, n, k, (hipStream_t)stream);
-  return awq_w4a16_forward_cdna4(x, workspace, scales, scaled_zeros, sz_packed, bias, out, m, n, k, group_size, dtype, nullptr, 0,
-                                 stream);
+  // prefill / batched decode: the v4 / v4n weight producers read the 768-byte tiles directly (three words per lane, the fourth
+  // rebuilt with six VALU operations per group); bias fused into the epilogue
+  if (bias && !aligned16(bias)) return AWQ_ERR_ALIGN;
+  if (workspace && (!aligned16(workspace) || workspace_bytes < awq_w3a16_forward_workspace_bytes(m, n, k))) {
+    workspace = nullptr;
+    workspace_bytes = 0;
+  }
+  if (awq::launch_gemm_cdna4_v3(x, qweight_w3, sz_packed, bias, out, m, n, k, 0, dtype, workspace, workspace_bytes, (hipStream_t)stream, 3) != 0)
+    return AWQ_ERR_SHAPE;
+  return finish_launch();
 }
 
 int awq_tune_set(const char* key, int value) {

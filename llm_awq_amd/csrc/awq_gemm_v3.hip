@@ -323,14 +323,14 @@ int g_small_m = 1;  // knob gemm_small_m: 0 = the prefill GEMM only takes m >= 2
 int g_splitk = 1;  // narrow tiles: split K over blocks when the tiles fill less than half of the chip and a workspace is given
 int g_v4 = 1;  // 1 (default): 256-wide tiles run the hand-scheduled K loop of awq_gemm_v4.hip; 0: v3's compiler-scheduled loop
 void launch_wide(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
-                 int n_end, int dtype, hipStream_t st) {
-  if (g_v4) launch_gemm_cdna4_v4(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st);
+                 int n_end, int dtype, hipStream_t st, int bits) {
+  if (g_v4 || bits == 3) launch_gemm_cdna4_v4(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits);
   else if (dtype == 0) launch_v3<F16, 2>(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
   else launch_v3<BF16, 2>(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
 }
 void launch_narrow(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
-                   int n_end, int dtype, void* ws, size_t ws_bytes, hipStream_t st) {
-  if (g_v4) launch_gemm_cdna4_v4n(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, g_splitk ? ws : nullptr, ws_bytes, st);
+                   int n_end, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits) {
+  if (g_v4 || bits == 3) launch_gemm_cdna4_v4n(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, g_splitk ? ws : nullptr, ws_bytes, st, bits);
   else if (dtype == 0) launch_v3<F16, 1>(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
   else launch_v3<BF16, 1>(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
 }
@@ -404,17 +404,27 @@ size_t gemm_cdna4_v3_workspace_bytes(int m, int n, int k) {
   return 0;
 }
 
+size_t gemm_cdna4_v3_workspace_bytes_w3(int m, int n, int k) {
+  if (m <= 8 || (n % 16) != 0 || (k % 128) != 0 || !g_splitk) return 0;
+  if (m < TM) return gemm_v4n_workspace_bytes(m, n, k);
+  const Plan p = plan_tiles(m, n, 0);
+  if (p.mode == 1) return gemm_v4n_workspace_bytes(m, n, k);
+  if (p.mode == 2) return gemm_v4n_workspace_bytes(m, n - (int)(p.cols_main * 256), k);
+  return 0;
+}
+
 int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                         int tile_n, int dtype, void* ws, size_t ws_bytes, hipStream_t st) {
-  if (!szp || !gemm_cdna4_v3_takes(m, k) || (n % 16) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return -1;
+                         int tile_n, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits) {
+  // (w3c tiles have no skinny kernel: the masked single-row-tile path of the narrow kernel serves every m > 8)
+  if (!szp || !(gemm_cdna4_v3_takes(m, k) || (bits == 3 && m > 8)) || (n % 16) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return -1;
   const Plan p = m < TM ? Plan{1, 0} : plan_tiles(m, n, tile_n);  // m < 256: only the narrow-tile kernel masks rows
   if (p.mode == 2) {
-    launch_wide(x, qw, szp, bias, out, m, n, k, 0, (int)(p.cols_main * 256), dtype, st);
-    launch_narrow(x, qw, szp, bias, out, m, n, k, (int)(p.cols_main * 256), n, dtype, ws, ws_bytes, st);
+    launch_wide(x, qw, szp, bias, out, m, n, k, 0, (int)(p.cols_main * 256), dtype, st, bits);
+    launch_narrow(x, qw, szp, bias, out, m, n, k, (int)(p.cols_main * 256), n, dtype, ws, ws_bytes, st, bits);
   } else if (p.mode == 1) {
-    launch_narrow(x, qw, szp, bias, out, m, n, k, 0, n, dtype, ws, ws_bytes, st);
+    launch_narrow(x, qw, szp, bias, out, m, n, k, 0, n, dtype, ws, ws_bytes, st, bits);
   } else {
-    launch_wide(x, qw, szp, bias, out, m, n, k, 0, n, dtype, st);
+    launch_wide(x, qw, szp, bias, out, m, n, k, 0, n, dtype, st, bits);
   }
   return 0;
 }

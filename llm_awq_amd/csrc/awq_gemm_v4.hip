@@ -67,7 +67,7 @@ struct NoJob {
 // 3 = no epilogue (one dword per lane is stored so that the accumulators stay live)
 // one 256 x 256 output tile: rows [m0, m0 + 256) of x (all of them must exist), weight rows [n0, n0 + 256) clipped to n_end;
 // stores are masked to rows [row_lo, row_hi) (dense: every row of the tile; grouped: the expert's rows inside it)
-template <typename DT, int PROBE>
+template <typename DT, int PROBE, int BITS = 4>
 __device__ __forceinline__ void v4_tile(char* smem, const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                         const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
                                         uint16_t* __restrict__ out, int N, int K, int m0, int n0, int n_end, int row_lo,
@@ -104,21 +104,27 @@ __device__ __forceinline__ void v4_tile(char* smem, const uint16_t* __restrict__
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int sl = min((n0 >> 4) + 2 * wv + s, min(nslab, n_end >> 4) - 1);
-    b_off[s] = (u32)sl * nit * 256 + lane * 4;
+    b_off[s] = (u32)sl * nit * (BITS == 4 ? 256 : 192) + lane * (BITS == 4 ? 4 : 3);
     sz_off[s] = (u32)sl * nit * 16 + i;
   }
   const int nl = 32 * wv + i;  // tile row of slab 0's lane row; slab 1 = + 16
   using vec8 = typename DT::vec8;
   Cdna4DequantT<DT> cd;
-  cd.init(lane);
+  cd.init(lane, BITS == 4 ? 0x000F000Fu : 0x00070007u);
 
   auto load_group = [&](int grp) {
     Raw r;
-    const u32* qg = qw + (size_t)grp * 256;
+    const u32* qg = qw + (size_t)grp * (BITS == 4 ? 256 : 192);
     const u32* sg = szp + (size_t)grp * 16;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      r.w[s] = *reinterpret_cast<const u32x4*>(qg + b_off[s]);
+      if (BITS == 4) {
+        r.w[s] = *reinterpret_cast<const u32x4*>(qg + b_off[s]);
+      } else {  // w3c tile: three words per lane, the fourth is rebuilt in prep()
+        typedef u32 u32x3 __attribute__((ext_vector_type(3)));
+        const u32x3 w3 = *reinterpret_cast<const u32x3*>(qg + b_off[s]);
+        r.w[s] = u32x4{w3.x, w3.y, w3.z, 0u};
+      }
       r.sz[s] = sg[sz_off[s]];
     }
     return r;
@@ -127,7 +133,7 @@ __device__ __forceinline__ void v4_tile(char* smem, const uint16_t* __restrict__
     Group gq;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      gq.w[s] = r.w[s];
+      gq.w[s] = BITS == 4 ? r.w[s] : w3_expand(r.w[s].x, r.w[s].y, r.w[s].z);
       const u32 sd = (r.sz[s] & 0xFFFFu) * 0x00010001u;
       gq.b01[s] = sd & cd.m01;
       gq.b23[s] = sd & cd.m23;
@@ -329,7 +335,7 @@ __device__ __forceinline__ void v4_tile(char* smem, const uint16_t* __restrict__
 }
 
 // dense: XCD-aware, two-row-band tile order as v3 (awq_gemm_v3.hip); the last row tile is shifted up to end at row M - 1
-template <typename DT, int PROBE>
+template <typename DT, int PROBE, int BITS = 4>
 __global__ __launch_bounds__(512) void gemm_cdna4_v4_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                             const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
                                                             uint16_t* __restrict__ out, int M, int N, int K, int tiles_m,
@@ -354,7 +360,7 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v4_kernel(const uint16_t* __re
       tm = tiles_m - 1;
     }
   }
-  v4_tile<DT, PROBE>(smem, x, qw, szp, bias, out, N, K, min(tm * TM, M - TM), n_begin + tn * TN, n_end, 0, M);
+  v4_tile<DT, PROBE, BITS>(smem, x, qw, szp, bias, out, N, K, min(tm * TM, M - TM), n_begin + tn * TN, n_end, 0, M);
 }
 
 // grouped (MoE): expert e owns rows [offsets[e], offsets[e+1]) of the sorted x / out and the e-th slice of the stacked
@@ -396,7 +402,7 @@ int g_v4_probe = 0;
 }
 // weight rows [n_begin, n_end) of the matrix with 256 x 256 tiles (m >= 256); same contract as v3's launch_v3<2>
 void launch_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                          int n_begin, int n_end, int dtype, hipStream_t st) {
+                          int n_begin, int n_end, int dtype, hipStream_t st, int bits) {
   constexpr int smem_main = 2 * kTileX + 2 * kTileW;
   constexpr int smem_epi = 8 * 128 * (2 * WN + 16);
   constexpr int smem = smem_main > smem_epi ? smem_main : smem_epi;
@@ -411,9 +417,11 @@ void launch_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const 
       {gemm_cdna4_v4_kernel<F16, 0>, gemm_cdna4_v4_kernel<F16, 0>, gemm_cdna4_v4_kernel<F16, 0>, gemm_cdna4_v4_kernel<F16, 0>},
       {gemm_cdna4_v4_kernel<BF16, 0>, gemm_cdna4_v4_kernel<BF16, 0>, gemm_cdna4_v4_kernel<BF16, 0>, gemm_cdna4_v4_kernel<BF16, 0>}};
 #endif
-  const Kern kern = kerns[dtype == 0 ? 0 : 1][g_v4_probe >= 0 && g_v4_probe <= 3 ? g_v4_probe : 0];
-  static LdsOptIn optin[2][4];  // per (kernel, device)
-  optin[dtype == 0 ? 0 : 1][g_v4_probe >= 0 && g_v4_probe <= 3 ? g_v4_probe : 0].ensure(reinterpret_cast<const void*>(kern), smem);
+  static const Kern kerns3[2] = {gemm_cdna4_v4_kernel<F16, 0, 3>, gemm_cdna4_v4_kernel<BF16, 0, 3>};  // w3c tiles
+  const int pi = g_v4_probe >= 0 && g_v4_probe <= 3 ? g_v4_probe : 0;
+  const Kern kern = bits == 3 ? kerns3[dtype == 0 ? 0 : 1] : kerns[dtype == 0 ? 0 : 1][pi];
+  static LdsOptIn optin[2][5];  // per (kernel, device)
+  optin[dtype == 0 ? 0 : 1][bits == 3 ? 4 : pi].ensure(reinterpret_cast<const void*>(kern), smem);
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw,
                      (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end);
 }

@@ -69,7 +69,8 @@ struct NoJob {
 #define V4N_WRITE(addr, val, off) asm volatile("ds_write_b128 %0, %1 offset:%2\n\ts_nop 1" : : "v"(addr), "v"(val), "n"(off) : "memory")
 #define V4N_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-template <typename DT, int KSPLIT, int PARTIAL>
+// BITS 4: cdna4 W4 tiles (1 KiB);  BITS 3: w3c tiles (768 B: three words per lane, the fourth rebuilt by w3_expand once per group)
+template <typename DT, int KSPLIT, int PARTIAL, int BITS = 4>
 __global__ __launch_bounds__(512) void gemm_cdna4_v4n_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                              const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
                                                              uint16_t* __restrict__ out, int M, int N, int K, int tiles_m,
@@ -134,19 +135,27 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v4n_kernel(const uint16_t* __r
   // ---- weight tile: wave wv owns slab wv of the 128-row tile ----
   const int nslab = N >> 4;
   const int sl = min((n0 >> 4) + wv, min(nslab, n_end >> 4) - 1);
-  const u32 b_off = (u32)sl * nit_all * 256 + lane * 4, sz_off = (u32)sl * nit_all * 16 + i;
+  constexpr int kTileWords = BITS == 4 ? 256 : 192, kLaneWords = BITS == 4 ? 4 : 3;
+  const u32 b_off = (u32)sl * nit_all * kTileWords + lane * kLaneWords, sz_off = (u32)sl * nit_all * 16 + i;
   const int nl = 16 * wv + i;  // tile row of the lane's weight row
   Cdna4DequantT<DT> cd;
-  cd.init(lane);
+  cd.init(lane, BITS == 4 ? 0x000F000Fu : 0x00070007u);
   auto load_group = [&](int grp) {
     Raw r;
-    r.w = *reinterpret_cast<const u32x4*>(qw + (size_t)(g0 + grp) * 256 + b_off);
+    const u32* wp = qw + (size_t)(g0 + grp) * kTileWords + b_off;
+    if (BITS == 4) {
+      r.w = *reinterpret_cast<const u32x4*>(wp);
+    } else {
+      typedef u32 u32x3 __attribute__((ext_vector_type(3)));
+      const u32x3 w3 = *reinterpret_cast<const u32x3*>(wp);
+      r.w = u32x4{w3.x, w3.y, w3.z, 0u};
+    }
     r.sz = szp[(size_t)(g0 + grp) * 16 + sz_off];
     return r;
   };
   auto prep = [&](const Raw& r) {
     Group gq;
-    gq.w = r.w;
+    gq.w = BITS == 4 ? r.w : w3_expand(r.w.x, r.w.y, r.w.z);
     const u32 sd = (r.sz & 0xFFFFu) * 0x00010001u;
     gq.b01 = sd & cd.m01;
     gq.b23 = sd & cd.m23;
@@ -462,17 +471,21 @@ size_t gemm_v4n_workspace_bytes(int m, int n_cols, int k) {
 // (one row tile whose missing rows are computed from row m - 1 and not stored).
 // ws / ws_bytes: optional fp32 workspace; when it holds gemm_v4n_workspace_bytes() the K loop is split (see the header)
 void launch_gemm_cdna4_v4n(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                           int n_begin, int n_end, int dtype, void* ws, size_t ws_bytes, hipStream_t st) {
+                           int n_begin, int n_end, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits) {
   constexpr int smem_main = 2 * kTileX + 2 * kTileW;
   constexpr int smem_epi = 8 * 128 * (2 * WN + 16);
   constexpr int smem = smem_main > smem_epi ? smem_main : smem_epi;
   const int tiles_m = (m + TM - 1) / TM, tiles_n = (n_end - n_begin + TN - 1) / TN;
   using Kern = void (*)(const uint16_t*, const u32*, const u32*, const uint16_t*, uint16_t*, int, int, int, int, int, int, int, int, float*);
-  static const Kern kerns[2][2][2] = {  // [dtype][split][partial]
+  static const Kern kerns4[2][2][2] = {  // [dtype][split][partial]
       {{gemm_cdna4_v4n_kernel<F16, 0, 0>, gemm_cdna4_v4n_kernel<F16, 0, 1>}, {gemm_cdna4_v4n_kernel<F16, 1, 0>, gemm_cdna4_v4n_kernel<F16, 1, 1>}},
       {{gemm_cdna4_v4n_kernel<BF16, 0, 0>, gemm_cdna4_v4n_kernel<BF16, 0, 1>}, {gemm_cdna4_v4n_kernel<BF16, 1, 0>, gemm_cdna4_v4n_kernel<BF16, 1, 1>}}};
-  static LdsOptIn optin[8];  // per (kernel, device)
-  for (int a = 0; a < 8; ++a) optin[a].ensure(reinterpret_cast<const void*>(kerns[a >> 2][(a >> 1) & 1][a & 1]), smem);
+  static const Kern kerns3[2][2][2] = {
+      {{gemm_cdna4_v4n_kernel<F16, 0, 0, 3>, gemm_cdna4_v4n_kernel<F16, 0, 1, 3>}, {gemm_cdna4_v4n_kernel<F16, 1, 0, 3>, gemm_cdna4_v4n_kernel<F16, 1, 1, 3>}},
+      {{gemm_cdna4_v4n_kernel<BF16, 0, 0, 3>, gemm_cdna4_v4n_kernel<BF16, 0, 1, 3>}, {gemm_cdna4_v4n_kernel<BF16, 1, 0, 3>, gemm_cdna4_v4n_kernel<BF16, 1, 1, 3>}}};
+  const Kern (*kerns)[2][2] = bits == 3 ? kerns3 : kerns4;
+  static LdsOptIn optin[2][8];  // per (kernel, device)
+  for (int a = 0; a < 8; ++a) optin[bits == 3][a].ensure(reinterpret_cast<const void*>(kerns[a >> 2][(a >> 1) & 1][a & 1]), smem);
   const int dt = dtype == 0 ? 0 : 1, partial = m <= TM - 32 ? 1 : 0;  // a whole 32-row fragment of the single row tile is empty
   const int ks = gemm_v4n_ksplit(m, n_end - n_begin, k);
   const size_t need = ks > 1 ? (size_t)tiles_m * tiles_n * ks * TM * TN * 4 : 0;

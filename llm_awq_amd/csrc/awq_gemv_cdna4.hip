@@ -393,7 +393,8 @@ int launch_gemv_cdna4(const void* x, const void* qw, const void* szp, const void
   if (bits == 4 && g_use_dma && launch_gemv_dma(x, qw, szp, bias, out, m, n, k, epi, dtype, 0, st) == 0) return 0;
   if (epi == 2) return -1;  // interleaved gate / up rows: only the streaming kernel pairs them
   if (bits == 3) {
-    if (epi != 0 || dtype != 1) return -1;
+    if (epi != 0) return -1;
+    if (dtype == 0) return m <= 4 ? launch_mb<F16, 1, 0, 3>(x, qw, szp, bias, out, m, n, k, st) : launch_mb<F16, 2, 0, 3>(x, qw, szp, bias, out, m, n, k, st);
     return m <= 4 ? launch_mb<BF16, 1, 0, 3>(x, qw, szp, bias, out, m, n, k, st) : launch_mb<BF16, 2, 0, 3>(x, qw, szp, bias, out, m, n, k, st);
   }
 #define AWQ_DT(DT_)                                                                                                     \

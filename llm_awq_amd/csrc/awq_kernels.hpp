@@ -45,7 +45,7 @@ int launch_skinny_v2(const void* x, const void* qw, const void* s, const void* z
 // W3 ("w3c") format helpers (awq_w3.hip)
 int launch_pack_w3(const void* q_u8, void* qw3, int n, int k, hipStream_t st);
 int launch_unpack_w3(const void* qw3, void* out_u8, int n, int k, hipStream_t st);
-int launch_dequant_w3(const void* qw3, const void* s, const void* z, void* out, int n, int k, hipStream_t st);
+int launch_dequant_w3(const void* qw3, const void* s, const void* z, void* out, int n, int k, int dtype, hipStream_t st);
 int launch_expand_w3_to_cdna4(const void* qw3, void* qw4, int n, int k, hipStream_t st);
 int gemv_cdna4_tune_set(const char* key, int value);
 // LDS-DMA streaming decode GEMV (awq_gemv_dma.hip): 1 <= m <= 8, cdna4 layout + packed sz.  epi 0: out[m,n] (+bias); epi 1: stacked
@@ -69,8 +69,9 @@ int launch_unpack_cdna4(const void* qw, void* out_u8, int n, int k, hipStream_t 
 int launch_dequant_cdna4(const void* qw, const void* s, const void* z, void* out, int n, int k, int dtype, hipStream_t st);
 size_t gemm_workspace_bytes(int m, int n, int k);
 // bias may be nullptr; when given it is added in the epilogue (`out + bias` in T)
+// bits 4: cdna4 W4 tiles; bits 3: w3c tiles (read natively by the v4 / v4n weight producers)
 int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                         int tile_n, int dtype, void* ws, size_t ws_bytes, hipStream_t st);
+                         int tile_n, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits = 4);
 int gemm_variant_get();
 // skinny GEMM, 9 <= m <= 255 (row chunks of <= 64), cdna4 layout + packed sz (awq_skinny_cdna4.hip); bias may be nullptr; -1 if unsupported
 int launch_skinny_cdna4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
@@ -83,18 +84,19 @@ int gemm_v3_tune_set(const char* key, int value);  // gemm_v4, gemm_v4_probe
 void gemm_v4_set_probe(int v);
 // 256 x 128 tiles with the same hand-scheduled K loop (awq_gemm_v4n.hip)
 void launch_gemm_cdna4_v4n(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                           int n_begin, int n_end, int dtype, void* ws, size_t ws_bytes, hipStream_t st);
+                           int n_begin, int n_end, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits = 4);
 size_t gemm_v4n_workspace_bytes(int m, int n_cols, int k);
 extern int g_v4n_ksplit_force;  // knob gemm_splitk > 1
 bool gemm_cdna4_v3_takes(int m, int k);  // m >= 256, or a shorter prompt the 256-row tile still beats the skinny kernel on
 size_t gemm_cdna4_v3_workspace_bytes(int m, int n, int k);
+size_t gemm_cdna4_v3_workspace_bytes_w3(int m, int n, int k);  // same rule for w3c tiles (every m > 8 takes the tile kernels)
 // grouped (MoE) GEMM with the same K loop: sorted rows, device expert offsets, stacked cdna4 weights + packed scales; total >= 256
 int launch_moe_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total, int experts,
                              int n, int k, int dtype, hipStream_t st);
 bool moe_v4_enabled();
 // 256 x 256-tile prefill GEMM with the hand-scheduled K loop (awq_gemm_v4.hip): weight rows [n_begin, n_end), m >= 256
 void launch_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                          int n_begin, int n_end, int dtype, hipStream_t st);
+                          int n_begin, int n_end, int dtype, hipStream_t st, int bits = 4);
 int launch_bias_add(void* out, const void* bias, int m, int n, int dtype, hipStream_t st);
 int launch_unpack_v2(const void* qw, void* out_u8, int n, int k, hipStream_t st);
 int launch_dequant_v2(const void* qw, const void* s, const void* z, void* out, int n, int k, int dtype, hipStream_t st);

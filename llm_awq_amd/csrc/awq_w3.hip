@@ -63,22 +63,24 @@ __global__ void unpack_w3_kernel(const u32* __restrict__ qw3, uint8_t* __restric
 }
 
 // one wave per tile, through the matrix-core dequant of the GEMV
+template <typename DT>
 __global__ __launch_bounds__(64) void dequant_w3_kernel(const u32* __restrict__ qw3, const uint16_t* __restrict__ scales,
                                                          const uint16_t* __restrict__ zeros, uint16_t* __restrict__ out,
                                                          int N, int K) {
   const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
   const int nit = K >> 7;
   const int nb = blockIdx.x / nit, kg = blockIdx.x % nit;
-  Cdna4Dequant cd;
+  using vec8 = typename DT::vec8;
+  Cdna4DequantT<DT> cd;
   cd.init(lane, 0x00070007u);
   const u32* src = qw3 + w3_tile_word(nb, kg, nit) + lane * 3;
   const u32x4 w = w3_expand(src[0], src[1], src[2]);
   const int n = nb * 16 + c;
-  bf16x8 op[4];
+  vec8 op[4];
   cd.tile(w, scales[(size_t)kg * N + n], zeros[(size_t)kg * N + n], op);
 #pragma unroll
   for (int a = 0; a < 4; ++a)
-    *reinterpret_cast<bf16x8*>(out + (size_t)n * K + (size_t)kg * 128 + 32 * a + 8 * g) = op[a];
+    *reinterpret_cast<vec8*>(out + (size_t)n * K + (size_t)kg * 128 + 32 * a + 8 * g) = op[a];
 }
 
 // w3c tiles -> cdna4 W4 tiles of the same integers (prefill: the W4 GEMM kernels then run unchanged)
@@ -102,8 +104,9 @@ int launch_unpack_w3(const void* qw3, void* out_u8, int n, int k, hipStream_t st
   hipLaunchKernelGGL(unpack_w3_kernel, dim3(nblk3(lanes, 256)), dim3(256), 0, st, (const u32*)qw3, (uint8_t*)out_u8, n, k);
   return 0;
 }
-int launch_dequant_w3(const void* qw3, const void* s, const void* z, void* out, int n, int k, hipStream_t st) {
-  hipLaunchKernelGGL(dequant_w3_kernel, dim3((n / 16) * (k / 128)), dim3(64), 0, st, (const u32*)qw3, (const uint16_t*)s,
+int launch_dequant_w3(const void* qw3, const void* s, const void* z, void* out, int n, int k, int dtype, hipStream_t st) {
+  auto kern = dtype == 0 ? dequant_w3_kernel<F16> : dequant_w3_kernel<BF16>;
+  hipLaunchKernelGGL(kern, dim3((n / 16) * (k / 128)), dim3(64), 0, st, (const u32*)qw3, (const uint16_t*)s,
                      (const uint16_t*)z, (uint16_t*)out, n, k);
   return 0;
 }

@@ -386,7 +386,7 @@ torch::Tensor pack_w3(torch::Tensor q_u8) {
 torch::Tensor forward_w3(torch::Tensor in_feats, torch::Tensor kernel, torch::Tensor scales, torch::Tensor zeros,
                          torch::Tensor sz_packed, c10::optional<torch::Tensor> bias) {
   check_inputs(in_feats, kernel, scales, zeros);
-  TORCH_CHECK(in_feats.scalar_type() == at::kBFloat16, "the W3 path is defined for bfloat16");
+  TORCH_CHECK(in_feats.scalar_type() == at::kBFloat16 || in_feats.scalar_type() == at::kHalf, "the W3 path is defined for bfloat16 / float16");
   TORCH_CHECK(sz_packed.is_cuda() && sz_packed.is_contiguous() && sz_packed.scalar_type() == at::kInt);
   const int64_t n = kernel.size(0) * 4, k = in_feats.size(-1);
   TORCH_CHECK(k > 0 && in_feats.numel() % k == 0 && kernel.numel() == n / 4 * (k * 3 / 4), "qweight must be int16 [n/4, 3k/4]");
@@ -406,7 +406,7 @@ torch::Tensor forward_w3(torch::Tensor in_feats, torch::Tensor kernel, torch::Te
   at::Tensor ws;
   if (wsb) ws = torch::empty({(int64_t)wsb}, in_feats.options().dtype(at::kByte));
   raise_on(awq_w3a16_forward(in_feats.data_ptr(), kernel.data_ptr(), scales.data_ptr(), zeros.data_ptr(), sz_packed.data_ptr(),
-                             bp, out.data_ptr(), (int)m, (int)n, (int)k, 128, AWQ_BF16, wsb ? ws.data_ptr() : nullptr, wsb,
+                             bp, out.data_ptr(), (int)m, (int)n, (int)k, 128, dtype_code(in_feats), wsb ? ws.data_ptr() : nullptr, wsb,
                              (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()));
   return out;
 }
@@ -428,6 +428,33 @@ torch::Tensor mlp_gate_up_cdna4(torch::Tensor in_feats, torch::Tensor kernel_gat
   raise_on(awq_w4a16_mlp_gate_up_cdna4(in_feats.data_ptr(), kernel_gate_up.data_ptr(), sz_packed.data_ptr(), out.data_ptr(),
                                        (int)m, (int)n2, (int)k, 128, dtype_code(in_feats),
                                        (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()));
+  return out;
+}
+
+// FTLlamaRMSNorm (tinychat/modules/fused_norm.py:7-21 -> layernorm.cu:39-61) fused in front of the decode GEMV: x is the
+// UN-normalised activation, gamma the norm weight [k]; <= 4 rows.  fused_gate_up: kernel = stacked [gate; up], out [.., n/2].
+torch::Tensor rmsnorm_forward_cdna4(torch::Tensor in_feats, torch::Tensor gamma, double eps, torch::Tensor kernel, torch::Tensor sz_packed,
+                                    c10::optional<torch::Tensor> bias, bool fused_gate_up) {
+  TORCH_CHECK(in_feats.is_cuda() && gamma.is_cuda() && kernel.is_cuda() && sz_packed.is_cuda());
+  TORCH_CHECK(in_feats.is_contiguous() && gamma.is_contiguous() && kernel.is_contiguous() && sz_packed.is_contiguous());
+  TORCH_CHECK((in_feats.scalar_type() == at::kBFloat16 || in_feats.scalar_type() == at::kHalf) && gamma.scalar_type() == in_feats.scalar_type() &&
+              kernel.scalar_type() == at::kShort && sz_packed.scalar_type() == at::kInt);
+  const int64_t n = kernel.size(0) * 4, k = in_feats.size(-1);
+  TORCH_CHECK(k > 0 && in_feats.numel() % k == 0 && kernel.numel() == n / 4 * k && gamma.numel() == k);
+  TORCH_CHECK(sz_packed.numel() == n * (k / 128), "sz_packed must be int32 [n/16, k/128, 16]");
+  const int64_t m = in_feats.numel() / k;
+  std::vector<int64_t> shape = in_feats.sizes().vec();
+  shape.back() = fused_gate_up ? n / 2 : n;
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(in_feats.device());
+  at::Tensor out = torch::empty(shape, in_feats.options());
+  const void* bp = nullptr;
+  if (bias.has_value() && bias->defined()) {
+    TORCH_CHECK(bias->is_cuda() && bias->is_contiguous() && bias->scalar_type() == in_feats.scalar_type() && bias->numel() == n);
+    bp = bias->data_ptr();
+  }
+  raise_on(awq_w4a16_rmsnorm_forward_cdna4(in_feats.data_ptr(), gamma.data_ptr(), (float)eps, kernel.data_ptr(), sz_packed.data_ptr(), bp,
+                                           out.data_ptr(), (int)m, (int)n, (int)k, 128, dtype_code(in_feats), fused_gate_up ? 1 : 0,
+                                           (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()));
   return out;
 }
 
@@ -503,5 +530,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("pack_szh_cdna4", &pack_szh_cdna4, "scales/scaled_zeros [Gpad,N] -> (sz_half int32 [N/16, K/128, 16], exact)");
   m.def("decode_cdna4", &decode_cdna4, "<= 8 rows on cdna4 weights + sz_half (LDS-DMA streaming kernel)", py::arg("in_feats"),
         py::arg("kernel"), py::arg("sz_half"), py::arg("bias") = py::none(), py::arg("epilogue") = 0);
+  m.def("rmsnorm_forward_cdna4", &rmsnorm_forward_cdna4, "RMSNorm fused in front of the decode GEMV (<= 4 rows)", py::arg("in_feats"),
+        py::arg("gamma"), py::arg("eps"), py::arg("kernel"), py::arg("sz_packed"), py::arg("bias") = py::none(),
+        py::arg("fused_gate_up") = false);
   m.def("mlp_gate_up_cdna4", &mlp_gate_up_cdna4, "silu(x Wg^T) * (x Wu^T) on stacked cdna4 gate/up buffers, <= 8 rows");
 }

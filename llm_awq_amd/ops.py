@@ -297,7 +297,7 @@ def dequant_w3(qweight_w3, scales, scaled_zeros, group_size: int = 128):
 
 
 def forward_w3(x, qweight_w3, scales, scaled_zeros, sz_packed, bias=None, group_size: int = 128):
-    """C-ABI awq_w3a16_forward: any M (M <= 8 streams the 3-bit tiles; larger M expands to W4 tiles in a workspace)."""
+    """C-ABI awq_w3a16_forward: any M; every kernel reads the 3-bit tiles natively (the workspace is the optional split-K scratch)."""
     _need_gpu(x, qweight_w3, scales, scaled_zeros, sz_packed, bias)
     k = x.shape[-1]
     m = x.numel() // k

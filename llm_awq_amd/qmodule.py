@@ -116,8 +116,8 @@ class WQLinear(nn.Module):
         if w_bit not in [3, 4]:
             # the reference supports 4 only (qmodule.py:82-83); 3 is this repository's INT3 extension (bf16, w3c tiles)
             raise NotImplementedError("Only 4-bit (and the MI355X build's 3-bit) are supported for now.")
-        if w_bit == 3 and dtype != torch.bfloat16:
-            raise NotImplementedError("w_bit=3 (w3c tiles, matrix-core dequant) is defined for bfloat16 only")
+        if w_bit == 3 and dtype not in (torch.bfloat16, torch.float16):
+            raise NotImplementedError("w_bit=3 (w3c tiles, matrix-core dequant) is defined for bfloat16 / float16")
         self.in_features = in_features
         self.out_features = out_features
         self.w_bit = w_bit

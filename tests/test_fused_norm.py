@@ -81,3 +81,25 @@ def test_gpu_rmsnorm_forward_rejects_what_it_cannot_serve():
     gamma = torch.ones(512, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(_capi.AwqNativeError):
         ops.rmsnorm_forward_cdna4(c["x"].cuda(), gamma, 1e-6, c4, szp)  # M = 5 > 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_module_matches_norm_then_linear(dtype):
+    """llm_awq_amd.fused_norm.RMSNormWQLinear through the torch extension's export: decode rows take the fused launch, more rows
+    the separate norm + WQLinear; both equal oracle norm -> oracle forward."""
+    from llm_awq_amd.fused_norm import RMSNormWQLinear
+    from llm_awq_amd.qmodule import WQLinear
+    from oracle import awq_oracle as O
+    from tests.helpers import check_forward, make_case
+    N, K, eps = 256, 4096, 1e-5
+    c = make_case(N, K, dtype, seed=21, M=16, bias=True)
+    gamma = (1.0 + 0.1 * torch.randn(K)).to(dtype)
+    lin = WQLinear(4, 128, K, N, True, "cuda", dtype=dtype)
+    lin.load_state_dict(dict(qweight=c["qweight"], scales=c["scales"], scaled_zeros=c["scaled_zeros"], bias=c["bias"]))
+    lin.to_cdna4()
+    mod = RMSNormWQLinear(gamma.cuda(), eps, lin)
+    for M in (1, 3, 4, 5, 16):
+        x = c["x"][:M].contiguous()
+        xn = O.rmsnorm(x, gamma, eps)
+        check_forward(mod(x.cuda()).cpu(), xn, c["q"], c["scales"], c["scaled_zeros"], dtype, bias=c["bias"])

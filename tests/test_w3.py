@@ -11,11 +11,11 @@ from tests.conftest import as_t
 from tests.helpers import check_forward
 
 
-def make_case_w3(N, K, seed=0, M=1, bias=False):
+def make_case_w3(N, K, seed=0, M=1, bias=False, dtype=torch.bfloat16):
     g = torch.Generator().manual_seed(seed)
-    d = O.quantize_linear_w3(torch.randn(N, K, generator=g) * 0.02)
-    d["x"] = torch.randn(M, K, generator=g).to(torch.bfloat16)
-    d["bias"] = (torch.randn(N, generator=g) * 0.02).to(torch.bfloat16) if bias else None
+    d = O.quantize_linear_w3(torch.randn(N, K, generator=g) * 0.02, dtype=dtype)
+    d["x"] = torch.randn(M, K, generator=g).to(dtype)
+    d["bias"] = (torch.randn(N, generator=g) * 0.02).to(dtype) if bias else None
     d["q"] = d["intweight"].numpy().astype(np.uint8)
     return d
 
@@ -52,8 +52,9 @@ def test_wqlinear_w3_contract():
     assert list(sd) == ["qweight", "scales", "scaled_zeros", "bias"]
     assert sd["qweight"].shape == (1024, 8256) and sd["qweight"].dtype == torch.int16
     assert sd["scales"].shape == (88, 4096) and m.layout == "w3c" and m.w_bit == 3
+    assert Q.WQLinear(3, 128, 256, 64, False, "cpu", dtype=torch.float16).layout == "w3c"  # fp16 models too
     with pytest.raises(NotImplementedError):
-        Q.WQLinear(3, 128, 256, 64, False, "cpu", dtype=torch.float16)
+        Q.WQLinear(3, 128, 256, 64, False, "cpu", dtype=torch.float32)
     with pytest.raises(NotImplementedError):
         Q.WQLinear(2, 128, 256, 64, False, "cpu", dtype=torch.bfloat16)
     d = make_case_w3(32, 256, seed=3)
@@ -95,23 +96,53 @@ def test_gpu_pack_unpack_bit_exact(ops, N, K):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,K", [(16, 128), (64, 768), (256, 1280)])
-def test_gpu_dequant_bit_exact(ops, N, K):
-    d = make_case_w3(N, K, seed=N + K)
+def test_gpu_dequant_bit_exact(ops, N, K, dtype):
+    d = make_case_w3(N, K, seed=N + K, dtype=dtype)
     W = O.dequant_weight(d["q"], d["scales"], d["scaled_zeros"], 128)
     got = ops.dequant_w3(d["qweight"].cuda(), d["scales"].cuda(), d["scaled_zeros"].cuda()).cpu()
     assert torch.equal(got.view(torch.int16), W.view(torch.int16))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M", [1, 2, 4, 7, 8, 9, 64, 200])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [1, 2, 4, 7, 8, 9, 64, 200, 300, 777])
 @pytest.mark.parametrize("N,K", [(768, 768), (256, 4096), (64, 11008), (1040, 1280)])
-def test_gpu_forward_vs_oracle(ops, M, N, K):
-    d = make_case_w3(N, K, seed=M * 13 + N + K, M=M, bias=(M in (4, 64)))
+def test_gpu_forward_vs_oracle(ops, M, N, K, dtype):
+    """every row count: decode GEMV (<= 8), the masked single row tile (9..255), full row tiles with and without split-K -- all of
+    them read the 768-byte tiles natively (no expanded copy: the workspace is the optional split-K scratch only)."""
+    d = make_case_w3(N, K, seed=M * 13 + N + K, M=M, bias=(M in (4, 64, 300)), dtype=dtype)
     szp = ops.pack_sz_cdna4(d["scales"].cuda(), d["scaled_zeros"].cuda(), K)
     y = ops.forward_w3(d["x"].cuda(), d["qweight"].cuda(), d["scales"].cuda(), d["scaled_zeros"].cuda(), szp,
                        d["bias"].cuda() if d["bias"] is not None else None).cpu()
-    check_forward(y, d["x"], d["q"], d["scales"], d["scaled_zeros"], torch.bfloat16, bias=d["bias"])
+    check_forward(y, d["x"], d["q"], d["scales"], d["scaled_zeros"], dtype, bias=d["bias"])
+    L = ops._capi.lib()
+    assert L.awq_w3a16_forward_workspace_bytes(M, N, K) < N * K // 2 or M < 256  # no N*K/2 expanded copy any more
+    assert L.awq_w3a16_forward_workspace_bytes(8, N, K) == 0 and L.awq_w3a16_forward_workspace_bytes(2048, 22016, 4096) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gpu_w3_prefill_full_shape_both_tile_widths(ops, dtype):
+    """Llama-2-7B's stacked gate/up (4096 -> 22016) at M = 2048 and 300: 256-wide tiles for the full rounds + 128-wide for the
+    rest, against fp32 torch on the weights of dequant_w3 (bit exact vs the oracle: test_gpu_dequant_bit_exact and
+    tests/test_gpu_oracle_fullsize.py)."""
+    K, N = 4096, 22016
+    g = torch.Generator(device="cuda").manual_seed(5)
+    q = torch.randint(0, 8, (N, K), dtype=torch.uint8, device="cuda", generator=g)
+    qw = ops.pack_w3(q)
+    s = ((5.2 + 0.8 * torch.rand(K // 128, N, device="cuda", generator=g)) * 0.02 / 7).to(dtype)
+    z = -(s * torch.randint(2, 6, (K // 128, N), device="cuda", generator=g).float()).to(dtype)
+    szp = ops.pack_sz_cdna4(s, z, K)
+    W = ops.dequant_w3(qw, s, z).float()
+    for M in (2048, 300):
+        x = torch.randn(M, K, device="cuda", generator=g).to(dtype)
+        y = ops.forward_w3(x, qw, s, z, szp)
+        ref = x.float() @ W.t()
+        rel = ((y.float() - ref).norm() / ref.norm()).item()
+        assert rel < (2.5e-3 if dtype == torch.bfloat16 else 4e-4), (M, rel)
+        assert (ref.to(dtype) == y).float().mean() > 0.97
 
 
 @pytest.mark.gpu
