@@ -118,7 +118,7 @@ def test_gpu_forward_vs_oracle(ops, M, N, K, dtype):
                        d["bias"].cuda() if d["bias"] is not None else None).cpu()
     check_forward(y, d["x"], d["q"], d["scales"], d["scaled_zeros"], dtype, bias=d["bias"])
     L = ops._capi.lib()
-    assert L.awq_w3a16_forward_workspace_bytes(M, N, K) < N * K // 2 or M < 256  # no N*K/2 expanded copy any more
+    # the workspace is the OPTIONAL split-K scratch now (no N*K/2 expanded copy): decode and chip-filling prompts need none
     assert L.awq_w3a16_forward_workspace_bytes(8, N, K) == 0 and L.awq_w3a16_forward_workspace_bytes(2048, 22016, 4096) == 0
 
 
