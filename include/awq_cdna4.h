@@ -187,6 +187,24 @@ int awq_w3a16_forward(const void* x, const void* qweight_w3, const void* scales,
                       const void* sz_packed, const void* bias, void* out, int m, int n, int k, int group_size, int dtype,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- One-shot all-reduce (sum, fp32 accumulation in rank order, one rounding to T) for the latency-class messages of
+ * K-sharded decode: M * N * 2 bytes = 8 .. 16 KiB after o_proj / down_proj (the reference has no multi-GPU path).
+ * Every rank owns one exchange buffer (awq_oneshot_alloc: fine-grained device memory, awq_oneshot_buffer_bytes(world, max_bytes)
+ * bytes), exports it with awq_oneshot_ipc_export (a 64-byte hipIpc handle) and opens its peers' with awq_oneshot_ipc_open;
+ * peer_buffers[q] is rank q's buffer as mapped in THIS process (peer_buffers[rank] = the local allocation).  A call stores
+ * `in` (count elements, count % 8 == 0, count * 2 <= max_bytes) into every rank's buffer over xGMI, raises one flag per peer and
+ * reduces locally when the `world` flags of this round have arrived.  `round` must be 1, 2, 3, ... in call order and equal on
+ * all ranks.  *status_dev (optional device int) is set to 1 if a peer's flag did not arrive within the spin bound (the kernel
+ * returns instead of hanging the queue).  world <= 8.  Messages above max_bytes belong to RCCL (bandwidth-bound). ---- */
+size_t awq_oneshot_buffer_bytes(int world, int max_bytes);
+int awq_oneshot_alloc(void** buffer, int world, int max_bytes);
+int awq_oneshot_free(void* buffer);
+int awq_oneshot_ipc_export(void* buffer, void* handle64);
+int awq_oneshot_ipc_open(const void* handle64, void** buffer);
+int awq_oneshot_ipc_close(void* buffer);
+int awq_oneshot_allreduce(void* const* peer_buffers, const void* in, void* out, int count, int dtype, int rank, int world,
+                          unsigned round, int max_bytes, int* status_dev, void* stream);
+
 /* Tuning hook for tests, experiments and benchmarks (not part of the reference surface): integer knobs that force one of the
  * shipped code paths ("gemm_variant", "gemm_splitk", "gemv_dma", "gemvd_waves", ...) so that tests can cover each of them; 0
  * restores the default heuristic.  A default process cannot reach it: unless AWQ_TUNING=1 is set in the environment every

@@ -47,6 +47,13 @@ SIGNATURES = {
     "awq_dequant_w3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "awq_w3a16_forward_workspace_bytes": (_sz, [_i, _i, _i]),
     "awq_w3a16_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "awq_oneshot_buffer_bytes": (_sz, [_i, _i]),
+    "awq_oneshot_alloc": (_i, [ctypes.POINTER(_vp), _i, _i]),
+    "awq_oneshot_free": (_i, [_vp]),
+    "awq_oneshot_ipc_export": (_i, [_vp, _vp]),
+    "awq_oneshot_ipc_open": (_i, [_vp, ctypes.POINTER(_vp)]),
+    "awq_oneshot_ipc_close": (_i, [_vp]),
+    "awq_oneshot_allreduce": (_i, [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, ctypes.c_uint, _i, _vp, _vp]),
     "awq_tune_set": (_i, [ctypes.c_char_p, _i]),
 }
 

@@ -84,7 +84,7 @@ class TPWQLinear(nn.Module):
     engine (WQLinear.forward's dispatch); tests on CPU inject the oracle instead."""
 
     def __init__(self, full: WQLinear, mode: str, group=None, world: Optional[int] = None, rank: Optional[int] = None,
-                 matmul: Optional[Callable] = None):
+                 matmul: Optional[Callable] = None, reducer: Optional[Callable] = None):
         super().__init__()
         import torch.distributed as dist
 
@@ -115,6 +115,9 @@ class TPWQLinear(nn.Module):
         else:
             self.bias = full.bias if mode == "row" else full.bias[self.bounds[0]: self.bounds[1]].contiguous()
         self._matmul = matmul
+        # reducer(y) -> reduced y: e.g. llm_awq_amd.oneshot.OneShotAllReduce for the 8 .. 16 KiB decode messages (it sends larger
+        # ones to RCCL itself); None = torch.distributed.all_reduce (RCCL on GPUs, gloo in the CPU tests)
+        self._reducer = reducer
 
     @torch.no_grad()
     def forward(self, x, input_is_sharded: bool = False):
@@ -127,7 +130,10 @@ class TPWQLinear(nn.Module):
         else:
             y = self._matmul(x, self.shard.qweight, self.shard.scales, self.shard.scaled_zeros)
         if self.mode == "row" and self.world > 1:
-            dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
+            if self._reducer is not None:
+                y = self._reducer(y)
+            else:
+                dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
         return y + self.bias if self.bias is not None else y
 
 
@@ -160,6 +166,10 @@ def run_tp_bench(args, eng, dist, rank, world, dev, shapes, algo_bytes):
             szp = eng.pack_sz_cdna4(w["scales"], w["scaled_zeros"], kl)
             shards.append((name, kl, nl, qw, w["scales"], w["scaled_zeros"], szp, mode))
             del w
+    from . import oneshot
+    reducer = None
+    if oneshot.enabled_by_env() and world > 1:  # opt-in: see llm_awq_amd/oneshot.py
+        reducer = oneshot.OneShotAllReduce(None, 64 * 1024, dev)
     g = torch.Generator(device=dev).manual_seed(1 + rank)
     xs = {}
     for (_nm, kl, *_r) in shards:
@@ -174,7 +184,10 @@ def run_tp_bench(args, eng, dist, rank, world, dev, shapes, algo_bytes):
             else:
                 y = eng.forward_cdna4(xs[kl], qw, s, sz, szp, None)
             if mode == "row":
-                dist.all_reduce(y)
+                if reducer is not None:
+                    y = reducer(y)
+                else:
+                    dist.all_reduce(y)
             outs.append(y)
         return outs
 
@@ -230,6 +243,9 @@ def run_tp_bench(args, eng, dist, rank, world, dev, shapes, algo_bytes):
                        "layers": L, "decode_m": 1, "graph": graph is not None, "layout": "cdna4",
                        "fused_gate_up_silu_mul": True, "launches_per_token": launches, "parallelism": f"tp{world}",
                        "allreduces_per_step": 2 * L},
+            "allreduce": {"kind": "oneshot (peer-mapped exchange buffers, csrc/awq_oneshot.hip)" if reducer is not None else "rccl (torch.distributed.all_reduce)",
+                          "bytes": 4096 * 2, "ranks": world, "per_step": 2 * L, "rccl_ranks": world,
+                          "weight_bytes_per_rank": int(bytes_rank)},
             "roofline": {"bound": "hbm", "kernel": "gemv_cdna4_kernel", "achieved": round(gbs_rank, 1),
                          "peak": 8000.0, "unit": "GB/s per GPU (incl. all-reduce time)", "frac": round(gbs_rank / 8000.0, 4),
                          "traffic": None},

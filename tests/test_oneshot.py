@@ -1,0 +1,128 @@
+"""One-shot all-reduce (csrc/awq_oneshot.hip, llm_awq_amd/oneshot.py).  not-gpu: the protocol restatement (HostMailbox) between
+two gloo processes over POSIX shared memory, many rounds (buffer halves are reused every second round), against
+torch.distributed.all_reduce.  -m gpu: the HIP kernel with two ranks played by two streams of one process sharing two exchange
+buffers (no second GPU on the test box) -- same protocol, same slot / flag addressing -- and, with >= 2 devices, the real thing."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def _host_worker(rank, world, port, names, nbytes, rounds, q):
+    import torch.distributed as dist
+    from multiprocessing import shared_memory
+    from llm_awq_amd.oneshot import HostMailbox
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shms = [shared_memory.SharedMemory(name=n) for n in names]
+    bufs = [np.ndarray((HostMailbox.buffer_bytes(world, nbytes),), dtype=np.uint8, buffer=s.buf) for s in shms]
+    box = HostMailbox(bufs, rank, world, nbytes)
+    ok = True
+    g = torch.Generator().manual_seed(100 + rank)
+    for r in range(rounds):
+        dtype = torch.bfloat16 if r % 2 == 0 else torch.float16
+        n = [8, 64, 4096, nbytes // 2][r % 4]
+        x = torch.randn(n, generator=g).to(dtype)
+        got = box.all_reduce(x)
+        parts = [torch.empty_like(x) for _ in range(world)]
+        dist.all_gather(parts, x)
+        want = sum(p.float() for p in parts).to(dtype)   # rank order, fp32, one rounding
+        ok = ok and torch.equal(got, want)
+    q.put((rank, ok))
+    dist.barrier()
+    for s in shms:
+        s.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_host_protocol_two_processes(world):
+    import torch.multiprocessing as mp
+    from multiprocessing import shared_memory
+    from llm_awq_amd.oneshot import HostMailbox
+    nbytes = 16384
+    shms = [shared_memory.SharedMemory(create=True, size=HostMailbox.buffer_bytes(world, nbytes)) for _ in range(world)]
+    try:
+        for s in shms:
+            np.ndarray((s.size,), dtype=np.uint8, buffer=s.buf)[:] = 0
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = 29500 + (os.getpid() % 2000) + world
+        ps = [ctx.Process(target=_host_worker, args=(r, world, port, [s.name for s in shms], nbytes, 12, q)) for r in range(world)]
+        [p.start() for p in ps]
+        res = sorted(q.get(timeout=120) for _ in range(world))
+        [p.join(timeout=60) for p in ps]
+        assert res == [(r, True) for r in range(world)]
+    finally:
+        for s in shms:
+            s.close()
+            s.unlink()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_kernel_two_ranks_on_two_streams(dtype):
+    import ctypes
+    from llm_awq_amd import _capi
+    L = _capi.lib()
+    world, max_bytes = 2, 16384
+    bufs = [ctypes.c_void_p() for _ in range(world)]
+    for b in bufs:
+        _capi.check(L.awq_oneshot_alloc(ctypes.byref(b), world, max_bytes))
+    try:
+        ptrs = (ctypes.c_void_p * 8)(*[bufs[q % world].value for q in range(8)])
+        streams = [torch.cuda.Stream() for _ in range(world)]
+        status = torch.zeros(1, dtype=torch.int32, device="cuda")
+        g = torch.Generator(device="cuda").manual_seed(3)
+        for rnd in range(1, 9):  # halves are reused from round 3 on
+            n = [8, 4096, 8192, 1024][rnd % 4]
+            xs = [torch.randn(n, device="cuda", generator=g).to(dtype) for _ in range(world)]
+            outs = [torch.empty_like(x) for x in xs]
+            torch.cuda.synchronize()
+            for r in range(world):
+                _capi.check(L.awq_oneshot_allreduce(ptrs, xs[r].data_ptr(), outs[r].data_ptr(), n, 0 if dtype == torch.float16 else 1, r, world,
+                                                    rnd, max_bytes, status.data_ptr(), streams[r].cuda_stream))
+            torch.cuda.synchronize()
+            assert int(status.item()) == 0, "a rank timed out waiting for its peer's flag"
+            want = (xs[0].float() + xs[1].float()).to(dtype)
+            assert torch.equal(outs[0], want) and torch.equal(outs[1], want), rnd
+    finally:
+        for b in bufs:
+            L.awq_oneshot_free(b)
+
+
+def _gpu_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    from llm_awq_amd.oneshot import OneShotAllReduce
+    ar = OneShotAllReduce(None, 64 * 1024)
+    ok = True
+    g = torch.Generator(device="cuda").manual_seed(7 + rank)
+    for r in range(10):
+        x = torch.randn(4096, device="cuda", generator=g).to(torch.bfloat16)
+        parts = [torch.empty_like(x) for _ in range(world)]
+        dist.all_gather(parts, x)
+        y = ar(x)
+        torch.cuda.synchronize()
+        ok = ok and torch.equal(y, sum(p.float() for p in parts).to(torch.bfloat16))
+    ar.check()
+    ar.close()
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_gpus_over_ipc():
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two devices")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_gpu_worker, args=(r, 2, 29650, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    [p.join(timeout=60) for p in ps]
+    assert res == [(0, True), (1, True)]
