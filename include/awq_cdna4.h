@@ -204,6 +204,10 @@ int awq_oneshot_ipc_open(const void* handle64, void** buffer);
 int awq_oneshot_ipc_close(void* buffer);
 int awq_oneshot_allreduce(void* const* peer_buffers, const void* in, void* out, int count, int dtype, int rank, int world,
                           unsigned round, int max_bytes, int* status_dev, void* stream);
+/* Single-GPU self-test of the device protocol: ONE launch of `world` co-resident blocks, block r playing rank r against the
+ * others on `world` exchange buffers of the same device (in_all / out_all: [world][count]).  Tests only. */
+int awq_oneshot_allreduce_selftest(void* const* peer_buffers, const void* in_all, void* out_all, int count, int dtype, int world,
+                                   unsigned round, int max_bytes, int* status_dev, void* stream);
 
 /* Tuning hook for tests, experiments and benchmarks (not part of the reference surface): integer knobs that force one of the
  * shipped code paths ("gemm_variant", "gemm_splitk", "gemv_dma", "gemvd_waves", ...) so that tests can cover each of them; 0

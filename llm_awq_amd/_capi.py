@@ -54,6 +54,7 @@ SIGNATURES = {
     "awq_oneshot_ipc_open": (_i, [_vp, ctypes.POINTER(_vp)]),
     "awq_oneshot_ipc_close": (_i, [_vp]),
     "awq_oneshot_allreduce": (_i, [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, ctypes.c_uint, _i, _vp, _vp]),
+    "awq_oneshot_allreduce_selftest": (_i, [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, ctypes.c_uint, _i, _vp, _vp]),
     "awq_tune_set": (_i, [ctypes.c_char_p, _i]),
 }
 

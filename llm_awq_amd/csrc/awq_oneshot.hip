@@ -32,9 +32,14 @@ struct OneShotPeers {
 };
 
 template <typename DT>
-__global__ __launch_bounds__(1024) void oneshot_allreduce_kernel(OneShotPeers peers, const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
-                                                                  int count, int rank, int world, u32 round, int max_bytes, u32 spin_limit,
+__global__ __launch_bounds__(1024) void oneshot_allreduce_kernel(OneShotPeers peers, const uint16_t* __restrict__ in_, uint16_t* __restrict__ out_,
+                                                                  int count, int rank0, int world, u32 round, int max_bytes, u32 spin_limit,
                                                                   int* __restrict__ status) {
+  // one block = one rank.  A real call launches ONE block (rank0 = this process' rank); the single-GPU self-test launches `world`
+  // co-resident blocks that play the ranks against each other (awq_oneshot_allreduce_selftest)
+  const int rank = rank0 + (int)blockIdx.x;
+  const uint16_t* in = in_ + (size_t)blockIdx.x * count;
+  uint16_t* out = out_ + (size_t)blockIdx.x * count;
   const int half = (int)(round & 1u);
   const int chunks = (count * 2 + 15) / 16;  // 16-byte chunks of the message (count % 8 == 0)
   const size_t slot_off = ((size_t)half * world + rank) * (size_t)max_bytes;
@@ -131,8 +136,21 @@ int awq_oneshot_ipc_open(const void* handle64, void** buffer) {
 
 int awq_oneshot_ipc_close(void* buffer) { return hipIpcCloseMemHandle(buffer) == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH; }
 
+static int oneshot_launch(void* const* peer_buffers, const void* in, void* out, int count, int dtype, int rank, int world, unsigned round,
+                          int max_bytes, int* status_dev, void* stream, int blocks);
+
 int awq_oneshot_allreduce(void* const* peer_buffers, const void* in, void* out, int count, int dtype, int rank, int world,
                           unsigned round, int max_bytes, int* status_dev, void* stream) {
+  return oneshot_launch(peer_buffers, in, out, count, dtype, rank, world, round, max_bytes, status_dev, stream, 1);
+}
+
+int awq_oneshot_allreduce_selftest(void* const* peer_buffers, const void* in_all, void* out_all, int count, int dtype, int world,
+                                   unsigned round, int max_bytes, int* status_dev, void* stream) {
+  return oneshot_launch(peer_buffers, in_all, out_all, count, dtype, 0, world, round, max_bytes, status_dev, stream, world);
+}
+
+static int oneshot_launch(void* const* peer_buffers, const void* in, void* out, int count, int dtype, int rank, int world, unsigned round,
+                          int max_bytes, int* status_dev, void* stream, int blocks) {
   if (!peer_buffers || !in || !out) return AWQ_ERR_NULL;
   if (dtype != AWQ_F16 && dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
   if (world < 1 || world > awq::kOneShotMaxWorld || rank < 0 || rank >= world || count <= 0 || (count % 8) != 0 || count * 2 > max_bytes ||
@@ -149,7 +167,7 @@ int awq_oneshot_allreduce(void* const* peer_buffers, const void* in, void* out, 
   const int chunks = count / 8;
   const int threads = chunks >= 1024 ? 1024 : (chunks < 64 ? 64 : ((chunks + 63) / 64) * 64);
   auto kern = dtype == AWQ_F16 ? awq::oneshot_allreduce_kernel<awq::F16> : awq::oneshot_allreduce_kernel<awq::BF16>;
-  hipLaunchKernelGGL(kern, dim3(1), dim3(threads), 0, (hipStream_t)stream, peers, (const uint16_t*)in, (uint16_t*)out, count, rank, world,
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, peers, (const uint16_t*)in, (uint16_t*)out, count, rank, world,
                      (awq::u32)round, max_bytes, 4000000u, status_dev);
   return hipGetLastError() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }

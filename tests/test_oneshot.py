@@ -61,32 +61,36 @@ def test_host_protocol_two_processes(world):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4, 8])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_kernel_two_ranks_on_two_streams(dtype):
+def test_kernel_ranks_as_coresident_blocks(dtype, world):
+    """the device protocol on one GPU: one launch of `world` blocks, block r = rank r, `world` exchange buffers (two streams of one
+    process may share a hardware queue and serialise -- co-resident blocks of one launch cannot)"""
     import ctypes
     from llm_awq_amd import _capi
     L = _capi.lib()
-    world, max_bytes = 2, 16384
+    max_bytes = 16384
     bufs = [ctypes.c_void_p() for _ in range(world)]
     for b in bufs:
         _capi.check(L.awq_oneshot_alloc(ctypes.byref(b), world, max_bytes))
     try:
         ptrs = (ctypes.c_void_p * 8)(*[bufs[q % world].value for q in range(8)])
-        streams = [torch.cuda.Stream() for _ in range(world)]
         status = torch.zeros(1, dtype=torch.int32, device="cuda")
         g = torch.Generator(device="cuda").manual_seed(3)
         for rnd in range(1, 9):  # halves are reused from round 3 on
             n = [8, 4096, 8192, 1024][rnd % 4]
-            xs = [torch.randn(n, device="cuda", generator=g).to(dtype) for _ in range(world)]
-            outs = [torch.empty_like(x) for x in xs]
+            xs = torch.randn(world, n, device="cuda", generator=g).to(dtype)
+            outs = torch.empty_like(xs)
+            _capi.check(L.awq_oneshot_allreduce_selftest(ptrs, xs.data_ptr(), outs.data_ptr(), n, 0 if dtype == torch.float16 else 1, world,
+                                                         rnd, max_bytes, status.data_ptr(), torch.cuda.current_stream().cuda_stream))
             torch.cuda.synchronize()
+            assert int(status.item()) == 0, "a rank timed out waiting for a peer's flag"
+            acc = torch.zeros(n, device="cuda")
             for r in range(world):
-                _capi.check(L.awq_oneshot_allreduce(ptrs, xs[r].data_ptr(), outs[r].data_ptr(), n, 0 if dtype == torch.float16 else 1, r, world,
-                                                    rnd, max_bytes, status.data_ptr(), streams[r].cuda_stream))
-            torch.cuda.synchronize()
-            assert int(status.item()) == 0, "a rank timed out waiting for its peer's flag"
-            want = (xs[0].float() + xs[1].float()).to(dtype)
-            assert torch.equal(outs[0], want) and torch.equal(outs[1], want), rnd
+                acc += xs[r].float()   # rank order
+            want = acc.to(dtype)
+            for r in range(world):
+                assert torch.equal(outs[r], want), (rnd, r)
     finally:
         for b in bufs:
             L.awq_oneshot_free(b)
