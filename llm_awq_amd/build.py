@@ -26,6 +26,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
 HIP_SOURCES = ["awq_gemv.hip", "awq_gemv_cdna4.hip", "awq_gemv_dma.hip", "awq_gemv_v2fast.hip", "awq_gemm.hip", "awq_gemm_v3.hip", "awq_gemm_v4.hip", "awq_gemm_v4n.hip", "awq_skinny_cdna4.hip", "awq_skinny_v2.hip", "awq_util.hip", "awq_w3.hip", "awq_oneshot.hip", "awq_capi.hip"]
+# evaluated alternatives that only AWQ_PROBES=1 builds compile (knob-reachable there, absent from the product library)
+PROBE_SOURCES = ["awq_gemm_v5.hip"]
 HIP_DEPS = ["awq_device.hpp", "awq_kernels.hpp", os.path.join(ROOT, "include", "awq_cdna4.h")]
 
 
@@ -66,8 +68,9 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(obj_dir, exist_ok=True)
     if not same_flags:
         force = True
+    sources = HIP_SOURCES + (PROBE_SOURCES if os.environ.get("AWQ_PROBES") == "1" else [])
     jobs = []
-    for name in HIP_SOURCES:
+    for name in sources:
         src, obj = os.path.join(CSRC, name), os.path.join(obj_dir, name + ".o")
         if force or _newer(obj, [src] + deps):
             jobs.append((name, [HIPCC, *flags, "-c", src, "-o", obj]))
@@ -75,7 +78,7 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(lambda j: _run(j[1], j[0]), jobs))
-    objs = [os.path.join(obj_dir, n + ".o") for n in HIP_SOURCES]
+    objs = [os.path.join(obj_dir, n + ".o") for n in sources]
     if jobs or _newer(LIB_PATH, objs):
         _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB_PATH], "libawq_cdna4.so")
         open(stamp, "w").write(" ".join(flags))

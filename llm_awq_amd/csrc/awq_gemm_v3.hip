@@ -321,9 +321,16 @@ void launch_v3(const void* x, const void* qw, const void* szp, const void* bias,
 constexpr double kNarrowRate = 0.83;  // 256 x 128 tiles (awq_gemm_v4n.hip) vs 256 x 256 (awq_gemm_v4.hip) at equal chip fill (profiles/r01_gemm_v4.txt)
 int g_small_m = 1;  // knob gemm_small_m: 0 = the prefill GEMM only takes m >= 256 (see gemm_cdna4_v3_takes)
 int g_splitk = 1;  // narrow tiles: split K over blocks when the tiles fill less than half of the chip and a workspace is given
+int g_v5 = 0;  // 1: 256-wide tiles run awq_gemm_v5.hip (weights never touch LDS); knob gemm_v5
 int g_v4 = 1;  // 1 (default): 256-wide tiles run the hand-scheduled K loop of awq_gemm_v4.hip; 0: v3's compiler-scheduled loop
 void launch_wide(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
                  int n_end, int dtype, hipStream_t st, int bits) {
+#ifdef AWQ_ENABLE_PROBES  // awq_gemm_v5.hip is an evaluated alternative (profiles/r02_gemm_v5_sweep.txt), not a product path
+  if (g_v5) {
+    launch_gemm_cdna4_v5(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, g_v5 == 3 ? 8 : 16);
+    return;
+  }
+#endif
   if (g_v4 || bits == 3) launch_gemm_cdna4_v4(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits);
   else if (dtype == 0) launch_v3<F16, 2>(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
   else launch_v3<BF16, 2>(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
@@ -343,6 +350,9 @@ bool moe_v4_enabled() { return g_moe_v4 != 0; }
 
 int gemm_v3_tune_set(const char* key, int value) {
   if (!strcmp(key, "gemm_v4")) g_v4 = value;
+#ifdef AWQ_ENABLE_PROBES
+  else if (!strcmp(key, "gemm_v5")) g_v5 = value;
+#endif
 #ifdef AWQ_ENABLE_PROBES
   else if (!strcmp(key, "gemm_v4_probe")) gemm_v4_set_probe(value);
 #endif
@@ -417,7 +427,8 @@ int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, const v
                          int tile_n, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits) {
   // (w3c tiles have no skinny kernel: the masked single-row-tile path of the narrow kernel serves every m > 8)
   if (!szp || !(gemm_cdna4_v3_takes(m, k) || (bits == 3 && m > 8)) || (n % 16) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return -1;
-  const Plan p = m < TM ? Plan{1, 0} : plan_tiles(m, n, tile_n);  // m < 256: only the narrow-tile kernel masks rows
+  Plan p = m < TM ? Plan{1, 0} : plan_tiles(m, n, tile_n);  // m < 256: only the narrow-tile kernel masks rows
+  if (g_v5 >= 2) p = Plan{0, 0};                            // experiments: every tile through awq_gemm_v5.hip (it masks rows itself)
   if (p.mode == 2) {
     launch_wide(x, qw, szp, bias, out, m, n, k, 0, (int)(p.cols_main * 256), dtype, st, bits);
     launch_narrow(x, qw, szp, bias, out, m, n, k, (int)(p.cols_main * 256), n, dtype, ws, ws_bytes, st, bits);

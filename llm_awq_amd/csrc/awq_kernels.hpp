@@ -97,6 +97,9 @@ bool moe_v4_enabled();
 // 256 x 256-tile prefill GEMM with the hand-scheduled K loop (awq_gemm_v4.hip): weight rows [n_begin, n_end), m >= 256
 void launch_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                           int n_begin, int n_end, int dtype, hipStream_t st, int bits = 4);
+// 256 x 256 blocks, weights streamed straight into registers per wave (awq_gemm_v5.hip); any m >= 1
+void launch_gemm_cdna4_v5(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
+                          int n_end, int dtype, hipStream_t st, int bits = 4, int mf = 16);
 int launch_bias_add(void* out, const void* bias, int m, int n, int dtype, hipStream_t st);
 int launch_unpack_v2(const void* qw, void* out_u8, int n, int k, hipStream_t st);
 int launch_dequant_v2(const void* qw, const void* s, const void* z, void* out, int n, int k, int dtype, hipStream_t st);
