@@ -60,7 +60,11 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
              "-mllvm", "-amdgpu-mfma-vgpr-form",
              # AWQ_PROBES=1: compile the timing-only probes (linear-read / null kernels, GEMM v4 no-DMA / no-epilogue)
              # behind the gemv_probe / gemm_v4_probe knobs; a default build has no knob that changes results
-             *(["-DAWQ_ENABLE_PROBES"] if os.environ.get("AWQ_PROBES") == "1" else [])]
+             *(["-DAWQ_ENABLE_PROBES"] if os.environ.get("AWQ_PROBES") == "1" else []),
+             # the command processor preloads the first 16 kernel-argument dwords into SGPRs at dispatch (gfx950): the waves of a
+             # decode launch issue their first loads without waiting for an s_load of the arguments -- +2.5 % decode tok/s
+             # (profiles/r02_kernarg_preload_ab.txt); AWQ_KERNARG_PRELOAD=0 builds without it
+             *([] if os.environ.get("AWQ_KERNARG_PRELOAD") == "0" else ["-mllvm", "-amdgpu-kernarg-preload-count=16"])]
     stamp = os.path.join(obj_dir, "flags.txt")
     same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(flags)
     if not force and not _newer(LIB_PATH, [os.path.join(CSRC, n) for n in HIP_SOURCES] + deps) and (same_flags or not os.path.exists(stamp)):

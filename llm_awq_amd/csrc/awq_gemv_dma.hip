@@ -87,16 +87,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_dma_kernel(const uint16_t* __
 #pragma unroll
   for (int s = 0; s < NS; ++s) slab_tile[s] = ((u32)nb + (u32)s * (u32)(N >> 5)) * (u32)nit;
 
-  // ---- up front: x slices and packed scales (out-of-range pieces read 0 through the buffer descriptor) ----
   const u32 lane16 = lane * 16u, lane4 = lane * 4u;
-  for (int r = 0; r < M; ++r)
-    for (int q = 0; q < TXp; q += 4)
-      dma_to_lds<16, 0>(rx, xs + r * xrow + q * 256, lane16, ((u32)r * (u32)K + (u32)(s0 + q) * 128u) * 2u);
-#pragma unroll
-  for (int s = 0; s < NS; ++s)
-    for (int q = 0; q < TXp; q += 4)
-      dma_to_lds<4, 0>(rs, szs + (s * TXp + q) * 64, lane4, (slab_tile[s] + (u32)(s0 + q)) * 64u);
-
   auto issue = [&](int t, int slot) {  // weight tile(s) of local step t into ring slot `slot`
     const u32 kg = (u32)min(s0 + t, nit - 1);  // steps past the end (ragged K split) re-read the last tile; their math is skipped
     if (probe & 2) return;
@@ -104,8 +95,19 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_dma_kernel(const uint16_t* __
     for (int s = 0; s < NS; ++s)
       dma_to_lds<16, 2>(rw, ring + (slot * NS + s) * 1024, lane16, (slab_tile[s] + kg) * 1024u);
   };
+  // ---- up front.  The first weight tile goes out FIRST (it has the longest way to come), then the packed scales and the x
+  // slices (out-of-range pieces read 0 through the buffer descriptor), then the rest of the ring: step 0's counted wait
+  // (D - 1 tiles may stay in flight) covers everything older than tile 1 ----
+  issue(0, 0);
 #pragma unroll
-  for (int d = 0; d < D; ++d) issue(d, d);
+  for (int s = 0; s < NS; ++s)
+    for (int q = 0; q < TXp; q += 4)
+      dma_to_lds<4, 0>(rs, szs + (s * TXp + q) * 64, lane4, (slab_tile[s] + (u32)(s0 + q)) * 64u);
+  for (int r = 0; r < M; ++r)
+    for (int q = 0; q < TXp; q += 4)
+      dma_to_lds<16, 0>(rx, xs + r * xrow + q * 256, lane16, ((u32)r * (u32)K + (u32)(s0 + q) * 128u) * 2u);
+#pragma unroll
+  for (int d = 1; d < D; ++d) issue(d, d);
 
   using vec8 = typename DT::vec8;
   Cdna4DequantT<DT> cd;   // DQ 0: sz_packed in T
