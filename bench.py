@@ -155,8 +155,10 @@ def main():
         for (name, K, N, qw, s, z, szp, szh, epi) in nat:
             x = xs[K]
             m = x.numel() // K
-            if m <= 8 and szh is not None:
-                outs.append(eng.decode_cdna4(x, qw, szh, None, epi))                 # WQLinear.forward / QuantLlamaMLP, decode
+            if epi == 2:
+                outs.append(eng.mlp_gate_up_forward_cdna4(x, qw, szp, szh))          # QuantLlamaMLP.our_llama_mlp, any row count
+            elif m <= 8 and szh is not None:
+                outs.append(eng.decode_cdna4(x, qw, szh, None, epi))                 # WQLinear.forward, decode
             elif m <= 8 and epi == 1:
                 outs.append(eng.mlp_gate_up_cdna4(x, qw, szp))
             else:
@@ -255,7 +257,9 @@ def main():
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": "Llama-3-8B W4A16 g128 " + ("bf16" if args.dtype == "bf16" else "fp16") + " activations on 1xMI355X (decode GEMV + prefill GEMM)",
                       "layers": L, "decode_m": 1, "prefill_m": args.prefill_m, "graph": graphed,
-                      "layout": args.layout, "mlp": args.mlp if native_leg else "unfused (two gemv_forward_cuda_new calls, as tinychat issues them)",
+                      "layout": args.layout,
+                      "prefill_mlp": "SiLU*mul fused into the gate/up GEMM epilogue" if (native_leg and args.mlp == "interleaved") else "separate",
+                      "mlp": args.mlp if native_leg else "unfused (two gemv_forward_cuda_new calls, as tinychat issues them)",
                       "decode_side_buffer": ("sz_half" if args.sz == "half" else "sz_packed") if native_leg else "engine cache",
                       "launches_per_token": launches, "parallelism": "tp1", **({"tune": args.tune} if args.tune else {})},
            "roofline": roofline, "device": torch.cuda.get_device_name(dev)}

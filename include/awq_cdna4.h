@@ -128,6 +128,14 @@ int awq_w4a16_gemv_cdna4(const void* x, const void* qweight_cdna4, const void* s
 int awq_w4a16_mlp_gate_up_cdna4(const void* x, const void* qweight_gate_up, const void* sz_packed, void* out, int m,
                                 int n2, int k, int group_size, int dtype, void* stream);
 
+/* QuantLlamaMLP.our_llama_mlp for ANY row count (tinychat/modules/fused_mlp.py:36-83: decode = two gemv_forward_cuda_new + F.silu +
+ * multiply, prefill = two gemm_forward_cuda_new + F.silu + multiply) on the pair as llm_awq_amd.fused_mlp stacks it: gate and up
+ * rows interleaved 8 + 8 inside every 16-row slab (n2 = 2 * intermediate rows).  out[m, n2/2] = T(T(silu(x.Wg^T)) * (x.Wu^T)).
+ * m <= 8: one streaming launch (sz_half if given, else sz_packed); m > 8: the prefill tile kernels with the SiLU * mul tail fused
+ * into their epilogue -- the [m, n2] intermediate is never written.  sz_half may be NULL. */
+int awq_w4a16_mlp_gate_up_forward_cdna4(const void* x, const void* qweight_interleaved, const void* sz_packed, const void* sz_half,
+                                        void* out, int m, int n2, int k, int group_size, int dtype, void* stream);
+
 /* gemm / WQLinear.forward dispatch on cdna4-interleaved weights (any m >= 1; m <= 16 runs the GEMV) */
 /* RMSNorm fused in front of the quantised linear: replaces the FTLlamaRMSNorm launch
  * (tinychat/modules/fused_norm.py:7-21 -> awq/kernels/csrc/layernorm/layernorm.cu:39-61, layernorm_forward_cuda) followed by

@@ -225,6 +225,28 @@ int awq_w4a16_mlp_gate_up_cdna4(const void* x, const void* qweight_gate_up, cons
   return finish_launch();
 }
 
+int awq_w4a16_mlp_gate_up_forward_cdna4(const void* x, const void* qweight_interleaved, const void* sz_packed, const void* sz_half,
+                                        void* out, int m, int n2, int k, int group_size, int dtype, void* stream) {
+  if (!x || !qweight_interleaved || !sz_packed || !out) return AWQ_ERR_NULL;
+  if (group_size != 128) return AWQ_ERR_GROUP;
+  if (dtype != AWQ_F16 && dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
+  if (m < 1) return AWQ_ERR_BATCH;
+  if (n2 < 16 || (n2 % 16) != 0 || k < 128 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return AWQ_ERR_SHAPE;
+  if (!aligned16(x) || !aligned16(qweight_interleaved) || !aligned16(out) || !aligned16(sz_packed) || (sz_half && !aligned16(sz_half)))
+    return AWQ_ERR_ALIGN;
+  if (m <= 8) {  // decode: one streaming launch, rows r and r + 8 of a slab paired in the epilogue
+    if (awq::launch_gemv_dma(x, qweight_interleaved, sz_half ? sz_half : sz_packed, nullptr, out, m, n2, k, 2, dtype, sz_half ? 1 : 0,
+                             (hipStream_t)stream) != 0)
+      return AWQ_ERR_SHAPE;
+    return finish_launch();
+  }
+  // prefill / batched decode: the tile kernels with the SiLU * mul tail fused into their epilogue (out is [m, n2 / 2]: the
+  // [m, n2] intermediate of the reference's two GEMMs + F.silu + multiply never exists)
+  if (awq::launch_gemm_cdna4_v3(x, qweight_interleaved, sz_packed, nullptr, out, m, n2, k, 0, dtype, nullptr, 0, (hipStream_t)stream, 4, 2) != 0)
+    return AWQ_ERR_SHAPE;
+  return finish_launch();
+}
+
 int awq_w4a16_rmsnorm_forward_cdna4(const void* x, const void* gamma, float eps, const void* qweight, const void* sz_packed,
                                     const void* bias, void* out, int m, int n, int k, int group_size, int dtype,
                                     int fused_gate_up, void* stream) {

@@ -188,6 +188,22 @@ __device__ __forceinline__ u32x4 ldg_nt_u32x4(const u32* p) {
 }
 
 
+// QuantLlamaMLP's elementwise tail on eight packed T values (fused_mlp.py:79-82): c = T(T(silu(gate)) * up), silu in fp32 on the
+// T-rounded gate -- the same roundings as the reference's separate F.silu and multiply, and as the decode epilogues
+template <typename DT>
+__device__ __forceinline__ u32 silu_mul_pair(u32 gate2, u32 up2) {
+  auto one = [](uint16_t gb, uint16_t ub) {
+    const float gt = DT::to_float(gb), up = DT::to_float(ub);
+    const float sl = DT::to_float(DT::from_float(gt / (1.0f + expf(-gt))));
+    return (u32)DT::from_float(sl * up);
+  };
+  return one((uint16_t)(gate2 & 0xFFFFu), (uint16_t)(up2 & 0xFFFFu)) | (one((uint16_t)(gate2 >> 16), (uint16_t)(up2 >> 16)) << 16);
+}
+template <typename DT>
+__device__ __forceinline__ u32x4 silu_mul_octet(const u32x4& g, const u32x4& u) {
+  return u32x4{silu_mul_pair<DT>(g.x, u.x), silu_mul_pair<DT>(g.y, u.y), silu_mul_pair<DT>(g.z, u.z), silu_mul_pair<DT>(g.w, u.w)};
+}
+
 // =============================================================================================
 // "cdna4" interleave (this repository's MI355X-native layout; emitted by the rewritten repacker).
 // Same bytes/shape as v2, nibbles permuted so that a 1-KiB tile = 16 rows x 128 k is ONE contiguous

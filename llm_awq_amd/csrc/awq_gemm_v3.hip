@@ -324,20 +324,20 @@ int g_splitk = 1;  // narrow tiles: split K over blocks when the tiles fill less
 int g_v5 = 0;  // 1: 256-wide tiles run awq_gemm_v5.hip (weights never touch LDS); knob gemm_v5
 int g_v4 = 1;  // 1 (default): 256-wide tiles run the hand-scheduled K loop of awq_gemm_v4.hip; 0: v3's compiler-scheduled loop
 void launch_wide(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
-                 int n_end, int dtype, hipStream_t st, int bits) {
+                 int n_end, int dtype, hipStream_t st, int bits, int epi) {
 #ifdef AWQ_ENABLE_PROBES  // awq_gemm_v5.hip is an evaluated alternative (profiles/r02_gemm_v5_sweep.txt), not a product path
   if (g_v5) {
-    launch_gemm_cdna4_v5(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, g_v5 == 3 ? 8 : 16);
+    launch_gemm_cdna4_v5(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, g_v5 == 3 ? 8 : (g_v5 == 4 ? 17 : 16));
     return;
   }
 #endif
-  if (g_v4 || bits == 3) launch_gemm_cdna4_v4(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits);
+  if (g_v4 || bits == 3 || epi) launch_gemm_cdna4_v4(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, epi);
   else if (dtype == 0) launch_v3<F16, 2>(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
   else launch_v3<BF16, 2>(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
 }
 void launch_narrow(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
-                   int n_end, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits) {
-  if (g_v4 || bits == 3) launch_gemm_cdna4_v4n(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, g_splitk ? ws : nullptr, ws_bytes, st, bits);
+                   int n_end, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits, int epi) {
+  if (g_v4 || bits == 3 || epi) launch_gemm_cdna4_v4n(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, g_splitk ? ws : nullptr, ws_bytes, st, bits, epi);
   else if (dtype == 0) launch_v3<F16, 1>(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
   else launch_v3<BF16, 1>(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
 }
@@ -424,18 +424,18 @@ size_t gemm_cdna4_v3_workspace_bytes_w3(int m, int n, int k) {
 }
 
 int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                         int tile_n, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits) {
+                         int tile_n, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits, int epi) {
   // (w3c tiles have no skinny kernel: the masked single-row-tile path of the narrow kernel serves every m > 8)
-  if (!szp || !(gemm_cdna4_v3_takes(m, k) || (bits == 3 && m > 8)) || (n % 16) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return -1;
+  if (!szp || !(gemm_cdna4_v3_takes(m, k) || ((bits == 3 || epi) && m > 8)) || (n % 16) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return -1;
   Plan p = m < TM ? Plan{1, 0} : plan_tiles(m, n, tile_n);  // m < 256: only the narrow-tile kernel masks rows
   if (g_v5 >= 2) p = Plan{0, 0};                            // experiments: every tile through awq_gemm_v5.hip (it masks rows itself)
   if (p.mode == 2) {
-    launch_wide(x, qw, szp, bias, out, m, n, k, 0, (int)(p.cols_main * 256), dtype, st, bits);
-    launch_narrow(x, qw, szp, bias, out, m, n, k, (int)(p.cols_main * 256), n, dtype, ws, ws_bytes, st, bits);
+    launch_wide(x, qw, szp, bias, out, m, n, k, 0, (int)(p.cols_main * 256), dtype, st, bits, epi);
+    launch_narrow(x, qw, szp, bias, out, m, n, k, (int)(p.cols_main * 256), n, dtype, ws, ws_bytes, st, bits, epi);
   } else if (p.mode == 1) {
-    launch_narrow(x, qw, szp, bias, out, m, n, k, 0, n, dtype, ws, ws_bytes, st, bits);
+    launch_narrow(x, qw, szp, bias, out, m, n, k, 0, n, dtype, ws, ws_bytes, st, bits, epi);
   } else {
-    launch_wide(x, qw, szp, bias, out, m, n, k, 0, n, dtype, st, bits);
+    launch_wide(x, qw, szp, bias, out, m, n, k, 0, n, dtype, st, bits, epi);
   }
   return 0;
 }

@@ -30,7 +30,14 @@ constexpr int kWBase = 2 * kTileX;
 constexpr int WN = 64;               // weight rows per wave
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ int tile_off(int row, int gc) { return row * 128 + ((gc ^ ((row >> 1) & 7)) << 4); }
+// 16-byte granule gc of tile row `row` (128-byte rows).  The XOR term serves both access shapes (MI355X_MICROARCH.md, LDS):
+//   * ds_read_b128 fragments (64 banks, lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} of the 32 rows a half-wave reads): the
+//     eight even and the eight odd rows of a group must hit eight different granules -- rows & 6 alone repeat, bit 4 separates them;
+//   * ds_write_b128 of a dequantised word (32 banks = ONE row width, eight consecutive lanes = eight consecutive rows, same gc):
+//     row & 7 must differ.  (Round 1 used (row >> 1) & 7: conflict-free reads, 2-way conflicts on every write = the 21 % of
+//     SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE in profiles/r01_pmc_gemm_v4.txt.)
+__device__ __forceinline__ int swz(int row) { return (row & 7) ^ ((row >> 4) & 1); }
+__device__ __forceinline__ int tile_off(int row, int gc) { return row * 128 + ((gc ^ swz(row)) << 4); }
 
 struct Group {  // one quantisation group (128 k) of the wave's two slabs
   u32x4 w[2];
@@ -64,14 +71,16 @@ struct NoJob {
 // (A variant with double-buffered x fragments -- the reads of k-step s+1 issued in cluster A of k-step s, 248 VGPRs -- measured
 // 5-8 % SLOWER, profiles/r01_gemm_v4.txt: read-to-use distance is not what limits this loop.)
 // PROBE (only with -DAWQ_ENABLE_PROBES): experiments (timing only, wrong results): 1 = the x DMA always fetches K-tile 0 (cache hits), 2 = no x DMA,
-// 3 = no epilogue (one dword per lane is stored so that the accumulators stay live)
+// 3 = no epilogue (one dword per lane is stored so that the accumulators stay live), 4 = no block barrier inside the K loop (the
+// vmcnt / lgkmcnt waits stay), 5 = no weight production inside the K loop (no dequant MFMAs, cvt, ds_write), 6 = production
+// arithmetic without its ds_write, 7 = the ds_write without the arithmetic, 8 = neither production nor x DMA
 // one 256 x 256 output tile: rows [m0, m0 + 256) of x (all of them must exist), weight rows [n0, n0 + 256) clipped to n_end;
 // stores are masked to rows [row_lo, row_hi) (dense: every row of the tile; grouped: the expert's rows inside it)
 template <typename DT, int PROBE, int BITS = 4>
 __device__ __forceinline__ void v4_tile(char* smem, const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                         const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
                                         uint16_t* __restrict__ out, int N, int K, int m0, int n0, int n_end, int row_lo,
-                                        int row_hi) {
+                                        int row_hi, int epi = 0) {
   constexpr int kEpiRow = 2 * WN + 16;  // bytes per staged output row (+16 pad)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
@@ -83,19 +92,31 @@ __device__ __forceinline__ void v4_tile(char* smem, const uint16_t* __restrict__
   u32 a_off0;
   {
     const int row = tid >> 3, gcp = tid & 7;
-    const int gc = gcp ^ ((row >> 1) & 7);
+    const int gc = gcp ^ swz(row);
     a_off0 = (u32)(m0 + row) * (u32)K + gc * 8;
   }
-  auto issue_a = [&](int kt, int stage) {
-    if (PROBE == 2) return;
+  // pieces [q0, q1) of the x tile of K-tile kt (piece q = rows 64 q .. 64 q + 63 of the tile, 8 rows per wave)
+  auto issue_a_pieces = [&](int kt, int stage, int q0, int q1) {
+    if (PROBE == 2 || PROBE == 8) return;
     if (PROBE == 1) kt = 0;
     char* dst = smem + stage * kTileX + wv * 1024;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+      if (q < q0 || q >= q1) continue;
       const uint16_t* xq = x + (size_t)kt * TK + (size_t)q * 64 * K;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xq + a_off0),
                                        (__attribute__((address_space(3))) void*)(dst + q * 8192), 16, 0, 0);
     }
+  };
+  auto issue_a = [&](int kt, int stage) { issue_a_pieces(kt, stage, 0, 4); };
+  // SPREAD: how the four pieces of a tile's DMA are spaced over the k-steps behind the barrier that frees their stage (each
+  // LDS-DMA instruction holds the wave's issue for ~100-185 cycles next to MFMAs and ds_reads -- MI355X_MICROARCH.md -- and both
+  // waves of a SIMD stand at the same point of the loop): slot 0 = right behind the barrier, slots 1..3 = behind the next k-steps
+  constexpr int SPREAD = PROBE == 9 ? 1 : (PROBE == 10 ? 2 : 0);
+  auto issue_a_slot = [&](int kt, int stage, int slot) {
+    if (SPREAD == 0) { if (slot == 0) issue_a_pieces(kt, stage, 0, 4); }
+    else if (SPREAD == 1) { if (slot == 0) issue_a_pieces(kt, stage, 0, 2); else if (slot == 1) issue_a_pieces(kt, stage, 2, 3); else if (slot == 2) issue_a_pieces(kt, stage, 3, 4); }
+    else { issue_a_pieces(kt, stage, slot, slot + 1); }
   };
 
   // ---- weight tile: wave wv owns slabs 2 wv, 2 wv + 1 of the 256-row tile ----
@@ -144,14 +165,16 @@ __device__ __forceinline__ void v4_tile(char* smem, const uint16_t* __restrict__
 
   // ---- LDS byte addresses (the dynamic segment starts at LDS offset of `smem`) ----
   const u32 lds0 = (u32)(size_t)(__attribute__((address_space(3))) char*)smem;
-  u32 xa[4], wa[4], ja[2];  // per k-step fragment addresses (stage 0, fragment 0); job destinations (word parity)
+  u32 xa[4], wa[4], ja[2][2];  // per k-step fragment addresses (stage 0, fragment 0); job destinations [word parity][slab]
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     xa[ks] = lds0 + tile_off(wm * 128 + l32, 2 * ks + hk);
     wa[ks] = lds0 + kWBase + tile_off(wn * WN + l32, 2 * ks + hk);
   }
 #pragma unroll
-  for (int b = 0; b < 2; ++b) ja[b] = lds0 + kWBase + tile_off(nl, 4 * b + g);
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) ja[b][sl] = lds0 + kWBase + tile_off(nl + 16 * sl, 4 * b + g);  // (row + 16 flips the swizzle)
 
   u32x4 w0, w1, x0, x1, x2, x3;  // fragments (single set)
   f32x16 acc[2][4];
@@ -186,23 +209,27 @@ __device__ __forceinline__ void v4_tile(char* smem, const uint16_t* __restrict__
     asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(x3));
     acc[0][3] = mf(w0, x3, acc[0][3]);
     typename Cdna4DequantT<DT>::Pending pj;
-    if constexpr (J::has) {  // the two dequant MFMAs of this step's weight word queue behind A4
+    constexpr bool kJob = J::has && PROBE != 5 && PROBE != 7 && PROBE != 8;
+    if constexpr (J::has && PROBE == 7) V4_WRITE(ja[J::j & 1][J::j >> 1], x3, J::st * kTileW);  // the LDS write without the arithmetic
+    if constexpr (kJob) {  // the two dequant MFMAs of this step's weight word queue behind A4
       constexpr int widx = 2 * J::h + (J::j & 1), s = J::j >> 1;
       const u32 word = widx == 0 ? gc.w[s].x : (widx == 1 ? gc.w[s].y : (widx == 2 ? gc.w[s].z : gc.w[s].w));
       pj = cd.word_issue(word, gc.b01[s], gc.b23[s], gc.c[s]);
     }
     if constexpr (BAR) {
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w1));
-      __syncthreads();  // + vmcnt(0): the next tile's x DMA and packed words have landed; every read of the other stage retired
+      if constexpr (PROBE == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else __syncthreads();  // + vmcnt(0): the next tile's x DMA and packed words have landed; every read of the other stage retired
     }
     V4_FENCE();
     if constexpr (RD) V4_READ(w0, wa[KN], SN * kTileW);
     if constexpr (!BAR) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(w1) : "n"(RD ? 1 : 0));
     V4_FENCE();
     acc[1][0] = mf(w1, x0, acc[1][0]);
-    if constexpr (J::has) {
+    if constexpr (kJob) {
       const vec8 v = Cdna4DequantT<DT>::word_finish(pj);
-      V4_WRITE(ja[J::j & 1], __builtin_bit_cast(u32x4, v), J::st * kTileW + (J::j >> 1) * 2048);
+      if constexpr (PROBE == 6) asm volatile("" : : "v"(v));  // dequant arithmetic without the LDS write
+      else V4_WRITE(ja[J::j & 1][J::j >> 1], __builtin_bit_cast(u32x4, v), J::st * kTileW);
     }
     V4_FENCE();
     if constexpr (RD) V4_READ(x0, xa[KN], SN * kTileX);
@@ -239,12 +266,12 @@ __device__ __forceinline__ void v4_tile(char* smem, const uint16_t* __restrict__
   __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and the ds_writes
 #pragma unroll
   for (int s = 0; s < 2; ++s) asm volatile("" : "+v"(rn.w[s]), "+v"(rn.sz[s]));  // as v3: no pending ordinary load enters the loop
-  issue_a(1, 1);
+  issue_a_slot(1, 1, 0);
   V4_FENCE();
   // first word of tile 1 = (group 0, half 1) -> stage 1, then the fragments of k-step 0 in the order the ladder expects
   {
     const vec8 v = cd.word(gc.w[0].z, gc.b01[0], gc.b23[0], gc.c[0]);
-    V4_WRITE(ja[0], __builtin_bit_cast(u32x4, v), kTileW);
+    V4_WRITE(ja[0][0], __builtin_bit_cast(u32x4, v), kTileW);
   }
   V4_READ(w0, wa[0], 0);
   V4_READ(x0, xa[0], 0);
@@ -261,19 +288,31 @@ __device__ __forceinline__ void v4_tile(char* smem, const uint16_t* __restrict__
     using F = bc<false>;
     // ---------- K-tile 2q (stage 0); writes words 1..3 of tile 2q+1 = (group q, half 1) into stage 1 ----------
     kstep(ic<0>{}, ic<0>{}, ic<1>{}, T{}, F{}, JobT<1, 1, 1>{});
+    issue_a_slot(2 * q + 1, 1, 1);
+    V4_FENCE();
     kstep(ic<1>{}, ic<0>{}, ic<2>{}, T{}, F{}, JobT<1, 2, 1>{});
+    issue_a_slot(2 * q + 1, 1, 2);
+    V4_FENCE();
     kstep(ic<0>{}, ic<0>{}, ic<3>{}, T{}, F{}, JobT<1, 3, 1>{});
+    issue_a_slot(2 * q + 1, 1, 3);
+    V4_FENCE();
     if constexpr (more) {
       gc = prep(rn);  // group q+1: loaded one iteration ago, retired by the previous barrier's vmcnt(0)
       kstep(ic<1>{}, ic<1>{}, ic<0>{}, T{}, T{}, JobT<0, 0, 0>{});  // barrier inside; first word of tile 2q+2 -> stage 0
       rn = load_group(min(q + 2, nit - 1));
-      issue_a(2 * q + 2, 0);
+      issue_a_slot(2 * q + 2, 0, 0);
       V4_FENCE();
       kstep(ic<0>{}, ic<1>{}, ic<1>{}, T{}, F{}, JobT<0, 1, 0>{});
+      issue_a_slot(2 * q + 2, 0, 1);
+      V4_FENCE();
       kstep(ic<1>{}, ic<1>{}, ic<2>{}, T{}, F{}, JobT<0, 2, 0>{});
+      issue_a_slot(2 * q + 2, 0, 2);
+      V4_FENCE();
       kstep(ic<0>{}, ic<1>{}, ic<3>{}, T{}, F{}, JobT<0, 3, 0>{});
+      issue_a_slot(2 * q + 2, 0, 3);
+      V4_FENCE();
       kstep(ic<1>{}, ic<0>{}, ic<0>{}, T{}, T{}, JobT<1, 0, 1>{});  // barrier inside; first word of tile 2q+3 -> stage 1
-      issue_a(2 * q + 3, 1);
+      issue_a_slot(2 * q + 3, 1, 0);
       V4_FENCE();
     } else {
       kstep(ic<1>{}, ic<1>{}, ic<0>{}, T{}, T{}, NoJob{});
@@ -319,6 +358,15 @@ __device__ __forceinline__ void v4_tile(char* smem, const uint16_t* __restrict__
     const int row = ps * RP + lane / GR, gc2 = lane % GR;
     const int m = m0 + wm * 128 + row, nn = n0 + wn * WN + gc2 * 8;
     u32x4 v = *reinterpret_cast<const u32x4*>(eb + row * kEpiRow + gc2 * 16);
+    if (epi == 2) {
+      // QuantLlamaMLP's interleaved pair (llm_awq_amd/fused_mlp.py): columns 16 j .. + 7 are gate rows 8 j .., + 8 .. + 15 the matching
+      // up rows -- the even granule of a pair stores silu(gate) * up to out[m, N/2], the odd one has nothing to store
+      if ((gc2 & 1) == 0 && nn < n_end && m >= row_lo && m < row_hi) {
+        const u32x4 u = *reinterpret_cast<const u32x4*>(eb + row * kEpiRow + (gc2 + 1) * 16);
+        __builtin_nontemporal_store(silu_mul_octet<DT>(v, u), reinterpret_cast<u32x4*>(out + (size_t)m * (N >> 1) + (nn >> 1)));
+      }
+      continue;
+    }
     if (nn < n_end && m >= row_lo && m < row_hi) {
       if (bias != nullptr) {  // `out + self.bias` in T (qmodule.py:221)
         const u32x4 bv = *reinterpret_cast<const u32x4*>(bias + nn);
@@ -339,7 +387,7 @@ template <typename DT, int PROBE, int BITS = 4>
 __global__ __launch_bounds__(512) void gemm_cdna4_v4_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                             const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
                                                             uint16_t* __restrict__ out, int M, int N, int K, int tiles_m,
-                                                            int tiles_n, int n_begin, int n_end) {
+                                                            int tiles_n, int n_begin, int n_end, int epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int T = tiles_m * tiles_n;
   int tile;
@@ -360,7 +408,7 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v4_kernel(const uint16_t* __re
       tm = tiles_m - 1;
     }
   }
-  v4_tile<DT, PROBE, BITS>(smem, x, qw, szp, bias, out, N, K, min(tm * TM, M - TM), n_begin + tn * TN, n_end, 0, M);
+  v4_tile<DT, PROBE, BITS>(smem, x, qw, szp, bias, out, N, K, min(tm * TM, M - TM), n_begin + tn * TN, n_end, 0, M, epi);
 }
 
 // grouped (MoE): expert e owns rows [offsets[e], offsets[e+1]) of the sorted x / out and the e-th slice of the stacked
@@ -402,28 +450,33 @@ int g_v4_probe = 0;
 }
 // weight rows [n_begin, n_end) of the matrix with 256 x 256 tiles (m >= 256); same contract as v3's launch_v3<2>
 void launch_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                          int n_begin, int n_end, int dtype, hipStream_t st, int bits) {
+                          int n_begin, int n_end, int dtype, hipStream_t st, int bits, int epi) {
   constexpr int smem_main = 2 * kTileX + 2 * kTileW;
   constexpr int smem_epi = 8 * 128 * (2 * WN + 16);
   constexpr int smem = smem_main > smem_epi ? smem_main : smem_epi;
   const int tiles_m = (m + TM - 1) / TM, tiles_n = (n_end - n_begin + TN - 1) / TN;
-  using Kern = void (*)(const uint16_t*, const u32*, const u32*, const uint16_t*, uint16_t*, int, int, int, int, int, int, int);
+  using Kern = void (*)(const uint16_t*, const u32*, const u32*, const uint16_t*, uint16_t*, int, int, int, int, int, int, int, int);
 #ifdef AWQ_ENABLE_PROBES
-  static const Kern kerns[2][4] = {
-      {gemm_cdna4_v4_kernel<F16, 0>, gemm_cdna4_v4_kernel<F16, 1>, gemm_cdna4_v4_kernel<F16, 2>, gemm_cdna4_v4_kernel<F16, 3>},
-      {gemm_cdna4_v4_kernel<BF16, 0>, gemm_cdna4_v4_kernel<BF16, 1>, gemm_cdna4_v4_kernel<BF16, 2>, gemm_cdna4_v4_kernel<BF16, 3>}};
+  constexpr int NP = 11;
+#define V4K(T, P) gemm_cdna4_v4_kernel<T, P>
+  static const Kern kerns[2][NP] = {
+      {V4K(F16, 0), V4K(F16, 0), V4K(F16, 0), V4K(F16, 0), V4K(F16, 0), V4K(F16, 0), V4K(F16, 0), V4K(F16, 0), V4K(F16, 0), V4K(F16, 0), V4K(F16, 0)},
+      {V4K(BF16, 0), V4K(BF16, 1), V4K(BF16, 2), V4K(BF16, 3), V4K(BF16, 4), V4K(BF16, 5), V4K(BF16, 6), V4K(BF16, 7), V4K(BF16, 8), V4K(BF16, 9), V4K(BF16, 10)}};
 #else  // a default build has no knob that changes results
-  static const Kern kerns[2][4] = {
-      {gemm_cdna4_v4_kernel<F16, 0>, gemm_cdna4_v4_kernel<F16, 0>, gemm_cdna4_v4_kernel<F16, 0>, gemm_cdna4_v4_kernel<F16, 0>},
-      {gemm_cdna4_v4_kernel<BF16, 0>, gemm_cdna4_v4_kernel<BF16, 0>, gemm_cdna4_v4_kernel<BF16, 0>, gemm_cdna4_v4_kernel<BF16, 0>}};
+  constexpr int NP = 11;
+#define V4K(T, P) gemm_cdna4_v4_kernel<T, 0>
+  static const Kern kerns[2][NP] = {
+      {V4K(F16, 0), V4K(F16, 0), V4K(F16, 0), V4K(F16, 0), V4K(F16, 0), V4K(F16, 0), V4K(F16, 0), V4K(F16, 0), V4K(F16, 0), V4K(F16, 0), V4K(F16, 0)},
+      {V4K(BF16, 0), V4K(BF16, 0), V4K(BF16, 0), V4K(BF16, 0), V4K(BF16, 0), V4K(BF16, 0), V4K(BF16, 0), V4K(BF16, 0), V4K(BF16, 0)}};
 #endif
+#undef V4K
   static const Kern kerns3[2] = {gemm_cdna4_v4_kernel<F16, 0, 3>, gemm_cdna4_v4_kernel<BF16, 0, 3>};  // w3c tiles
-  const int pi = g_v4_probe >= 0 && g_v4_probe <= 3 ? g_v4_probe : 0;
+  const int pi = g_v4_probe >= 0 && g_v4_probe < NP ? g_v4_probe : 0;
   const Kern kern = bits == 3 ? kerns3[dtype == 0 ? 0 : 1] : kerns[dtype == 0 ? 0 : 1][pi];
-  static LdsOptIn optin[2][5];  // per (kernel, device)
-  optin[dtype == 0 ? 0 : 1][bits == 3 ? 4 : pi].ensure(reinterpret_cast<const void*>(kern), smem);
+  static LdsOptIn optin[2][NP + 1];  // per (kernel, device)
+  optin[dtype == 0 ? 0 : 1][bits == 3 ? NP : pi].ensure(reinterpret_cast<const void*>(kern), smem);
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw,
-                     (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end);
+                     (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end, epi);
 }
 void gemm_v4_set_probe(int v) { g_v4_probe = v; }
 

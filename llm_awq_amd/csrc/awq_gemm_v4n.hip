@@ -39,7 +39,14 @@ constexpr int kWBase = 2 * kTileX;
 constexpr int WN = 32;  // weight rows per wave
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ int tile_off(int row, int gc) { return row * 128 + ((gc ^ ((row >> 1) & 7)) << 4); }
+// 16-byte granule gc of tile row `row` (128-byte rows).  The XOR term serves both access shapes (MI355X_MICROARCH.md, LDS):
+//   * ds_read_b128 fragments (64 banks, lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} of the 32 rows a half-wave reads): the
+//     eight even and the eight odd rows of a group must hit eight different granules -- rows & 6 alone repeat, bit 4 separates them;
+//   * ds_write_b128 of a dequantised word (32 banks = ONE row width, eight consecutive lanes = eight consecutive rows, same gc):
+//     row & 7 must differ.  (Round 1 used (row >> 1) & 7: conflict-free reads, 2-way conflicts on every write = the 21 % of
+//     SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE in profiles/r01_pmc_gemm_v4.txt.)
+__device__ __forceinline__ int swz(int row) { return (row & 7) ^ ((row >> 4) & 1); }
+__device__ __forceinline__ int tile_off(int row, int gc) { return row * 128 + ((gc ^ swz(row)) << 4); }
 
 struct Group {  // one quantisation group (128 k) of the wave's slab
   u32x4 w;
@@ -75,7 +82,7 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v4n_kernel(const uint16_t* __r
                                                              const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
                                                              uint16_t* __restrict__ out, int M, int N, int K, int tiles_m,
                                                              int tiles_n, int n_begin, int n_end, int ksplit,
-                                                             float* __restrict__ partial) {
+                                                             float* __restrict__ partial, int epi) {
   using vec8 = typename DT::vec8;
   constexpr int kEpiRow = 2 * WN + 16;  // bytes per staged output row (+16 pad)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -114,9 +121,9 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v4n_kernel(const uint16_t* __r
   u32 a_off[4];
   {
     const int row = tid >> 3, gcp = tid & 7;
-    const int gc = gcp ^ ((row >> 1) & 7);
+    const int gc = gcp ^ swz(row);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) a_off[q] = (u32)min(m0 + row + 64 * q, M - 1) * (u32)K + gc * 8;  // (64 q keeps (row >> 1) & 7)
+    for (int q = 0; q < 4; ++q) a_off[q] = (u32)min(m0 + row + 64 * q, M - 1) * (u32)K + gc * 8;  // (64 q keeps swz(row))
   }
   // PARTIAL: rows >= M are not even fetched (their LDS rows keep stale bits; output rows depend on their own x row only and
   // rows >= M are never stored)
@@ -354,6 +361,13 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v4n_kernel(const uint16_t* __r
     const int row = ps * RP + lane / GR, gc2 = lane % GR;
     const int m = m0 + wm * 128 + row, nn = n0 + wn * WN + gc2 * 8;
     u32x4 v = *reinterpret_cast<const u32x4*>(eb + row * kEpiRow + gc2 * 16);
+    if (epi == 2) {  // QuantLlamaMLP's interleaved gate / up pair: see awq_gemm_v4.hip
+      if ((gc2 & 1) == 0 && nn < n_end && m < M) {
+        const u32x4 u = *reinterpret_cast<const u32x4*>(eb + row * kEpiRow + (gc2 + 1) * 16);
+        __builtin_nontemporal_store(silu_mul_octet<DT>(v, u), reinterpret_cast<u32x4*>(out + (size_t)m * (N >> 1) + (nn >> 1)));
+      }
+      continue;
+    }
     if (nn < n_end && m < M) {
       if (bias != nullptr) {  // `out + self.bias` in T (qmodule.py:221)
         const u32x4 bv = *reinterpret_cast<const u32x4*>(bias + nn);
@@ -471,12 +485,12 @@ size_t gemm_v4n_workspace_bytes(int m, int n_cols, int k) {
 // (one row tile whose missing rows are computed from row m - 1 and not stored).
 // ws / ws_bytes: optional fp32 workspace; when it holds gemm_v4n_workspace_bytes() the K loop is split (see the header)
 void launch_gemm_cdna4_v4n(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                           int n_begin, int n_end, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits) {
+                           int n_begin, int n_end, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits, int epi) {
   constexpr int smem_main = 2 * kTileX + 2 * kTileW;
   constexpr int smem_epi = 8 * 128 * (2 * WN + 16);
   constexpr int smem = smem_main > smem_epi ? smem_main : smem_epi;
   const int tiles_m = (m + TM - 1) / TM, tiles_n = (n_end - n_begin + TN - 1) / TN;
-  using Kern = void (*)(const uint16_t*, const u32*, const u32*, const uint16_t*, uint16_t*, int, int, int, int, int, int, int, int, float*);
+  using Kern = void (*)(const uint16_t*, const u32*, const u32*, const uint16_t*, uint16_t*, int, int, int, int, int, int, int, int, float*, int);
   static const Kern kerns4[2][2][2] = {  // [dtype][split][partial]
       {{gemm_cdna4_v4n_kernel<F16, 0, 0>, gemm_cdna4_v4n_kernel<F16, 0, 1>}, {gemm_cdna4_v4n_kernel<F16, 1, 0>, gemm_cdna4_v4n_kernel<F16, 1, 1>}},
       {{gemm_cdna4_v4n_kernel<BF16, 0, 0>, gemm_cdna4_v4n_kernel<BF16, 0, 1>}, {gemm_cdna4_v4n_kernel<BF16, 1, 0>, gemm_cdna4_v4n_kernel<BF16, 1, 1>}}};
@@ -489,16 +503,16 @@ void launch_gemm_cdna4_v4n(const void* x, const void* qw, const void* szp, const
   const int dt = dtype == 0 ? 0 : 1, partial = m <= TM - 32 ? 1 : 0;  // a whole 32-row fragment of the single row tile is empty
   const int ks = gemm_v4n_ksplit(m, n_end - n_begin, k);
   const size_t need = ks > 1 ? (size_t)tiles_m * tiles_n * ks * TM * TN * 4 : 0;
-  if (ks > 1 && ws != nullptr && ws_bytes >= need && (reinterpret_cast<uintptr_t>(ws) & 15) == 0) {
+  if (epi == 0 && ks > 1 && ws != nullptr && ws_bytes >= need && (reinterpret_cast<uintptr_t>(ws) & 15) == 0) {  // (the split-K reduce has no fused tail)
     hipLaunchKernelGGL(kerns[dt][1][partial], dim3(tiles_m * tiles_n * ks), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw,
-                       (const u32*)szp, (const uint16_t*)nullptr, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end, ks, (float*)ws);
+                       (const u32*)szp, (const uint16_t*)nullptr, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end, ks, (float*)ws, 0);
     auto red = dtype == 0 ? splitk_reduce_kernel<F16> : splitk_reduce_kernel<BF16>;
     hipLaunchKernelGGL(red, dim3((unsigned)(tiles_m * tiles_n * 8)), dim3(256), 0, st, (const float*)ws, (const uint16_t*)bias, (uint16_t*)out,
                        m, n, tiles_m, tiles_n, n_begin, n_end, ks);
     return;
   }
   hipLaunchKernelGGL(kerns[dt][0][partial], dim3(tiles_m * tiles_n), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw,
-                     (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end, 1, (float*)nullptr);
+                     (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end, 1, (float*)nullptr, epi);
 }
 
 }  // namespace awq

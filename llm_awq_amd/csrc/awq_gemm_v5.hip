@@ -34,7 +34,8 @@ constexpr int kV5Pitch = 2 * V5_TN + 16;  // epilogue staging: bytes per output 
 
 // MF = row fragments (of 16 rows) per wave: 16 -> 256-row blocks, 8 -> 128-row blocks (twice the blocks for the same matrix:
 // prompts whose 256-row tiles would fill only half of the CUs)
-template <typename DT, int BITS, int MF>
+// SPR: 1 = the DMA pieces of the next x tile are issued in three groups behind the first three k-steps instead of one burst
+template <typename DT, int BITS, int MF, int SPR = 0>
 __global__ __launch_bounds__(512) void gemm_cdna4_v5_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                             const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
                                                             uint16_t* __restrict__ out, int M, int N, int K, int tiles_m, int tiles_n,
@@ -77,13 +78,16 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v5_kernel(const uint16_t* __re
     const int row = 4 * NQ * wv + 4 * q + (lane >> 4), p = lane & 15;
     xsrc[q] = (u32)min(m0 + row, M - 1) * (u32)K + (u32)((p ^ (row & 15)) * 8);
   }
-  auto issue_x = [&](int kt, int stage) {
+  auto issue_x_pieces = [&](int kt, int stage, int q0, int q1) {
     char* dst = smem + stage * kV5Stage + wv * (NQ * 1024);
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
+    for (int q = 0; q < NQ; ++q) {
+      if (q < q0 || q >= q1) continue;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x + (size_t)kt * V5_TK + xsrc[q]),
                                        V5_LDS_PTR(dst + q * 1024), 16, 0, 0);
+    }
   };
+  auto issue_x = [&](int kt, int stage) { issue_x_pieces(kt, stage, 0, NQ); };
 
   // ---- weights: slabs 2 wv, 2 wv + 1 of the block's 16 ----
   const int nslab = N >> 4, slab_end = min(nslab, n_end >> 4);
@@ -145,7 +149,10 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v5_kernel(const uint16_t* __re
     asm volatile("" : "+v"(cur.w[0]), "+v"(cur.w[1]), "+v"(cur.sz[0]), "+v"(cur.sz[1]));
     __builtin_amdgcn_s_barrier();
     WG nxt = load_w(min(t + 1, nit - 1));
-    if (t + 1 < nit) issue_x(t + 1, stage ^ 1);
+    if (t + 1 < nit) {
+      if (SPR == 0) issue_x(t + 1, stage ^ 1);
+      else issue_x_pieces(t + 1, stage ^ 1, 0, (3 * NQ) / 8);
+    }
     // (expand w3c tiles once per group)
     u32x4 wt[2];
 #pragma unroll
@@ -169,6 +176,10 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v5_kernel(const uint16_t* __re
         op[s] = cd.word(word, b01[s], b23[s], cv[s]);
       }
       const u32 addr = xa[a] + sbase;
+      if (SPR != 0 && t + 1 < nit) {
+        if (a == 1) issue_x_pieces(t + 1, stage ^ 1, (3 * NQ) / 8, (6 * NQ) / 8);
+        if (a == 2) issue_x_pieces(t + 1, stage ^ 1, (6 * NQ) / 8, NQ);
+      }
 #pragma unroll
       for (int h = 0; h < MF / 8; ++h) {
         u32x4 xf[8];
@@ -241,18 +252,20 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v5_kernel(const uint16_t* __re
 // weight rows [n_begin, n_end) with (16 mf) x 256 blocks, mf = 16 or 8; any m >= 1 (rows past m are clamped / not stored)
 void launch_gemm_cdna4_v5(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
                           int n_end, int dtype, hipStream_t st, int bits, int mf) {
-  const int tm = 16 * mf;
+  const int tm = mf == 17 ? 256 : 16 * mf;
   const int stage = tm * V5_TK * 2, epi = tm * kV5Pitch;
   const int smem = 2 * stage > epi ? 2 * stage : epi;
   const int tiles_m = (m + tm - 1) / tm, tiles_n = (n_end - n_begin + V5_TN - 1) / V5_TN;
   using Kern = void (*)(const uint16_t*, const u32*, const u32*, const uint16_t*, uint16_t*, int, int, int, int, int, int, int);
+  static const Kern spread[2] = {gemm_cdna4_v5_kernel<F16, 4, 16, 1>, gemm_cdna4_v5_kernel<BF16, 4, 16, 1>};
   static const Kern kerns[2][2][2] = {
       {{gemm_cdna4_v5_kernel<F16, 4, 16>, gemm_cdna4_v5_kernel<F16, 4, 8>}, {gemm_cdna4_v5_kernel<F16, 3, 16>, gemm_cdna4_v5_kernel<F16, 3, 8>}},
       {{gemm_cdna4_v5_kernel<BF16, 4, 16>, gemm_cdna4_v5_kernel<BF16, 4, 8>}, {gemm_cdna4_v5_kernel<BF16, 3, 16>, gemm_cdna4_v5_kernel<BF16, 3, 8>}}};
   const int a = dtype == 0 ? 0 : 1, b = bits == 3 ? 1 : 0, c = mf == 8 ? 1 : 0;
-  const Kern kern = kerns[a][b][c];
-  static LdsOptIn optin[2][2][2];
-  optin[a][b][c].ensure(reinterpret_cast<const void*>(kern), smem);
+  const bool spr = mf == 17;  // experiments: 256-row blocks with the spread DMA
+  const Kern kern = spr ? spread[a] : kerns[a][b][c];
+  static LdsOptIn optin[2][2][2], optin_s[2];
+  (spr ? optin_s[a] : optin[a][b][c]).ensure(reinterpret_cast<const void*>(kern), smem);
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp,
                      (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end);
 }

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_dma_kernel(const uint16_t* __
       } else {
         // fused_mlp.py:79-82: c = F.silu(gate_output) * up_output, every op rounded to T
         const float gt = to_f(DT::from_float(v[0])), up = to_f(DT::from_float(v[NS - 1]));
-        const float sl = to_f(DT::from_float(gt / (1.0f + __expf(-gt))));
+        const float sl = to_f(DT::from_float(gt / (1.0f + expf(-gt))));
         out[(size_t)i * (N >> 1) + nn] = DT::from_float(sl * up);
       }
     }
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_dma_kernel(const uint16_t* __
         usum += p[r * 64 + lane + 32];
       }
       const float gt = to_f(DT::from_float(gsum)), up = to_f(DT::from_float(usum));
-      const float sl = to_f(DT::from_float(gt / (1.0f + __expf(-gt))));
+      const float sl = to_f(DT::from_float(gt / (1.0f + expf(-gt))));
       out[(size_t)i * (N >> 1) + nb * 8 + 4 * g + r] = DT::from_float(sl * up);
     }
   }

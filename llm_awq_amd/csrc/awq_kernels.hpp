@@ -71,7 +71,8 @@ size_t gemm_workspace_bytes(int m, int n, int k);
 // bias may be nullptr; when given it is added in the epilogue (`out + bias` in T)
 // bits 4: cdna4 W4 tiles; bits 3: w3c tiles (read natively by the v4 / v4n weight producers)
 int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                         int tile_n, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits = 4);
+                         int tile_n, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits = 4, int epi = 0);
+// epi 2: qw holds QuantLlamaMLP's 8 + 8 row-interleaved gate / up pair, out[m, n/2] = silu(gate) * up fused into the tile epilogue
 int gemm_variant_get();
 // skinny GEMM, 9 <= m <= 255 (row chunks of <= 64), cdna4 layout + packed sz (awq_skinny_cdna4.hip); bias may be nullptr; -1 if unsupported
 int launch_skinny_cdna4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
@@ -84,7 +85,7 @@ int gemm_v3_tune_set(const char* key, int value);  // gemm_v4, gemm_v4_probe
 void gemm_v4_set_probe(int v);
 // 256 x 128 tiles with the same hand-scheduled K loop (awq_gemm_v4n.hip)
 void launch_gemm_cdna4_v4n(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                           int n_begin, int n_end, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits = 4);
+                           int n_begin, int n_end, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits = 4, int epi = 0);
 size_t gemm_v4n_workspace_bytes(int m, int n_cols, int k);
 extern int g_v4n_ksplit_force;  // knob gemm_splitk > 1
 bool gemm_cdna4_v3_takes(int m, int k);  // m >= 256, or a shorter prompt the 256-row tile still beats the skinny kernel on
@@ -96,7 +97,7 @@ int launch_moe_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, con
 bool moe_v4_enabled();
 // 256 x 256-tile prefill GEMM with the hand-scheduled K loop (awq_gemm_v4.hip): weight rows [n_begin, n_end), m >= 256
 void launch_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                          int n_begin, int n_end, int dtype, hipStream_t st, int bits = 4);
+                          int n_begin, int n_end, int dtype, hipStream_t st, int bits = 4, int epi = 0);
 // 256 x 256 blocks, weights streamed straight into registers per wave (awq_gemm_v5.hip); any m >= 1
 void launch_gemm_cdna4_v5(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
                           int n_end, int dtype, hipStream_t st, int bits = 4, int mf = 16);

@@ -458,6 +458,31 @@ torch::Tensor rmsnorm_forward_cdna4(torch::Tensor in_feats, torch::Tensor gamma,
   return out;
 }
 
+// QuantLlamaMLP.our_llama_mlp for any row count on the 8 + 8 interleaved gate / up pair: out [.., n2 / 2]
+torch::Tensor mlp_gate_up_forward_cdna4(torch::Tensor in_feats, torch::Tensor kernel, torch::Tensor sz_packed, c10::optional<torch::Tensor> sz_half) {
+  TORCH_CHECK(in_feats.is_cuda() && kernel.is_cuda() && sz_packed.is_cuda());
+  TORCH_CHECK(in_feats.is_contiguous() && kernel.is_contiguous() && sz_packed.is_contiguous());
+  TORCH_CHECK((in_feats.scalar_type() == at::kBFloat16 || in_feats.scalar_type() == at::kHalf) && kernel.scalar_type() == at::kShort &&
+              sz_packed.scalar_type() == at::kInt);
+  const int64_t n2 = kernel.size(0) * 4, k = in_feats.size(-1);
+  TORCH_CHECK(k > 0 && in_feats.numel() % k == 0 && kernel.numel() == n2 / 4 * k);
+  TORCH_CHECK(sz_packed.numel() == n2 * (k / 128), "sz_packed must be int32 [n2/16, k/128, 16]");
+  const void* hp = nullptr;
+  if (sz_half.has_value() && sz_half->defined()) {
+    TORCH_CHECK(sz_half->is_cuda() && sz_half->is_contiguous() && sz_half->scalar_type() == at::kInt && sz_half->numel() == sz_packed.numel());
+    hp = sz_half->data_ptr();
+  }
+  const int64_t m = in_feats.numel() / k;
+  std::vector<int64_t> shape = in_feats.sizes().vec();
+  shape.back() = n2 / 2;
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(in_feats.device());
+  at::Tensor out = torch::empty(shape, in_feats.options());
+  if (m == 0) return out;
+  raise_on(awq_w4a16_mlp_gate_up_forward_cdna4(in_feats.data_ptr(), kernel.data_ptr(), sz_packed.data_ptr(), hp, out.data_ptr(), (int)m, (int)n2,
+                                               (int)k, 128, dtype_code(in_feats), (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()));
+  return out;
+}
+
 // "sz_half" side buffer of the decode kernels; returns (int32 [n/16, k/128, 16], exact).  Synchronises once (reads the flag).
 std::tuple<torch::Tensor, bool> pack_szh_cdna4(torch::Tensor scales, torch::Tensor zeros, int k) {
   TORCH_CHECK(scales.is_cuda() && zeros.is_cuda() && scales.is_contiguous() && zeros.is_contiguous());
@@ -533,5 +558,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("rmsnorm_forward_cdna4", &rmsnorm_forward_cdna4, "RMSNorm fused in front of the decode GEMV (<= 4 rows)", py::arg("in_feats"),
         py::arg("gamma"), py::arg("eps"), py::arg("kernel"), py::arg("sz_packed"), py::arg("bias") = py::none(),
         py::arg("fused_gate_up") = false);
+  m.def("mlp_gate_up_forward_cdna4", &mlp_gate_up_forward_cdna4, "silu(x Wg^T) * (x Wu^T) for any row count on the 8 + 8 interleaved gate/up pair",
+        py::arg("in_feats"), py::arg("kernel"), py::arg("sz_packed"), py::arg("sz_half") = py::none());
   m.def("mlp_gate_up_cdna4", &mlp_gate_up_cdna4, "silu(x Wg^T) * (x Wu^T) on stacked cdna4 gate/up buffers, <= 8 rows");
 }

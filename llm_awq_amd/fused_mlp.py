@@ -9,8 +9,9 @@ The reference module keeps gate_proj / up_proj as raw v2 buffers, issues two `ge
     two streams (896: 3.5 per CU, so half the CUs carried 4 blocks and the rest 3);
   * decode (< 8 rows): `decode_cdna4(..., epilogue=2)` -- gate, up, SiLU and the multiply in one launch, every intermediate
     rounded to T exactly like the reference's separate ops (fused_mlp.py:39-61, :79-82);
-  * prefill (>= 8 rows): one GEMM over the interleaved weight (x is read once for both projections), then SiLU * up on the
-    de-interleaved halves.
+  * prefill (>= 8 rows): one GEMM over the interleaved weight (x is read once for both projections) whose tile epilogue pairs
+    column n with column n + 8 and stores silu(gate) * up directly -- the [rows, 2 * ffn] intermediate of the reference's two
+    GEMMs + F.silu + multiply is never written.
 
 `scaled_zeros - 8 * scales` (fused_mlp.py:69,76): the reference's GEMM branch shifts the zero point by 8 while its GEMV
 branch, `WQLinear.forward` (qmodule.py:220, shift commented out), `from_linear` and the offline repacker (`zp_shift = 0`,
@@ -87,14 +88,8 @@ class QuantLlamaMLP(nn.Module):
         c4, s, z, szp, szh = self._fused
         if not x.is_contiguous():
             x = x.contiguous()
-        rows = x.numel() // x.shape[-1]
-        if rows < 8 and szh is not None:
-            return eng.decode_cdna4(x, c4, szh, None, 2)
-        # prefill (or a layer whose scales are not f16-exact): one GEMM over the interleaved pair, x read once
-        y = eng.forward_cdna4(x, c4, s, z, szp, None)
-        y = y.view(*y.shape[:-1], self.intermediate_size // 8, 2, 8)
-        gate, up = y[..., 0, :], y[..., 1, :]
-        return (F.silu(gate) * up).reshape(*x.shape[:-1], self.intermediate_size)
+        # one entry point for every row count: <= 8 rows the streaming decode launch, more the tile kernels with the fused tail
+        return eng.mlp_gate_up_forward_cdna4(x, c4, szp, szh)
 
 
 def make_fused_mlp(m, parent_name=""):

@@ -248,6 +248,20 @@ def mlp_gate_up_cdna4(x, qweight_gate_up, sz_packed, group_size: int = 128):
     return out
 
 
+def mlp_gate_up_forward_cdna4(x, qweight_interleaved, sz_packed, sz_half=None, group_size: int = 128):
+    """C-ABI awq_w4a16_mlp_gate_up_forward_cdna4: QuantLlamaMLP.our_llama_mlp for any row count on the 8 + 8 interleaved pair."""
+    _need_gpu(x, qweight_interleaved, sz_packed, sz_half)
+    k = x.shape[-1]
+    m = x.numel() // k
+    n2 = qweight_interleaved.shape[0] * 4
+    out = torch.empty(*x.shape[:-1], n2 // 2, dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _capi.check(_capi.lib().awq_w4a16_mlp_gate_up_forward_cdna4(x.data_ptr(), qweight_interleaved.data_ptr(), sz_packed.data_ptr(),
+                                                                     sz_half.data_ptr() if sz_half is not None else None, out.data_ptr(),
+                                                                     m, n2, k, group_size, _dt(x), _stream(x)))
+    return out
+
+
 def rmsnorm_forward_cdna4(x, gamma, eps: float, qweight, sz_packed, bias=None, fused_gate_up: bool = False, group_size: int = 128):
     """C-ABI awq_w4a16_rmsnorm_forward_cdna4: T5/Llama RMSNorm (FTLlamaRMSNorm, fused_norm.py:7-21) fused in front of the
     quantised linear -- or, with fused_gate_up, of the gate/up pair + SiLU*mul.  x: un-normalised [.., K], 1 <= M <= 4."""

@@ -1,0 +1,109 @@
+"""-m gpu: QuantLlamaMLP / make_fused_mlp (tinychat/modules/fused_mlp.py:11-101) and the C-ABI entry behind it,
+`awq_w4a16_mlp_gate_up_forward_cdna4`, for every row count: <= 8 rows the streaming decode launch, more rows the prefill tile
+kernels with the SiLU * mul tail fused into their epilogue.  The checker is the oracle's statement of the reference sequence:
+two WQLinear forwards, F.silu, multiply, every op rounded to T (fused_mlp.py:36-83), then down_proj."""
+import pytest
+import torch
+
+from oracle import awq_oracle as O
+from tests.helpers import check_forward, make_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(F, K, dtype, seed, M):
+    cg = make_case(F, K, dtype, seed=seed, M=M)
+    cu = make_case(F, K, dtype, seed=seed + 1, M=M)
+    x = cg["x"]
+    g = O.wqlinear_forward(x, None, cg["scales"], cg["scaled_zeros"], None, 128, q_int=cg["q"])
+    u = O.wqlinear_forward(x, None, cu["scales"], cu["scaled_zeros"], None, 128, q_int=cu["q"])
+    return cg, cu, x, torch.nn.functional.silu(g) * u
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [1, 7, 8, 9, 16, 17, 64, 300, 2048])
+@pytest.mark.parametrize("F,K", [(256, 768), (1376, 512), (2048, 2048), (14336, 4096)])
+def test_gate_up_entry_every_row_count(dtype, M, F, K):
+    from llm_awq_amd import ops
+    from llm_awq_amd.fused_mlp import interleave_gate_up
+    if F >= 4096 and (M not in (1, 9, 2048) or dtype != torch.bfloat16):
+        pytest.skip("full-size case: bf16, M = 1, 9, 2048 only")
+    if M == 2048 and F * K < 2048 * 2048:
+        pytest.skip("M = 2048 on the two larger shapes only")
+    cg, cu, x, ref = _pair(F, K, dtype, F + K + M, M)
+    qi, si, zi = interleave_gate_up(cg["qweight"].cuda(), cu["qweight"].cuda(), cg["scales"].cuda(), cu["scales"].cuda(),
+                                    cg["scaled_zeros"].cuda(), cu["scaled_zeros"].cuda())
+    c4 = ops.repack_v2_to_cdna4(qi)
+    szp = ops.pack_sz_cdna4(si, zi, K)
+    szh, exact = ops.pack_szh_cdna4(si, zi, K)
+    assert exact
+    ys = [ops.mlp_gate_up_forward_cdna4(x.cuda(), c4, szp, szh).cpu(), ops.mlp_gate_up_forward_cdna4(x.cuda(), c4, szp, None).cpu()]
+    for y in ys:
+        assert y.shape == (M, F)
+        rel = ((y.float() - ref.float()).norm() / ref.float().norm()).item()
+        assert rel <= 3e-3, rel          # three roundings to T deep; the exact-match fraction is the sharper check
+        assert (y == ref).float().mean() > (0.95 if M <= 300 else 0.93)
+    assert (ys[0] == ys[1]).float().mean() > 0.99
+    # the fused tail == the unfused product path on the same interleaved stream: GEMM, de-interleave, F.silu * up, all in T
+    full = ops.gemm_cdna4(x.cuda(), c4, si, zi, None, szp)
+    full = full.view(M, F // 8, 2, 8)
+    unfused = (torch.nn.functional.silu(full[:, :, 0, :]) * full[:, :, 1, :]).reshape(M, F).cpu()
+    if M > 8:
+        # same accumulators, same roundings; only the fp32 exp inside silu is another implementation (v_exp_f32 vs torch's expf)
+        assert (ys[1] == unfused).float().mean() > 0.999
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_module_matches_reference_sequence(dtype):
+    """QuantLlamaMLP built from three WQLinear modules (the reference's constructor), through make_fused_mlp."""
+    import torch.nn as nn
+    from llm_awq_amd.fused_mlp import QuantLlamaMLP, make_fused_mlp
+    from llm_awq_amd.qmodule import WQLinear
+    H, F = 1024, 2816
+    cg, cu, x, act = _pair(F, H, dtype, 77, 40)
+    cd = make_case(H, F, dtype, seed=79, M=1)
+
+    def lin(c, k, n):
+        m = WQLinear(4, 128, k, n, False, "cuda", dtype=dtype)
+        m.load_state_dict(dict(qweight=c["qweight"], scales=c["scales"], scaled_zeros=c["scaled_zeros"]))
+        return m
+
+    class LlamaMLP(nn.Module):  # the class name make_fused_mlp keys on (fused_mlp.py:87)
+        def __init__(self):
+            super().__init__()
+            self.gate_proj, self.up_proj, self.down_proj = lin(cg, H, F), lin(cu, H, F), lin(cd, F, H)
+
+    class Block(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.mlp = LlamaMLP()
+
+    blk = make_fused_mlp(Block())
+    assert isinstance(blk.mlp, QuantLlamaMLP)
+    sd = blk.mlp.state_dict()
+    assert {"gate_proj_qweight", "gate_proj_scales", "gate_proj_scaled_zeros", "up_proj_qweight", "up_proj_scales",
+            "up_proj_scaled_zeros"} <= set(sd)  # fused_mlp.py:19-27
+    for M in (1, 5, 8, 9, 40):
+        xm = x[:M].contiguous()
+        a = blk.mlp.our_llama_mlp(xm.cuda()).cpu()
+        assert (a == act[:M]).float().mean() > 0.95
+        y = blk.mlp(xm.cuda()).cpu()
+        # down_proj on the module's own activations must satisfy the forward bound; against the oracle's activations the few
+        # last-bit differences of `a` pass through a 2816-term dot product
+        check_forward(y, a, cd["q"], cd["scales"], cd["scaled_zeros"], dtype)
+        ref = O.wqlinear_forward(act[:M], None, cd["scales"], cd["scaled_zeros"], None, 128, q_int=cd["q"])
+        assert ((y.float() - ref.float()).norm() / ref.float().norm()).item() < 4e-3
+    # 3-D input [batch, seq, hidden] like the model passes
+    y3 = blk.mlp(x[:12].view(2, 6, H).cuda())
+    assert y3.shape == (2, 6, H)
+
+
+def test_entry_rejects_bad_arguments():
+    from llm_awq_amd import ops, _capi
+    c = make_case(64, 256, torch.bfloat16, seed=1, M=4)
+    c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
+    szp = ops.pack_sz_cdna4(c["scales"].cuda(), c["scaled_zeros"].cuda(), 256)
+    with pytest.raises(_capi.AwqNativeError):
+        ops.mlp_gate_up_forward_cdna4(c["x"].cuda(), c4, szp, None, group_size=64)
+    with pytest.raises((TypeError, _capi.AwqNativeError)):
+        ops.mlp_gate_up_forward_cdna4(c["x"].cuda().float(), c4, szp, None)

@@ -94,7 +94,8 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     for (int v : variants) {
-      (void)awq_tune_set("gemm_v4_probe", v / 1000);  // probe builds only (AWQ_PROBES=1)  // Nxxx: timing-only probes of the v4 kernel (results are wrong by design)
+      (void)awq_tune_set("gemm_v5", v / 100000);  // probe builds only: N00xxx = awq_gemm_v5.hip variant N for the 256-wide tiles
+      (void)awq_tune_set("gemm_v4_probe", (v / 1000) % 100);  // probe builds only (AWQ_PROBES=1)  // Nxxx: timing-only probes of the v4 kernel (results are wrong by design)
       AQ(awq_tune_set("gemm_v4", (v % 1000) >= 100));  // 1xx: wide tiles run the hand-scheduled K loop (awq_gemm_v4.hip)  // 1xx: wide tiles run the hand-scheduled K loop (awq_gemm_v4.hip)
       AQ(awq_tune_set("gemm_variant", v % 100));
       CK(hipMemset(dout, 0xFF, (size_t)M * N * 2));
@@ -131,6 +132,7 @@ int main(int argc, char** argv) {
     AQ(awq_tune_set("gemm_variant", 0));
     AQ(awq_tune_set("gemm_v4", 1));
     (void)awq_tune_set("gemm_v4_probe", 0);
+    (void)awq_tune_set("gemm_v5", 0);
     hipFree(dq); hipFree(qw2); hipFree(qw4); hipFree(ds); hipFree(dz); hipFree(dszp); hipFree(dx); hipFree(dout); hipFree(dref);
   }
   return 0;
