@@ -318,10 +318,12 @@ void launch_v3(const void* x, const void* qw, const void* szp, const void* bias,
   hipLaunchKernelGGL((gemm_cdna4_v3_kernel<DT, NSL>), dim3(tiles_m * tiles_n), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw,
                      (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end);
 }
-constexpr double kNarrowRate = 0.83;  // 256 x 128 tiles (awq_gemm_v4n.hip) vs 256 x 256 (awq_gemm_v4.hip) at equal chip fill (profiles/r01_gemm_v4.txt)
+constexpr double kNarrowRate = 0.80;  // 256 x 128 tiles (awq_gemm_v4n.hip) vs 256 x 256 (awq_gemm_v6.hip) at equal chip fill (0.83 against awq_gemm_v4.hip, profiles/r01_gemm_v4.txt)
 int g_small_m = 1;  // knob gemm_small_m: 0 = the prefill GEMM only takes m >= 256 (see gemm_cdna4_v3_takes)
 int g_splitk = 1;  // narrow tiles: split K over blocks when the tiles fill less than half of the chip and a workspace is given
 int g_v5 = 0;  // 1: 256-wide tiles run awq_gemm_v5.hip (weights never touch LDS); knob gemm_v5
+int g_v6 = 1;  // 1 (default): 256-wide tiles of m >= 256 run awq_gemm_v6.hip (one software-pipelined wave per SIMD); 0: awq_gemm_v4.hip
+int g_tile_n = 0;  // knob gemm_tile_n: 128 / 256 force one tile width for callers that pass tile_n = 0 (tests of a specific kernel)
 int g_v4 = 1;  // 1 (default): 256-wide tiles run the hand-scheduled K loop of awq_gemm_v4.hip; 0: v3's compiler-scheduled loop
 void launch_wide(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
                  int n_end, int dtype, hipStream_t st, int bits, int epi) {
@@ -331,7 +333,8 @@ void launch_wide(const void* x, const void* qw, const void* szp, const void* bia
     return;
   }
 #endif
-  if (g_v4 || bits == 3 || epi) launch_gemm_cdna4_v4(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, epi);
+  if (g_v6 && m >= 256) launch_gemm_cdna4_v6(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, epi);
+  else if (g_v4 || bits == 3 || epi) launch_gemm_cdna4_v4(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, epi);
   else if (dtype == 0) launch_v3<F16, 2>(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
   else launch_v3<BF16, 2>(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
 }
@@ -350,12 +353,17 @@ bool moe_v4_enabled() { return g_moe_v4 != 0; }
 
 int gemm_v3_tune_set(const char* key, int value) {
   if (!strcmp(key, "gemm_v4")) g_v4 = value;
+  else if (!strcmp(key, "gemm_v6")) {  // units: 0 off, 1 = the 256-wide tiles, 2 = every tile; tens (probe builds): timing-only probe of the kernel
+    g_v6 = value % 10;
+    gemm_v6_set_probe(value / 10);
+  }
 #ifdef AWQ_ENABLE_PROBES
   else if (!strcmp(key, "gemm_v5")) g_v5 = value;
 #endif
 #ifdef AWQ_ENABLE_PROBES
   else if (!strcmp(key, "gemm_v4_probe")) gemm_v4_set_probe(value);
 #endif
+  else if (!strcmp(key, "gemm_tile_n")) g_tile_n = value;
   else if (!strcmp(key, "moe_v4")) g_moe_v4 = value;
   else if (!strcmp(key, "gemm_small_m")) g_small_m = value;
   else if (!strcmp(key, "gemm_splitk")) {  // 0 = off, 1 = auto, n > 1 = force n K ranges
@@ -427,8 +435,8 @@ int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, const v
                          int tile_n, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits, int epi) {
   // (w3c tiles have no skinny kernel: the masked single-row-tile path of the narrow kernel serves every m > 8)
   if (!szp || !(gemm_cdna4_v3_takes(m, k) || ((bits == 3 || epi) && m > 8)) || (n % 16) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return -1;
-  Plan p = m < TM ? Plan{1, 0} : plan_tiles(m, n, tile_n);  // m < 256: only the narrow-tile kernel masks rows
-  if (g_v5 >= 2) p = Plan{0, 0};                            // experiments: every tile through awq_gemm_v5.hip (it masks rows itself)
+  Plan p = m < TM ? Plan{1, 0} : plan_tiles(m, n, tile_n ? tile_n : g_tile_n);  // m < 256: only the narrow-tile kernel masks rows
+  if (g_v5 >= 2 || g_v6 >= 2) p = Plan{0, 0};                            // experiments: every tile through awq_gemm_v5.hip (it masks rows itself)
   if (p.mode == 2) {
     launch_wide(x, qw, szp, bias, out, m, n, k, 0, (int)(p.cols_main * 256), dtype, st, bits, epi);
     launch_narrow(x, qw, szp, bias, out, m, n, k, (int)(p.cols_main * 256), n, dtype, ws, ws_bytes, st, bits, epi);

@@ -1,0 +1,442 @@
+// Prefill GEMM v6 on cdna4-interleaved weights (bf16 and fp16, gfx950): one wave per SIMD, 256 x 64 per wave.
+//
+// Why (profiles/r02_gemm_v4_probes.txt): the 8-wave kernels are bound by LDS occupancy -- per 16-k step v4 holds the LDS 192 cycles
+// with fragment reads, 104 with the writes of the dequantised weight tile and ~115 with the x tile's LDS-DMA (411 of the 512 cycles
+// the product MFMAs need), v5 256 + 115.  LDS bytes per flop fall with the number of output COLUMNS a wave owns (an x fragment is
+// read once per column strip), and weights that stay in the registers of the wave that dequantised them cost no LDS at all: a wave
+// that owns 64 columns for all 256 rows of the block reads 16 x fragments per 64 MFMAs (128 cycles per 16-k step) and the block needs
+// no weight traffic -- but its accumulators are 256 registers, i.e. ONE wave per SIMD.  So this kernel is a 256-thread block whose
+// four waves are software pipelined by hand instead of hiding each other's stalls:
+//   block  = 256 rows x 256 columns, 4 waves; wave w = columns [64 w, 64 w + 64) = 4 weight slabs, all 256 rows
+//   K tile = 128 (one quantisation group); x tile 256 x 128 bf16 = 64 KiB per LDS stage, two stages
+//   x path = global -> registers -> ds_write_b128 (NOT LDS-DMA: a DMA instruction holds the issuing wave ~60-100 cycles, and here no
+//            second wave fills the matrix pipe meanwhile); a wave stages the 64 rows it owns: 16 pieces of 4 rows per K tile, loaded a
+//            full K tile before they are written (64 staging VGPRs), written during the first half of each 32-k step
+//   weights = 4 x (16 B + one scale dword) per lane per K tile straight into registers one tile ahead; dequantised on the matrix core
+//            (Cdna4DequantT) into the A operand of v_mfma_f32_16x16x32 one 32-k step ahead of its use
+//   per 32-k step and wave: 16 x fragments (two sets of 4, each read while the other feeds 16 MFMAs), 64 product MFMAs (1024 cycles)
+//   block barrier: once per K tile, inside the last quarter-step (the fragments of the next tile's first quarter are read behind it
+//            while 12 MFMAs still run); by then every read of the current stage has returned, so the stage can be overwritten
+// All LDS operations of the K loop are inline asm in a fixed order (hipcc neither counts nor moves them); every quarter-step starts
+// with lgkmcnt(0): the reads of its set were issued behind the first MFMA group of the previous quarter-step (~240 cycles earlier).
+// Register budget (one wave per SIMD: 256 VGPRs + 256 AGPRs): accumulators 256 AGPRs; fragments 32, operands 32, weights of two
+// groups 40, staging 32 VGPRs.
+// Numerics: products and fp32 accumulation order along K are v5's (= v4's up to the association inside one 32-k MFMA).
+#include <type_traits>
+
+#include "awq_device.hpp"
+#include "awq_kernels.hpp"
+
+namespace awq {
+
+namespace {
+constexpr int V6_TM = 256, V6_TN = 256, V6_TK = 128;
+constexpr int kV6Stage = V6_TM * V6_TK * 2;  // 64 KiB
+constexpr int kV6Pitch = 2 * V6_TN + 16;     // epilogue staging: bytes per output row (+16: consecutive rows start 4 banks apart)
+template <int V>
+using ic6 = std::integral_constant<int, V>;
+}  // namespace
+
+#define V6_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define V6_WR(addr, val, off) asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(addr), "v"(val), "n"(off) : "memory")
+#define V6_FENCE() __builtin_amdgcn_sched_barrier(0)
+// product MFMA with the accumulator pinned in AGPRs: with 256 accumulator registers next to ~200 live VGPRs hipcc's allocator otherwise
+// rotates accumulators between the two files every iteration (1580 v_accvgpr moves per K tile).  Opaque to the hazard recogniser:
+// operands come from ds_read + s_waitcnt or from VALU results several instructions back, and an accumulator is reused 64 MFMAs later.
+// the dequant MFMA in its VGPR form, as asm: once a function holds AGPR-constrained values hipcc selects the AGPR form for every builtin
+// MFMA and would evict accumulators to make room for the 4x4x4 operands.  Early-clobber output (no partial overlap with C); the s_nop
+// covers the VALU -> MFMA operand hazard the opaque statement hides from the hazard recogniser; results are read >= 8 MFMAs later.
+template <typename DT>
+__device__ __forceinline__ f32x4 v6_mfma4(const u32x2& a, const u32x2& b, const f32x4& c) {
+  f32x4 d;
+  if constexpr (DT::id == 1) asm volatile("s_nop 1\n\tv_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+  else asm volatile("s_nop 1\n\tv_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+template <typename DT, typename V8>
+__device__ __forceinline__ void v6_mfma(f32x4& acc, const V8& a, const u32x4& b) {
+  if constexpr (DT::id == 1) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
+// PROBE (AWQ_ENABLE_PROBES builds, timing only, wrong results): 1 = no x staging (no global loads / ds_writes of x in the K loop),
+// 2 = no weight dequantisation in the K loop, 3 = no fragment reads in the K loop, 4 = all three (product MFMAs + barrier only)
+template <typename DT, int BITS, int PROBE = 0>
+__global__ __launch_bounds__(256) void gemm_cdna4_v6_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
+                                                            const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
+                                                            uint16_t* __restrict__ out, int M, int N, int K, int tiles_m, int tiles_n,
+                                                            int n_begin, int n_end, int epi) {
+  using vec8 = typename DT::vec8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int nit = K >> 7;
+
+  // XCD-aware, two-row-band tile order (as awq_gemm_v4.hip)
+  const int T = tiles_m * tiles_n;
+  int tile;
+  {
+    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    const int q = T >> 3, r = T & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tm, tn;
+  {
+    const int full = (tiles_m >> 1) * 2 * tiles_n;
+    if (tile < full) {
+      const int band = tile / (2 * tiles_n), rem = tile - band * 2 * tiles_n;
+      tn = rem >> 1;
+      tm = 2 * band + (rem & 1);
+    } else {
+      tn = tile - full;
+      tm = tiles_m - 1;
+    }
+  }
+  // the last row tile is shifted up to end at row M - 1 (M >= 256: the launcher's contract): no row index needs clamping or masking
+  const int m0 = min(tm * V6_TM, M - V6_TM), n0 = n_begin + tn * V6_TN;
+
+  // ---- x staging: piece q (0..15) of this wave = rows 64 wv + 4 q .. + 3, one 16-byte granule per lane ----
+  // LDS layout of a stage: row r (256 B = 16 granules of 8 k) stores logical granule p at slot p ^ (r & 15)
+  const int r4 = lane >> 4, p16 = lane & 15;
+  const u32 lds0 = (u32)(size_t)(__attribute__((address_space(3))) char*)smem;
+  u32 wpat[4];  // LDS byte offset of this lane's slot inside piece q, q & 3 = c (rows 4 c + r4 of a 16-row group)
+#pragma unroll
+  for (int c = 0; c < 4; ++c) wpat[c] = (u32)(64 * wv) * 256u + (u32)r4 * 256u + (u32)((p16 ^ (4 * c + r4)) << 4);
+  // global side: wave-uniform base (SGPRs) + one lane offset: global_load_dwordx4 v, v_off, s[base]
+  const uint16_t* xw = x + (size_t)(m0 + 64 * wv) * (size_t)K;
+  const u32 xlane = (u32)r4 * (u32)K + (u32)p16 * 8u;
+  auto load_piece = [&](int kt, int q) {
+    const uint16_t* base = xw + (size_t)kt * V6_TK + (size_t)(4 * q) * (size_t)K;
+    return *reinterpret_cast<const u32x4*>(base + xlane);
+  };
+
+  // ---- weights: slabs 4 wv .. 4 wv + 3 of the block's 16 ----
+  const int nslab = N >> 4, slab_end = min(nslab, n_end >> 4);
+  constexpr int kTileWords = BITS == 4 ? 256 : 192, kLaneWords = BITS == 4 ? 4 : 3;
+  u32 w_off[4], s_off[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int slc = min((n0 >> 4) + 4 * wv + s, slab_end - 1);
+    w_off[s] = (u32)slc * (u32)nit * kTileWords + lane * kLaneWords;
+    s_off[s] = (u32)slc * (u32)nit * 16 + i;
+  }
+  struct WG {
+    u32x4 w[4];
+    u32 sz[4];
+  };
+  auto load_w = [&](int grp) {
+    WG r;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const u32* wp = qw + (size_t)grp * kTileWords + w_off[s];
+      if (BITS == 4) {
+        r.w[s] = *reinterpret_cast<const u32x4*>(wp);
+      } else {
+        typedef u32 u32x3 __attribute__((ext_vector_type(3)));
+        const u32x3 w3 = *reinterpret_cast<const u32x3*>(wp);
+        r.w[s] = w3_expand(w3.x, w3.y, w3.z);
+      }
+      r.sz[s] = szp[(size_t)grp * 16 + s_off[s]];
+    }
+    return r;
+  };
+  Cdna4DequantT<DT> cd;
+  cd.init(lane, BITS == 4 ? 0x000F000Fu : 0x00070007u);
+  struct DP {
+    u32 b01, b23;
+    float cv;
+  };
+  auto params = [&](u32 sz) {
+    DP d;
+    const u32 sdup = __builtin_amdgcn_perm(sz, sz, 0x01000100u);
+    d.b01 = sdup & cd.m01;
+    d.b23 = sdup & cd.m23;
+    d.cv = DT::dq_offset(sz);
+    return d;
+  };
+
+  struct Pend {
+    f32x4 d0, d1;
+  };
+  auto word_issue = [&](u32 w, const DP& d) {  // Cdna4DequantT::word_issue with the asm MFMA
+    const u32x2 a0 = {(w & cd.kMask) | cd.kMagic, ((w >> 4) & cd.kMask) | cd.kMagic};
+    const u32x2 a1 = {((w >> 8) & cd.kMask) | cd.kMagic, ((w >> 12) & cd.kMask) | cd.kMagic};
+    const u32x2 b = {d.b01, d.b23};
+    const f32x4 c = {d.cv, d.cv, d.cv, d.cv};
+    Pend p;
+    p.d0 = v6_mfma4<DT>(a0, b, c);
+    p.d1 = v6_mfma4<DT>(a1, b, c);
+    return p;
+  };
+
+  // ---- x fragment addresses: fragment f (rows 16 f + i), 32-k step a: logical granule 4 a + g; + f * 4096 as immediate ----
+  u32 xa[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) xa[a] = lds0 + i * 256 + (((4 * a + g) ^ i) << 4);
+
+  // accumulators: every definition and every use inside the K loop is an asm statement with an AGPR constraint, so the allocator
+  // has no choice of file for them (zeroed by an MFMA of zero operands with the inline constant 0 as C: 64 instructions, once)
+  f32x4 acc[16][4];
+  {
+    u32x4 zero = {0u, 0u, 0u, 0u};
+    asm volatile("" : "+v"(zero));
+#pragma unroll
+    for (int f = 0; f < 16; ++f)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if constexpr (DT::id == 1) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, 0" : "=a"(acc[f][s]) : "v"(zero));
+        else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %1, 0" : "=a"(acc[f][s]) : "v"(zero));
+      }
+  }
+
+  // ---------------- prologue: x tile 0 in stage 0, x tile 1 in the staging registers, weights of group 0, operands of step 0 ----
+  // staging registers: stg[0..3] carry the even quarters (pieces 0-3, 8-11) of an x tile, stg[4..7] the odd ones; a quarter is loaded two
+  // 32-k steps (~2 k cycles) before it is written to LDS
+  u32x4 stg[8];
+  {
+    u32x4 t0[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t0[q] = load_piece(0, q);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) V6_WR(lds0 + wpat[q & 3], t0[q], q * 1024);
+  }
+  WG cur = load_w(0);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) stg[q] = load_piece(nit > 1 ? 1 : 0, q);
+  vec8 op[2][4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const DP d0 = params(cur.sz[s]);
+    const Pend p0 = word_issue(cur.w[s].x, d0);
+    asm volatile("s_nop 7\n\ts_nop 7" : : : "memory");  // (prologue only: let the dequant MFMAs retire before their results are read)
+    op[0][s] = DT::pack8(p0.d0, p0.d1);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
+  __builtin_amdgcn_s_barrier();
+  u32x4 xf[2][4];
+  V6_RD(xf[0][0], xa[0], 0 * 4096);
+  V6_RD(xf[0][1], xa[0], 1 * 4096);
+  V6_RD(xf[0][2], xa[0], 2 * 4096);
+  V6_RD(xf[0][3], xa[0], 3 * 4096);
+
+  for (int t = 0; t < nit; ++t) {
+    const u32 sbase = (u32)(t & 1) * (u32)kV6Stage, obase = sbase ^ (u32)kV6Stage;
+    WG nxt = load_w(min(t + 1, nit - 1));
+    const int kt1 = min(t + 1, nit - 1), kt2 = min(t + 2, nit - 1);
+
+    // one quarter-step: 16 product MFMAs on the four fragments 4 Q .. 4 Q + 3 of 32-k step A (set Q & 1).  A single wave issues
+    // everything, and the matrix pipe takes a new 16x16x32 every 16 cycles = one MFMA + at most three other instructions: the side
+    // work of a quarter-step (four fragment reads of the next quarter, ONE dequantised word of step A + 1 -- slab Q --, one staged
+    // piece of x tile t + 1 written and its registers reloaded) is spread over the 16 MFMA slots by hand, a scheduling fence per slot.
+    auto quarter = [&](auto a_, auto q_) {
+      constexpr int A = decltype(a_)::value, Q = decltype(q_)::value;
+      constexpr bool kLast = A == 3 && Q == 3;
+      constexpr int AN = Q < 3 ? A : ((A + 1) & 3), QN = (Q + 1) & 3, S = Q & 1, SN = S ^ 1;
+      constexpr int RS = kLast ? 2 : 0;  // slot of the first fragment read (the last quarter of a tile reads behind the barrier)
+      const u32 raddr = xa[AN] + (kLast ? obase : sbase);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[S][0]), "+v"(xf[S][1]), "+v"(xf[S][2]), "+v"(xf[S][3]) : : "memory");
+      // dequant state of this quarter's word
+      u32 word = 0, sz = 0;
+      if (PROBE != 2 && PROBE != 4) {
+        if (A == 3) {
+          sz = nxt.sz[Q];
+          word = nxt.w[Q].x;
+        } else {
+          sz = cur.sz[Q];
+          word = A == 0 ? cur.w[Q].y : (A == 1 ? cur.w[Q].z : cur.w[Q].w);
+        }
+      }
+      u32x2 a0, a1, bq;
+      f32x4 cq;
+      Pend pj;
+      auto stage_piece = [&](auto q_c, auto part) {  // part 0: write piece q of tile t + 1; part 1: reload its registers
+        constexpr int q = decltype(q_c)::value, r = 4 * ((q >> 2) & 1) + (q & 3), q2 = (q + 8) & 15;
+        if (decltype(part)::value == 0) {
+          const u32 waddr = lds0 + obase + wpat[q & 3];
+          V6_WR(waddr, stg[r], q * 1024);
+        } else {
+          stg[r] = load_piece(q < 8 ? kt1 : kt2, q2);
+        }
+      };
+      auto slot = [&](auto k_) {
+        constexpr int k = decltype(k_)::value, j = k >> 2, s = k & 3;
+        v6_mfma<DT>(acc[4 * Q + j][s], op[A & 1][s], xf[S][j]);
+        if (kLast && k == 1) {
+          // every read of this stage has returned (the set in use was complete at the top), this wave's writes of tile t + 1 are done:
+          // meet the other waves, then the other stage is readable and this one writable
+          asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+        if (PROBE != 3 && PROBE != 4) {
+          if (k == RS) {
+            V6_RD(xf[SN][0], raddr, (4 * QN + 0) * 4096);
+            V6_RD(xf[SN][1], raddr, (4 * QN + 1) * 4096);
+          }
+          if (k == RS + 1) {
+            V6_RD(xf[SN][2], raddr, (4 * QN + 2) * 4096);
+            V6_RD(xf[SN][3], raddr, (4 * QN + 3) * 4096);
+          }
+        }
+        if (PROBE != 2 && PROBE != 4) {
+          if (k == 4) a0.x = (word & cd.kMask) | cd.kMagic, a0.y = ((word >> 4) & cd.kMask) | cd.kMagic;
+          if (k == 5) a1.x = ((word >> 8) & cd.kMask) | cd.kMagic, a1.y = ((word >> 12) & cd.kMask) | cd.kMagic;
+          if (k == 6) {
+            const u32 sdup = __builtin_amdgcn_perm(sz, sz, 0x01000100u);
+            bq.x = sdup & cd.m01;
+            bq.y = sdup & cd.m23;
+          }
+          if (k == 7) {
+            const float cv = DT::dq_offset(sz);
+            cq = f32x4{cv, cv, cv, cv};
+          }
+          if (k == 8) pj.d0 = v6_mfma4<DT>(a0, bq, cq);
+          if (k == 9) pj.d1 = v6_mfma4<DT>(a1, bq, cq);
+          if (k == 14) op[(A + 1) & 1][Q] = DT::pack8(pj.d0, pj.d1);
+        }
+        if (PROBE != 1 && PROBE != 4) {
+          // piece 4 A + Q in slots 10 / 11 (and piece 15 next to piece 14 in quarter (3, 2): quarter (3, 3) holds the barrier)
+          if (!kLast && k == 10) stage_piece(ic6<4 * A + Q>{}, ic6<0>{});
+          if (!kLast && k == 11) stage_piece(ic6<4 * A + Q>{}, ic6<1>{});
+          if (A == 3 && Q == 2 && k == 12) stage_piece(ic6<15>{}, ic6<0>{});
+          if (A == 3 && Q == 2 && k == 13) stage_piece(ic6<15>{}, ic6<1>{});
+        }
+        V6_FENCE();
+      };
+      slot(ic6<0>{});
+      slot(ic6<1>{});
+      slot(ic6<2>{});
+      slot(ic6<3>{});
+      slot(ic6<4>{});
+      slot(ic6<5>{});
+      slot(ic6<6>{});
+      slot(ic6<7>{});
+      slot(ic6<8>{});
+      slot(ic6<9>{});
+      slot(ic6<10>{});
+      slot(ic6<11>{});
+      slot(ic6<12>{});
+      slot(ic6<13>{});
+      slot(ic6<14>{});
+      slot(ic6<15>{});
+    };
+    quarter(ic6<0>{}, ic6<0>{});
+    quarter(ic6<0>{}, ic6<1>{});
+    quarter(ic6<0>{}, ic6<2>{});
+    quarter(ic6<0>{}, ic6<3>{});
+    quarter(ic6<1>{}, ic6<0>{});
+    quarter(ic6<1>{}, ic6<1>{});
+    quarter(ic6<1>{}, ic6<2>{});
+    quarter(ic6<1>{}, ic6<3>{});
+    quarter(ic6<2>{}, ic6<0>{});
+    quarter(ic6<2>{}, ic6<1>{});
+    quarter(ic6<2>{}, ic6<2>{});
+    quarter(ic6<2>{}, ic6<3>{});
+    quarter(ic6<3>{}, ic6<0>{});
+    quarter(ic6<3>{}, ic6<1>{});
+    quarter(ic6<3>{}, ic6<2>{});
+    quarter(ic6<3>{}, ic6<3>{});
+    cur = nxt;
+  }
+
+  // ---------------- epilogue through LDS: acc[f][s][r] = C[n = n0 + 64 wv + 16 s + 4 g + r][m = m0 + 16 f + i], staged row-major ----
+  asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
+  __builtin_amdgcn_s_barrier();  // every wave is done with the x stages (the trailing reads of the unused stage have returned)
+  {
+    const u32 wbase = lds0 + i * kV6Pitch + (64 * wv + 4 * g) * 2;
+#pragma unroll
+    for (int f = 0; f < 16; ++f)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        u32x2 v;
+        v.x = (u32)DT::from_float(acc[f][s][0]) | ((u32)DT::from_float(acc[f][s][1]) << 16);
+        v.y = (u32)DT::from_float(acc[f][s][2]) | ((u32)DT::from_float(acc[f][s][3]) << 16);
+        asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(wbase + f * (16 * kV6Pitch)), "v"(v), "n"(s * 32) : "memory");
+      }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
+  if (epi == 2) {
+    // QuantLlamaMLP's interleaved pair: columns 16 j .. + 7 are gate rows, + 8 .. + 15 the matching up rows.  A lane takes one pair
+    // (32 staged bytes) and stores silu(gate) * up: 16 lanes = one 256-byte output row, four rows per wave-instruction
+    const int pr = lane & 15, nn = n0 + 16 * pr;
+    const bool ok = nn < n_end;
+#pragma unroll
+    for (int it0 = 0; it0 < 16; it0 += 4) {
+      u32x4 v[4], u[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const u32 ra = lds0 + (64 * wv + 4 * (it0 + b) + (lane >> 4)) * kV6Pitch + 32 * pr;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(v[b]) : "v"(ra) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(u[b]) : "v"(ra) : "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]) : : "memory");
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int m = m0 + 64 * wv + 4 * (it0 + b) + (lane >> 4);
+        if (ok) __builtin_nontemporal_store(silu_mul_octet<DT>(v[b], u[b]), reinterpret_cast<u32x4*>(out + (size_t)m * (N >> 1) + (nn >> 1)));
+      }
+    }
+  } else {
+    const int col = (lane & 31) * 8;  // 8 columns (16 B) per lane, two rows per wave-instruction; eight instructions per wait
+    const int nn = n0 + col;
+    const bool ncol_ok = nn < n_end;
+    u32x4 bv = {0u, 0u, 0u, 0u};
+    if (bias != nullptr && ncol_ok) bv = *reinterpret_cast<const u32x4*>(bias + nn);
+#pragma unroll
+    for (int it0 = 0; it0 < 32; it0 += 8) {
+      u32x4 v[8];
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const u32 ra = lds0 + (64 * wv + 2 * (it0 + b) + (lane >> 5)) * kV6Pitch + col * 2;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(v[b]) : "v"(ra) : "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : : "memory");
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const int m = m0 + 64 * wv + 2 * (it0 + b) + (lane >> 5);
+        u32x4 o = v[b];
+        if (bias != nullptr) {  // `out + self.bias` in T (qmodule.py:221)
+          auto add2 = [](u32 a, u32 b2) {
+            const float lo = DT::to_float((uint16_t)(a & 0xFFFFu)) + DT::to_float((uint16_t)(b2 & 0xFFFFu));
+            const float hi = DT::to_float((uint16_t)(a >> 16)) + DT::to_float((uint16_t)(b2 >> 16));
+            return (u32)DT::from_float(lo) | ((u32)DT::from_float(hi) << 16);
+          };
+          o = u32x4{add2(o.x, bv.x), add2(o.y, bv.y), add2(o.z, bv.z), add2(o.w, bv.w)};
+        }
+        if (ncol_ok) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(out + (size_t)m * N + nn));  // streamed: keep x / weight panels in L2
+      }
+    }
+  }
+}
+
+namespace {
+int g_v6_probe = 0;
+}
+void gemm_v6_set_probe(int v) { g_v6_probe = v; }
+
+// weight rows [n_begin, n_end) with 256 x 256 blocks; any m >= 1 (rows past m are clamped / not stored)
+void launch_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
+                          int n_end, int dtype, hipStream_t st, int bits, int epi) {
+  constexpr int stage2 = 2 * kV6Stage, stg_epi = V6_TM * kV6Pitch;
+  constexpr int smem = stage2 > stg_epi ? stage2 : stg_epi;
+  const int tiles_m = (m + V6_TM - 1) / V6_TM, tiles_n = (n_end - n_begin + V6_TN - 1) / V6_TN;
+  using Kern = void (*)(const uint16_t*, const u32*, const u32*, const uint16_t*, uint16_t*, int, int, int, int, int, int, int, int);
+  static const Kern kerns[2][2] = {{gemm_cdna4_v6_kernel<F16, 4>, gemm_cdna4_v6_kernel<F16, 3>},
+                                   {gemm_cdna4_v6_kernel<BF16, 4>, gemm_cdna4_v6_kernel<BF16, 3>}};
+  const int a = dtype == 0 ? 0 : 1, b = bits == 3 ? 1 : 0;
+  Kern kern = kerns[a][b];
+  static LdsOptIn optin[2][2];
+#ifdef AWQ_ENABLE_PROBES
+  static const Kern probes[5] = {gemm_cdna4_v6_kernel<BF16, 4>, gemm_cdna4_v6_kernel<BF16, 4, 1>, gemm_cdna4_v6_kernel<BF16, 4, 2>,
+                                 gemm_cdna4_v6_kernel<BF16, 4, 3>, gemm_cdna4_v6_kernel<BF16, 4, 4>};
+  static LdsOptIn optin_p[5];
+  if (g_v6_probe > 0 && g_v6_probe < 5) {
+    kern = probes[g_v6_probe];
+    optin_p[g_v6_probe].ensure(reinterpret_cast<const void*>(kern), smem);
+  } else
+#endif
+  optin[a][b].ensure(reinterpret_cast<const void*>(kern), smem);
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp,
+                     (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end, epi);
+}
+
+}  // namespace awq

@@ -99,6 +99,10 @@ bool moe_v4_enabled();
 void launch_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                           int n_begin, int n_end, int dtype, hipStream_t st, int bits = 4, int epi = 0);
 // 256 x 256 blocks, weights streamed straight into registers per wave (awq_gemm_v5.hip); any m >= 1
+// awq_gemm_v6.hip: 256 x 256 blocks of four software-pipelined waves (256 x 64 per wave, weights in registers, x through ds_write)
+void launch_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
+                          int n_end, int dtype, hipStream_t st, int bits = 4, int epi = 0);
+void gemm_v6_set_probe(int v);
 void launch_gemm_cdna4_v5(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
                           int n_end, int dtype, hipStream_t st, int bits = 4, int mf = 16);
 int launch_bias_add(void* out, const void* bias, int m, int n, int dtype, hipStream_t st);

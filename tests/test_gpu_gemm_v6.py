@@ -1,0 +1,118 @@
+"""-m gpu: awq_gemm_v6.hip, the default kernel of the 256-wide prefill tiles (one software-pipelined wave per SIMD, 256 x 64 per wave,
+weights dequantised into registers, x staged through ds_write).  Knob gemm_variant=4 forces 256-wide tiles for every shape, so
+ragged column tiles (N % 256 != 0), the shifted last row tile (M % 256 != 0), bias, both dtypes, the W3 tiles and the SiLU * mul
+epilogue all run through it; the checker is the oracle (tests/helpers.check_forward) and, for sizes the oracle does not take,
+awq_gemm_v4.hip (same products, fp32 accumulation in the same K order; the two differ only in the association inside one 32-k
+MFMA: 16x16x32 against two 32x32x16)."""
+import pytest
+import torch
+
+from oracle import awq_oracle as O
+from tests.helpers import check_forward, make_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from llm_awq_amd import ops as o
+    return o
+
+
+def _wide(ops, v6):
+    ops._capi.tune(gemm_variant=4, gemm_tile_n=256, gemm_v6=v6, gemm_splitk=0)
+
+
+def _reset(ops):
+    ops._capi.tune(gemm_variant=0, gemm_tile_n=0, gemm_v6=1, gemm_splitk=1)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("bias", [False, True])
+@pytest.mark.parametrize("M", [256, 300, 777])
+@pytest.mark.parametrize("N,K", [(512, 1024), (1296, 512), (272, 2048)])
+def test_v6_against_the_oracle(ops, dtype, bias, M, N, K):
+    c = make_case(N, K, dtype, seed=N + K + M, M=M, bias=bias)
+    c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
+    s, z = c["scales"].cuda(), c["scaled_zeros"].cuda()
+    szp = ops.pack_sz_cdna4(s, z, K)
+    b = c["bias"].cuda() if bias else None
+    try:
+        _wide(ops, 1)
+        y = ops.gemm_cdna4(c["x"].cuda(), c4, s, z, b, szp)
+        _wide(ops, 0)
+        y4 = ops.gemm_cdna4(c["x"].cuda(), c4, s, z, b, szp)
+    finally:
+        _reset(ops)
+    check_forward(y.cpu(), c["x"], c["q"], c["scales"], c["scaled_zeros"], dtype, bias=c["bias"])
+    assert (y == y4).float().mean() > 0.999
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_v6_full_shapes_against_v4(ops, dtype):
+    from llm_awq_amd import synth
+    for (K, N) in ((4096, 6144), (14336, 4096)):
+        w = synth.random_wq(K, N, dtype=dtype, seed=K + N, keep_q=False)
+        c4 = ops.repack_v2_to_cdna4(w["qweight"])
+        szp = ops.pack_sz_cdna4(w["scales"], w["scaled_zeros"], K)
+        for M in (300, 2048, 4096):
+            x = torch.randn(M, K, device="cuda").to(dtype)
+            try:
+                _wide(ops, 1)
+                y = ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], None, szp)
+                _wide(ops, 0)
+                y4 = ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], None, szp)
+            finally:
+                _reset(ops)
+            assert (y == y4).float().mean() > 0.999, (K, N, M)
+            assert ((y.float() - y4.float()).norm() / y4.float().norm()).item() < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [256, 300, 1000])
+def test_v6_fused_silu_mul(ops, dtype, M):
+    from llm_awq_amd.fused_mlp import interleave_gate_up
+    F, K = 1376, 512
+    cg = make_case(F, K, dtype, seed=M, M=M)
+    cu = make_case(F, K, dtype, seed=M + 1, M=M)
+    x = cg["x"]
+    g = O.wqlinear_forward(x, None, cg["scales"], cg["scaled_zeros"], None, 128, q_int=cg["q"])
+    u = O.wqlinear_forward(x, None, cu["scales"], cu["scaled_zeros"], None, 128, q_int=cu["q"])
+    ref = torch.nn.functional.silu(g) * u
+    qi, si, zi = interleave_gate_up(cg["qweight"].cuda(), cu["qweight"].cuda(), cg["scales"].cuda(), cu["scales"].cuda(),
+                                    cg["scaled_zeros"].cuda(), cu["scaled_zeros"].cuda())
+    c4 = ops.repack_v2_to_cdna4(qi)
+    szp = ops.pack_sz_cdna4(si, zi, K)
+    try:
+        _wide(ops, 1)
+        y = ops.mlp_gate_up_forward_cdna4(x.cuda(), c4, szp, None).cpu()
+        _wide(ops, 0)
+        y4 = ops.mlp_gate_up_forward_cdna4(x.cuda(), c4, szp, None).cpu()
+    finally:
+        _reset(ops)
+    assert y.shape == (M, F)
+    assert ((y.float() - ref.float()).norm() / ref.float().norm()).item() <= 3e-3
+    assert (y == ref).float().mean() > 0.95
+    assert (y == y4).float().mean() > 0.999
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_v6_w3_tiles(ops, dtype):
+    K, N = 1024, 1296
+    g = torch.Generator(device="cuda").manual_seed(7)
+    q = torch.randint(0, 8, (N, K), dtype=torch.uint8, device="cuda", generator=g)
+    qw = ops.pack_w3(q)
+    s = ((5.2 + 0.8 * torch.rand(K // 128, N, device="cuda", generator=g)) * 0.02 / 7).to(dtype)
+    z = -(s * torch.randint(2, 6, (K // 128, N), device="cuda", generator=g).float()).to(dtype)
+    szp = ops.pack_sz_cdna4(s, z, K)
+    W = ops.dequant_w3(qw, s, z).float()   # bit exact vs the oracle: tests/test_w3.py, tests/test_gpu_oracle_fullsize.py
+    for M in (256, 500):
+        x = torch.randn(M, K, device="cuda", generator=g).to(dtype)
+        try:
+            _wide(ops, 1)
+            y = ops.forward_w3(x, qw, s, z, szp)
+        finally:
+            _reset(ops)
+        ref = x.float() @ W.t()
+        assert ((y.float() - ref).norm() / ref.norm()).item() < (2.5e-3 if dtype == torch.bfloat16 else 4e-4)
+        assert (ref.to(dtype) == y).float().mean() > 0.97

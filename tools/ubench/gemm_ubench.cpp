@@ -94,7 +94,8 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     for (int v : variants) {
-      (void)awq_tune_set("gemm_v5", v / 100000);  // probe builds only: N00xxx = awq_gemm_v5.hip variant N for the 256-wide tiles
+      (void)awq_tune_set("gemm_v6", v / 1000000);  // N000xxx = awq_gemm_v6.hip for the 256-wide tiles (2: every tile)
+      (void)awq_tune_set("gemm_v5", (v / 100000) % 10);  // probe builds only: N00xxx = awq_gemm_v5.hip variant N for the 256-wide tiles
       (void)awq_tune_set("gemm_v4_probe", (v / 1000) % 100);  // probe builds only (AWQ_PROBES=1)  // Nxxx: timing-only probes of the v4 kernel (results are wrong by design)
       AQ(awq_tune_set("gemm_v4", (v % 1000) >= 100));  // 1xx: wide tiles run the hand-scheduled K loop (awq_gemm_v4.hip)  // 1xx: wide tiles run the hand-scheduled K loop (awq_gemm_v4.hip)
       AQ(awq_tune_set("gemm_variant", v % 100));
@@ -133,6 +134,7 @@ int main(int argc, char** argv) {
     AQ(awq_tune_set("gemm_v4", 1));
     (void)awq_tune_set("gemm_v4_probe", 0);
     (void)awq_tune_set("gemm_v5", 0);
+    (void)awq_tune_set("gemm_v6", 0);
     hipFree(dq); hipFree(qw2); hipFree(qw4); hipFree(ds); hipFree(dz); hipFree(dszp); hipFree(dx); hipFree(dout); hipFree(dref);
   }
   return 0;
