@@ -267,13 +267,13 @@ def main():
     # ---------------- prefill leg ----------------
     def prefill(M, run_pass, kernel):
         pms, tfl = timed_prefill(run_pass, M, launches)
-        ptraffic, psrc = pmc_traffic(["awq::gemm_cdna4_v4"]) if M == 2048 else (None, None)
+        ptraffic, psrc = pmc_traffic(["awq::gemm_cdna4_v6", "awq::gemm_cdna4_v4"]) if M == 2048 else (None, None)
         return {"m": M, "ms_per_pass": round(pms, 3), "tok_s": round(M / (pms * 1e-3) * (LAYERS / L), 1),
                 "roofline": {"bound": "mfma", "kernel": kernel, "achieved": round(tfl, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(tfl / MFMA_PEAK_TFLOPS, 4), "traffic": ptraffic,
-                             **({"traffic_source": psrc, "traffic_note": "HBM bytes per launch, averaged over the 256-wide and 128-wide tile kernels of the M = 2048 pass"} if ptraffic else {})}}
+                             **({"traffic_source": psrc, "traffic_note": "HBM bytes per launch, averaged over the tile-kernel launches of the M = 2048 pass (the PMC passes run with --prefill-m2 0 --prefill-m3 0)"} if ptraffic else {})}}
 
-    pk = "gemm_cdna4_v4_kernel (256-wide tiles) + gemm_cdna4_v4n_kernel (128-wide remainder)"
+    pk = "gemm_cdna4_v6_kernel (256-wide tiles) + gemm_cdna4_v4n_kernel (128-wide tiles / remainder)"
     if not args.no_prefill:
         out["prefill"] = prefill(args.prefill_m, run_main, pk)
         for extra in (args.prefill_m2, args.prefill_m3):

@@ -192,17 +192,18 @@ __global__ __launch_bounds__(256) void gemm_cdna4_v6_kernel(const uint16_t* __re
   // ---------------- prologue: x tile 0 in stage 0, x tile 1 in the staging registers, weights of group 0, operands of step 0 ----
   // staging registers: stg[0..3] carry the even quarters (pieces 0-3, 8-11) of an x tile, stg[4..7] the odd ones; a quarter is loaded two
   // 32-k steps (~2 k cycles) before it is written to LDS
+  // every global load of the prologue goes out before the first wait: weights of group 0, x tile 0, the first half of x tile 1
   u32x4 stg[8];
+  WG cur = load_w(0);
   {
     u32x4 t0[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) t0[q] = load_piece(0, q);
 #pragma unroll
+    for (int q = 0; q < 8; ++q) stg[q] = load_piece(nit > 1 ? 1 : 0, q);
+#pragma unroll
     for (int q = 0; q < 16; ++q) V6_WR(lds0 + wpat[q & 3], t0[q], q * 1024);
   }
-  WG cur = load_w(0);
-#pragma unroll
-  for (int q = 0; q < 8; ++q) stg[q] = load_piece(nit > 1 ? 1 : 0, q);
   vec8 op[2][4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
