@@ -46,11 +46,16 @@ using ic6 = std::integral_constant<int, V>;
 // the dequant MFMA in its VGPR form, as asm: once a function holds AGPR-constrained values hipcc selects the AGPR form for every builtin
 // MFMA and would evict accumulators to make room for the 4x4x4 operands.  Early-clobber output (no partial overlap with C); the s_nop
 // covers the VALU -> MFMA operand hazard the opaque statement hides from the hazard recogniser; results are read >= 8 MFMAs later.
-template <typename DT>
+template <typename DT, bool NOP = true>
 __device__ __forceinline__ f32x4 v6_mfma4(const u32x2& a, const u32x2& b, const f32x4& c) {
   f32x4 d;
-  if constexpr (DT::id == 1) asm volatile("s_nop 1\n\tv_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
-  else asm volatile("s_nop 1\n\tv_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+  if constexpr (NOP) {
+    if constexpr (DT::id == 1) asm volatile("s_nop 1\n\tv_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+    else asm volatile("s_nop 1\n\tv_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+  } else {  // K loop: the operands were written at least one MFMA slot (>= 16 cycles) earlier
+    if constexpr (DT::id == 1) asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+    else asm volatile("v_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+  }
   return d;
 }
 template <typename DT, typename V8>
@@ -104,10 +109,10 @@ __global__ __launch_bounds__(256) void gemm_cdna4_v6_kernel(const uint16_t* __re
   for (int c = 0; c < 4; ++c) wpat[c] = (u32)(64 * wv) * 256u + (u32)r4 * 256u + (u32)((p16 ^ (4 * c + r4)) << 4);
   // global side: wave-uniform base (SGPRs) + one lane offset: global_load_dwordx4 v, v_off, s[base]
   const uint16_t* xw = x + (size_t)(m0 + 64 * wv) * (size_t)K;
-  const u32 xlane = (u32)r4 * (u32)K + (u32)p16 * 8u;
+  const u32 xlane_b = ((u32)r4 * (u32)K + (u32)p16 * 8u) * 2u;  // bytes, < 2^32: (SGPR base + 32-bit VGPR offset) is one instruction
   auto load_piece = [&](int kt, int q) {
     const uint16_t* base = xw + (size_t)kt * V6_TK + (size_t)(4 * q) * (size_t)K;
-    return *reinterpret_cast<const u32x4*>(base + xlane);
+    return *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(base) + xlane_b);
   };
 
   // ---- weights: slabs 4 wv .. 4 wv + 3 of the block's 16 ----
@@ -290,8 +295,8 @@ __global__ __launch_bounds__(256) void gemm_cdna4_v6_kernel(const uint16_t* __re
             const float cv = DT::dq_offset(sz);
             cq = f32x4{cv, cv, cv, cv};
           }
-          if (k == 8) pj.d0 = v6_mfma4<DT>(a0, bq, cq);
-          if (k == 9) pj.d1 = v6_mfma4<DT>(a1, bq, cq);
+          if (k == 8) pj.d0 = v6_mfma4<DT, false>(a0, bq, cq);
+          if (k == 9) pj.d1 = v6_mfma4<DT, false>(a1, bq, cq);
           if (k == 14) op[(A + 1) & 1][Q] = DT::pack8(pj.d0, pj.d1);
         }
         if (PROBE != 1 && PROBE != 4) {
