@@ -147,8 +147,12 @@ def run_tp_bench(args, eng, dist, rank, world, dev, shapes, algo_bytes):
     down are K-sharded with one RCCL all-reduce each.  Every rank builds ONLY its own shard (weights are synthetic)."""
     from . import synth
 
+    import os
     dtype = torch.bfloat16
     L = args.layers
+    # AWQ_BENCH_SHARD_WORLD=W on fewer ranks: every rank times the shard shapes of a W-way split (rank r of W); the all-reduces still
+    # run over the real ranks.  It gives the compute floor of a W-GPU step on boxes that have fewer GPUs; `config.shard_world` says so.
+    shard_world = int(os.environ.get("AWQ_BENCH_SHARD_WORLD", world))
     # (name, K, N, mode) of the unsharded linears of one decoder block
     block = [("qkv", 4096, 6144, "column"), ("o", 4096, 4096, "row"), ("gate_up", 4096, 28672, "column"),
              ("down", 14336, 4096, "row")]
@@ -156,15 +160,16 @@ def run_tp_bench(args, eng, dist, rank, world, dev, shapes, algo_bytes):
     for li in range(L):
         for si, (name, K, N, mode) in enumerate(block):
             if mode == "row":
-                k0, k1 = shard_bounds(K, world, rank, GROUP)
+                k0, k1 = shard_bounds(K, shard_world, rank, GROUP)
                 kl, nl = k1 - k0, N
             else:
-                n0, n1 = shard_bounds(N, world, rank, 32)  # 32: the stacked gate/up pair splits in matching 16-row slabs
+                n0, n1 = shard_bounds(N, shard_world, rank, 32)  # 32: the stacked gate/up pair splits in matching 16-row slabs
                 kl, nl = K, n1 - n0
             w = synth.random_wq(kl, nl, dtype=dtype, device=dev, seed=(li * 16 + si) * 64 + rank, keep_q=False)
             qw = eng.repack_v2_to_cdna4(w["qweight"])
             szp = eng.pack_sz_cdna4(w["scales"], w["scaled_zeros"], kl)
-            shards.append((name, kl, nl, qw, w["scales"], w["scaled_zeros"], szp, mode))
+            szh, exact = eng.pack_szh_cdna4(w["scales"], w["scaled_zeros"], kl)  # the streaming decode kernel's side buffer
+            shards.append((name, kl, nl, qw, w["scales"], w["scaled_zeros"], szp, mode, szh if exact else None))
             del w
     from . import oneshot
     reducer = None
@@ -173,14 +178,16 @@ def run_tp_bench(args, eng, dist, rank, world, dev, shapes, algo_bytes):
     g = torch.Generator(device=dev).manual_seed(1 + rank)
     xs = {}
     for (_nm, kl, *_r) in shards:
-        if kl not in xs:
+        if kl not in xs:  # noqa: E501
             xs[kl] = torch.randn(1, kl, device=dev, generator=g).to(dtype)
 
     def run_pass():
         outs = []
-        for (name, kl, nl, qw, s, sz, szp, mode) in shards:
-            if name == "gate_up":
-                y = eng.mlp_gate_up_cdna4(xs[kl], qw, szp)
+        for (name, kl, nl, qw, s, sz, szp, mode, szh) in shards:
+            if name == "gate_up":  # the shard's rows are taken as QuantLlamaMLP's 8 + 8 interleaved gate / up pair (synthetic weights)
+                y = eng.mlp_gate_up_forward_cdna4(xs[kl], qw, szp, szh)
+            elif szh is not None:
+                y = eng.decode_cdna4(xs[kl], qw, szh, None, 0)
             else:
                 y = eng.forward_cdna4(xs[kl], qw, s, sz, szp, None)
             if mode == "row":
@@ -242,11 +249,12 @@ def run_tp_bench(args, eng, dist, rank, world, dev, shapes, algo_bytes):
                                    "(qkv and gate/up N-sharded, o/down K-sharded + RCCL all-reduce)",
                        "layers": L, "decode_m": 1, "graph": graph is not None, "layout": "cdna4",
                        "fused_gate_up_silu_mul": True, "launches_per_token": launches, "parallelism": f"tp{world}",
-                       "allreduces_per_step": 2 * L},
+                       "allreduces_per_step": 2 * L,
+                       **({"shard_world": shard_world, "note": "shard shapes of a larger split timed on fewer ranks: a compute floor, not a scaling point"} if shard_world != world else {})},
             "allreduce": {"kind": "oneshot (peer-mapped exchange buffers, csrc/awq_oneshot.hip)" if reducer is not None else "rccl (torch.distributed.all_reduce)",
                           "bytes": 4096 * 2, "ranks": world, "per_step": 2 * L, "rccl_ranks": world,
                           "weight_bytes_per_rank": int(bytes_rank)},
-            "roofline": {"bound": "hbm", "kernel": "gemv_cdna4_kernel", "achieved": round(gbs_rank, 1),
+            "roofline": {"bound": "hbm", "kernel": "awq::gemv_dma_kernel", "achieved": round(gbs_rank, 1),
                          "peak": 8000.0, "unit": "GB/s per GPU (incl. all-reduce time)", "frac": round(gbs_rank / 8000.0, 4),
                          "traffic": None},
             "device": torch.cuda.get_device_name(dev)}
