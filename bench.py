@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--layers", type=int, default=LAYERS)
     ap.add_argument("--tune", action="append", default=[], help="experiments only: awq_tune_set knobs as key=value")
     ap.add_argument("--layout", default="cdna4", choices=["cdna4", "v2"], help="cdna4 = what the rewritten repacker emits (default); v2 = reference checkpoint layout through gemv/gemm_forward_cuda_new only")
+    ap.add_argument("--repeat-layers", type=int, default=1, help="experiments: run the --layers layers this many times per step (with --layers 1/2 the weights stay in the 256 MB Infinity Cache)")
     ap.add_argument("--mlp", default="interleaved", choices=["interleaved", "stacked", "unfused"],
                     help="gate/up: one launch on the 8+8 row-interleaved stack QuantLlamaMLP builds (default), one launch on the plain [gate; up] stack, or two launches + F.silu * mul left out (160 launches per token)")
     ap.add_argument("--sz", default="half", choices=["half", "packed"], help="decode side buffer: sz_half (f16-mantissa dequant) or the T-typed sz_packed")
@@ -152,7 +153,7 @@ def main():
 
     def run_native(xs):
         outs = []
-        for (name, K, N, qw, s, z, szp, szh, epi) in nat:
+        for (name, K, N, qw, s, z, szp, szh, epi) in nat * (args.repeat_layers if xs[4096].numel() == 4096 else 1):
             x = xs[K]
             m = x.numel() // K
             if epi == 2:
@@ -238,8 +239,8 @@ def main():
     # ---------------- decode leg: K timed steps ----------------
     wall_ms, ev_ms, graphed = timed_decode(run_main, args.steps, args.warmup, not args.no_graph)
     ms_per_step = wall_ms / args.steps
-    launches = len(nat) if native_leg else len(raw)
-    bytes_step = bytes_native(1) if native_leg else sum(algo_bytes(1, K, N) for (_n, K, N, *_r) in raw)
+    launches = len(nat) * args.repeat_layers if native_leg else len(raw)
+    bytes_step = bytes_native(1) * args.repeat_layers if native_leg else sum(algo_bytes(1, K, N) for (_n, K, N, *_r) in raw)
     avg_launch_us = ev_ms * 1e3 / (args.steps * launches)
     gbs = bytes_step * args.steps / (ev_ms * 1e-3) / 1e9
     kname = "awq::gemv_dma_kernel" if native_leg else "awq::gemv_dma_kernel (via gemv_forward_cuda_new + the engine's repack cache)"
@@ -248,7 +249,7 @@ def main():
                 "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_us": round(avg_launch_us, 3), "algorithmic_bytes_per_launch": bytes_step // launches,
                 "launches_per_step": launches, "timing": "hip events on the launch stream over the timed region"}
-    tok_s = 1e3 / ms_per_step * (L / LAYERS)  # tokens/s of a full 32-layer model
+    tok_s = 1e3 / ms_per_step * (L * args.repeat_layers / LAYERS)  # tokens/s of a full 32-layer model
 
     out = {"metric": "W4A16 decode+prefill tok/s, Llama-3-8B; achieved %HBM (GEMV) / %MFMA (GEMM)",
            "value": round(tok_s, 2),
