@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--layers", type=int, default=LAYERS)
     ap.add_argument("--tune", action="append", default=[], help="experiments only: awq_tune_set knobs as key=value")
     ap.add_argument("--layout", default="cdna4", choices=["cdna4", "v2"], help="cdna4 = what the rewritten repacker emits (default); v2 = reference checkpoint layout through gemv/gemm_forward_cuda_new only")
+    ap.add_argument("--mlp-decode", default="two", choices=["one", "two"],
+                    help="decode, --mlp interleaved: QuantLlamaMLP.forward as the fused gate/up launch followed by down_proj's (default: faster), or as ONE launch (awq_w4a16_mlp_decode_cdna4; measured slower: profiles/r02_mlp_one_launch.txt)")
+    ap.add_argument("--overlap-probe", type=int, default=0, help="experiments (NOT a valid decode figure): issue the decode launches round-robin on this many streams inside the graph, i.e. drop the dependency between consecutive linears -- the upper bound of what cross-launch overlap could give")
     ap.add_argument("--repeat-layers", type=int, default=1, help="experiments: run the --layers layers this many times per step (with --layers 1/2 the weights stay in the 256 MB Infinity Cache)")
     ap.add_argument("--mlp", default="interleaved", choices=["interleaved", "stacked", "unfused"],
                     help="gate/up: one launch on the 8+8 row-interleaved stack QuantLlamaMLP builds (default), one launch on the plain [gate; up] stack, or two launches + F.silu * mul left out (160 launches per token)")
@@ -151,9 +154,34 @@ def main():
         raw = []
     torch.cuda.synchronize()
 
+    probe_streams = [torch.cuda.Stream(device=dev) for _ in range(args.overlap_probe)] if args.overlap_probe > 1 else []
+    one_launch_mlp = args.layout == "cdna4" and args.mlp == "interleaved" and args.mlp_decode == "one" and args.sz == "half"
+    mlp_ctr = torch.zeros(4096, dtype=torch.int32, device=dev)  # device counters of the one-launch MLP (zero between calls)
+
     def run_native(xs):
         outs = []
-        for (name, K, N, qw, s, z, szp, szh, epi) in nat * (args.repeat_layers if xs[4096].numel() == 4096 else 1):
+        decode = xs[4096].numel() == 4096
+        if probe_streams and decode:
+            cur = torch.cuda.current_stream()
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            for st in probe_streams:
+                st.wait_event(ev)
+        seq = nat * (args.repeat_layers if decode else 1)
+        skip = False
+        for li, (name, K, N, qw, s, z, szp, szh, epi) in enumerate(seq):
+            if skip:  # down_proj: done inside the one-launch MLP
+                skip = False
+                continue
+            if decode and one_launch_mlp and not probe_streams and epi == 2 and szh is not None and seq[li + 1][0] == "down" and seq[li + 1][7] is not None:
+                dn = seq[li + 1]
+                outs.append(eng.mlp_decode_cdna4(xs[K], qw, szh, dn[3], dn[7], mlp_ctr, None))   # QuantLlamaMLP.forward, <= 8 rows
+                skip = True
+                continue
+            if probe_streams and decode:
+                with torch.cuda.stream(probe_streams[li % len(probe_streams)]):
+                    outs.append(eng.mlp_gate_up_forward_cdna4(xs[K], qw, szp, szh) if epi == 2 else eng.decode_cdna4(xs[K], qw, szh, None, epi))
+                continue
             x = xs[K]
             m = x.numel() // K
             if epi == 2:
@@ -164,6 +192,11 @@ def main():
                 outs.append(eng.mlp_gate_up_cdna4(x, qw, szp))
             else:
                 outs.append(eng.forward_cdna4(x, qw, s, z, szp, None))               # prefill GEMM (gate/up: one GEMM over the pair)
+        if probe_streams and decode:
+            for st in probe_streams:
+                e2 = torch.cuda.Event()
+                e2.record(st)
+                torch.cuda.current_stream().wait_event(e2)
         return outs
 
     def run_dropin(xs):
@@ -239,12 +272,12 @@ def main():
     # ---------------- decode leg: K timed steps ----------------
     wall_ms, ev_ms, graphed = timed_decode(run_main, args.steps, args.warmup, not args.no_graph)
     ms_per_step = wall_ms / args.steps
-    launches = len(nat) * args.repeat_layers if native_leg else len(raw)
+    launches = (len(nat) - (L if one_launch_mlp else 0)) * args.repeat_layers if native_leg else len(raw)
     bytes_step = bytes_native(1) * args.repeat_layers if native_leg else sum(algo_bytes(1, K, N) for (_n, K, N, *_r) in raw)
     avg_launch_us = ev_ms * 1e3 / (args.steps * launches)
     gbs = bytes_step * args.steps / (ev_ms * 1e-3) / 1e9
-    kname = "awq::gemv_dma_kernel" if native_leg else "awq::gemv_dma_kernel (via gemv_forward_cuda_new + the engine's repack cache)"
-    traffic, traffic_src = pmc_traffic(["awq::gemv_dma_kernel", "awq::gemv_cdna4_kernel"])
+    kname = ("awq::gemv_dma_kernel (qkv, o) + awq::mlp_decode_kernel (gate/up + SiLU*mul + down)" if one_launch_mlp else "awq::gemv_dma_kernel") if native_leg else "awq::gemv_dma_kernel (via gemv_forward_cuda_new + the engine's repack cache)"
+    traffic, traffic_src = pmc_traffic(["awq::gemv_dma_kernel", "awq::gemv_cdna4_kernel", "awq::mlp_decode_kernel"])
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_us": round(avg_launch_us, 3), "algorithmic_bytes_per_launch": bytes_step // launches,
@@ -259,6 +292,7 @@ def main():
            "config": {"workload": "Llama-3-8B W4A16 g128 " + ("bf16" if args.dtype == "bf16" else "fp16") + " activations on 1xMI355X (decode GEMV + prefill GEMM)",
                       "layers": L, "decode_m": 1, "prefill_m": args.prefill_m, "graph": graphed,
                       "layout": args.layout,
+                      "decode_mlp": ("one launch per QuantLlamaMLP (gate/up + SiLU*mul + down_proj)" if one_launch_mlp else "gate/up + SiLU*mul launch, then down_proj") if native_leg else "separate",
                       "prefill_mlp": "SiLU*mul fused into the gate/up GEMM epilogue" if (native_leg and args.mlp == "interleaved") else "separate",
                       "mlp": args.mlp if native_leg else "unfused (two gemv_forward_cuda_new calls, as tinychat issues them)",
                       "decode_side_buffer": ("sz_half" if args.sz == "half" else "sz_packed") if native_leg else "engine cache",

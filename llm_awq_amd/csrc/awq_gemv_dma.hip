@@ -37,6 +37,7 @@ __device__ __forceinline__ void dma_to_lds(const __amdgpu_buffer_rsrc_t& rsrc, c
   if constexpr (SIZE == 16 && AUX == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, DMA_LDS_PTR(dst), 16, voff, soff, 0, 2);
   if constexpr (SIZE == 16 && AUX == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, DMA_LDS_PTR(dst), 16, voff, soff, 0, 0);
   if constexpr (SIZE == 4 && AUX == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, DMA_LDS_PTR(dst), 4, voff, soff, 0, 0);
+  if constexpr (SIZE == 16 && AUX == 17) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, DMA_LDS_PTR(dst), 16, voff, soff, 0, 17);  // sc0 sc1
 #endif
 }
 // timing probes (builds with AWQ_PROBES=1 only; wrong results): bit 0 = no math (stream only), bit 1 = no weight DMA and no
@@ -60,17 +61,19 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // EPI 0: out[m, n] (+ bias);  EPI 1: qw = [gate; up] stacked along N, out[m, n/2] = silu(gate) * up (two slabs per block);
 // EPI 2: gate / up rows interleaved 8 + 8 inside every 16-row slab (fused_mlp.QuantLlamaMLP stacks them that way), out[m, n/2]
+// `gate` (fused MLP launch, awq_w4a16_mlp_decode_cdna4): the block streams its weights and scales first, then waits until *gate has
+// reached gate_target (the producer blocks of the same launch have stored and released the activations), and only then fetches x,
+// past the caches.  nullptr: x is fetched up front (a plain launch: its input was complete before the kernel started).
 template <typename DT, int WAVES, int D, int DQ, int EPI>
-__global__ __launch_bounds__(64 * WAVES) void gemv_dma_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
-                                                               const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
-                                                               uint16_t* __restrict__ out, int M, int N, int K, int TX, int probe_) {
+__device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __restrict__ x, const u32* __restrict__ qw,
+                                              const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
+                                              uint16_t* __restrict__ out, int M, int N, int K, int TX, int probe_, int nb,
+                                              int* gate, int gate_target, bool out_through = false) {
   constexpr int NS = EPI == 1 ? 2 : 1;
   const int probe = DMA_PROBE(probe_);
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, g = lane >> 4;
   const int nit = K >> 7;
-  const int nb = blockIdx.x;
   const int TXp = (TX + 3) & ~3;                 // steps covered by the 4-step DMA pieces of x / sz
   const int xrow = TXp * 256 + 16;               // bytes per staged x row (+16: the M rows of an operand land in different banks)
   const int wave_bytes = D * NS * 1024 + NS * TXp * 64 + M * xrow;
@@ -103,11 +106,33 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_dma_kernel(const uint16_t* __
   for (int s = 0; s < NS; ++s)
     for (int q = 0; q < TXp; q += 4)
       dma_to_lds<4, 0>(rs, szs + (s * TXp + q) * 64, lane4, (slab_tile[s] + (u32)(s0 + q)) * 64u);
-  for (int r = 0; r < M; ++r)
-    for (int q = 0; q < TXp; q += 4)
-      dma_to_lds<16, 0>(rx, xs + r * xrow + q * 256, lane16, ((u32)r * (u32)K + (u32)(s0 + q) * 128u) * 2u);
+  if (gate == nullptr) {
+    for (int r = 0; r < M; ++r)
+      for (int q = 0; q < TXp; q += 4)
+        dma_to_lds<16, 0>(rx, xs + r * xrow + q * 256, lane16, ((u32)r * (u32)K + (u32)(s0 + q) * 128u) * 2u);
+  }
 #pragma unroll
   for (int d = 1; d < D; ++d) issue(d, d);
+  if (gate != nullptr) {
+    // the ring is in flight; now wait for the producers: ONE lane per block polls (bounded: a lost producer turns into a flagged
+    // error, not a hung queue), the other waves sit at the block barrier.  No cache maintenance on either side: the producers
+    // store h write-through (sc0 sc1) and count only after their stores were acknowledged, and x is fetched past the caches below.
+    if (wv == 0 && lane == 0) {
+      int spins = 0;
+      while (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gate_target) {
+        if (++spins > 100000) {
+          __hip_atomic_store(gate + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(16);
+      }
+    }
+    __syncthreads();
+    for (int r = 0; r < M; ++r)
+      for (int q = 0; q < TXp; q += 4)
+        dma_to_lds<16, 17>(rx, xs + r * xrow + q * 256, lane16, ((u32)r * (u32)K + (u32)(s0 + q) * 128u) * 2u);
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");  // x and (long since) the ring: the counted waits below start from an empty queue
+  }
 
   using vec8 = typename DT::vec8;
   Cdna4DequantT<DT> cd;   // DQ 0: sz_packed in T
@@ -214,7 +239,60 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_dma_kernel(const uint16_t* __
       }
       const float gt = to_f(DT::from_float(gsum)), up = to_f(DT::from_float(usum));
       const float sl = to_f(DT::from_float(gt / (1.0f + expf(-gt))));
-      out[(size_t)i * (N >> 1) + nb * 8 + 4 * g + r] = DT::from_float(sl * up);
+      const uint16_t hv = DT::from_float(sl * up);
+      const size_t oi = (size_t)i * (N >> 1) + nb * 8 + 4 * g + r;
+      if (out_through) {  // consumers of the same launch read this: write through to memory (sc0 sc1), no L2 write-back needed later
+        asm volatile("global_store_short %0, %1, off sc0 sc1" : : "v"(out + oi), "v"((u32)hv) : "memory");
+      } else {
+        out[oi] = hv;
+      }
+    }
+  }
+}
+
+template <typename DT, int WAVES, int D, int DQ, int EPI>
+__global__ __launch_bounds__(64 * WAVES) void gemv_dma_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
+                                                               const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
+                                                               uint16_t* __restrict__ out, int M, int N, int K, int TX, int probe_) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemv_dma_body<DT, WAVES, D, DQ, EPI>(smem, x, qw, szp, bias, out, M, N, K, TX, probe_, blockIdx.x, nullptr, 0);
+}
+
+// QuantLlamaMLP.forward at decode in ONE launch (tinychat/modules/fused_mlp.py:33-83: gate/up GEMVs, F.silu, multiply, down_proj):
+// blocks [0, nA) are the gate/up slabs (8 + 8 interleaved pair, SiLU * mul epilogue) and store h = silu(gate) * up; blocks [nA, nA + nB)
+// are down_proj's slabs: they are dispatched behind the last gate/up block (workgroups start in index order, so a waiting block can
+// never keep a producer off the chip), stream their weights while the gate/up tail drains, wait for ctr[0] == nA, then read h.
+// ctr: AWQ_MLP_DECODE_COUNTER_BYTES of device memory, all zero between launches: [0] producer groups done, [1] consumers done, [2] timeout
+// flag (sticky), [16 (1 + g)] blocks of producer group g done (one 64-byte line per group of 32 blocks).
+template <typename DT, int DA, int DB>
+__global__ __launch_bounds__(512) void mlp_decode_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw_gu,
+                                                         const u32* __restrict__ szh_gu, const u32* __restrict__ qw_d,
+                                                         const u32* __restrict__ szh_d, const uint16_t* __restrict__ bias_d,
+                                                         uint16_t* __restrict__ h, uint16_t* __restrict__ out, int M, int hidden,
+                                                         int ffn, int n_out, int txa, int txb, int* ctr) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nA = ffn >> 3;  // 2 * ffn rows / 16
+  if ((int)blockIdx.x < nA) {
+    gemv_dma_body<DT, 8, DA, 1, 2>(smem, x, qw_gu, szh_gu, nullptr, h, M, 2 * ffn, hidden, txa, 0, blockIdx.x, nullptr, 0, true);
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");  // this wave's write-through stores of h have been acknowledged ...
+    __syncthreads();                                     // ... and so have every other wave's
+    // two-level count (1792 read-modify-writes of ONE address from eight XCDs serialise at the memory side, ~40 ns each): the block
+    // counts in its group of 32 (own 64-byte line), the last of a group counts the group
+    if (threadIdx.x == 0) {
+      const int grp = (int)blockIdx.x >> 5, gsize = min(32, nA - (grp << 5));
+      if (__hip_atomic_fetch_add(ctr + 16 * (1 + grp), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1)
+        __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else {
+    const int nB = n_out >> 4;
+    const int ngrp = (nA + 31) >> 5;
+    gemv_dma_body<DT, 8, DB, 1, 0>(smem, h, qw_d, szh_d, bias_d, out, M, n_out, ffn, txb, 0, (int)blockIdx.x - nA, ctr, ngrp);
+    __syncthreads();
+    if (threadIdx.x == 0 && __hip_atomic_fetch_add(ctr + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nB - 1) {
+      // last consumer: every block has passed the gate; the next launch starts after this one ends
+      for (int q = 0; q < ngrp; ++q) __hip_atomic_store(ctr + 16 * (1 + q), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ctr + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -333,6 +411,33 @@ int launch_gemv_dma(const void* x, const void* qw, const void* szp, const void* 
   }
   AWQ_DDT(BF16, 0)
 #undef AWQ_DDT
+}
+
+// gate/up (8 + 8 interleaved, n2 = 2 * ffn rows, K = hidden) + SiLU * mul + down (K = ffn, n_out rows) in one launch; sz_half side buffers.
+// h: [m, ffn] scratch in T; ctr: int32[4] device memory, zero before the first call.  Returns -1 if the shape is not served.
+int launch_mlp_decode(const void* x, const void* qw_gu, const void* szh_gu, const void* qw_d, const void* szh_d, const void* bias_d,
+                      void* h, void* out, int m, int hidden, int ffn, int n_out, int dtype, int* ctr, hipStream_t st) {
+  if (m < 1 || m > 8 || (hidden % 128) != 0 || (ffn % 128) != 0 || (n_out % 16) != 0) return -1;
+  const int nita = hidden / kGroup, nitb = ffn / kGroup;
+  const int txa = (nita + 7) / 8, txb = (nitb + 7) / 8;
+  const int da = txa >= 4 ? 4 : (txa >= 2 ? 2 : 1), db = txb >= 2 ? 2 : 1;
+  if (da != 4 || db != 2) return -1;  // compiled for rings of 4 / 2 tiles (hidden >= 4096, ffn >= 2048)
+  const size_t smem_a = dma_smem(8, da, 1, txa, m), smem_b = dma_smem(8, db, 1, txb, m);
+  const size_t smem = smem_a > smem_b ? smem_a : smem_b;
+  if (smem > 160 * 1024) return -1;
+  const int blocks = ffn / 8 + n_out / 16;
+#define AWQ_MLPD(DT_)                                                                                                              \
+  {                                                                                                                                \
+    auto kern = mlp_decode_kernel<DT_, 4, 2>;                                                                                      \
+    static LdsOptIn optin;                                                                                                         \
+    if (smem > 64 * 1024) optin.ensure(reinterpret_cast<const void*>(kern), (int)smem);                                           \
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw_gu, (const u32*)szh_gu,         \
+                       (const u32*)qw_d, (const u32*)szh_d, (const uint16_t*)bias_d, (uint16_t*)h, (uint16_t*)out, m, hidden, ffn, \
+                       n_out, txa, txb, ctr);                                                                                      \
+  }
+  if (dtype == 0) AWQ_MLPD(F16) else AWQ_MLPD(BF16)
+#undef AWQ_MLPD
+  return 0;
 }
 
 }  // namespace awq

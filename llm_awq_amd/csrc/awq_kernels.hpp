@@ -103,6 +103,9 @@ void launch_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const 
 void launch_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
                           int n_end, int dtype, hipStream_t st, int bits = 4, int epi = 0);
 void gemm_v6_set_probe(int v);
+// awq_gemv_dma.hip: QuantLlamaMLP.forward at decode (gate/up + SiLU * mul + down) in one launch; -1 if the shape is not served
+int launch_mlp_decode(const void* x, const void* qw_gu, const void* szh_gu, const void* qw_d, const void* szh_d, const void* bias_d,
+                      void* h, void* out, int m, int hidden, int ffn, int n_out, int dtype, int* ctr, hipStream_t st);
 void launch_gemm_cdna4_v5(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
                           int n_end, int dtype, hipStream_t st, int bits = 4, int mf = 16);
 int launch_bias_add(void* out, const void* bias, int m, int n, int dtype, hipStream_t st);

@@ -7,8 +7,12 @@ The reference module keeps gate_proj / up_proj as raw v2 buffers, issues two `ge
     8j..8j+7; in the v2 buffers that is a permutation of whole packed rows, 4 logical rows each) and repacks the result to the
     cdna4 interleave.  2 * ffn / 16 blocks of one tile stream each (1792 for Llama-3-8B: 7 per CU) instead of ffn / 16 blocks of
     two streams (896: 3.5 per CU, so half the CUs carried 4 blocks and the rest 3);
-  * decode (< 8 rows): `decode_cdna4(..., epilogue=2)` -- gate, up, SiLU and the multiply in one launch, every intermediate
-    rounded to T exactly like the reference's separate ops (fused_mlp.py:39-61, :79-82);
+  * decode (<= 8 rows): `decode_cdna4(..., epilogue=2)` -- gate, up, SiLU and the multiply in one launch, every intermediate
+    rounded to T exactly like the reference's separate ops (fused_mlp.py:39-61, :79-82) -- then down_proj's launch.  With
+    AWQ_MLP_ONE_LAUNCH=1 the WHOLE module is one launch (`mlp_decode_cdna4`: down_proj's blocks sit behind the gate/up blocks in
+    the same grid, stream their first weight tiles while the gate/up tail drains and wait on a device-side count for h); it is
+    correct and measured SLOWER (profiles/r02_mlp_one_launch.txt: the device-side hand-over costs more than the launch gap it
+    removes), so it is opt-in;
   * prefill (>= 8 rows): one GEMM over the interleaved weight (x is read once for both projections) whose tile epilogue pairs
     column n with column n + 8 and stores silu(gate) * up directly -- the [rows, 2 * ffn] intermediate of the reference's two
     GEMMs + F.silu + multiply is never written.
@@ -21,6 +25,8 @@ uses it for every row count -- decode and prefill agree with each other and with
 branches do not.
 """
 from __future__ import annotations
+
+import os
 
 import torch
 import torch.nn as nn
@@ -64,6 +70,7 @@ class QuantLlamaMLP(nn.Module):
         self.down_proj = down_proj
         self.split_k_iters = down_proj.split_k_iters
         self._fused = None  # (qweight cdna4, scales, scaled_zeros, sz_packed, sz_half or None): built on the first GPU forward
+        self._ctr = None    # int32[4] device counters of the one-launch decode path (zero between calls)
 
     @torch.no_grad()
     def _build(self):
@@ -77,8 +84,40 @@ class QuantLlamaMLP(nn.Module):
         if getattr(self.down_proj, "layout", None) == "v2" and self.down_proj.out_features % 16 == 0:
             self.down_proj.to_cdna4()
 
+    @torch.no_grad()
     def forward(self, x):
+        rows = x.numel() // x.shape[-1]
+        if rows <= 8 and x.is_cuda and os.environ.get("AWQ_MLP_ONE_LAUNCH") == "1":  # opt-in: measured slower than two launches
+            y = self._decode_one_launch(x)
+            if y is not None:
+                return y
         return self.down_proj(self.our_llama_mlp(x))
+
+    def _decode_one_launch(self, x):
+        """gate/up + SiLU * mul + down_proj in ONE launch (`awq_w4a16_mlp_decode_cdna4`): down_proj's blocks stream their weights while
+        the gate/up tail drains and wait on a device-side count for h.  None when this layer cannot take it (scales not f16-exact,
+        down_proj not in the cdna4 layout, shape outside the kernel's range)."""
+        eng = load_engine()
+        if self._fused is None or self._fused[0].device != x.device:
+            self._build()
+        c4, s, z, szp, szh = self._fused
+        d = self.down_proj
+        if szh is None or getattr(d, "layout", None) != "cdna4" or d.w_bit != 4 or self.in_features < 4096 or self.intermediate_size < 2048:
+            return None
+        # the down blocks stage their K slice of h for every row: 8 waves x (ring 2 KiB + scales + rows x slice) must fit in 160 KiB
+        txp = (((self.intermediate_size // 128 + 7) // 8) + 3) & ~3
+        rows = x.numel() // x.shape[-1]
+        if 8 * (2 * 1024 + txp * 64 + rows * (txp * 256 + 16)) > 160 * 1024:
+            return None
+        if d.szh_cdna4 is None:
+            d._build_szh(eng)
+        if d.szh_cdna4 is False:
+            return None
+        if self._ctr is None or self._ctr.device != x.device:
+            self._ctr = torch.zeros(4096, dtype=torch.int32, device=x.device)
+        if not x.is_contiguous():
+            x = x.contiguous()
+        return eng.mlp_decode_cdna4(x, c4, szh, d.qweight, d.szh_cdna4, self._ctr, d.bias)
 
     @torch.no_grad()
     def our_llama_mlp(self, x):

@@ -248,6 +248,24 @@ def mlp_gate_up_cdna4(x, qweight_gate_up, sz_packed, group_size: int = 128):
     return out
 
 
+def mlp_decode_cdna4(x, gate_up_qweight, gate_up_sz_half, down_qweight, down_sz_half, counters, down_bias=None, group_size: int = 128):
+    """C-ABI awq_w4a16_mlp_decode_cdna4: QuantLlamaMLP.forward for <= 8 rows in one launch.  counters: int32[4] zeros (kept by the caller)."""
+    _need_gpu(x, gate_up_qweight, gate_up_sz_half, down_qweight, down_sz_half, counters, down_bias)
+    hidden = x.shape[-1]
+    m = x.numel() // hidden
+    ffn = gate_up_qweight.shape[0] * 4 // 2
+    n_out = down_qweight.shape[0] * 4
+    h = torch.empty(m, ffn, dtype=x.dtype, device=x.device)
+    out = torch.empty(*x.shape[:-1], n_out, dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _capi.check(_capi.lib().awq_w4a16_mlp_decode_cdna4(x.data_ptr(), gate_up_qweight.data_ptr(), gate_up_sz_half.data_ptr(),
+                                                            down_qweight.data_ptr(), down_sz_half.data_ptr(),
+                                                            down_bias.data_ptr() if down_bias is not None else None, h.data_ptr(),
+                                                            out.data_ptr(), m, hidden, ffn, n_out, group_size, _dt(x),
+                                                            counters.data_ptr(), _stream(x)))
+    return out
+
+
 def mlp_gate_up_forward_cdna4(x, qweight_interleaved, sz_packed, sz_half=None, group_size: int = 128):
     """C-ABI awq_w4a16_mlp_gate_up_forward_cdna4: QuantLlamaMLP.our_llama_mlp for any row count on the 8 + 8 interleaved pair."""
     _need_gpu(x, qweight_interleaved, sz_packed, sz_half)
