@@ -258,7 +258,7 @@ int awq_w4a16_mlp_gate_up_forward_cdna4(const void* x, const void* qweight_inter
   }
   // prefill / batched decode: the tile kernels with the SiLU * mul tail fused into their epilogue (out is [m, n2 / 2]: the
   // [m, n2] intermediate of the reference's two GEMMs + F.silu + multiply never exists)
-  if (awq::launch_gemm_cdna4_v3(x, qweight_interleaved, sz_packed, nullptr, out, m, n2, k, 0, dtype, nullptr, 0, (hipStream_t)stream, 4, 2) != 0)
+  if (awq::launch_gemm_cdna4_v3(x, qweight_interleaved, sz_packed, nullptr, out, m, n2, k, 0, dtype, nullptr, 0, (hipStream_t)stream, 4, 2, sz_half) != 0)
     return AWQ_ERR_SHAPE;
   return finish_launch();
 }

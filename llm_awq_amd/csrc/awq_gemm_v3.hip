@@ -324,16 +324,20 @@ int g_splitk = 1;  // narrow tiles: split K over blocks when the tiles fill less
 int g_v5 = 0;  // 1: 256-wide tiles run awq_gemm_v5.hip (weights never touch LDS); knob gemm_v5
 int g_v6 = 1;  // 1 (default): 256-wide tiles of m >= 256 run awq_gemm_v6.hip (one software-pipelined wave per SIMD); 0: awq_gemm_v4.hip
 int g_tile_n = 0;  // knob gemm_tile_n: 128 / 256 force one tile width for callers that pass tile_n = 0 (tests of a specific kernel)
+int g_v6_szh = 0;  // knob gemm_v6_szh: 1 = v6 dequantises in the f16-mantissa form when the caller hands its sz_half buffer (-40 VALU per K tile; measured neutral, profiles/r02_gemm_v6.txt)
 int g_v4 = 1;  // 1 (default): 256-wide tiles run the hand-scheduled K loop of awq_gemm_v4.hip; 0: v3's compiler-scheduled loop
 void launch_wide(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
-                 int n_end, int dtype, hipStream_t st, int bits, int epi) {
+                 int n_end, int dtype, hipStream_t st, int bits, int epi, const void* szh = nullptr) {
 #ifdef AWQ_ENABLE_PROBES  // awq_gemm_v5.hip is an evaluated alternative (profiles/r02_gemm_v5_sweep.txt), not a product path
   if (g_v5) {
     launch_gemm_cdna4_v5(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, g_v5 == 3 ? 8 : (g_v5 == 4 ? 17 : 16));
     return;
   }
 #endif
-  if (g_v6 && m >= 256) launch_gemm_cdna4_v6(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, epi);
+  if (g_v6 && m >= 256) {  // (szh: the caller's sz_half side buffer, reported exact for this layer -> the f16-mantissa dequant form)
+    if (szh != nullptr && bits == 4 && g_v6_szh) launch_gemm_cdna4_v6(x, qw, szh, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, epi, 1);
+    else launch_gemm_cdna4_v6(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, epi, 0);
+  }
   else if (g_v4 || bits == 3 || epi) launch_gemm_cdna4_v4(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, epi);
   else if (dtype == 0) launch_v3<F16, 2>(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
   else launch_v3<BF16, 2>(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
@@ -364,6 +368,7 @@ int gemm_v3_tune_set(const char* key, int value) {
   else if (!strcmp(key, "gemm_v4_probe")) gemm_v4_set_probe(value);
 #endif
   else if (!strcmp(key, "gemm_tile_n")) g_tile_n = value;
+  else if (!strcmp(key, "gemm_v6_szh")) g_v6_szh = value;
   else if (!strcmp(key, "moe_v4")) g_moe_v4 = value;
   else if (!strcmp(key, "gemm_small_m")) g_small_m = value;
   else if (!strcmp(key, "gemm_splitk")) {  // 0 = off, 1 = auto, n > 1 = force n K ranges
@@ -432,18 +437,18 @@ size_t gemm_cdna4_v3_workspace_bytes_w3(int m, int n, int k) {
 }
 
 int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                         int tile_n, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits, int epi) {
+                         int tile_n, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits, int epi, const void* szh) {
   // (w3c tiles have no skinny kernel: the masked single-row-tile path of the narrow kernel serves every m > 8)
   if (!szp || !(gemm_cdna4_v3_takes(m, k) || ((bits == 3 || epi) && m > 8)) || (n % 16) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return -1;
   Plan p = m < TM ? Plan{1, 0} : plan_tiles(m, n, tile_n ? tile_n : g_tile_n);  // m < 256: only the narrow-tile kernel masks rows
   if (g_v5 >= 2 || g_v6 >= 2) p = Plan{0, 0};                            // experiments: every tile through awq_gemm_v5.hip (it masks rows itself)
   if (p.mode == 2) {
-    launch_wide(x, qw, szp, bias, out, m, n, k, 0, (int)(p.cols_main * 256), dtype, st, bits, epi);
+    launch_wide(x, qw, szp, bias, out, m, n, k, 0, (int)(p.cols_main * 256), dtype, st, bits, epi, szh);
     launch_narrow(x, qw, szp, bias, out, m, n, k, (int)(p.cols_main * 256), n, dtype, ws, ws_bytes, st, bits, epi);
   } else if (p.mode == 1) {
     launch_narrow(x, qw, szp, bias, out, m, n, k, 0, n, dtype, ws, ws_bytes, st, bits, epi);
   } else {
-    launch_wide(x, qw, szp, bias, out, m, n, k, 0, n, dtype, st, bits, epi);
+    launch_wide(x, qw, szp, bias, out, m, n, k, 0, n, dtype, st, bits, epi, szh);
   }
   return 0;
 }

@@ -46,14 +46,14 @@ using ic6 = std::integral_constant<int, V>;
 // the dequant MFMA in its VGPR form, as asm: once a function holds AGPR-constrained values hipcc selects the AGPR form for every builtin
 // MFMA and would evict accumulators to make room for the 4x4x4 operands.  Early-clobber output (no partial overlap with C); the s_nop
 // covers the VALU -> MFMA operand hazard the opaque statement hides from the hazard recogniser; results are read >= 8 MFMAs later.
-template <typename DT, bool NOP = true>
+template <typename DT, bool NOP = true, bool F16FORM = false>
 __device__ __forceinline__ f32x4 v6_mfma4(const u32x2& a, const u32x2& b, const f32x4& c) {
   f32x4 d;
   if constexpr (NOP) {
-    if constexpr (DT::id == 1) asm volatile("s_nop 1\n\tv_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+    if constexpr (DT::id == 1 && !F16FORM) asm volatile("s_nop 1\n\tv_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
     else asm volatile("s_nop 1\n\tv_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
   } else {  // K loop: the operands were written at least one MFMA slot (>= 16 cycles) earlier
-    if constexpr (DT::id == 1) asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+    if constexpr (DT::id == 1 && !F16FORM) asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
     else asm volatile("v_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
   }
   return d;
@@ -66,7 +66,10 @@ __device__ __forceinline__ void v6_mfma(f32x4& acc, const V8& a, const u32x4& b)
 
 // PROBE (AWQ_ENABLE_PROBES builds, timing only, wrong results): 1 = no x staging (no global loads / ds_writes of x in the K loop),
 // 2 = no weight dequantisation in the K loop, 3 = no fragment reads in the K loop, 4 = all three (product MFMAs + barrier only)
-template <typename DT, int BITS, int PROBE = 0>
+// DQ 1: szp is the "sz_half" side buffer and the dequant runs in its f16-mantissa form (Cdna4DequantH: one shift + four v_and_or per word
+// instead of three + four, two v_perm + one v_dot2 for the operands instead of perm / and / and / dot2c; exact for layers
+// awq_pack_szh_cdna4 reports exact; W4 tiles only)
+template <typename DT, int BITS, int PROBE = 0, int DQ = 0>
 __global__ __launch_bounds__(256) void gemm_cdna4_v6_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                             const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
                                                             uint16_t* __restrict__ out, int M, int N, int K, int tiles_m, int tiles_n,
@@ -151,26 +154,41 @@ __global__ __launch_bounds__(256) void gemm_cdna4_v6_kernel(const uint16_t* __re
     u32 b01, b23;
     float cv;
   };
+  Cdna4DequantH<DT> ch;
+  if (DQ == 1) ch.init(lane);
   auto params = [&](u32 sz) {
     DP d;
-    const u32 sdup = __builtin_amdgcn_perm(sz, sz, 0x01000100u);
-    d.b01 = sdup & cd.m01;
-    d.b23 = sdup & cd.m23;
-    d.cv = DT::dq_offset(sz);
+    if (DQ == 1) {
+      d.b01 = __builtin_amdgcn_perm(sz, sz, ch.sel01);
+      d.b23 = __builtin_amdgcn_perm(sz, sz, ch.sel23);
+      d.cv = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, sz), __builtin_bit_cast(f16x2, ch.kDotC), 0.0f, false);
+    } else {
+      const u32 sdup = __builtin_amdgcn_perm(sz, sz, 0x01000100u);
+      d.b01 = sdup & cd.m01;
+      d.b23 = sdup & cd.m23;
+      d.cv = DT::dq_offset(sz);
+    }
     return d;
   };
 
   struct Pend {
     f32x4 d0, d1;
   };
-  auto word_issue = [&](u32 w, const DP& d) {  // Cdna4DequantT::word_issue with the asm MFMA
-    const u32x2 a0 = {(w & cd.kMask) | cd.kMagic, ((w >> 4) & cd.kMask) | cd.kMagic};
-    const u32x2 a1 = {((w >> 8) & cd.kMask) | cd.kMagic, ((w >> 12) & cd.kMask) | cd.kMagic};
+  auto word_issue = [&](u32 w, const DP& d) {  // Cdna4DequantT / Cdna4DequantH ::word_issue with the asm MFMA (prologue)
+    u32x2 a0, a1;
+    if (DQ == 1) {
+      const u32 w8 = w >> 8;
+      a0 = u32x2{(w & ch.kMaskLo) | ch.kMagic, (w & ch.kMaskHi) | ch.kMagic};
+      a1 = u32x2{(w8 & ch.kMaskLo) | ch.kMagic, (w8 & ch.kMaskHi) | ch.kMagic};
+    } else {
+      a0 = u32x2{(w & cd.kMask) | cd.kMagic, ((w >> 4) & cd.kMask) | cd.kMagic};
+      a1 = u32x2{((w >> 8) & cd.kMask) | cd.kMagic, ((w >> 12) & cd.kMask) | cd.kMagic};
+    }
     const u32x2 b = {d.b01, d.b23};
     const f32x4 c = {d.cv, d.cv, d.cv, d.cv};
     Pend p;
-    p.d0 = v6_mfma4<DT>(a0, b, c);
-    p.d1 = v6_mfma4<DT>(a1, b, c);
+    p.d0 = v6_mfma4<DT, true, DQ == 1>(a0, b, c);
+    p.d1 = v6_mfma4<DT, true, DQ == 1>(a1, b, c);
     return p;
   };
 
@@ -284,19 +302,32 @@ __global__ __launch_bounds__(256) void gemm_cdna4_v6_kernel(const uint16_t* __re
           }
         }
         if (PROBE != 2 && PROBE != 4) {
-          if (k == 4) a0.x = (word & cd.kMask) | cd.kMagic, a0.y = ((word >> 4) & cd.kMask) | cd.kMagic;
-          if (k == 5) a1.x = ((word >> 8) & cd.kMask) | cd.kMagic, a1.y = ((word >> 12) & cd.kMask) | cd.kMagic;
-          if (k == 6) {
-            const u32 sdup = __builtin_amdgcn_perm(sz, sz, 0x01000100u);
-            bq.x = sdup & cd.m01;
-            bq.y = sdup & cd.m23;
+          if (DQ == 1) {
+            if (k == 4) a0.x = (word & ch.kMaskLo) | ch.kMagic, a0.y = (word & ch.kMaskHi) | ch.kMagic;
+            if (k == 5) {
+              const u32 w8 = word >> 8;
+              a1.x = (w8 & ch.kMaskLo) | ch.kMagic, a1.y = (w8 & ch.kMaskHi) | ch.kMagic;
+            }
+            if (k == 6) bq.x = __builtin_amdgcn_perm(sz, sz, ch.sel01), bq.y = __builtin_amdgcn_perm(sz, sz, ch.sel23);
+            if (k == 7) {
+              const float cv = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, sz), __builtin_bit_cast(f16x2, ch.kDotC), 0.0f, false);
+              cq = f32x4{cv, cv, cv, cv};
+            }
+          } else {
+            if (k == 4) a0.x = (word & cd.kMask) | cd.kMagic, a0.y = ((word >> 4) & cd.kMask) | cd.kMagic;
+            if (k == 5) a1.x = ((word >> 8) & cd.kMask) | cd.kMagic, a1.y = ((word >> 12) & cd.kMask) | cd.kMagic;
+            if (k == 6) {
+              const u32 sdup = __builtin_amdgcn_perm(sz, sz, 0x01000100u);
+              bq.x = sdup & cd.m01;
+              bq.y = sdup & cd.m23;
+            }
+            if (k == 7) {
+              const float cv = DT::dq_offset(sz);
+              cq = f32x4{cv, cv, cv, cv};
+            }
           }
-          if (k == 7) {
-            const float cv = DT::dq_offset(sz);
-            cq = f32x4{cv, cv, cv, cv};
-          }
-          if (k == 8) pj.d0 = v6_mfma4<DT, false>(a0, bq, cq);
-          if (k == 9) pj.d1 = v6_mfma4<DT, false>(a1, bq, cq);
+          if (k == 8) pj.d0 = v6_mfma4<DT, false, DQ == 1>(a0, bq, cq);
+          if (k == 9) pj.d1 = v6_mfma4<DT, false, DQ == 1>(a1, bq, cq);
           if (k == 14) op[(A + 1) & 1][Q] = DT::pack8(pj.d0, pj.d1);
         }
         if (PROBE != 1 && PROBE != 4) {
@@ -421,7 +452,7 @@ void gemm_v6_set_probe(int v) { g_v6_probe = v; }
 
 // weight rows [n_begin, n_end) with 256 x 256 blocks; any m >= 1 (rows past m are clamped / not stored)
 void launch_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
-                          int n_end, int dtype, hipStream_t st, int bits, int epi) {
+                          int n_end, int dtype, hipStream_t st, int bits, int epi, int szfmt) {
   constexpr int stage2 = 2 * kV6Stage, stg_epi = V6_TM * kV6Pitch;
   constexpr int smem = stage2 > stg_epi ? stage2 : stg_epi;
   const int tiles_m = (m + V6_TM - 1) / V6_TM, tiles_n = (n_end - n_begin + V6_TN - 1) / V6_TN;
@@ -429,8 +460,15 @@ void launch_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, const 
   static const Kern kerns[2][2] = {{gemm_cdna4_v6_kernel<F16, 4>, gemm_cdna4_v6_kernel<F16, 3>},
                                    {gemm_cdna4_v6_kernel<BF16, 4>, gemm_cdna4_v6_kernel<BF16, 3>}};
   const int a = dtype == 0 ? 0 : 1, b = bits == 3 ? 1 : 0;
-  Kern kern = kerns[a][b];
-  static LdsOptIn optin[2][2];
+  static const Kern kerns_h[2] = {gemm_cdna4_v6_kernel<F16, 4, 0, 1>, gemm_cdna4_v6_kernel<BF16, 4, 0, 1>};  // szp = sz_half
+  Kern kern = (szfmt == 1 && bits == 4) ? kerns_h[a] : kerns[a][b];
+  static LdsOptIn optin[2][2], optin_h[2];
+  if (szfmt == 1 && bits == 4) {
+    optin_h[a].ensure(reinterpret_cast<const void*>(kern), smem);
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp,
+                       (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end, epi);
+    return;
+  }
 #ifdef AWQ_ENABLE_PROBES
   static const Kern probes[5] = {gemm_cdna4_v6_kernel<BF16, 4>, gemm_cdna4_v6_kernel<BF16, 4, 1>, gemm_cdna4_v6_kernel<BF16, 4, 2>,
                                  gemm_cdna4_v6_kernel<BF16, 4, 3>, gemm_cdna4_v6_kernel<BF16, 4, 4>};

@@ -30,7 +30,7 @@ def _reset(ops):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("bias", [False, True])
 @pytest.mark.parametrize("M", [256, 300, 777])
-@pytest.mark.parametrize("N,K", [(512, 1024), (1296, 512), (272, 2048)])
+@pytest.mark.parametrize("N,K", [(512, 1024), (1296, 512), (272, 2048), (256, 128), (528, 256)])
 def test_v6_against_the_oracle(ops, dtype, bias, M, N, K):
     c = make_case(N, K, dtype, seed=N + K + M, M=M, bias=bias)
     c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
