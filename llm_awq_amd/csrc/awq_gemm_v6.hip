@@ -1,4 +1,6 @@
 // Prefill GEMM v6 on cdna4-interleaved weights (bf16 and fp16, gfx950): one wave per SIMD, 256 x 64 per wave.
+// Replaces gemm_w4a16_T1 / gemm_w4a16_T2 (reference awq/kernels/csrc/quantization_new/gemm/gemm_cuda.cu:312-1124) behind
+// gemm_forward_cuda_new / WQLinear.forward for the 256-wide tiles of prompts with >= 256 rows.
 //
 // Why (profiles/r02_gemm_v4_probes.txt): the 8-wave kernels are bound by LDS occupancy -- per 16-k step v4 holds the LDS 192 cycles
 // with fragment reads, 104 with the writes of the dequantised weight tile and ~115 with the x tile's LDS-DMA (411 of the 512 cycles
@@ -10,8 +12,8 @@
 //   block  = 256 rows x 256 columns, 4 waves; wave w = columns [64 w, 64 w + 64) = 4 weight slabs, all 256 rows
 //   K tile = 128 (one quantisation group); x tile 256 x 128 bf16 = 64 KiB per LDS stage, two stages
 //   x path = global -> registers -> ds_write_b128 (NOT LDS-DMA: a DMA instruction holds the issuing wave ~60-100 cycles, and here no
-//            second wave fills the matrix pipe meanwhile); a wave stages the 64 rows it owns: 16 pieces of 4 rows per K tile, loaded a
-//            full K tile before they are written (64 staging VGPRs), written during the first half of each 32-k step
+//            second wave fills the matrix pipe meanwhile); a wave stages the 64 rows it owns: 16 pieces of 4 rows per K tile, each loaded
+//            two 32-k steps (~2 k cycles) before it is written (32 staging VGPRs), one piece per quarter-step
 //   weights = 4 x (16 B + one scale dword) per lane per K tile straight into registers one tile ahead; dequantised on the matrix core
 //            (Cdna4DequantT) into the A operand of v_mfma_f32_16x16x32 one 32-k step ahead of its use
 //   per 32-k step and wave: 16 x fragments (two sets of 4, each read while the other feeds 16 MFMAs), 64 product MFMAs (1024 cycles)
