@@ -324,10 +324,11 @@ int g_splitk = 1;  // narrow tiles: split K over blocks when the tiles fill less
 int g_v5 = 0;  // 1: 256-wide tiles run awq_gemm_v5.hip (weights never touch LDS); knob gemm_v5
 int g_v6 = 1;  // 1 (default): 256-wide tiles of m >= 256 run awq_gemm_v6.hip (one software-pipelined wave per SIMD); 0: awq_gemm_v4.hip
 int g_tile_n = 0;  // knob gemm_tile_n: 128 / 256 force one tile width for callers that pass tile_n = 0 (tests of a specific kernel)
+int g_v6_192 = 1;  // knob gemm_v6_192: 0 = no 192-wide blocks in the tile plan
 int g_v6_szh = 0;  // knob gemm_v6_szh: 1 = v6 dequantises in the f16-mantissa form when the caller hands its sz_half buffer (-40 VALU per K tile; measured neutral, profiles/r02_gemm_v6.txt)
 int g_v4 = 1;  // 1 (default): 256-wide tiles run the hand-scheduled K loop of awq_gemm_v4.hip; 0: v3's compiler-scheduled loop
 void launch_wide(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
-                 int n_end, int dtype, hipStream_t st, int bits, int epi, const void* szh = nullptr) {
+                 int n_end, int dtype, hipStream_t st, int bits, int epi, const void* szh = nullptr, int tile_n = 256) {
 #ifdef AWQ_ENABLE_PROBES  // awq_gemm_v5.hip is an evaluated alternative (profiles/r02_gemm_v5_sweep.txt), not a product path
   if (g_v5) {
     launch_gemm_cdna4_v5(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, g_v5 == 3 ? 8 : (g_v5 == 4 ? 17 : 16));
@@ -336,9 +337,10 @@ void launch_wide(const void* x, const void* qw, const void* szp, const void* bia
 #endif
   if (g_v6 && m >= 256) {  // (szh: the caller's sz_half side buffer, reported exact for this layer -> the f16-mantissa dequant form)
     if (szh != nullptr && bits == 4 && g_v6_szh) launch_gemm_cdna4_v6(x, qw, szh, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, epi, 1);
-    else launch_gemm_cdna4_v6(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, epi, 0);
+    else launch_gemm_cdna4_v6(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, epi, 0, tile_n);
+    return;
   }
-  else if (g_v4 || bits == 3 || epi) launch_gemm_cdna4_v4(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, epi);
+  if (g_v4 || bits == 3 || epi) launch_gemm_cdna4_v4(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, epi);
   else if (dtype == 0) launch_v3<F16, 2>(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
   else launch_v3<BF16, 2>(x, qw, szp, bias, out, m, n, k, n_begin, n_end, st);
 }
@@ -369,6 +371,7 @@ int gemm_v3_tune_set(const char* key, int value) {
 #endif
   else if (!strcmp(key, "gemm_tile_n")) g_tile_n = value;
   else if (!strcmp(key, "gemm_v6_szh")) g_v6_szh = value;
+  else if (!strcmp(key, "gemm_v6_192")) g_v6_192 = value;
   else if (!strcmp(key, "moe_v4")) g_moe_v4 = value;
   else if (!strcmp(key, "gemm_small_m")) g_small_m = value;
   else if (!strcmp(key, "gemm_splitk")) {  // 0 = off, 1 = auto, n > 1 = force n K ranges
@@ -384,12 +387,14 @@ int gemm_v3_tune_set(const char* key, int value) {
 // tiles and the remaining weight rows with 128-wide tiles in a second launch when that is faster.
 namespace {
 struct Plan {
-  int mode;        // 0 = all 256-wide, 1 = all 128-wide, 2 = 256-wide for [0, cols_main * 256) + 128-wide for the rest
+  int mode;        // 0 = all 256-wide, 1 = all 128-wide, 2 = 256-wide for [0, cols_main * 256) + 128-wide for the rest, 3 = all 192-wide
   long cols_main;
 };
-Plan plan_tiles(int m, int n, int tile_n) {
+constexpr double k192Rate = 0.97;  // 256 x 192 blocks of awq_gemm_v6.hip (three slabs per wave) vs its 256 x 256 blocks at equal chip fill
+Plan plan_tiles(int m, int n, int tile_n, bool allow192 = false) {
   if (tile_n == 128) return {1, 0};
   if (tile_n == 256) return {0, 0};
+  if (tile_n == 192) return {allow192 ? 3 : 0, 0};
   const long tiles_m = (m + TM - 1) / TM;
   auto rounds = [](long t) { return (double)((t + 255) / 256); };
   const long cols256 = (n + 255) / 256, t256 = tiles_m * cols256;
@@ -402,6 +407,9 @@ Plan plan_tiles(int m, int n, int tile_n) {
     const long n_rest = n - cols_main * 256;
     cost_mixed = rounds(tiles_m * cols_main) + rounds(tiles_m * ((n_rest + 127) / 128)) * 0.5 / kNarrowRate + 0.02;
   }
+  // 192-wide blocks: three quarters of the work per block; they win where they turn a partial round into a full one
+  const double cost_192 = allow192 ? rounds(tiles_m * ((n + 191) / 192)) * 0.75 / k192Rate : 1e30;
+  if (cost_192 < cost_wide && cost_192 < cost_narrow && cost_192 < cost_mixed) return {3, 0};
   if (cost_mixed < cost_wide && cost_mixed < cost_narrow) return {2, cols_main};
   return {cost_narrow < cost_wide ? 1 : 0, 0};
 }
@@ -440,9 +448,12 @@ int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, const v
                          int tile_n, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits, int epi, const void* szh) {
   // (w3c tiles have no skinny kernel: the masked single-row-tile path of the narrow kernel serves every m > 8)
   if (!szp || !(gemm_cdna4_v3_takes(m, k) || ((bits == 3 || epi) && m > 8)) || (n % 16) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return -1;
-  Plan p = m < TM ? Plan{1, 0} : plan_tiles(m, n, tile_n ? tile_n : g_tile_n);  // m < 256: only the narrow-tile kernel masks rows
+  const bool allow192 = g_v6 != 0 && g_v6_192 != 0 && bits == 4 && m >= TM;
+  Plan p = m < TM ? Plan{1, 0} : plan_tiles(m, n, tile_n ? tile_n : g_tile_n, allow192);  // m < 256: only the narrow-tile kernel masks rows
   if (g_v5 >= 2 || g_v6 >= 2) p = Plan{0, 0};                            // experiments: every tile through awq_gemm_v5.hip (it masks rows itself)
-  if (p.mode == 2) {
+  if (p.mode == 3) {
+    launch_wide(x, qw, szp, bias, out, m, n, k, 0, n, dtype, st, bits, epi, nullptr, 192);
+  } else if (p.mode == 2) {
     launch_wide(x, qw, szp, bias, out, m, n, k, 0, (int)(p.cols_main * 256), dtype, st, bits, epi, szh);
     launch_narrow(x, qw, szp, bias, out, m, n, k, (int)(p.cols_main * 256), n, dtype, ws, ws_bytes, st, bits, epi);
   } else if (p.mode == 1) {

@@ -34,7 +34,7 @@ namespace awq {
 namespace {
 constexpr int V6_TM = 256, V6_TN = 256, V6_TK = 128;
 constexpr int kV6Stage = V6_TM * V6_TK * 2;  // 64 KiB
-constexpr int kV6Pitch = 2 * V6_TN + 16;     // epilogue staging: bytes per output row (+16: consecutive rows start 4 banks apart)
+constexpr int kV6Pitch = 2 * V6_TN + 16;     // epilogue staging: bytes per output row (+16: consecutive rows start 4 banks apart); all widths
 template <int V>
 using ic6 = std::integral_constant<int, V>;
 }  // namespace
@@ -71,7 +71,10 @@ __device__ __forceinline__ void v6_mfma(f32x4& acc, const V8& a, const u32x4& b)
 // DQ 1: szp is the "sz_half" side buffer and the dequant runs in its f16-mantissa form (Cdna4DequantH: one shift + four v_and_or per word
 // instead of three + four, two v_perm + one v_dot2 for the operands instead of perm / and / and / dot2c; exact for layers
 // awq_pack_szh_cdna4 reports exact; W4 tiles only)
-template <typename DT, int BITS, int PROBE = 0, int DQ = 0>
+// NS = weight slabs (16 columns) per wave: 4 -> 256-column blocks; 3 -> 192-column blocks (accumulators 192 AGPRs) for matrices
+// whose 256-wide tile count leaves a partial round that 192-wide tiles fill (qkv of Llama-3-8B: 6144 = 32 x 192 -> 8 x 32 = 256 tiles
+// at M = 2048 instead of 192)
+template <typename DT, int BITS, int PROBE = 0, int DQ = 0, int NS = 4>
 __global__ __launch_bounds__(256) void gemm_cdna4_v6_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                             const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
                                                             uint16_t* __restrict__ out, int M, int N, int K, int tiles_m, int tiles_n,
@@ -103,7 +106,8 @@ __global__ __launch_bounds__(256) void gemm_cdna4_v6_kernel(const uint16_t* __re
     }
   }
   // the last row tile is shifted up to end at row M - 1 (M >= 256: the launcher's contract): no row index needs clamping or masking
-  const int m0 = min(tm * V6_TM, M - V6_TM), n0 = n_begin + tn * V6_TN;
+  constexpr int TN = 64 * NS;  // columns per block
+  const int m0 = min(tm * V6_TM, M - V6_TM), n0 = n_begin + tn * TN;
 
   // ---- x staging: piece q (0..15) of this wave = rows 64 wv + 4 q .. + 3, one 16-byte granule per lane ----
   // LDS layout of a stage: row r (256 B = 16 granules of 8 k) stores logical granule p at slot p ^ (r & 15)
@@ -123,21 +127,21 @@ __global__ __launch_bounds__(256) void gemm_cdna4_v6_kernel(const uint16_t* __re
   // ---- weights: slabs 4 wv .. 4 wv + 3 of the block's 16 ----
   const int nslab = N >> 4, slab_end = min(nslab, n_end >> 4);
   constexpr int kTileWords = BITS == 4 ? 256 : 192, kLaneWords = BITS == 4 ? 4 : 3;
-  u32 w_off[4], s_off[4];
+  u32 w_off[NS], s_off[NS];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int slc = min((n0 >> 4) + 4 * wv + s, slab_end - 1);
+  for (int s = 0; s < NS; ++s) {
+    const int slc = min((n0 >> 4) + NS * wv + s, slab_end - 1);
     w_off[s] = (u32)slc * (u32)nit * kTileWords + lane * kLaneWords;
     s_off[s] = (u32)slc * (u32)nit * 16 + i;
   }
   struct WG {
-    u32x4 w[4];
-    u32 sz[4];
+    u32x4 w[NS];
+    u32 sz[NS];
   };
   auto load_w = [&](int grp) {
     WG r;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < NS; ++s) {
       const u32* wp = qw + (size_t)grp * kTileWords + w_off[s];
       if (BITS == 4) {
         r.w[s] = *reinterpret_cast<const u32x4*>(wp);
@@ -201,14 +205,14 @@ __global__ __launch_bounds__(256) void gemm_cdna4_v6_kernel(const uint16_t* __re
 
   // accumulators: every definition and every use inside the K loop is an asm statement with an AGPR constraint, so the allocator
   // has no choice of file for them (zeroed by an MFMA of zero operands with the inline constant 0 as C: 64 instructions, once)
-  f32x4 acc[16][4];
+  f32x4 acc[16][NS];
   {
     u32x4 zero = {0u, 0u, 0u, 0u};
     asm volatile("" : "+v"(zero));
 #pragma unroll
     for (int f = 0; f < 16; ++f)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < NS; ++s) {
         if constexpr (DT::id == 1) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, 0" : "=a"(acc[f][s]) : "v"(zero));
         else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %1, 0" : "=a"(acc[f][s]) : "v"(zero));
       }
@@ -229,9 +233,9 @@ __global__ __launch_bounds__(256) void gemm_cdna4_v6_kernel(const uint16_t* __re
 #pragma unroll
     for (int q = 0; q < 16; ++q) V6_WR(lds0 + wpat[q & 3], t0[q], q * 1024);
   }
-  vec8 op[2][4];
+  vec8 op[2][NS];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
+  for (int s = 0; s < NS; ++s) {
     const DP d0 = params(cur.sz[s]);
     const Pend p0 = word_issue(cur.w[s].x, d0);
     asm volatile("s_nop 7\n\ts_nop 7" : : : "memory");  // (prologue only: let the dequant MFMAs retire before their results are read)
@@ -263,7 +267,8 @@ __global__ __launch_bounds__(256) void gemm_cdna4_v6_kernel(const uint16_t* __re
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[S][0]), "+v"(xf[S][1]), "+v"(xf[S][2]), "+v"(xf[S][3]) : : "memory");
       // dequant state of this quarter's word
       u32 word = 0, sz = 0;
-      if (PROBE != 2 && PROBE != 4) {
+      constexpr bool kDeq = PROBE != 2 && PROBE != 4 && Q < NS;  // (NS = 3: the fourth quarter of a step has no slab to dequantise)
+      if constexpr (kDeq) {
         if (A == 3) {
           sz = nxt.sz[Q];
           word = nxt.w[Q].x;
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(256) void gemm_cdna4_v6_kernel(const uint16_t* __re
       };
       auto slot = [&](auto k_) {
         constexpr int k = decltype(k_)::value, j = k >> 2, s = k & 3;
-        v6_mfma<DT>(acc[4 * Q + j][s], op[A & 1][s], xf[S][j]);
+        if constexpr (s < NS) v6_mfma<DT>(acc[4 * Q + j][s], op[A & 1][s], xf[S][j]);  // (NS = 3: every fourth slot carries side work only)
         if (kLast && k == 1) {
           // every read of this stage has returned (the set in use was complete at the top), this wave's writes of tile t + 1 are done:
           // meet the other waves, then the other stage is readable and this one writable
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(256) void gemm_cdna4_v6_kernel(const uint16_t* __re
             V6_RD(xf[SN][3], raddr, (4 * QN + 3) * 4096);
           }
         }
-        if (PROBE != 2 && PROBE != 4) {
+        if constexpr (kDeq) {
           if (DQ == 1) {
             if (k == 4) a0.x = (word & ch.kMaskLo) | ch.kMagic, a0.y = (word & ch.kMaskHi) | ch.kMagic;
             if (k == 5) {
@@ -381,11 +386,11 @@ __global__ __launch_bounds__(256) void gemm_cdna4_v6_kernel(const uint16_t* __re
   asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
   __builtin_amdgcn_s_barrier();  // every wave is done with the x stages (the trailing reads of the unused stage have returned)
   {
-    const u32 wbase = lds0 + i * kV6Pitch + (64 * wv + 4 * g) * 2;
+    const u32 wbase = lds0 + i * kV6Pitch + (16 * NS * wv + 4 * g) * 2;
 #pragma unroll
     for (int f = 0; f < 16; ++f)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < NS; ++s) {
         u32x2 v;
         v.x = (u32)DT::from_float(acc[f][s][0]) | ((u32)DT::from_float(acc[f][s][1]) << 16);
         v.y = (u32)DT::from_float(acc[f][s][2]) | ((u32)DT::from_float(acc[f][s][3]) << 16);
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(256) void gemm_cdna4_v6_kernel(const uint16_t* __re
     // QuantLlamaMLP's interleaved pair: columns 16 j .. + 7 are gate rows, + 8 .. + 15 the matching up rows.  A lane takes one pair
     // (32 staged bytes) and stores silu(gate) * up: 16 lanes = one 256-byte output row, four rows per wave-instruction
     const int pr = lane & 15, nn = n0 + 16 * pr;
-    const bool ok = nn < n_end;
+    const bool ok = nn < n_end && 16 * pr < TN;
 #pragma unroll
     for (int it0 = 0; it0 < 16; it0 += 4) {
       u32x4 v[4], u[4];
@@ -417,7 +422,7 @@ __global__ __launch_bounds__(256) void gemm_cdna4_v6_kernel(const uint16_t* __re
   } else {
     const int col = (lane & 31) * 8;  // 8 columns (16 B) per lane, two rows per wave-instruction; eight instructions per wait
     const int nn = n0 + col;
-    const bool ncol_ok = nn < n_end;
+    const bool ncol_ok = nn < n_end && col < TN;
     u32x4 bv = {0u, 0u, 0u, 0u};
     if (bias != nullptr && ncol_ok) bv = *reinterpret_cast<const u32x4*>(bias + nn);
 #pragma unroll
@@ -454,14 +459,24 @@ void gemm_v6_set_probe(int v) { g_v6_probe = v; }
 
 // weight rows [n_begin, n_end) with 256 x 256 blocks; any m >= 1 (rows past m are clamped / not stored)
 void launch_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
-                          int n_end, int dtype, hipStream_t st, int bits, int epi, int szfmt) {
+                          int n_end, int dtype, hipStream_t st, int bits, int epi, int szfmt, int tile_n) {
   constexpr int stage2 = 2 * kV6Stage, stg_epi = V6_TM * kV6Pitch;
   constexpr int smem = stage2 > stg_epi ? stage2 : stg_epi;
-  const int tiles_m = (m + V6_TM - 1) / V6_TM, tiles_n = (n_end - n_begin + V6_TN - 1) / V6_TN;
+  const int tn_cols = tile_n == 192 ? 192 : V6_TN;
+  const int tiles_m = (m + V6_TM - 1) / V6_TM, tiles_n = (n_end - n_begin + tn_cols - 1) / tn_cols;
   using Kern = void (*)(const uint16_t*, const u32*, const u32*, const uint16_t*, uint16_t*, int, int, int, int, int, int, int, int);
   static const Kern kerns[2][2] = {{gemm_cdna4_v6_kernel<F16, 4>, gemm_cdna4_v6_kernel<F16, 3>},
                                    {gemm_cdna4_v6_kernel<BF16, 4>, gemm_cdna4_v6_kernel<BF16, 3>}};
   const int a = dtype == 0 ? 0 : 1, b = bits == 3 ? 1 : 0;
+  if (tn_cols == 192 && bits == 4) {  // 192-column blocks (three slabs per wave)
+    static const Kern kerns_3[2] = {gemm_cdna4_v6_kernel<F16, 4, 0, 0, 3>, gemm_cdna4_v6_kernel<BF16, 4, 0, 0, 3>};
+    static LdsOptIn optin_3[2];
+    const int a3 = dtype == 0 ? 0 : 1;
+    optin_3[a3].ensure(reinterpret_cast<const void*>(kerns_3[a3]), smem);
+    hipLaunchKernelGGL(kerns_3[a3], dim3(tiles_m * tiles_n), dim3(256), smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp,
+                       (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end, epi);
+    return;
+  }
   static const Kern kerns_h[2] = {gemm_cdna4_v6_kernel<F16, 4, 0, 1>, gemm_cdna4_v6_kernel<BF16, 4, 0, 1>};  // szp = sz_half
   Kern kern = (szfmt == 1 && bits == 4) ? kerns_h[a] : kerns[a][b];
   static LdsOptIn optin[2][2], optin_h[2];

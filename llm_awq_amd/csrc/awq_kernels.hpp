@@ -101,7 +101,7 @@ void launch_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const 
 // 256 x 256 blocks, weights streamed straight into registers per wave (awq_gemm_v5.hip); any m >= 1
 // awq_gemm_v6.hip: 256 x 256 blocks of four software-pipelined waves (256 x 64 per wave, weights in registers, x through ds_write)
 void launch_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
-                          int n_end, int dtype, hipStream_t st, int bits = 4, int epi = 0, int szfmt = 0);
+                          int n_end, int dtype, hipStream_t st, int bits = 4, int epi = 0, int szfmt = 0, int tile_n = 256);
 void gemm_v6_set_probe(int v);
 // awq_gemv_dma.hip: QuantLlamaMLP.forward at decode (gate/up + SiLU * mul + down) in one launch; -1 if the shape is not served
 int launch_mlp_decode(const void* x, const void* qw_gu, const void* szh_gu, const void* qw_d, const void* szh_d, const void* bias_d,

@@ -19,8 +19,8 @@ def ops():
     return o
 
 
-def _wide(ops, v6):
-    ops._capi.tune(gemm_variant=4, gemm_tile_n=256, gemm_v6=v6, gemm_splitk=0)
+def _wide(ops, v6, tile_n=256):
+    ops._capi.tune(gemm_variant=4 if tile_n == 256 else 3, gemm_tile_n=tile_n, gemm_v6=v6, gemm_splitk=0)
 
 
 def _reset(ops):
@@ -116,3 +116,39 @@ def test_v6_w3_tiles(ops, dtype):
         ref = x.float() @ W.t()
         assert ((y.float() - ref).norm() / ref.norm()).item() < (2.5e-3 if dtype == torch.bfloat16 else 4e-4)
         assert (ref.to(dtype) == y).float().mean() > 0.97
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("bias", [False, True])
+@pytest.mark.parametrize("M", [256, 300])
+@pytest.mark.parametrize("N,K", [(768, 512), (1296, 1024), (400, 256)])
+def test_v6_192_wide_blocks_against_the_oracle(ops, dtype, bias, M, N, K):
+    """three slabs per wave: the tile plan uses these blocks where they turn a partial round into a full one (qkv of Llama-3-8B)"""
+    c = make_case(N, K, dtype, seed=N + K + M + 1, M=M, bias=bias)
+    c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
+    s, z = c["scales"].cuda(), c["scaled_zeros"].cuda()
+    szp = ops.pack_sz_cdna4(s, z, K)
+    b = c["bias"].cuda() if bias else None
+    try:
+        _wide(ops, 1, 192)
+        y = ops.gemm_cdna4(c["x"].cuda(), c4, s, z, b, szp)
+    finally:
+        _reset(ops)
+    check_forward(y.cpu(), c["x"], c["q"], c["scales"], c["scaled_zeros"], dtype, bias=c["bias"])
+
+
+def test_v6_192_wide_is_what_the_plan_picks_for_qkv(ops):
+    """Llama-3-8B qkv (4096 -> 6144) at M = 2048: 8 x 32 blocks of 256 x 192 (one full round) == the 256-wide plan's output"""
+    from llm_awq_amd import synth
+    K, N = 4096, 6144
+    w = synth.random_wq(K, N, dtype=torch.bfloat16, seed=9, keep_q=False)
+    c4 = ops.repack_v2_to_cdna4(w["qweight"])
+    szp = ops.pack_sz_cdna4(w["scales"], w["scaled_zeros"], K)
+    x = torch.randn(2048, K, device="cuda").bfloat16()
+    y = ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], None, szp)  # default plan
+    try:
+        ops._capi.tune(gemm_v6_192=0)
+        y256 = ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], None, szp)
+    finally:
+        ops._capi.tune(gemm_v6_192=1)
+    assert torch.equal(y, y256), "same products in the same K order: the block width only moves columns between waves"
