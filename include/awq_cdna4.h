@@ -165,6 +165,11 @@ int awq_w4a16_rmsnorm_forward_cdna4(const void* x, const void* gamma, float eps,
  * K loop is split over blocks and a second kernel adds the partial tiles in a fixed order -- the role of the reference's
  * split_k_iters + semaphore (gemm_cuda.cu:546-619).  Without a workspace the call runs unsplit (slower, same contract). */
 size_t awq_w4a16_forward_cdna4_workspace_bytes(int m, int n, int k);
+/* host-side query (no GPU work): the tiles the prefill GEMM launches for an [m, n] output of a 3- or 4-bit matrix.  *mode: 0 = 256 x 256
+ * blocks, 1 = 256 x 128, 2 = 256 x 256 for the first *cols_main column tiles and 256 x 128 for the rest, 3 = 256 x 192; returns the number
+ * of thread blocks, 0 if the GEMM does not take this m (decode / skinny kernels do).  The counterpart of the reference's tile table,
+ * gemm_cuda.cu:1155-1232. */
+int awq_w4a16_gemm_cdna4_plan(int m, int n, int bits, int* mode, int* cols_main);
 int awq_w4a16_gemm_cdna4(const void* x, const void* qweight_cdna4, const void* scales, const void* scaled_zeros,
                          const void* sz_packed, void* out, int m, int n, int k, int group_size, int dtype,
                          void* workspace, size_t workspace_bytes, void* stream);

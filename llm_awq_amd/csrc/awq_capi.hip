@@ -280,6 +280,7 @@ int awq_w4a16_rmsnorm_forward_cdna4(const void* x, const void* gamma, float eps,
 }
 
 size_t awq_w4a16_forward_cdna4_workspace_bytes(int m, int n, int k) { return awq::gemm_cdna4_v3_workspace_bytes(m, n, k); }
+int awq_w4a16_gemm_cdna4_plan(int m, int n, int bits, int* mode, int* cols_main) { return awq::gemm_cdna4_v3_plan(m, n, bits, mode, cols_main); }
 
 int awq_w4a16_gemm_cdna4(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
                          const void* sz_packed, void* out, int m, int n, int k, int group_size, int dtype, void* workspace,

@@ -444,6 +444,21 @@ size_t gemm_cdna4_v3_workspace_bytes_w3(int m, int n, int k) {
   return 0;
 }
 
+// which tiles the prefill GEMM would launch for (m, n) of a `bits`-bit matrix: *mode = 0 all 256-wide, 1 all 128-wide, 2 = 256-wide for the
+// first *cols_main column tiles + 128-wide for the rest, 3 all 192-wide; returns the number of thread blocks (0: the GEMM does not take m)
+int gemm_cdna4_v3_plan(int m, int n, int bits, int* mode, int* cols_main) {
+  if (m <= 8 || (n % 16) != 0) return 0;
+  const bool allow192 = g_v6 != 0 && g_v6_192 != 0 && bits == 4 && m >= TM;
+  const Plan p = m < TM ? Plan{1, 0} : plan_tiles(m, n, g_tile_n, allow192);
+  if (mode) *mode = p.mode;
+  if (cols_main) *cols_main = (int)p.cols_main;
+  const long tm = (m + TM - 1) / TM;
+  if (p.mode == 0) return (int)(tm * ((n + 255) / 256));
+  if (p.mode == 1) return (int)(tm * ((n + 127) / 128));
+  if (p.mode == 3) return (int)(tm * ((n + 191) / 192));
+  return (int)(tm * p.cols_main + tm * ((n - p.cols_main * 256 + 127) / 128));
+}
+
 int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                          int tile_n, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits, int epi, const void* szh) {
   // (w3c tiles have no skinny kernel: the masked single-row-tile path of the narrow kernel serves every m > 8)

@@ -85,3 +85,23 @@ def test_prefill_routing_and_workspace_rule_without_gpu():
     finally:
         L.awq_tune_set(b"gemm_splitk", 1)
         L.awq_tune_set(b"gemm_small_m", 1)
+
+
+def test_prefill_tile_plan_for_the_llama3_shapes():
+    """host-side query of the tile plan (no GPU): every Llama-3-8B launch at M = 2048 / 4096 fills the 256 CUs in whole rounds or says why not"""
+    import ctypes
+    from llm_awq_amd import _capi
+    L = _capi.lib()
+
+    def plan(m, n, bits=4):
+        mode, cols = ctypes.c_int(-1), ctypes.c_int(-1)
+        blocks = L.awq_w4a16_gemm_cdna4_plan(m, n, bits, ctypes.byref(mode), ctypes.byref(cols))
+        return blocks, mode.value, cols.value
+
+    assert plan(2048, 6144) == (256, 3, 0)        # qkv: 8 x 32 blocks of 256 x 192 = one full round (256-wide: 192 tiles, 75 %)
+    assert plan(4096, 6144) == (512, 3, 0)        # two full rounds (256-wide: 384 tiles = 1.5)
+    assert plan(2048, 4096) == (256, 1, 0)        # o / down: 256 x 128 blocks, one round
+    assert plan(2048, 28672) == (8 * 96 + 8 * 32, 2, 96)   # gate/up: three full rounds of 256-wide + one round of 128-wide
+    assert plan(4096, 28672) == (16 * 112, 0, 0)  # seven full rounds of 256-wide
+    assert plan(2048, 6144, bits=3)[1] != 3       # the 192-wide blocks are W4 only
+    assert plan(100, 4096)[1] == 1 and plan(4, 4096)[0] == 0
