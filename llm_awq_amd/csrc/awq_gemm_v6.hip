@@ -52,11 +52,12 @@ template <typename DT, bool NOP = true, bool F16FORM = false>
 __device__ __forceinline__ f32x4 v6_mfma4(const u32x2& a, const u32x2& b, const f32x4& c) {
   f32x4 d;
   if constexpr (NOP) {
-    if constexpr (DT::id == 1 && !F16FORM) asm volatile("s_nop 1\n\tv_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
-    else asm volatile("s_nop 1\n\tv_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
-  } else {  // K loop: the operands were written at least one MFMA slot (>= 16 cycles) earlier
-    if constexpr (DT::id == 1 && !F16FORM) asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
-    else asm volatile("v_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+    if constexpr (DT::id == 1 && !F16FORM) asm volatile("s_nop 3\n\tv_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+    else asm volatile("s_nop 3\n\tv_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+  } else {  // K loop (the nops stay: hipcc materialises the C splat with v_mov copies right in front of the statement, and a VALU write
+            // followed directly by the MFMA's read of that register returned the stale value -- found in the 32x32x16 experiment, tools/experiments/awq_gemm_v7_32x32_rowswap.hip.txt)
+    if constexpr (DT::id == 1 && !F16FORM) asm volatile("s_nop 3\n\tv_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+    else asm volatile("s_nop 3\n\tv_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
   }
   return d;
 }
@@ -237,8 +238,8 @@ __global__ __launch_bounds__(256) void gemm_cdna4_v6_kernel(const uint16_t* __re
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const DP d0 = params(cur.sz[s]);
-    const Pend p0 = word_issue(cur.w[s].x, d0);
-    asm volatile("s_nop 7\n\ts_nop 7" : : : "memory");  // (prologue only: let the dequant MFMAs retire before their results are read)
+    Pend p0 = word_issue(cur.w[s].x, d0);
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(p0.d0), "+v"(p0.d1) : : "memory");  // (prologue only: let the dequant MFMAs retire; tied to the results so the rounding stays behind it)
     op[0][s] = DT::pack8(p0.d0, p0.d1);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
