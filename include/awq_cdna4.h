@@ -219,7 +219,8 @@ int awq_w3a16_forward(const void* x, const void* qweight_w3, const void* scales,
  * peer_buffers[q] is rank q's buffer as mapped in THIS process (peer_buffers[rank] = the local allocation).  A call stores
  * `in` (count elements, count % 8 == 0, count * 2 <= max_bytes) into every rank's buffer over xGMI, raises one flag per peer and
  * reduces locally when the `world` flags of this round have arrived.  `round` must be 1, 2, 3, ... in call order and equal on
- * all ranks.  *status_dev (optional device int) is set to 1 if a peer's flag did not arrive within the spin bound (the kernel
+ * all ranks, or 0 on every call of a communicator: the epoch then lives in the rank's own buffer and advances by one per call, which
+ * is what a captured and replayed hipGraph needs (its kernel arguments are frozen); the two modes must not be mixed on one buffer set.  *status_dev (optional device int) is set to 1 if a peer's flag did not arrive within the spin bound (the kernel
  * returns instead of hanging the queue).  world <= 8.  Messages above max_bytes belong to RCCL (bandwidth-bound). ---- */
 size_t awq_oneshot_buffer_bytes(int world, int max_bytes);
 int awq_oneshot_alloc(void** buffer, int world, int max_bytes);

@@ -40,6 +40,12 @@ __global__ __launch_bounds__(1024) void oneshot_allreduce_kernel(OneShotPeers pe
   const int rank = rank0 + (int)blockIdx.x;
   const uint16_t* in = in_ + (size_t)blockIdx.x * count;
   uint16_t* out = out_ + (size_t)blockIdx.x * count;
+  // round == 0: the epoch lives in this rank's own buffer (u32 [32] of the flag area) and advances by one per call -- every rank issues
+  // the same sequence of calls, so the counters agree, and a REPLAYED hipGraph (whose kernel arguments are frozen) still sees a new
+  // round every time.  One mode per communicator: explicit rounds and device epochs must not be mixed on the same buffers.
+  u32* epoch = peers.flags[rank] + 32;
+  const bool dev_epoch = round == 0u;
+  if (dev_epoch) round = *reinterpret_cast<volatile u32*>(epoch) + 1u;  // (written by this rank's previous call only: stream order)
   const int half = (int)(round & 1u);
   const int chunks = (count * 2 + 15) / 16;  // 16-byte chunks of the message (count % 8 == 0)
   const size_t slot_off = ((size_t)half * world + rank) * (size_t)max_bytes;
@@ -92,6 +98,10 @@ __global__ __launch_bounds__(1024) void oneshot_allreduce_kernel(OneShotPeers pe
     o.z = (u32)DT::from_float(acc[4]) | ((u32)DT::from_float(acc[5]) << 16);
     o.w = (u32)DT::from_float(acc[6]) | ((u32)DT::from_float(acc[7]) << 16);
     *reinterpret_cast<u32x4*>(out + (size_t)c * 8) = o;
+  }
+  if (dev_epoch) {
+    __syncthreads();  // every thread has read the old value
+    if (threadIdx.x == 0) *reinterpret_cast<volatile u32*>(epoch) = round;
   }
 }
 
@@ -154,8 +164,8 @@ static int oneshot_launch(void* const* peer_buffers, const void* in, void* out, 
   if (!peer_buffers || !in || !out) return AWQ_ERR_NULL;
   if (dtype != AWQ_F16 && dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
   if (world < 1 || world > awq::kOneShotMaxWorld || rank < 0 || rank >= world || count <= 0 || (count % 8) != 0 || count * 2 > max_bytes ||
-      (max_bytes % 16) != 0 || round == 0)
-    return AWQ_ERR_SHAPE;
+      (max_bytes % 16) != 0)
+    return AWQ_ERR_SHAPE;  // (round == 0 selects the device-resident epoch)
   if ((reinterpret_cast<uintptr_t>(in) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u)) return AWQ_ERR_ALIGN;
   awq::OneShotPeers peers;
   for (int p = 0; p < awq::kOneShotMaxWorld; ++p) {

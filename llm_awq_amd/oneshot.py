@@ -70,7 +70,7 @@ class OneShotAllReduce:
     """GPU side: one exchange buffer per rank, peers mapped through hipIpc.  `__call__(t)` returns the reduced tensor (new
     storage) for messages up to max_bytes and falls back to `dist.all_reduce` (in place) above."""
 
-    def __init__(self, group=None, max_bytes: int = 64 * 1024, device=None):
+    def __init__(self, group=None, max_bytes: int = 64 * 1024, device=None, device_epoch: bool = True):
         import torch.distributed as dist
         from . import _capi
         self.dist, self.group, self.L = dist, group, _capi.lib()
@@ -79,6 +79,9 @@ class OneShotAllReduce:
         self.max_bytes = max_bytes
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.round = 0
+        # device_epoch: the round counter lives in the exchange buffer and the kernel advances it (round argument 0) -- safe inside a
+        # captured and replayed hipGraph; False: the host passes 1, 2, 3, ... (eager launches only)
+        self.device_epoch = device_epoch
         with torch.cuda.device(self.device):
             buf = ctypes.c_void_p()
             _capi.check(self.L.awq_oneshot_alloc(ctypes.byref(buf), self.world, max_bytes))
@@ -111,7 +114,7 @@ class OneShotAllReduce:
         out = torch.empty_like(t)
         with torch.cuda.device(self.device):
             _capi.check(self.L.awq_oneshot_allreduce(self.ptrs, t.data_ptr(), out.data_ptr(), t.numel(), 0 if t.dtype == torch.float16 else 1,
-                                                     self.rank, self.world, self.round, self.max_bytes, self.status.data_ptr(),
+                                                     self.rank, self.world, 0 if self.device_epoch else self.round, self.max_bytes, self.status.data_ptr(),
                                                      torch.cuda.current_stream(self.device).cuda_stream))
         return out
 

@@ -204,8 +204,7 @@ def run_tp_bench(args, eng, dist, rank, world, dev, shapes, algo_bytes):
         for _ in range(2):
             run_pass()  # communicator + lazy init outside capture
         torch.cuda.synchronize()
-        # (the one-shot all-reduce passes its round number as a kernel argument: a replayed graph would repeat it -- eager launches then)
-        if not args.no_graph and reducer is None:
+        if not args.no_graph:  # (the one-shot reducer keeps its round counter on the device: replay-safe)
             try:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=side):

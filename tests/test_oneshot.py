@@ -96,6 +96,55 @@ def test_kernel_ranks_as_coresident_blocks(dtype, world):
             L.awq_oneshot_free(b)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 8])
+def test_kernel_device_epoch_survives_graph_replay(world):
+    """round argument 0: the epoch lives in the exchange buffer and advances per call, so a captured graph (frozen kernel arguments)
+    of several all-reduces can be replayed with new inputs every time -- the way tensor-parallel decode runs"""
+    import ctypes
+    from llm_awq_amd import _capi
+    L = _capi.lib()
+    dtype, max_bytes, n, per_graph = torch.bfloat16, 16384, 4096, 5
+    bufs = [ctypes.c_void_p() for _ in range(world)]
+    for b in bufs:
+        _capi.check(L.awq_oneshot_alloc(ctypes.byref(b), world, max_bytes))
+    try:
+        ptrs = (ctypes.c_void_p * 8)(*[bufs[q % world].value for q in range(8)])
+        status = torch.zeros(1, dtype=torch.int32, device="cuda")
+        xs = [torch.zeros(world, n, device="cuda", dtype=dtype) for _ in range(per_graph)]
+        outs = [torch.empty_like(x) for x in xs]
+        side = torch.cuda.Stream()
+
+        def run():
+            for x, o in zip(xs, outs):
+                _capi.check(L.awq_oneshot_allreduce_selftest(ptrs, x.data_ptr(), o.data_ptr(), n, 1, world, 0, max_bytes, status.data_ptr(),
+                                                             torch.cuda.current_stream().cuda_stream))
+
+        with torch.cuda.stream(side):
+            run()  # eager rounds 1..5 first: the epoch continues across eager calls and replays
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                run()
+            g = torch.Generator(device="cuda").manual_seed(11)
+            for rep in range(4):
+                for x in xs:
+                    x.copy_(torch.randn(world, n, device="cuda", generator=g).to(dtype))
+                graph.replay()
+                torch.cuda.synchronize()
+                assert int(status.item()) == 0
+                for x, o in zip(xs, outs):
+                    acc = torch.zeros(n, device="cuda")
+                    for r in range(world):
+                        acc += x[r].float()
+                    want = acc.to(dtype)
+                    for r in range(world):
+                        assert torch.equal(o[r], want), (rep, r)
+    finally:
+        for b in bufs:
+            L.awq_oneshot_free(b)
+
+
 def _gpu_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
