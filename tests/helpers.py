@@ -1,18 +1,53 @@
-"""Shared test helpers: seeded synthetic cases built by the ORACLE (CPU) and error bounds."""
+"""Shared test helpers: host-independent seeded synthetic cases built by the ORACLE (CPU) and error bounds.
+
+Inputs.  Every CPU-side random draw of the suite comes from numpy's PCG64 (`Gen`), not from torch's CPU generator: torch's
+CPU `randn` runs vectorised math whose last bits depend on the host's SIMD level, so two boxes would test different data.
+`AWQ_TEST_SEED` (default 0) is mixed into every seed, so the whole suite can be re-run on other data.
+
+Bounds.  Hard criteria are always elementwise / norm-wise error bounds.  "How many elements are bit-identical" is a
+STATISTICAL criterion: the expected number of flipped roundings is modelled (or stated by the caller) and the observed count
+must stay inside a Poisson tail (lambda + 6 sqrt(lambda) + 3: false-failure probability below 1e-6 per assertion)."""
+import json
+import math
+import os
+
 import numpy as np
 import torch
 
 from oracle import awq_oracle as O
 
 MANT = {torch.float16: 10, torch.bfloat16: 7}
+SEED0 = int(os.environ.get("AWQ_TEST_SEED", "0"))
+_STATS = os.environ.get("AWQ_TEST_STATS")  # path of a jsonl file: observed flip counts next to what was allowed
+
+
+class Gen:
+    """numpy PCG64 stream -> torch tensors (bit-identical on every host)."""
+
+    def __init__(self, seed):
+        self.g = np.random.Generator(np.random.PCG64([SEED0, int(seed)]))
+
+    def randn(self, *shape):
+        return torch.from_numpy(self.g.standard_normal(size=shape, dtype=np.float32))
+
+    def rand(self, *shape):
+        return torch.from_numpy(self.g.random(size=shape, dtype=np.float32))
+
+    def randint(self, lo, hi, shape):
+        return torch.from_numpy(self.g.integers(lo, hi, size=tuple(shape), dtype=np.int64))
+
+
+def cuda_gen(seed):
+    """device-side Philox stream (the algorithm runs on the GPU: the same on every MI355X box)."""
+    return torch.Generator(device="cuda").manual_seed(SEED0 * 1000003 + int(seed))
 
 
 def make_case(N, K, dtype, seed=0, bias=False, M=1, x_scale=1.0):
-    g = torch.Generator().manual_seed(seed)
-    w = torch.randn(N, K, generator=g) * 0.02
+    g = Gen(seed)
+    w = g.randn(N, K) * 0.02
     d = O.quantize_linear(w, dtype=dtype, n_bit=4, group_size=128)
-    d["x"] = (torch.randn(M, K, generator=g) * x_scale).to(dtype)
-    d["bias"] = (torch.randn(N, generator=g) * 0.02).to(dtype) if bias else None
+    d["x"] = (g.randn(M, K) * x_scale).to(dtype)
+    d["bias"] = (g.randn(N) * 0.02).to(dtype) if bias else None
     d["q"] = d["intweight"].numpy().astype(np.uint8)
     return d
 
@@ -22,20 +57,67 @@ def ulp(v: torch.Tensor, dtype) -> torch.Tensor:
     return torch.pow(2.0, e - MANT[dtype])
 
 
-def check_forward(y_gpu: torch.Tensor, x, q, scales, scaled_zeros, dtype, bias=None):
-    """y_gpu (T, on cpu) against the oracle: (1) elementwise within half an ulp of T around the
-    float64 contraction of the T-rounded weights, plus the fp32 accumulation slack 2e-6*sum|x||w|
-    (plus one more rounding when a bias add follows); (2) norm-wise <= 1e-3 (BASELINE.json);
-    (3) the fp32-accumulate oracle agrees on almost every element bit for bit."""
+def flips_allowed(lam: float) -> float:
+    return lam + 6.0 * math.sqrt(lam) + 3.0
+
+
+def _record(what, count, lam, numel):
+    if _STATS:
+        with open(_STATS, "a") as f:
+            f.write(json.dumps({"test": os.environ.get("PYTEST_CURRENT_TEST", ""), "what": what, "count": int(count),
+                                "lambda": float(lam), "allowed": flips_allowed(lam), "numel": int(numel)}) + "\n")
+
+
+def assert_bits(a: torch.Tensor, b: torch.Tensor, rate: float, what: str = "", ulps: float = None, dtype=None):
+    """`a` and `b` state the same math with different rounding points / reduction orders: at most `rate` of the elements are
+    EXPECTED to differ (the caller's model); the observed count must stay inside the Poisson tail of rate * numel.  With `ulps`
+    every differing pair must also be within that many ulps of T of each other (plus 1e-4 of the rms value for results that
+    cancel to ~0, where the fp32 accumulation error exceeds an ulp of the tiny result)."""
+    assert a.shape == b.shape, (a.shape, b.shape)
+    n = a.numel()
+    count = int((a != b).sum().item())
+    lam = rate * n
+    _record(what or "bits", count, lam, n)
+    assert count <= flips_allowed(lam), f"{what}: {count} of {n} elements differ ({100.0 * count / n:.3f} %), expected <= {100 * rate:.2f} %"
+    if ulps is not None:
+        dtype = dtype or a.dtype
+        ad, bd = a.double(), b.double()
+        tol = ulps * 1.001 * ulp(torch.maximum(ad.abs(), bd.abs()), dtype) + 1e-4 * bd.pow(2).mean().sqrt()
+        worst = ((ad - bd).abs() / tol).max().item()
+        assert worst <= 1.0, f"{what}: elementwise distance {worst:.2f} x ({ulps} ulp + 1e-4 rms)"
+
+
+def check_forward(y_gpu: torch.Tensor, x, q, scales, scaled_zeros, dtype, bias=None, x_unc=None):
+    """y_gpu (T, on cpu) against the oracle:
+    (1) HARD, elementwise: within half an ulp of T around the float64 contraction of the T-rounded weights, plus the fp32
+        accumulation slack 2e-6 * sum|x||w| (plus one more rounding when a bias add follows);
+    (2) HARD, norm-wise <= 1e-3 against the oracle's T-rounded output (BASELINE.json);
+    (3) STATISTICAL: the fp32-accumulate oracle agrees bit for bit except where the two fp32 accumulation orders land on
+        different sides of a rounding boundary of T.  Model: the two fp32 sums differ by ~ eps32 * sqrt(K)/4 * sqrt(sum (x w)^2)
+        (random-walk bound of a sequential fp32 accumulation; blocked / tree orders do better), so output i flips with
+        probability p_i = min(1, that / ulp_T(y_i)); the number of flips must stay inside the Poisson tail of sum p_i.
+
+    `x_unc` [M, K] (fused-norm callers): absolute uncertainty of the activations the kernel really multiplied -- elements of
+    the normalised x whose rounding to T depends on the last fp32 bits of rstd.  It widens (1) by x_unc @ |W|^T and (3) by the
+    flips that slack can cause; (2) is unchanged."""
     W = O.dequant_weight(q, scales, scaled_zeros, 128)
     K = x.shape[-1]
     x2 = x.reshape(-1, K)
-    y64 = x2.double() @ W.double().t()
-    S = x2.double().abs() @ W.double().abs().t()
+    Wd = W.double()
+    y64 = x2.double() @ Wd.t()
+    S = x2.double().abs() @ Wd.abs().t()
+    Q = ((x2.double() ** 2) @ (Wd ** 2).t()).sqrt()
     yg = y_gpu.reshape(y64.shape).double()
-    bound = 0.501 * ulp(y64, dtype) + 2e-6 * S + 1e-30
+    u = ulp(y64, dtype)
+    bound = 0.501 * u + 2e-6 * S + 1e-30
+    acc = (2.0 ** -24) * (math.sqrt(K) / 4.0 + 1.0) * Q
+    if x_unc is not None:
+        extra = x_unc.reshape(-1, K).double() @ Wd.abs().t()
+        bound = bound + extra
+        acc = acc + extra
     if bias is not None:
         y64 = y64 + bias.double()
+        u = torch.minimum(u, ulp(y64, dtype))
         bound = bound + 0.501 * ulp(y64, dtype) + ulp(y64, dtype) * 0.5
     err = (yg - y64).abs()
     worst = (err / bound).max().item()
@@ -45,7 +127,21 @@ def check_forward(y_gpu: torch.Tensor, x, q, scales, scaled_zeros, dtype, bias=N
     y_or = O.wqlinear_forward(x, None, scales, scaled_zeros, bias, 128, q_int=q).reshape(y64.shape).double()
     rel = ((yg - y_or).norm() / y_or.norm()).item()
     assert rel <= 1e-3, rel
-    mism = (y_or != yg).double().mean().item()
-    # (two elements are always allowed: tiny outputs -- 64 values -- would otherwise fail on a pair of 1-ulp flips)
-    assert mism <= max(0.02, 2.5 / y_or.numel()), f"{mism*100:.2f}% of elements differ from the fp32-accumulate oracle"
-    return worst, rel, mism
+    count = int((y_or != yg).sum().item())
+    lam = torch.clamp(acc / u, max=1.0).sum().item()
+    _record("check_forward", count, lam, y_or.numel())
+    assert count <= flips_allowed(lam), (f"{count} of {y_or.numel()} elements differ from the fp32-accumulate oracle; the "
+                                         f"accumulation-order model expects {lam:.1f} (allowed {flips_allowed(lam):.1f})")
+    return worst, rel, count / y_or.numel()
+
+
+def rmsnorm_uncertainty(x: torch.Tensor, gamma: torch.Tensor, eps: float) -> torch.Tensor:
+    """[M, K] uncertainty of T((x * rstd) * gamma) under a relative perturbation of 2^-21 of the fp32 product (one ulp of the
+    hardware rsqrt, the order of the fp32 sum of squares, two fp32 multiplies): where the rounding to T is not decided, one
+    ulp of T; elsewhere 0.  (layernorm.cu:48-60: the reference kernel's own rsqrtf / reduction order are just as free.)"""
+    xd = x.double()
+    rstd = torch.rsqrt((xd * xd).mean(-1, keepdim=True) + eps)
+    v = xd * rstd * gamma.double()
+    d = 2.0 ** -21
+    lo, hi = (v * (1 - d)).to(x.dtype), (v * (1 + d)).to(x.dtype)
+    return torch.where(lo != hi, ulp(v, x.dtype), torch.zeros_like(v))

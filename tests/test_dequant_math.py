@@ -12,12 +12,14 @@ import numpy as np
 import pytest
 import torch
 
+from tests.helpers import Gen
+
 
 def _cases(dtype, emin, emax, seed):
-    g = torch.Generator().manual_seed(seed)
+    g = Gen(seed)
     n = 4096
-    s = ((torch.rand(n, generator=g) * 2 + 0.5) * torch.pow(2.0, torch.randint(emin, emax, (n,), generator=g).float())).to(dtype)
-    z = torch.randint(0, 16, (n,), generator=g)
+    s = ((g.rand(n) * 2 + 0.5) * torch.pow(2.0, g.randint(emin, emax, (n,)).float())).to(dtype)
+    z = g.randint(0, 16, (n,))
     sz = (-(s.float() * z.float())).to(dtype)  # qmodule.py:191-197: scaled_zeros = -(scales * zeros.float()).to(T): ROUNDED to T
     q = torch.arange(16).view(16, 1).expand(16, n)
     return q.numpy().astype(np.float64), s.double().numpy(), sz.double().numpy()

@@ -5,16 +5,16 @@ import pytest
 import torch
 
 from oracle import awq_oracle as O
-from tests.helpers import make_case
+from tests.helpers import Gen, assert_bits, check_forward, make_case, rmsnorm_uncertainty
 
 
 def test_oracle_rmsnorm_matches_llama_rmsnorm_formula():
     """FTLlamaRMSNorm "is equivalent to T5LayerNorm" (fused_norm.py:10-13): the oracle restatement against the textbook
     LlamaRMSNorm computation in fp64 -- at most one ulp of T apart (different rounding points)."""
-    g = torch.Generator().manual_seed(0)
+    g = Gen(0)
     for dtype, tol in ((torch.bfloat16, 2.0 ** -7), (torch.float16, 2.0 ** -10)):
-        x = (torch.randn(3, 512, generator=g) * 3).to(dtype)
-        gamma = (1 + 0.1 * torch.randn(512, generator=g)).to(dtype)
+        x = (g.randn(3, 512) * 3).to(dtype)
+        gamma = (1 + 0.1 * g.randn(512)).to(dtype)
         got = O.rmsnorm(x, gamma, 1e-6).double()
         xd = x.double()
         want = xd * torch.rsqrt((xd * xd).mean(-1, keepdim=True) + 1e-6) * gamma.double()
@@ -28,22 +28,21 @@ def test_oracle_rmsnorm_matches_llama_rmsnorm_formula():
 def test_gpu_rmsnorm_linear_vs_oracle(dtype, M, N, K):
     from llm_awq_amd import ops
     c = make_case(N, K, dtype, seed=M + N + K, M=M, bias=(M == 2))
-    g = torch.Generator().manual_seed(N + M)
-    x = (torch.randn(M, K, generator=g) * 2.5).to(dtype)
-    gamma = (1 + 0.2 * torch.randn(K, generator=g)).to(dtype)
+    g = Gen(N + M)
+    x = (g.randn(M, K) * 2.5).to(dtype)
+    gamma = (1 + 0.2 * g.randn(K)).to(dtype)
     eps = 1e-5
     c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
     szp = ops.pack_sz_cdna4(c["scales"].cuda(), c["scaled_zeros"].cuda(), K)
     y = ops.rmsnorm_forward_cdna4(x.cuda(), gamma.cuda(), eps, c4, szp, c["bias"].cuda() if c["bias"] is not None else None).cpu()
     xn = O.rmsnorm(x, gamma, eps)
     ref = O.wqlinear_forward(xn, None, c["scales"], c["scaled_zeros"], c["bias"], 128, q_int=c["q"])
-    rel = ((y.float() - ref.float()).norm() / ref.float().norm()).item()
-    assert rel <= 1e-3, rel
-    # the normalised activations can differ in the last bit where the fp32 sum of squares is reduced in another order
-    assert (y == ref).float().mean() > 0.9
+    # the normalised activations can differ in the last bit where the fp32 sum of squares is reduced in another order / the
+    # hardware rsqrt rounds the other way: those x carry one ulp of T of slack (tests/helpers.rmsnorm_uncertainty)
+    check_forward(y, xn, c["q"], c["scales"], c["scaled_zeros"], dtype, bias=c["bias"], x_unc=rmsnorm_uncertainty(x, gamma, eps))
     # and against the two-launch product path: oracle-normalised x through the plain kernel
     y2 = ops.gemm_cdna4(xn.cuda(), c4, c["scales"].cuda(), c["scaled_zeros"].cuda(), c["bias"].cuda() if c["bias"] is not None else None, szp).cpu()
-    assert (y == y2).float().mean() > 0.9
+    assert_bits(y, y2, 0.1)
 
 
 @pytest.mark.gpu
@@ -54,9 +53,9 @@ def test_gpu_rmsnorm_gate_up_vs_oracle(dtype, M):
     F, K = 1376, 2048
     cg = make_case(F, K, dtype, seed=F + M, M=M)
     cu = make_case(F, K, dtype, seed=F + M + 1, M=M)
-    g = torch.Generator().manual_seed(M)
-    x = (torch.randn(M, K, generator=g) * 1.7).to(dtype)
-    gamma = (1 + 0.2 * torch.randn(K, generator=g)).to(dtype)
+    g = Gen(M)
+    x = (g.randn(M, K) * 1.7).to(dtype)
+    gamma = (1 + 0.2 * g.randn(K)).to(dtype)
     qgu = torch.cat([cg["qweight"], cu["qweight"]], 0).cuda()
     s = torch.cat([cg["scales"], cu["scales"]], 1).cuda()
     z = torch.cat([cg["scaled_zeros"], cu["scaled_zeros"]], 1).cuda()
@@ -69,7 +68,7 @@ def test_gpu_rmsnorm_gate_up_vs_oracle(dtype, M):
     ref = torch.nn.functional.silu(gt) * up
     rel = ((y.float() - ref.float()).norm() / ref.float().norm()).item()
     assert rel <= 3e-3, rel
-    assert (y == ref).float().mean() > 0.85
+    assert_bits(y, ref, 0.15)
 
 
 @pytest.mark.gpu
@@ -91,10 +90,10 @@ def test_module_matches_norm_then_linear(dtype):
     from llm_awq_amd.fused_norm import RMSNormWQLinear
     from llm_awq_amd.qmodule import WQLinear
     from oracle import awq_oracle as O
-    from tests.helpers import check_forward, make_case
+    from tests.helpers import check_forward, make_case, rmsnorm_uncertainty
     N, K, eps = 256, 4096, 1e-5
     c = make_case(N, K, dtype, seed=21, M=16, bias=True)
-    gamma = (1.0 + 0.1 * torch.randn(K)).to(dtype)
+    gamma = (1.0 + 0.1 * Gen(22).randn(K)).to(dtype)
     lin = WQLinear(4, 128, K, N, True, "cuda", dtype=dtype)
     lin.load_state_dict(dict(qweight=c["qweight"], scales=c["scales"], scaled_zeros=c["scaled_zeros"], bias=c["bias"]))
     lin.to_cdna4()
@@ -102,4 +101,7 @@ def test_module_matches_norm_then_linear(dtype):
     for M in (1, 3, 4, 5, 16):
         x = c["x"][:M].contiguous()
         xn = O.rmsnorm(x, gamma, eps)
-        check_forward(mod(x.cuda()).cpu(), xn, c["q"], c["scales"], c["scaled_zeros"], dtype, bias=c["bias"])
+        # the fused launch (M <= 4) normalises with the hardware rsqrt and its own reduction order (as layernorm.cu:48-60 does
+        # on its hardware): where T(x * rstd * gamma) hangs on the last fp32 bits of rstd, one ulp of T of slack on that x
+        unc = rmsnorm_uncertainty(x, gamma, eps)
+        check_forward(mod(x.cuda()).cpu(), xn, c["q"], c["scales"], c["scaled_zeros"], dtype, bias=c["bias"], x_unc=unc)

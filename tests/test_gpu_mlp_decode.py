@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import awq_oracle as O
-from tests.helpers import make_case
+from tests.helpers import make_case, Gen, assert_bits
 
 pytestmark = pytest.mark.gpu
 
@@ -45,10 +45,10 @@ def test_one_launch_mlp_vs_oracle_and_two_launches(ops, dtype, H, F, NO):
     cg, cu, cd, gu, gu_szh, dq, d_szh = _build(ops, H, F, NO, dtype, 11 + F)
     ctr = torch.zeros(4096, dtype=torch.int32, device="cuda")
     bias = cd["bias"].cuda()
-    g = torch.Generator().manual_seed(F)
+    g = Gen(F)
     for M in ((1, 2, 8) if F < 4096 else (1, 4)):
         for it in range(6):  # new activations every call: a stale h (or a missed wait) cannot pass
-            x = torch.randn(M, H, generator=g).to(dtype)
+            x = g.randn(M, H).to(dtype)
             y = ops.mlp_decode_cdna4(x.cuda(), gu, gu_szh, dq, d_szh, ctr, bias)
             h2 = ops.decode_cdna4(x.cuda(), gu, gu_szh, None, 2)
             y2 = ops.decode_cdna4(h2, dq, d_szh, bias, 0)
@@ -57,7 +57,7 @@ def test_one_launch_mlp_vs_oracle_and_two_launches(ops, dtype, H, F, NO):
             # against the two-launch product path: same arithmetic, another split of K over the waves of a block
             rel2 = ((y.float() - y2.float()).norm() / y2.float().norm()).item()
             assert rel2 < 2e-3, (M, it, rel2)
-            assert (y == y2).float().mean() > (0.9 if dtype == torch.bfloat16 else 0.8)  # last-bit differences of h pass through a 14336-term dot product
+            assert_bits(y, y2, (0.1 if dtype == torch.bfloat16 else 0.2))  # last-bit differences of h pass through a 14336-term dot product
             if it == 0 and F < 4096:
                 _h, ref = _oracle(x, cg, cu, cd)
                 rel = ((y.cpu().float() - ref.float()).norm() / ref.float().norm()).item()

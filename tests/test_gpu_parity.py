@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import awq_oracle as O
-from tests.helpers import check_forward, make_case
+from tests.helpers import check_forward, make_case, Gen
 
 pytestmark = pytest.mark.gpu
 DTYPES = [torch.float16, torch.bfloat16]
@@ -51,12 +51,12 @@ def test_dequant_bit_exact(ops, dtype, N, K):
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_dequant_adversarial_scales(ops, dtype):
     """random scales over a wide exponent range + every zero point: rounding ties, subnormal fp16."""
-    g = torch.Generator().manual_seed(5)
+    g = Gen(5)
     N, K = 64, 512
-    q = torch.randint(0, 16, (N, K), generator=g).numpy().astype(np.uint8)
+    q = g.randint(0, 16, (N, K)).numpy().astype(np.uint8)
     scales = torch.zeros(8, N, dtype=dtype)
-    scales[:4] = (torch.rand(4, N, generator=g) * 2 + 0.5) * torch.pow(2.0, torch.randint(-14, 3, (4, N), generator=g).float())
-    zeros = torch.randint(0, 16, (4, N), generator=g)
+    scales[:4] = (g.rand(4, N) * 2 + 0.5) * torch.pow(2.0, g.randint(-14, 3, (4, N)).float())
+    zeros = g.randint(0, 16, (4, N))
     sz = torch.zeros(8, N, dtype=dtype)
     sz[:4] = -(scales[:4] * zeros.float()).to(dtype)
     W = O.dequant_weight(q, scales, sz, 128)

@@ -50,7 +50,7 @@ def test_splitk_vs_unsplit_and_torch_fp32(env, dtype, K, N):
     c4 = ops.repack_v2_to_cdna4(w["qweight"])
     szp = ops.pack_sz_cdna4(w["scales"], w["scaled_zeros"], K)
     W = ops.dequant_cdna4(c4, w["scales"], w["scaled_zeros"]).float()
-    g = torch.Generator(device="cuda").manual_seed(5)
+    g = cuda_gen(5)
     bias = (torch.randn(N, device="cuda", generator=g) * 0.02).to(dtype)
     split_seen = 0
     for M in (256, 300, 512, 777, 1024):
@@ -76,8 +76,8 @@ def test_splitk_vs_unsplit_and_torch_fp32(env, dtype, K, N):
                 for name, v in (("split", y), ("unsplit", y0)):
                     rel = ((v.float() - ref.float()).norm() / ref.float().norm()).item()
                     assert rel < 1e-3, (name, M, knob, rel)
-                    assert (ref == v).float().mean().item() > 0.97, (name, M, knob)
-                assert (y == y0).float().mean().item() > 0.97, (M, knob)
+                    assert_bits(ref, v, 0.03, what=str((name, M, knob)))
+                assert_bits(y, y0, 0.03, what=str((M, knob)))
                 assert ((y.float() - y0.float()).norm() / y0.float().norm()).item() < 1e-3, (M, knob)
     assert split_seen >= 10, "the split path was not exercised"
 
@@ -137,7 +137,7 @@ def test_splitk_through_the_engine_and_graph(env):
 def test_small_m_gemm_vs_oracle(env, dtype, M, N, K):
     """knob gemm_small_m=2 sends every 9 <= m <= 255 to awq_gemm_v4n.hip's single row tile: rows >= m are computed from
     row m - 1 and not stored (the guard rows around `out` must stay untouched), split-K on or off."""
-    from tests.helpers import check_forward, make_case
+    from tests.helpers import check_forward, make_case, cuda_gen, assert_bits
     ops, _ = env
     c = make_case(N, K, dtype, seed=M + N + K, M=M, bias=(M % 2 == 1))
     c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
@@ -176,7 +176,8 @@ def test_small_m_gemm_writes_only_its_rows(env):
             assert torch.all(buf[M:] == 7.0), (M, knob)
             ref = (x.float() @ W.t()).bfloat16()
             rel = ((buf[:M].float() - ref.float()).norm() / ref.float().norm()).item()
-            assert rel < 1e-3 and (ref == buf[:M]).float().mean().item() > 0.97, (M, knob, rel)
+            assert rel < 1e-3, (M, knob, rel)
+            assert_bits(ref, buf[:M], 0.03, what=str((M, knob)))
 
 
 def test_small_m_rule(env):

@@ -7,7 +7,7 @@ import torch
 from llm_awq_amd import moe as MOE
 from llm_awq_amd.qmodule import WQLinear
 from oracle import awq_oracle as O
-from tests.helpers import check_forward, make_case
+from tests.helpers import check_forward, make_case, Gen, cuda_gen, assert_bits
 
 
 def oracle_grouped(x_sorted, qweight, scales, scaled_zeros, offsets):
@@ -46,9 +46,9 @@ def test_sparse_moe_block_with_oracle_matmul():
     w2 = MOE.GroupedWQLinear(_experts(E, H, F, dtype, 30)[0], matmul=oracle_grouped)
     assert w1.qweight.shape == (E, F // 4, H) and w1.scales.shape == (E, 8, F)
     blk = MOE.SparseMoeMLP(w1, w3, w2, top_k=2)
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn(T, H, generator=g).to(dtype)
-    logits = torch.randn(T, E, generator=g)
+    g = Gen(0)
+    x = g.randn(T, H).to(dtype)
+    logits = g.randn(T, E)
     logits[:, 3] = -1e9  # expert 3 gets no tokens (empty group)
     y = blk(x, logits)
     # dense reference: every token through its two experts, one at a time
@@ -77,8 +77,8 @@ def test_gpu_grouped_gemm_vs_oracle(layout, dtype, counts):
     mods, cases = _experts(E, N, K, dtype, seed=sum(counts) + 7)
     grp = MOE.GroupedWQLinear(mods)
     T = sum(counts)
-    g = torch.Generator().manual_seed(T)
-    x = torch.randn(T, K, generator=g).to(dtype)
+    g = Gen(T)
+    x = g.randn(T, K).to(dtype)
     off = torch.tensor([0] + list(np.cumsum(counts)), dtype=torch.int32)
     qw = grp.qweight.cuda()
     if layout == "cdna4":
@@ -102,7 +102,7 @@ def test_gpu_mixtral_block_shapes():
     qw = torch.stack([w["qweight"] for w in ws])
     s = torch.stack([w["scales"] for w in ws])
     z = torch.stack([w["scaled_zeros"] for w in ws])
-    g = torch.Generator(device=dev).manual_seed(1)
+    g = cuda_gen(1)
     x = torch.randn(T, H, device=dev, generator=g).to(torch.bfloat16)
     ids = torch.stack([torch.randperm(E, device=dev, generator=g)[:2] for _ in range(T)])
     order, off = MOE.sort_by_expert(ids, E)
@@ -113,7 +113,7 @@ def test_gpu_mixtral_block_shapes():
         lo, hi = offc[e], offc[e + 1]
         if hi > lo:
             ref = ops.gemm(xs[lo:hi].contiguous(), qw[e], s[e], z[e])
-            assert (ref == y[lo:hi]).float().mean() > 0.98
+            assert_bits(ref, y[lo:hi], 0.02)
 
 
 @pytest.mark.gpu
@@ -126,8 +126,8 @@ def test_gpu_grouped_decode_and_module(counts):
     mods, cases = _experts(E, N, K, dtype, seed=sum(counts) + 3)
     grp = MOE.GroupedWQLinear(mods).cuda().to_cdna4()
     T = sum(counts)
-    g = torch.Generator().manual_seed(T + 1)
-    x = torch.randn(T, K, generator=g).to(dtype)
+    g = Gen(T + 1)
+    x = g.randn(T, K).to(dtype)
     off = torch.tensor([0] + list(np.cumsum(counts)), dtype=torch.int32)
     y = grp(x.cuda(), off.cuda()).cpu()
     assert y.shape == (T, N)
@@ -148,8 +148,8 @@ def test_gpu_grouped_prefill_v4(counts):
     mods, cases = _experts(E, N, K, dtype, seed=sum(counts) + 11)
     grp = MOE.GroupedWQLinear(mods).cuda().to_cdna4()
     T = sum(counts)
-    g = torch.Generator().manual_seed(T + 5)
-    x = torch.randn(T, K, generator=g).to(dtype).cuda()
+    g = Gen(T + 5)
+    x = g.randn(T, K).to(dtype).cuda()
     off = torch.tensor([0] + list(np.cumsum(counts)), dtype=torch.int32).cuda()
     y = grp(x, off)
     ops._capi.tune(moe_v4=0)
@@ -177,8 +177,8 @@ def test_gpu_grouped_skinny(counts, dtype):
     mods, cases = _experts(E, N, K, dtype, seed=sum(counts) + 17)
     grp = MOE.GroupedWQLinear(mods).cuda().to_cdna4()
     T = sum(counts)
-    g = torch.Generator().manual_seed(T + 9)
-    x = torch.randn(T, K, generator=g).to(dtype).cuda()
+    g = Gen(T + 9)
+    x = g.randn(T, K).to(dtype).cuda()
     off = torch.tensor([0] + list(np.cumsum(counts)), dtype=torch.int32).cuda()
     y = grp(x, off)
     ops._capi.tune(moe_v4=0)
@@ -186,7 +186,7 @@ def test_gpu_grouped_skinny(counts, dtype):
         y_ref = grp(x, off)
     finally:
         ops._capi.tune(moe_v4=1)
-    assert (y == y_ref).float().mean() > 0.97  # different K split -> a few 1-ulp flips
+    assert_bits(y, y_ref, 0.03)  # different K split -> a few 1-ulp flips
     y, x = y.cpu(), x.cpu()
     for e in range(E):
         lo, hi = int(off[e]), int(off[e + 1])

@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.helpers import Gen, cuda_gen
+
 
 def _host_worker(rank, world, port, names, nbytes, rounds, q):
     import torch.distributed as dist
@@ -19,11 +21,11 @@ def _host_worker(rank, world, port, names, nbytes, rounds, q):
     bufs = [np.ndarray((HostMailbox.buffer_bytes(world, nbytes),), dtype=np.uint8, buffer=s.buf) for s in shms]
     box = HostMailbox(bufs, rank, world, nbytes)
     ok = True
-    g = torch.Generator().manual_seed(100 + rank)
+    g = Gen(100 + rank)
     for r in range(rounds):
         dtype = torch.bfloat16 if r % 2 == 0 else torch.float16
         n = [8, 64, 4096, nbytes // 2][r % 4]
-        x = torch.randn(n, generator=g).to(dtype)
+        x = g.randn(n).to(dtype)
         got = box.all_reduce(x)
         parts = [torch.empty_like(x) for _ in range(world)]
         dist.all_gather(parts, x)
@@ -76,7 +78,7 @@ def test_kernel_ranks_as_coresident_blocks(dtype, world):
     try:
         ptrs = (ctypes.c_void_p * 8)(*[bufs[q % world].value for q in range(8)])
         status = torch.zeros(1, dtype=torch.int32, device="cuda")
-        g = torch.Generator(device="cuda").manual_seed(3)
+        g = cuda_gen(3)
         for rnd in range(1, 9):  # halves are reused from round 3 on
             n = [8, 4096, 8192, 1024][rnd % 4]
             xs = torch.randn(world, n, device="cuda", generator=g).to(dtype)
@@ -126,7 +128,7 @@ def test_kernel_device_epoch_survives_graph_replay(world):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side):
                 run()
-            g = torch.Generator(device="cuda").manual_seed(11)
+            g = cuda_gen(11)
             for rep in range(4):
                 for x in xs:
                     x.copy_(torch.randn(world, n, device="cuda", generator=g).to(dtype))
@@ -153,7 +155,7 @@ def _gpu_worker(rank, world, port, q):
     from llm_awq_amd.oneshot import OneShotAllReduce
     ar = OneShotAllReduce(None, 64 * 1024)
     ok = True
-    g = torch.Generator(device="cuda").manual_seed(7 + rank)
+    g = cuda_gen(7 + rank)
     for r in range(10):
         x = torch.randn(4096, device="cuda", generator=g).to(torch.bfloat16)
         parts = [torch.empty_like(x) for _ in range(world)]

@@ -3,6 +3,8 @@ reference's own Python (oracle/gen_golden.py).  Integer / index work is bit exac
 import numpy as np
 import pytest
 import torch
+
+from tests.helpers import Gen
 from hypothesis import given, settings, strategies as st
 
 from oracle import awq_oracle as O
@@ -117,12 +119,12 @@ def test_repack_v1_v2_golden(golden):
 
 def test_dequant_is_single_rounded_fma():
     """the fp32 mul+add used by the oracle is exact before the one rounding to T: compare with float64."""
-    g = torch.Generator().manual_seed(0)
+    g = Gen(0)
     for dt in (torch.float16, torch.bfloat16):
-        s = ((torch.rand(4, 64, generator=g) + 0.5) * 2.0 ** torch.randint(-12, 2, (4, 64), generator=g).float()).to(dt)
-        z = torch.randint(0, 16, (4, 64), generator=g)
+        s = ((g.rand(4, 64) + 0.5) * 2.0 ** g.randint(-12, 2, (4, 64)).float()).to(dt)
+        z = g.randint(0, 16, (4, 64))
         sz = -(s * z.float()).to(dt)
-        q = torch.randint(0, 16, (64, 512), generator=g).numpy()
+        q = g.randint(0, 16, (64, 512)).numpy()
         W = O.dequant_weight(q, s, sz, 128)
         gi = torch.arange(512) // 128
         exact = torch.from_numpy(q).double() * s.double()[gi].t() + sz.double()[gi].t()

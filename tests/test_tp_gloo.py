@@ -28,15 +28,16 @@ def _worker(rank, world, port, dtype_name, result_q):
     try:
         from llm_awq_amd.qmodule import WQLinear
         from oracle import awq_oracle as O
+        from tests.helpers import Gen
 
         dtype = getattr(torch, dtype_name)
         K, N, M = 1280, 96, 5  # 10 groups -> 5 per rank; N/16 = 6 slabs -> 3 per rank
-        g = torch.Generator().manual_seed(11)
-        d = O.quantize_linear(torch.randn(N, K, generator=g) * 0.02, dtype=dtype)
+        g = Gen(11)
+        d = O.quantize_linear(g.randn(N, K) * 0.02, dtype=dtype)
         full = WQLinear(4, 128, K, N, True, "cpu", dtype=dtype)
         full.qweight, full.scales, full.scaled_zeros = d["qweight"], d["scales"], d["scaled_zeros"]
-        full.bias = (torch.randn(N, generator=g) * 0.02).to(dtype)
-        x = torch.randn(M, K, generator=g).to(dtype)
+        full.bias = (g.randn(N) * 0.02).to(dtype)
+        x = g.randn(M, K).to(dtype)
 
         def oracle_mm(xs, qw, s, z):
             return O.wqlinear_forward(xs, qw, s, z, None, 128)
@@ -99,7 +100,7 @@ def test_stacked_gate_up_column_shards_pair_matching_rows():
     import torch
     from llm_awq_amd.parallel import shard_stacked_column_parallel
     from oracle import awq_oracle as O
-    from tests.helpers import make_case
+    from tests.helpers import make_case, Gen
     F, K, world = 128, 256, 4
     cg, cu = make_case(F, K, torch.bfloat16, seed=1, M=3), make_case(F, K, torch.bfloat16, seed=2, M=3)
     x = cg["x"]
