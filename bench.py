@@ -57,6 +57,30 @@ def pmc_traffic(kernel_prefixes):
         return None, None
 
 
+def profile_consistency(ms_per_step, layers):
+    """Sum of the decode kernels' AVERAGE durations (one launch of each kernel row per layer) from the last committed
+    `rocprofv3 --kernel-trace --stats` summary (profiles/*bench_kernel_stats.csv, eager launches) next to this run's ms_per_step
+    (graph replay): the two must agree to within the launch-mode difference (a few per cent)."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*bench_kernel_stats.csv")))
+    if not files:
+        return None
+    try:
+        tot_ns, rows = 0.0, 0
+        for r in csv.DictReader(open(files[-1])):
+            if "awq::gemv_dma_kernel" in r["kernel"] or "awq::gemv_cdna4_kernel" in r["kernel"]:
+                tot_ns += float(r["avg_ns"]) * layers
+                rows += 1
+        if not rows:
+            return None
+        prof_ms = tot_ns * 1e-6
+        return {"source": os.path.relpath(files[-1], ROOT), "decode_kernel_rows": rows, "sum_kernel_avg_ms_per_step": round(prof_ms, 4),
+                "ms_per_step": round(ms_per_step, 4), "ratio": round(prof_ms / ms_per_step, 4)}
+    except Exception:
+        return None
+
+
 def algo_bytes(M, K, N, esz=2, group=128):
     """packed int4 + scales + scaled_zeros + x + out."""
     return N * K // 2 + 2 * (K // group) * N * esz + M * K * esz + M * N * esz
@@ -75,6 +99,7 @@ def main():
     ap.add_argument("--no-dropin", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-batched-decode", action="store_true", help="skip the M = 4 / M = 7 decode legs")
     ap.add_argument("--layers", type=int, default=LAYERS)
     ap.add_argument("--tune", action="append", default=[], help="experiments only: awq_tune_set knobs as key=value")
     ap.add_argument("--layout", default="cdna4", choices=["cdna4", "v2"], help="cdna4 = what the rewritten repacker emits (default); v2 = reference checkpoint layout through gemv/gemm_forward_cuda_new only")
@@ -160,7 +185,7 @@ def main():
 
     def run_native(xs):
         outs = []
-        decode = xs[4096].numel() == 4096
+        decode = xs[4096].numel() <= 8 * 4096
         if probe_streams and decode:
             cur = torch.cuda.current_stream()
             ev = torch.cuda.Event()
@@ -226,8 +251,8 @@ def main():
 
     side = torch.cuda.Stream(device=dev)
 
-    def timed_decode(run_pass, steps, warmup, use_graph=True):
-        xs1 = make_x(1)
+    def timed_decode(run_pass, steps, warmup, use_graph=True, M=1):
+        xs1 = make_x(M)
         graph = None
         with torch.cuda.stream(side):
             run_pass(xs1)  # lazy init / cache builds outside capture
@@ -299,6 +324,19 @@ def main():
                       "launches_per_token": launches, "parallelism": "tp1", **({"tune": args.tune} if args.tune else {})},
            "roofline": roofline, "device": torch.cuda.get_device_name(dev)}
 
+    # ---------------- batched decode (the reference GEMV serves 1..7 rows, gemv_cuda.cu:291-329): same launches, M = 4 and 7 ----------------
+    if native_leg and not args.no_batched_decode:
+        for Mb in (4, 7):
+            b_wall, b_ev, _g = timed_decode(run_main, max(5, args.steps // 2), max(2, args.warmup // 2), not args.no_graph, M=Mb)
+            b_steps = max(5, args.steps // 2)
+            b_bytes = bytes_native(Mb) * args.repeat_layers
+            b_gbs = b_bytes * b_steps / (b_ev * 1e-3) / 1e9
+            out["decode_m%d" % Mb] = {"m": Mb, "ms_per_step": round(b_wall / b_steps, 4), "tok_s": round(Mb * 1e3 / (b_wall / b_steps) * (L * args.repeat_layers / LAYERS), 1),
+                                      "roofline": {"bound": "hbm", "achieved": round(b_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b_gbs / HBM_PEAK_GBS, 4),
+                                                   "avg_launch_us": round(b_ev * 1e3 / (b_steps * launches), 3)}}
+    # ---------------- self-check: the committed rocprofv3 kernel-trace summary of this command against this run ----------------
+    out["profile_consistency"] = profile_consistency(ms_per_step, L)
+
     # ---------------- prefill leg ----------------
     def prefill(M, run_pass, kernel):
         pms, tfl = timed_prefill(run_pass, M, launches)
@@ -317,6 +355,9 @@ def main():
 
     # ---------------- the same work through the reference's entry points on raw v2 buffers ----------------
     if native_leg and raw:
+        # the engine converts the reference-layout qweights WHERE THEY LIE (AWQ_CDNA4_INPLACE; `raw` is this leg's own copy): no second
+        # copy of the weights -- cache.bytes reports what the cache holds beside them
+        eng.cdna4_cache_inplace(os.environ.get("AWQ_CDNA4_INPLACE", "1") != "0")
         d_wall, d_ev, _g = timed_decode(run_dropin, args.steps, args.warmup, not args.no_graph)
         d_bytes = sum(algo_bytes(1, K, N) for (_n, K, N, *_r) in raw)
         d_gbs = d_bytes * args.steps / (d_ev * 1e-3) / 1e9

@@ -193,12 +193,17 @@ __device__ __forceinline__ u32x4 ldg_nt_u32x4(const u32* p) {
 // the prefill form: 32 k evaluations per 256 x 256 tile sit in the tile's exposed epilogue, so silu is x * rcp(1 + exp2(-x log2 e))
 // on the hardware transcendentals (5 VALU, ~3 ulp of fp32 -- it changes the T rounding of ~0.05 % (bf16) / 0.2 % (fp16) of the
 // outputs by one ulp of T against an exact silu, which is also how far torch's own GPU silu sits from its CPU one); libm's expf and
-// an IEEE division cost ~40 instructions = +9 % on the gate/up GEMM at M = 2048.  The decode epilogues (a few lanes, once) keep expf.
+// an IEEE division cost ~40 instructions = +9 % on the gate/up GEMM at M = 2048.  The decode epilogues use the same form (silu_f32).
+// The ONE fp32 silu of the library (decode and prefill epilogues alike, so a row's QuantLlamaMLP output does not depend on how many
+// rows were batched with it): x * rcp(1 + exp2(-x log2 e)) on the hardware transcendentals.
+__device__ __forceinline__ float silu_f32(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
 template <typename DT>
 __device__ __forceinline__ u32 silu_mul_pair(u32 gate2, u32 up2) {
   auto one = [](uint16_t gb, uint16_t ub) {
     const float gt = DT::to_float(gb), up = DT::to_float(ub);
-    const float sl = DT::to_float(DT::from_float(gt * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gt * -1.4426950408889634f))));
+    const float sl = DT::to_float(DT::from_float(silu_f32(gt)));
     return (u32)DT::from_float(sl * up);
   };
   return one((uint16_t)(gate2 & 0xFFFFu), (uint16_t)(up2 & 0xFFFFu)) | (one((uint16_t)(gate2 >> 16), (uint16_t)(up2 >> 16)) << 16);

@@ -250,7 +250,7 @@ __device__ __forceinline__ void gemv_cdna4_body(char* smem, const uint16_t* __re
     } else {
       // fused_mlp.py:79-82: c = F.silu(gate_output) * up_output, every op rounded to T
       const float gt = to_f(DT::from_float(v[0])), up = to_f(DT::from_float(v[NS - 1]));
-      const float sl = to_f(DT::from_float(gt / (1.0f + expf(-gt))));
+      const float sl = to_f(DT::from_float(silu_f32(gt)));
       out[(size_t)i * (N >> 1) + nn] = DT::from_float(sl * up);
     }
   }

@@ -222,7 +222,7 @@ __device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __rest
       } else {
         // fused_mlp.py:79-82: c = F.silu(gate_output) * up_output, every op rounded to T
         const float gt = to_f(DT::from_float(v[0])), up = to_f(DT::from_float(v[NS - 1]));
-        const float sl = to_f(DT::from_float(gt / (1.0f + expf(-gt))));
+        const float sl = to_f(DT::from_float(silu_f32(gt)));
         out[(size_t)i * (N >> 1) + nn] = DT::from_float(sl * up);
       }
     }
@@ -238,7 +238,7 @@ __device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __rest
         usum += p[r * 64 + lane + 32];
       }
       const float gt = to_f(DT::from_float(gsum)), up = to_f(DT::from_float(usum));
-      const float sl = to_f(DT::from_float(gt / (1.0f + expf(-gt))));
+      const float sl = to_f(DT::from_float(silu_f32(gt)));
       const uint16_t hv = DT::from_float(sl * up);
       const size_t oi = (size_t)i * (N >> 1) + nb * 8 + 4 * g + r;
       if (out_through) {  // consumers of the same launch read this: write through to memory (sc0 sc1), no L2 write-back needed later
@@ -258,6 +258,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_dma_kernel(const uint16_t* __
   gemv_dma_body<DT, WAVES, D, DQ, EPI>(smem, x, qw, szp, bias, out, M, N, K, TX, probe_, blockIdx.x, nullptr, 0);
 }
 
+#ifdef AWQ_ENABLE_PROBES  // measured slower than two launches (profiles/r02_mlp_one_launch.txt): experiment builds only
 // QuantLlamaMLP.forward at decode in ONE launch (tinychat/modules/fused_mlp.py:33-83: gate/up GEMVs, F.silu, multiply, down_proj):
 // blocks [0, nA) are the gate/up slabs (8 + 8 interleaved pair, SiLU * mul epilogue) and store h = silu(gate) * up; blocks [nA, nA + nB)
 // are down_proj's slabs: they are dispatched behind the last gate/up block (workgroups start in index order, so a waiting block can
@@ -296,6 +297,8 @@ __global__ __launch_bounds__(512) void mlp_decode_kernel(const uint16_t* __restr
     }
   }
 }
+
+#endif
 
 namespace {
 struct DmaCfg {
@@ -414,9 +417,14 @@ int launch_gemv_dma(const void* x, const void* qw, const void* szp, const void* 
 }
 
 // gate/up (8 + 8 interleaved, n2 = 2 * ffn rows, K = hidden) + SiLU * mul + down (K = ffn, n_out rows) in one launch; sz_half side buffers.
-// h: [m, ffn] scratch in T; ctr: int32[4] device memory, zero before the first call.  Returns -1 if the shape is not served.
+// h: [m, ffn] scratch in T; ctr: AWQ_MLP_DECODE_COUNTER_BYTES (16 KiB) of device memory, zero before the first call.  Returns -1 if the
+// shape is not served -- and always in a product build: the kernel exists in AWQ_PROBES builds only (measured slower, and a consumer
+// that times out on its gate would go on with stale h).
 int launch_mlp_decode(const void* x, const void* qw_gu, const void* szh_gu, const void* qw_d, const void* szh_d, const void* bias_d,
                       void* h, void* out, int m, int hidden, int ffn, int n_out, int dtype, int* ctr, hipStream_t st) {
+#ifndef AWQ_ENABLE_PROBES
+  return -1;  // not in the product library
+#else
   if (m < 1 || m > 8 || (hidden % 128) != 0 || (ffn % 128) != 0 || (n_out % 16) != 0) return -1;
   const int nita = hidden / kGroup, nitb = ffn / kGroup;
   const int txa = (nita + 7) / 8, txb = (nitb + 7) / 8;
@@ -438,6 +446,7 @@ int launch_mlp_decode(const void* x, const void* qw_gu, const void* szh_gu, cons
   if (dtype == 0) AWQ_MLPD(F16) else AWQ_MLPD(BF16)
 #undef AWQ_MLPD
   return 0;
+#endif
 }
 
 }  // namespace awq

@@ -47,6 +47,8 @@ __global__ __launch_bounds__(1024) void oneshot_allreduce_kernel(OneShotPeers pe
   const bool dev_epoch = round == 0u;
   if (dev_epoch) round = *reinterpret_cast<volatile u32*>(epoch) + 1u;  // (written by this rank's previous call only: stream order)
   const int half = (int)(round & 1u);
+  __shared__ int timed_out;
+  if (threadIdx.x == 0) timed_out = 0;
   const int chunks = (count * 2 + 15) / 16;  // 16-byte chunks of the message (count % 8 == 0)
   const size_t slot_off = ((size_t)half * world + rank) * (size_t)max_bytes;
   // (1) my partial -> slot `rank` of every rank's buffer (write-through system-scope stores: they must leave this GPU's L2)
@@ -71,12 +73,20 @@ __global__ __launch_bounds__(1024) void oneshot_allreduce_kernel(OneShotPeers pe
     while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != round) {
       if (++spins > spin_limit) {
         if (status) atomicExch(status, 1);
+        timed_out = 1;  // (shared) a slot of this round never arrived: the sum below would mix rounds
         break;
       }
       __builtin_amdgcn_s_sleep(2);
     }
   }
   __syncthreads();
+  if (timed_out) {
+    // never hand back a sum of stale slots: the output is poisoned with NaNs (0x7FFF is a NaN in fp16 and in bf16) and the sticky
+    // status word is set -- OneShotAllReduce.check() raises, and a caller that does not check sees NaNs, not a plausible number
+    for (int c = threadIdx.x; c < chunks; c += blockDim.x)
+      *reinterpret_cast<u32x4*>(out + (size_t)c * 8) = u32x4{0x7FFF7FFFu, 0x7FFF7FFFu, 0x7FFF7FFFu, 0x7FFF7FFFu};
+    return;  // (the device epoch is NOT advanced: the communicator is dead until it is rebuilt)
+  }
   // (4) fixed-order fp32 sum of the W slots of my buffer (system-scope loads: the bytes were written by other GPUs)
   const char* mine = peers.data[rank] + (size_t)half * world * (size_t)max_bytes;
   for (int c = threadIdx.x; c < chunks; c += blockDim.x) {
@@ -119,9 +129,12 @@ int awq_oneshot_alloc(void** buffer, int world, int max_bytes) {
   const size_t bytes = awq_oneshot_buffer_bytes(world, max_bytes);
   if (!bytes) return AWQ_ERR_SHAPE;
   // fine-grained (uncached across agents) device memory: peers' stores and this GPU's polling loads meet in memory, not in an L2
-  hipError_t e = hipExtMallocWithFlags(buffer, bytes, hipDeviceMallocFinegrained);
-  if (e != hipSuccess) e = hipMalloc(buffer, bytes);
-  if (e != hipSuccess) return AWQ_ERR_LAUNCH;
+  // (NO fallback to plain hipMalloc: in coarse-grained memory a peer's xGMI stores need not become visible to a kernel that is
+  // already polling, and the round would time out -- the caller falls back to RCCL instead)
+  if (hipExtMallocWithFlags(buffer, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+    *buffer = nullptr;
+    return AWQ_ERR_LAUNCH;
+  }
   if (hipMemset(*buffer, 0, bytes) != hipSuccess) return AWQ_ERR_LAUNCH;
   return hipDeviceSynchronize() == hipSuccess ? AWQ_OK : AWQ_ERR_LAUNCH;
 }

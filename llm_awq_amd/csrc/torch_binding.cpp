@@ -69,6 +69,10 @@ struct SzSlot {
   uint32_t vs = 0, vz = 0;
   at::Tensor szp, szh;  // sz_packed (T) and sz_half (decode; undefined when the layer's scales are not f16-exact)
   uint64_t stamp = 0;
+  hipEvent_t built = nullptr;  // recorded behind the pack kernels; a hit from another stream waits for it until it has completed
+  hipStream_t build_stream = nullptr;
+  bool settled = false;
+  bool expired() const { return !szp.defined() || s.expired() || z.expired(); }
   SzSlot() : s(c10::weak_intrusive_ptr<c10::TensorImpl>(c10::intrusive_ptr<c10::TensorImpl>())), z(s) {}
 };
 struct CacheEntry {
@@ -79,11 +83,12 @@ struct CacheEntry {
   hipEvent_t built = nullptr;  // recorded on the building stream; other streams wait for it until it has completed
   hipStream_t build_stream = nullptr;
   bool settled = false;
+  bool inplace = false;  // AWQ_CDNA4_INPLACE=1: c4 IS the caller's qweight storage, converted where it lies (no second copy)
   explicit CacheEntry(const torch::Tensor& tw) : w(tw.getIntrusivePtr()), vw(tensor_version(tw)) {}
 };
 std::mutex g_cache_mu;
 std::unordered_map<const void*, CacheEntry> g_cache;
-int g_cache_enabled = -1;
+int g_cache_enabled = -1, g_cache_inplace = -1;
 int64_t g_cache_hits = 0, g_cache_builds = 0, g_cache_sz_builds = 0, g_cache_bytes = 0, g_cache_max_bytes = -1;
 uint64_t g_cache_clock = 0;
 
@@ -96,12 +101,38 @@ bool cache_enabled() {
     const char* e = std::getenv("AWQ_CDNA4_AUTOCACHE_MAX_GB");
     g_cache_max_bytes = e ? (int64_t)(std::atof(e) * (double)(1ull << 30)) : 0;
   }
+  if (g_cache_inplace < 0) {
+    // AWQ_CDNA4_INPLACE=1: the first call through the reference entry points converts the qweight WHERE IT LIES (via one layer-sized
+    // temporary that is freed at once) instead of keeping a permuted second copy: no extra weight memory (35 GB on Llama-3-70B), but
+    // the module's `qweight` then holds the cdna4 interleave -- save checkpoints with llm_awq_amd.repacker / cdna4_restore first.
+    const char* e = std::getenv("AWQ_CDNA4_INPLACE");
+    g_cache_inplace = (e && e[0] == '1') ? 1 : 0;
+  }
   return g_cache_enabled == 1;
 }
 
+// an in-place entry whose qweight is still alive: put the reference (v2) interleave back before the entry is forgotten, or the next
+// call would take the permuted bytes for v2 data and permute them again
+void restore_inplace(CacheEntry& e) {
+  if (!e.inplace || !e.c4.defined()) return;
+  auto lw = e.w.lock();
+  if (!lw) return;
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(e.c4.device());
+  hipStream_t st = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+  if (e.built && st != e.build_stream) (void)hipStreamWaitEvent(st, e.built, 0);
+  at::Tensor tmp = torch::empty_like(e.c4);
+  const int n = (int)e.c4.size(0) * 4, k = (int)e.c4.size(1);
+  if (awq_repack_cdna4_to_v2(e.c4.data_ptr(), tmp.data_ptr(), n, k, (void*)st) == AWQ_OK)
+    (void)hipMemcpyAsync(e.c4.data_ptr(), tmp.data_ptr(), e.c4.nbytes(), hipMemcpyDeviceToDevice, st);
+  e.inplace = false;
+  e.c4 = at::Tensor();
+}
+
 void drop_entry(std::unordered_map<const void*, CacheEntry>::iterator it) {
-  if (it->second.c4.defined()) g_cache_bytes -= (int64_t)it->second.c4.nbytes();
+  if (it->second.c4.defined() && !it->second.inplace) g_cache_bytes -= (int64_t)it->second.c4.nbytes();
   if (it->second.built) (void)hipEventDestroy(it->second.built);
+  for (SzSlot& sl : it->second.slot)
+    if (sl.built) (void)hipEventDestroy(sl.built);
   g_cache.erase(it);
 }
 
@@ -133,16 +164,25 @@ bool cdna4_view(const torch::Tensor& kernel, const torch::Tensor& scales, const 
     for (auto i2 = g_cache.begin(); i2 != g_cache.end();) {
       auto cur = i2++;
       auto lw = cur->second.w.lock();
-      if (!lw || lw->storage().data() != cur->first) drop_entry(cur);
+      // (the key is the tensor's data pointer INCLUDING its storage offset: sharded / flattened parameter buffers are views)
+      if (!lw || lw->data() != cur->first) drop_entry(cur);
     }
     const int64_t need = (int64_t)kernel.nbytes();
-    if (g_cache_max_bytes > 0 && g_cache_bytes + need > g_cache_max_bytes) return false;  // over budget: reference-layout kernels
+    if (g_cache_inplace != 1 && g_cache_max_bytes > 0 && g_cache_bytes + need > g_cache_max_bytes) return false;  // over budget: reference-layout kernels
     CacheEntry e(kernel);
-    e.c4 = torch::empty_like(kernel);
-    if (awq_repack_v2_to_cdna4(kernel.data_ptr(), e.c4.data_ptr(), (int)n, (int)k, (void*)stream) != AWQ_OK) return false;
+    if (g_cache_inplace == 1) {
+      at::Tensor tmp = torch::empty_like(kernel);  // stream-ordered allocation: returned to the pool when it goes out of scope
+      if (awq_repack_v2_to_cdna4(kernel.data_ptr(), tmp.data_ptr(), (int)n, (int)k, (void*)stream) != AWQ_OK) return false;
+      if (hipMemcpyAsync(kernel.data_ptr(), tmp.data_ptr(), kernel.nbytes(), hipMemcpyDeviceToDevice, stream) != hipSuccess) return false;
+      e.c4 = kernel;  // (a raw copy: the tensor's version counter does not move, so the entry stays valid)
+      e.inplace = true;
+    } else {
+      e.c4 = torch::empty_like(kernel);
+      if (awq_repack_v2_to_cdna4(kernel.data_ptr(), e.c4.data_ptr(), (int)n, (int)k, (void*)stream) != AWQ_OK) return false;
+      g_cache_bytes += need;
+    }
     if (hipEventCreateWithFlags(&e.built, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(e.built, stream);
     e.build_stream = stream;
-    g_cache_bytes += need;
     ++g_cache_builds;
     it = g_cache.emplace(key, std::move(e)).first;
   }
@@ -160,9 +200,22 @@ bool cdna4_view(const torch::Tensor& kernel, const torch::Tensor& scales, const 
       hit = &sl;
   }
   if (hit == nullptr) {
-    SzSlot& sl = e.slot[0].stamp <= e.slot[1].stamp ? e.slot[0] : e.slot[1];
+    // victim: a slot whose (scales, zeros) pair is gone (a prefill call's `scaled_zeros - 8 * scales` temporary) before a live one --
+    // two temporaries in a row must not evict the persistent decode pair; among equals the least recently used
+    SzSlot* victim = &e.slot[0];
+    if (e.slot[0].expired() != e.slot[1].expired()) victim = e.slot[0].expired() ? &e.slot[0] : &e.slot[1];
+    else if (e.slot[1].stamp < e.slot[0].stamp) victim = &e.slot[1];
+    SzSlot& sl = *victim;
     at::Tensor nszp = torch::empty({n / 16, k / 128, 16}, scales.options().dtype(at::kInt));
     if (awq_pack_sz_cdna4(scales.data_ptr(), zeros.data_ptr(), nszp.data_ptr(), (int)n, (int)k, (void*)stream) != AWQ_OK) return false;
+    if (capturing) {
+      // built while a graph is being captured: the pack kernel is only RECORDED, so the buffer must not be published (an eager call
+      // could hit it before the first replay); it lives for this call's launch alone, decode uses the T-typed sz_packed
+      c4 = e.c4;
+      szp = nszp;
+      if (szh) *szh = at::Tensor();
+      return true;
+    }
     at::Tensor nszh;
     if (!capturing) {  // the exactness flag is read back once: not inside a capture (decode then uses sz_packed)
       at::Tensor h = torch::empty({n / 16, k / 128, 16}, scales.options().dtype(at::kInt));
@@ -178,10 +231,18 @@ bool cdna4_view(const torch::Tensor& kernel, const torch::Tensor& scales, const 
     sl.vz = tensor_version(zeros);
     sl.szp = nszp;
     sl.szh = nszh;
+    if (!sl.built && hipEventCreateWithFlags(&sl.built, hipEventDisableTiming) != hipSuccess) sl.built = nullptr;
+    if (sl.built) (void)hipEventRecord(sl.built, stream);
+    sl.build_stream = stream;
+    sl.settled = false;
     hit = &sl;
     ++g_cache_sz_builds;
   } else {
     ++g_cache_hits;
+    if (!hit->settled && hit->built) {  // packed on another stream: order this one behind it until the event has completed
+      if (stream != hit->build_stream && !capturing) (void)hipStreamWaitEvent(stream, hit->built, 0);
+      if (!capturing && hipEventQuery(hit->built) == hipSuccess) hit->settled = true;
+    }
   }
   hit->stamp = ++g_cache_clock;
   c4 = e.c4;
@@ -562,13 +623,35 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("cdna4_cache_info", []() {
     std::lock_guard<std::mutex> lock(g_cache_mu);
     return py::dict(py::arg("enabled") = cache_enabled(), py::arg("entries") = (int64_t)g_cache.size(), py::arg("hits") = g_cache_hits,
-                    py::arg("builds") = g_cache_builds, py::arg("sz_builds") = g_cache_sz_builds, py::arg("bytes") = g_cache_bytes);
+                    py::arg("builds") = g_cache_builds, py::arg("sz_builds") = g_cache_sz_builds, py::arg("bytes") = g_cache_bytes,
+                    py::arg("inplace") = g_cache_inplace == 1);
   }, "state of the lazy v2 -> cdna4 weight cache behind gemv/gemm_forward_cuda_new");
-  m.def("cdna4_cache_clear", []() {
+  auto clear_all = []() {
     std::lock_guard<std::mutex> lock(g_cache_mu);
-    while (!g_cache.empty()) drop_entry(g_cache.begin());
+    while (!g_cache.empty()) {
+      restore_inplace(g_cache.begin()->second);  // (in-place entries: the qweight gets its v2 interleave back)
+      drop_entry(g_cache.begin());
+    }
+  };
+  m.def("cdna4_cache_clear", clear_all);
+  m.def("cdna4_cache_enable", [clear_all](bool on) {
+    if (!on) clear_all();  // with the cache off the reference-layout kernels read the qweights: none may stay converted in place
+    g_cache_enabled = on ? 1 : 0;
   });
-  m.def("cdna4_cache_enable", [](bool on) { g_cache_enabled = on ? 1 : 0; });
+  m.def("cdna4_cache_inplace", [clear_all](bool on) {
+    cache_enabled();
+    clear_all();
+    g_cache_inplace = on ? 1 : 0;
+  }, "AWQ_CDNA4_INPLACE at run time: convert qweights where they lie (no second copy) on their first call through the reference entry points");
+  m.def("cdna4_restore", [](torch::Tensor kernel) {
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    auto it = g_cache.find(kernel.data_ptr());
+    if (it == g_cache.end()) return false;
+    const bool was = it->second.inplace;
+    restore_inplace(it->second);
+    drop_entry(it);
+    return was;
+  }, "undo an in-place conversion of this qweight (e.g. before saving a reference-layout checkpoint); true if it was converted");
   // extras of the MI355X build (not part of the reference module)
   m.def("repack_v2_to_cdna4", &repack_v2_to_cdna4, "qweight v2 -> cdna4 interleave (same shape)");
   m.def("repack_cdna4_to_v2", &repack_cdna4_to_v2, "qweight cdna4 -> v2 interleave (same shape)");

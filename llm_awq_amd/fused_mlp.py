@@ -49,9 +49,29 @@ def interleave_gate_up(gq, uq, gs, us, gz, uz):
     return q, cols(gs, us), cols(gz, uz)
 
 
+def deinterleave_gate_up(q, s, z):
+    """inverse of interleave_gate_up: (gate qweight, up qweight, gate scales, up scales, gate scaled_zeros, up scaled_zeros)"""
+    F2, K = q.shape
+    q4 = q.view(F2 // 4, 2, 2, K)
+    Fo = s.shape[1] // 2
+
+    def cols(a):
+        a4 = a.view(a.shape[0], Fo // 8, 2, 8)
+        return a4[:, :, 0, :].reshape(a.shape[0], Fo).contiguous(), a4[:, :, 1, :].reshape(a.shape[0], Fo).contiguous()
+
+    (gs, us), (gz, uz) = cols(s), cols(z)
+    return q4[:, 0].reshape(F2 // 2, K).contiguous(), q4[:, 1].reshape(F2 // 2, K).contiguous(), gs, us, gz, uz
+
+
+_V2_NAMES = ("gate_proj_qweight", "gate_proj_scales", "gate_proj_scaled_zeros", "up_proj_qweight", "up_proj_scales", "up_proj_scaled_zeros")
+
+
 class QuantLlamaMLP(nn.Module):
-    """Same constructor and attributes as the reference (gate_proj, down_proj, up_proj are WQLinear modules); the original
-    v2 buffers stay registered under the reference's names so state dicts are interchangeable."""
+    """Same constructor and attributes as the reference (gate_proj, down_proj, up_proj are WQLinear modules); the v2 buffers are
+    registered under the reference's names so state dicts are interchangeable (fused_mlp.py:19-27).  Once the fused cdna4 stream
+    has been built on the GPU the six v2 buffers are RELEASED (they would be a second copy of two thirds of the block's weights:
+    14 GB on Llama-3-70B) -- `state_dict()` rebuilds them bit-exactly from the fused stream, `load_state_dict()` re-materialises them
+    first.  AWQ_MLP_KEEP_V2=1 keeps both copies."""
 
     def __init__(self, gate_proj, down_proj, up_proj):
         super().__init__()
@@ -70,11 +90,42 @@ class QuantLlamaMLP(nn.Module):
         self.down_proj = down_proj
         self.split_k_iters = down_proj.split_k_iters
         self._fused = None  # (qweight cdna4, scales, scaled_zeros, sz_packed, sz_half or None): built on the first GPU forward
-        self._ctr = None    # int32[4] device counters of the one-launch decode path (zero between calls)
+        self._ctr = None    # device counters of the one-launch decode path (AWQ_PROBES builds)
+        self._v2_released = False
+        self._v2_meta = None  # (shape, dtype) of the six released buffers
+        self._register_state_dict_hook(QuantLlamaMLP._fill_state_dict)
+        self._register_load_state_dict_pre_hook(self._rematerialise_v2)
+
+    # ---- the v2 buffers while they are released ----
+    @torch.no_grad()
+    def _v2_from_fused(self):
+        c4, s, z, _szp, _szh = self._fused
+        q = load_engine().repack_cdna4_to_v2(c4)
+        return dict(zip(("gate_proj_qweight", "up_proj_qweight", "gate_proj_scales", "up_proj_scales", "gate_proj_scaled_zeros",
+                         "up_proj_scaled_zeros"), deinterleave_gate_up(q, s, z)))
+
+    @staticmethod
+    def _fill_state_dict(module, state_dict, prefix, local_metadata):
+        if module._v2_released:
+            for name, t in module._v2_from_fused().items():
+                state_dict[prefix + name] = t
+        return state_dict
+
+    def _rematerialise_v2(self, *args, **kwargs):
+        """before load_state_dict: the incoming tensors need full-size buffers to be copied into; the fused stream is rebuilt after"""
+        if self._v2_released:
+            for name, t in self._v2_from_fused().items():
+                setattr(self, name, t)
+            self._v2_released = False
+        self._fused = None
 
     @torch.no_grad()
-    def _build(self):
+    def _build(self, device=None):
         eng = load_engine()
+        if self._v2_released:  # (the module moved to another device after the buffers were released: carry them over)
+            for name, t in self._v2_from_fused().items():
+                setattr(self, name, t if device is None else t.to(device))
+            self._v2_released = False
         q, s, z = interleave_gate_up(self.gate_proj_qweight, self.up_proj_qweight, self.gate_proj_scales, self.up_proj_scales,
                                      self.gate_proj_scaled_zeros, self.up_proj_scaled_zeros)
         c4 = eng.repack_v2_to_cdna4(q)
@@ -83,6 +134,11 @@ class QuantLlamaMLP(nn.Module):
         self._fused = (c4, s, z, szp, szh if exact else None)
         if getattr(self.down_proj, "layout", None) == "v2" and self.down_proj.out_features % 16 == 0:
             self.down_proj.to_cdna4()
+        if c4.is_cuda and os.environ.get("AWQ_MLP_KEEP_V2") != "1":
+            for name in _V2_NAMES:  # (registered names stay: zero-size placeholders on the same device)
+                t = getattr(self, name)
+                setattr(self, name, torch.empty(0, dtype=t.dtype, device=t.device))
+            self._v2_released = True
 
     @torch.no_grad()
     def forward(self, x):
@@ -99,7 +155,7 @@ class QuantLlamaMLP(nn.Module):
         down_proj not in the cdna4 layout, shape outside the kernel's range)."""
         eng = load_engine()
         if self._fused is None or self._fused[0].device != x.device:
-            self._build()
+            self._build(x.device)
         c4, s, z, szp, szh = self._fused
         d = self.down_proj
         if szh is None or getattr(d, "layout", None) != "cdna4" or d.w_bit != 4 or self.in_features < 4096 or self.intermediate_size < 2048:
@@ -117,13 +173,16 @@ class QuantLlamaMLP(nn.Module):
             self._ctr = torch.zeros(4096, dtype=torch.int32, device=x.device)
         if not x.is_contiguous():
             x = x.contiguous()
-        return eng.mlp_decode_cdna4(x, c4, szh, d.qweight, d.szh_cdna4, self._ctr, d.bias)
+        try:
+            return eng.mlp_decode_cdna4(x, c4, szh, d.qweight, d.szh_cdna4, self._ctr, d.bias)
+        except RuntimeError:  # a product library does not carry the one-launch kernel (AWQ_PROBES builds only): two launches
+            return None
 
     @torch.no_grad()
     def our_llama_mlp(self, x):
         eng = load_engine()
         if self._fused is None or self._fused[0].device != x.device:
-            self._build()
+            self._build(x.device)
         c4, s, z, szp, szh = self._fused
         if not x.is_contiguous():
             x = x.contiguous()

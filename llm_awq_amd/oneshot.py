@@ -7,9 +7,11 @@ own buffer and reduces the W slots in rank order with fp32 accumulation and one 
 which a rank can only enter after it saw every peer's flag of round e + 1 -- raised after that peer finished reading round e.
 
 `OneShotAllReduce` wires the GPU kernel to a torch.distributed group: buffers are allocated fine-grained, exported with hipIpc
-handles (all_gather_object over the group) and opened on every peer.  It is OPT-IN (`AWQ_ONESHOT=1` or an explicit object handed to
-TPWQLinear): the round-end scaling bench runs on hardware this repository's author could not reach, and an RCCL all-reduce is the
-path that is known to work there; messages above `max_bytes` always go to RCCL (bandwidth-bound: ring / direct RS+AG territory).
+handles (all_gather_object over the group) and opened on every peer.  It is the DEFAULT reducer of the tensor-parallel paths for
+messages up to `max_bytes` when world > 1 (`AWQ_ONESHOT=0` is the escape hatch; `make_reducer` falls back to RCCL when the exchange
+buffers cannot be set up -- no fine-grained memory, no hipIpc -- and every rank agrees on that through one all-reduce); messages
+above `max_bytes` always go to RCCL (bandwidth-bound: ring / direct RS+AG territory).  A round whose peer flag does not arrive within
+the spin bound poisons its output with NaNs and sets a sticky status word: `check()` (after a synchronize) raises.
 """
 from __future__ import annotations
 
@@ -82,24 +84,43 @@ class OneShotAllReduce:
         # device_epoch: the round counter lives in the exchange buffer and the kernel advances it (round argument 0) -- safe inside a
         # captured and replayed hipGraph; False: the host passes 1, 2, 3, ... (eager launches only)
         self.device_epoch = device_epoch
+        # every step that can fail on one rank only (no fine-grained memory, no hipIpc) is followed by an exchange of the outcomes, so
+        # that ALL ranks raise together and nobody is left waiting inside a collective
+        self.local, self.opened = None, []
         with torch.cuda.device(self.device):
-            buf = ctypes.c_void_p()
-            _capi.check(self.L.awq_oneshot_alloc(ctypes.byref(buf), self.world, max_bytes))
-            self.local = buf
-            handle = ctypes.create_string_buffer(64)
-            _capi.check(self.L.awq_oneshot_ipc_export(buf, handle))
+            raw, err = None, None
+            try:
+                buf = ctypes.c_void_p()
+                _capi.check(self.L.awq_oneshot_alloc(ctypes.byref(buf), self.world, max_bytes))
+                self.local = buf
+                handle = ctypes.create_string_buffer(64)
+                _capi.check(self.L.awq_oneshot_ipc_export(buf, handle))
+                raw = bytes(handle.raw)
+            except Exception as e:  # noqa: BLE001
+                err = f"{type(e).__name__}: {e}"
             handles = [None] * self.world
-            dist.all_gather_object(handles, bytes(handle.raw), group=group)
-            self.opened = []
+            dist.all_gather_object(handles, raw, group=group)
+            if any(h is None for h in handles):
+                self.close()
+                raise RuntimeError(f"one-shot all-reduce: exchange buffer unavailable on rank(s) {[q for q, h in enumerate(handles) if h is None]}"
+                                   + (f" (here: {err})" if err else ""))
             ptrs = (ctypes.c_void_p * MAX_WORLD)()
-            for q in range(self.world):
-                if q == self.rank:
-                    ptrs[q] = buf.value
-                else:
-                    p = ctypes.c_void_p()
-                    _capi.check(self.L.awq_oneshot_ipc_open(ctypes.create_string_buffer(handles[q], 64), ctypes.byref(p)))
-                    self.opened.append(p)
-                    ptrs[q] = p.value
+            try:
+                for q in range(self.world):
+                    if q == self.rank:
+                        ptrs[q] = self.local.value
+                    else:
+                        p = ctypes.c_void_p()
+                        _capi.check(self.L.awq_oneshot_ipc_open(ctypes.create_string_buffer(handles[q], 64), ctypes.byref(p)))
+                        self.opened.append(p)
+                        ptrs[q] = p.value
+            except Exception as e:  # noqa: BLE001
+                err = f"{type(e).__name__}: {e}"
+            outcomes = [None] * self.world
+            dist.all_gather_object(outcomes, err, group=group)
+            if any(o is not None for o in outcomes):
+                self.close()
+                raise RuntimeError(f"one-shot all-reduce: peer buffers could not be mapped: {[o for o in outcomes if o]}")
             self.ptrs = ptrs
             self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
         dist.barrier(group=group)  # every buffer is zeroed and mapped before the first round
@@ -133,4 +154,18 @@ class OneShotAllReduce:
 
 
 def enabled_by_env() -> bool:
-    return os.environ.get("AWQ_ONESHOT", "0") == "1"
+    return os.environ.get("AWQ_ONESHOT", "1") != "0"
+
+
+def make_reducer(dist, group=None, max_bytes: int = 64 * 1024, device=None):
+    """The default small-message reducer of a tensor-parallel group: a OneShotAllReduce if EVERY rank could build one, else None
+    (= torch.distributed.all_reduce).  Collective: every rank of the group must call it."""
+    world = dist.get_world_size(group)
+    if world <= 1 or world > MAX_WORLD or not enabled_by_env() or not torch.cuda.is_available():
+        return None
+    try:
+        return OneShotAllReduce(group, max_bytes, device)  # (raises on EVERY rank or on none: see __init__)
+    except Exception as e:  # noqa: BLE001 -- no fine-grained memory / hipIpc on this box: RCCL serves the messages
+        import sys
+        print(f"[oneshot] rank {dist.get_rank(group)}: {e}; using RCCL for the small messages", file=sys.stderr)
+        return None

@@ -249,8 +249,11 @@ def mlp_gate_up_cdna4(x, qweight_gate_up, sz_packed, group_size: int = 128):
 
 
 def mlp_decode_cdna4(x, gate_up_qweight, gate_up_sz_half, down_qweight, down_sz_half, counters, down_bias=None, group_size: int = 128):
-    """C-ABI awq_w4a16_mlp_decode_cdna4: QuantLlamaMLP.forward for <= 8 rows in one launch.  counters: int32[4] zeros (kept by the caller)."""
+    """C-ABI awq_w4a16_mlp_decode_cdna4: QuantLlamaMLP.forward for <= 8 rows in one launch (AWQ_PROBES builds only: a product library
+    answers AWQ_ERR_SHAPE).  counters: AWQ_MLP_DECODE_COUNTER_BYTES = 16 KiB of int32 zeros kept by the caller (the kernel counts per
+    group of 32 producer blocks on separate 64-byte lines)."""
     _need_gpu(x, gate_up_qweight, gate_up_sz_half, down_qweight, down_sz_half, counters, down_bias)
+    assert counters.dtype == torch.int32 and counters.numel() * 4 >= 16384, "counters: at least AWQ_MLP_DECODE_COUNTER_BYTES (16 KiB) of int32"
     hidden = x.shape[-1]
     m = x.numel() // hidden
     ffn = gate_up_qweight.shape[0] * 4 // 2

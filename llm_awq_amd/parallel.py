@@ -115,8 +115,11 @@ class TPWQLinear(nn.Module):
         else:
             self.bias = full.bias if mode == "row" else full.bias[self.bounds[0]: self.bounds[1]].contiguous()
         self._matmul = matmul
-        # reducer(y) -> reduced y: e.g. llm_awq_amd.oneshot.OneShotAllReduce for the 8 .. 16 KiB decode messages (it sends larger
-        # ones to RCCL itself); None = torch.distributed.all_reduce (RCCL on GPUs, gloo in the CPU tests)
+        # reducer(y) -> reduced y.  Default on GPUs with world > 1: the group's shared llm_awq_amd.oneshot.OneShotAllReduce for the
+        # 8 .. 64 KiB decode messages (it sends larger ones to RCCL itself; AWQ_ONESHOT=0 or a box without fine-grained memory /
+        # hipIpc -> None); None = torch.distributed.all_reduce (RCCL on GPUs, gloo in the CPU tests)
+        if reducer is None and mode == "row" and self.world > 1 and qw.is_cuda and matmul is None:
+            reducer = default_reducer(dist, group)
         self._reducer = reducer
 
     @torch.no_grad()
@@ -136,28 +139,39 @@ class TPWQLinear(nn.Module):
                 dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
         return y + self.bias if self.bias is not None else y
 
+    def check(self):
+        """after a synchronize: raise if a one-shot round of this module's reducer timed out (its output was poisoned with NaNs)"""
+        if self._reducer is not None and hasattr(self._reducer, "check"):
+            self._reducer.check()
+
+
+_REDUCERS = {}
+
+
+def default_reducer(dist, group=None):
+    """One OneShotAllReduce per process group, built at the first row-parallel module (a collective: every rank builds its modules
+    in the same order), or None where it is disabled / unavailable."""
+    key = id(group) if group is not None else 0
+    if key not in _REDUCERS:
+        from . import oneshot
+        _REDUCERS[key] = oneshot.make_reducer(dist, group)
+    return _REDUCERS[key]
+
 
 # ---------------------------------------------------------------------------------------------------
-# bench leg for N > 1 (called from bench.py): Llama-3-8B decode with Megatron-paired TP
+# bench leg for N > 1 (called from bench.py): Megatron-paired tensor parallelism of the decoder block's quantised linears
 # ---------------------------------------------------------------------------------------------------
 
-def run_tp_bench(args, eng, dist, rank, world, dev, shapes, algo_bytes):
-    """Llama-3-8B decode (M = 1) under Megatron-paired tensor parallelism, in the layout the rewritten repacker emits:
-    qkv and the stacked gate/up pair are N-sharded (no communication; gate/up run with the SiLU*mul epilogue), o and
-    down are K-sharded with one RCCL all-reduce each.  Every rank builds ONLY its own shard (weights are synthetic)."""
+def _block(shapes):
+    """(name, K, N, mode) of one decoder block: qkv and the gate/up pair N-sharded (no communication), o / down K-sharded + all-reduce"""
+    return [("qkv",) + shapes["qkv"] + ("column",), ("o",) + shapes["o"] + ("row",),
+            ("gate_up", shapes["gate"][0], 2 * shapes["gate"][1], "column"), ("down",) + shapes["down"] + ("row",)]
+
+
+def _build_shards(eng, block, layers, shard_world, rank, dev, dtype, seed0=0):
     from . import synth
-
-    import os
-    dtype = torch.bfloat16
-    L = args.layers
-    # AWQ_BENCH_SHARD_WORLD=W on fewer ranks: every rank times the shard shapes of a W-way split (rank r of W); the all-reduces still
-    # run over the real ranks.  It gives the compute floor of a W-GPU step on boxes that have fewer GPUs; `config.shard_world` says so.
-    shard_world = int(os.environ.get("AWQ_BENCH_SHARD_WORLD", world))
-    # (name, K, N, mode) of the unsharded linears of one decoder block
-    block = [("qkv", 4096, 6144, "column"), ("o", 4096, 4096, "row"), ("gate_up", 4096, 28672, "column"),
-             ("down", 14336, 4096, "row")]
     shards = []
-    for li in range(L):
+    for li in range(layers):
         for si, (name, K, N, mode) in enumerate(block):
             if mode == "row":
                 k0, k1 = shard_bounds(K, shard_world, rank, GROUP)
@@ -165,46 +179,46 @@ def run_tp_bench(args, eng, dist, rank, world, dev, shapes, algo_bytes):
             else:
                 n0, n1 = shard_bounds(N, shard_world, rank, 32)  # 32: the stacked gate/up pair splits in matching 16-row slabs
                 kl, nl = K, n1 - n0
-            w = synth.random_wq(kl, nl, dtype=dtype, device=dev, seed=(li * 16 + si) * 64 + rank, keep_q=False)
+            w = synth.random_wq(kl, nl, dtype=dtype, device=dev, seed=seed0 + (li * 16 + si) * 64 + rank, keep_q=False)
             qw = eng.repack_v2_to_cdna4(w["qweight"])
             szp = eng.pack_sz_cdna4(w["scales"], w["scaled_zeros"], kl)
             szh, exact = eng.pack_szh_cdna4(w["scales"], w["scaled_zeros"], kl)  # the streaming decode kernel's side buffer
             shards.append((name, kl, nl, qw, w["scales"], w["scaled_zeros"], szp, mode, szh if exact else None))
             del w
-    from . import oneshot
-    reducer = None
-    if oneshot.enabled_by_env() and world > 1:  # opt-in: see llm_awq_amd/oneshot.py
-        reducer = oneshot.OneShotAllReduce(None, 64 * 1024, dev)
-    g = torch.Generator(device=dev).manual_seed(1 + rank)
-    xs = {}
-    for (_nm, kl, *_r) in shards:
-        if kl not in xs:  # noqa: E501
-            xs[kl] = torch.randn(1, kl, device=dev, generator=g).to(dtype)
+    return shards
 
+
+def _make_pass(eng, shards, xs, reducer, dist, world):
     def run_pass():
         outs = []
         for (name, kl, nl, qw, s, sz, szp, mode, szh) in shards:
+            x = xs[kl]
+            m = x.numel() // kl
             if name == "gate_up":  # the shard's rows are taken as QuantLlamaMLP's 8 + 8 interleaved gate / up pair (synthetic weights)
-                y = eng.mlp_gate_up_forward_cdna4(xs[kl], qw, szp, szh)
-            elif szh is not None:
-                y = eng.decode_cdna4(xs[kl], qw, szh, None, 0)
+                y = eng.mlp_gate_up_forward_cdna4(x, qw, szp, szh)
+            elif m <= 8 and szh is not None:
+                y = eng.decode_cdna4(x, qw, szh, None, 0)
             else:
-                y = eng.forward_cdna4(xs[kl], qw, s, sz, szp, None)
-            if mode == "row":
+                y = eng.forward_cdna4(x, qw, s, sz, szp, None)
+            if mode == "row" and world > 1:
                 if reducer is not None:
                     y = reducer(y)
                 else:
                     dist.all_reduce(y)
             outs.append(y)
         return outs
+    return run_pass
 
+
+def _timed(run_pass, steps, warmup, dist, dev, use_graph, rank):
+    """K timed steps bracketed by barrier + synchronize on both sides, max over ranks; returns (ms_per_step, graphed)"""
     side = torch.cuda.Stream(device=dev)
     graph = None
     with torch.cuda.stream(side):
         for _ in range(2):
             run_pass()  # communicator + lazy init outside capture
         torch.cuda.synchronize()
-        if not args.no_graph:  # (the one-shot reducer keeps its round counter on the device: replay-safe)
+        if use_graph:  # (the one-shot reducer keeps its round counter on the device: replay-safe)
             try:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=side):
@@ -222,13 +236,13 @@ def run_tp_bench(args, eng, dist, rank, world, dev, shapes, algo_bytes):
         if flag.item() == 0:
             graph = None
         step = (lambda: graph.replay()) if graph is not None else run_pass
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             step()
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             step()
         torch.cuda.synchronize()
         dist.barrier()
@@ -236,24 +250,116 @@ def run_tp_bench(args, eng, dist, rank, world, dev, shapes, algo_bytes):
         dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    ms_per_step = tmax.item() * 1e3 / args.steps
+    return tmax.item() * 1e3 / steps, graph is not None
+
+
+def _allreduce_record(dist, reducer, dev, world, numel, dtype, iters=200):
+    """one message class on its own: microseconds per all-reduce (max over ranks), RCCL and -- where it serves the size -- one-shot"""
+    rec = {"bytes": numel * 2, "ranks": world}
+    if world <= 1:
+        return rec
+    t = torch.ones(numel, device=dev, dtype=dtype)
+
+    def timeit(fn):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        return dt.item() * 1e6 / iters
+
+    rec["rccl_us"] = round(timeit(lambda: dist.all_reduce(t.fill_(1.0))), 2)
+    if reducer is not None and numel * 2 <= reducer.max_bytes:
+        rec["oneshot_us"] = round(timeit(lambda: reducer(t)), 2)
+    return rec
+
+
+def run_tp_bench(args, eng, dist, rank, world, dev, shapes, algo_bytes):
+    """Headline: Llama-3-8B decode (M = 1) under Megatron-paired tensor parallelism in the layout the rewritten repacker emits.
+    Beside it (`tp70b`): the configuration BASELINE.json names for TP -- Llama-3-70B shapes sharded the same way, decode M = 1 and
+    prefill M = 2048 -- and (`allreduce`) the two message classes on their own: 16 KiB (decode, one-shot / RCCL) and 32 MiB
+    (prefill, RCCL).  Every rank builds ONLY its own shards (weights are synthetic)."""
+    from . import oneshot, synth
+
+    import os
+    dtype = torch.bfloat16
+    L = args.layers
+    # AWQ_BENCH_SHARD_WORLD=W on fewer ranks: every rank times the shard shapes of a W-way split (rank r of W); the all-reduces still
+    # run over the real ranks.  It gives the compute floor of a W-GPU step on boxes that have fewer GPUs; `config.shard_world` says so.
+    shard_world = int(os.environ.get("AWQ_BENCH_SHARD_WORLD", world))
+    reducer = oneshot.make_reducer(dist, None, 64 * 1024, dev)  # default for <= 64 KiB when world > 1 (AWQ_ONESHOT=0: RCCL)
+    g = torch.Generator(device=dev).manual_seed(1 + rank)
+
+    def make_xs(shards, M):
+        xs = {}
+        for (_nm, kl, *_r) in shards:
+            if kl not in xs:
+                xs[kl] = torch.randn(M, kl, device=dev, generator=g).to(dtype)
+        return xs
+
+    # ---------------- Llama-3-8B decode: the headline line ----------------
+    shards = _build_shards(eng, _block(synth.LLAMA3_8B), L, shard_world, rank, dev, dtype)
+    ms_per_step, graphed = _timed(_make_pass(eng, shards, make_xs(shards, 1), reducer, dist, world), args.steps, args.warmup, dist, dev,
+                                  not args.no_graph, rank)
     bytes_rank = sum(algo_bytes(1, kl, nl) for (_nm, kl, nl, *_r) in shards)
     gbs_rank = bytes_rank / (ms_per_step * 1e-3) / 1e9
     launches = len(shards)
+    del shards
+    torch.cuda.empty_cache()
+
+    # ---------------- Llama-3-70B TP (BASELINE.json configs[3]): decode M = 1 and prefill M = 2048 ----------------
+    tp70 = None
+    L70 = int(os.environ.get("AWQ_BENCH_TP70B_LAYERS", "8"))
+    if L70 > 0:
+        sh70 = _build_shards(eng, _block(synth.LLAMA3_70B), L70, shard_world, rank, dev, dtype, seed0=1 << 20)
+        b70 = sum(algo_bytes(1, kl, nl) for (_nm, kl, nl, *_r) in sh70)
+        d_ms, d_graph = _timed(_make_pass(eng, sh70, make_xs(sh70, 1), reducer, dist, world), max(5, args.steps // 2), max(2, args.warmup // 2),
+                               dist, dev, not args.no_graph, rank)
+        Mp = 2048
+        p_ms, _pg = _timed(_make_pass(eng, sh70, make_xs(sh70, Mp), reducer, dist, world), 2, 1, dist, dev, False, rank)
+        flops_rank = sum(2.0 * Mp * kl * nl for (_nm, kl, nl, *_r) in sh70)
+        tp70 = {"workload": f"Llama-3-70B W4A16 g128 bf16, {L70} of 80 decoder blocks timed, tensor parallel over {world} GPUs"
+                            + (f" (shard shapes of a {shard_world}-way split)" if shard_world != world else ""),
+                "layers_timed": L70,
+                "decode": {"m": 1, "ms_per_step_80_layers": round(d_ms * 80 / L70, 4), "tok_s": round(1e3 / (d_ms * 80 / L70), 2), "graph": d_graph,
+                           "hbm_gbs_per_gpu": round(b70 / (d_ms * 1e-3) / 1e9, 1), "hbm_frac_per_gpu": round(b70 / (d_ms * 1e-3) / 1e9 / 8000.0, 4),
+                           "allreduce_bytes": 8192 * 2, "allreduces_per_token": 2 * 80},
+                "prefill": {"m": Mp, "ms_per_pass_80_layers": round(p_ms * 80 / L70, 3), "tok_s": round(Mp / (p_ms * 80 / L70 * 1e-3), 1),
+                            "mfma_tflops_per_gpu": round(flops_rank / (p_ms * 1e-3) / 1e12, 1),
+                            "mfma_frac_per_gpu": round(flops_rank / (p_ms * 1e-3) / 1e12 / 2500.0, 4),
+                            "allreduce_bytes": Mp * 8192 * 2, "allreduces_per_pass": 2 * 80}}
+        del sh70
+        torch.cuda.empty_cache()
+
+    ar = {"kind": "oneshot (peer-mapped exchange buffers, csrc/awq_oneshot.hip) for <= 64 KiB, RCCL above" if reducer is not None
+                  else "rccl (torch.distributed.all_reduce)",
+          "rccl_ranks": world, "per_step": 2 * L,
+          "decode_8b": _allreduce_record(dist, reducer, dev, world, 4096, dtype),
+          "decode_70b": _allreduce_record(dist, reducer, dev, world, 8192, dtype),
+          "prefill_70b_m2048": _allreduce_record(dist, reducer, dev, world, 2048 * 8192, dtype, iters=10),
+          "weight_bytes_per_rank": int(bytes_rank)}
+    if reducer is not None:
+        torch.cuda.synchronize()
+        reducer.check()  # a timed-out round poisons its output and must not be reported as a timing
     return {"metric": "W4A16 decode+prefill tok/s, Llama-3-8B; achieved %HBM (GEMV) / %MFMA (GEMM)",
             "value": round(1e3 / ms_per_step * (L / 32), 2),
             "unit": "decode tok/s (the 160 quantised linears of one token: 32 x {qkv, o, gate, up, down}; attention/norm/lm_head off-path)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"Llama-3-8B W4A16 g128 bf16, decode M=1, tensor parallel over {world} GPUs "
-                                   "(qkv and gate/up N-sharded, o/down K-sharded + RCCL all-reduce)",
-                       "layers": L, "decode_m": 1, "graph": graph is not None, "layout": "cdna4",
+                                   "(qkv and gate/up N-sharded, o/down K-sharded + all-reduce)",
+                       "layers": L, "decode_m": 1, "graph": graphed, "layout": "cdna4",
                        "fused_gate_up_silu_mul": True, "launches_per_token": launches, "parallelism": f"tp{world}",
                        "allreduces_per_step": 2 * L,
                        **({"shard_world": shard_world, "note": "shard shapes of a larger split timed on fewer ranks: a compute floor, not a scaling point"} if shard_world != world else {})},
-            "allreduce": {"kind": "oneshot (peer-mapped exchange buffers, csrc/awq_oneshot.hip)" if reducer is not None else "rccl (torch.distributed.all_reduce)",
-                          "bytes": 4096 * 2, "ranks": world, "per_step": 2 * L, "rccl_ranks": world,
-                          "weight_bytes_per_rank": int(bytes_rank)},
+            "allreduce": ar,
+            **({"tp70b": tp70} if tp70 is not None else {}),
             "roofline": {"bound": "hbm", "kernel": "awq::gemv_dma_kernel", "achieved": round(gbs_rank, 1),
                          "peak": 8000.0, "unit": "GB/s per GPU (incl. all-reduce time)", "frac": round(gbs_rank / 8000.0, 4),
                          "traffic": None},

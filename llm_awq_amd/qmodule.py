@@ -189,12 +189,20 @@ class WQLinear(nn.Module):
             raise ValueError("cdna4 interleave needs out_features % 16 == 0 and group_size == 128")
         eng = load_engine()
         self.qweight = eng.repack_v2_to_cdna4(self.qweight.contiguous())
-        self.sz_cdna4 = eng.pack_sz_cdna4(self.scales.contiguous(), self.scaled_zeros.contiguous(), self.in_features)
+        self.scales, self.scaled_zeros = self.scales.contiguous(), self.scaled_zeros.contiguous()
+        self.sz_cdna4 = eng.pack_sz_cdna4(self.scales, self.scaled_zeros, self.in_features)
+        self._sz_key = self._side_key()  # the first forward finds both side buffers current (no rebuild, no host sync)
         self._build_szh(eng)
         self.layout = "cdna4"
         return self
 
+    def _side_key(self):
+        """identity of what the side buffers were derived from: rebuilt when scales / scaled_zeros moved, changed dtype or were edited in place"""
+        return (self.scales.device, self.scales.dtype, self.scales.data_ptr(), self.scales._version, self.scaled_zeros.data_ptr(),
+                self.scaled_zeros._version)
+
     def _build_szh(self, eng):
+        """the decode side buffer; reads one flag back from the device (a host sync): never called while a stream is capturing"""
         szh, exact = eng.pack_szh_cdna4(self.scales.contiguous(), self.scaled_zeros.contiguous(), self.in_features)
         self.szh_cdna4 = szh if exact else False
 
@@ -236,17 +244,21 @@ class WQLinear(nn.Module):
             if self.group_size != 128:
                 raise ValueError("the cdna4 / w3c kernels implement group_size 128 only")
             # side buffers are derived from scales / scaled_zeros: rebuild when those moved, changed dtype or were edited in place
-            key = (self.scales.device, self.scales.dtype, self.scales.data_ptr(), self.scales._version, self.scaled_zeros.data_ptr(),
-                   self.scaled_zeros._version)
+            key = self._side_key()
             if self.sz_cdna4 is None or getattr(self, "_sz_key", None) != key:
                 self.sz_cdna4 = eng.pack_sz_cdna4(self.scales, self.scaled_zeros, self.in_features)
                 self.szh_cdna4 = None
                 self._sz_key = key
             if self.layout == "cdna4" and x.numel() // x.shape[-1] <= 8:
-                if self.szh_cdna4 is None:
+                # (building sz_half reads a flag back: inside a graph capture this call keeps the T-typed sz_packed instead)
+                if self.szh_cdna4 is None and not (x.is_cuda and torch.cuda.is_current_stream_capturing()):
                     self._build_szh(eng)
-                if self.szh_cdna4 is not False:
-                    return eng.decode_cdna4(x, self.qweight, self.szh_cdna4, self.bias, 0)
+                if self.szh_cdna4 is not None and self.szh_cdna4 is not False:
+                    try:
+                        return eng.decode_cdna4(x, self.qweight, self.szh_cdna4, self.bias, 0)
+                    except RuntimeError as e:  # a shape the streaming kernel does not serve: the general entry takes every shape
+                        if "shape" not in str(e).lower():
+                            raise
             fwd = eng.forward_cdna4 if self.layout == "cdna4" else eng.forward_w3
             return fwd(x, self.qweight, self.scales, self.scaled_zeros, self.sz_cdna4, self.bias)
         rows = x.numel() // x.shape[-1]

@@ -128,3 +128,46 @@ def test_temporary_zeros_rebuild_only_the_scale_buffer(eng):
     assert info["builds"] == b0["builds"] + 1, info          # the weights: once
     assert info["sz_builds"] == b0["sz_builds"] + 1 + 4, info  # the module's pair once, one per temporary
     assert info["entries"] == 1
+
+
+def test_in_place_conversion_keeps_no_second_copy_and_can_be_undone(eng):
+    """AWQ_CDNA4_INPLACE (here switched on at run time): the qweight is converted where it lies -- cache bytes stay 0, the buffer holds
+    the oracle's cdna4 interleave, every row count still matches the oracle, an in-place update of the weights is picked up, and
+    cdna4_restore / cdna4_cache_clear / switching the cache off put the reference interleave back bit for bit."""
+    import numpy as np
+    from oracle import awq_oracle as O
+    N, K = 512, 1280
+    a, b = make_case(N, K, torch.bfloat16, seed=12, M=40), make_case(N, K, torch.bfloat16, seed=13, M=40)
+    try:
+        eng.cdna4_cache_inplace(True)
+        qw, s, z = _dev(a)
+        v2 = qw.clone()
+        for M in (1, 7, 8, 40):
+            x = a["x"][:M].contiguous()
+            y = (eng.gemv_forward_cuda_new(x.cuda(), qw, s, z, M, N, K, 128) if M < 8 else eng.gemm_forward_cuda_new(x.cuda(), qw, s, z)).cpu()
+            check_forward(y, x, a["q"], a["scales"], a["scaled_zeros"], torch.bfloat16)
+        info = eng.cdna4_cache_info()
+        assert info["bytes"] == 0 and info["entries"] == 1 and info["inplace"]
+        assert np.array_equal(qw.cpu().numpy(), O.pack_cdna4(a["q"])), "the module's buffer now holds the cdna4 interleave"
+        # new reference-layout weights copied over it (load_state_dict does this): converted again, never served stale
+        qw.copy_(b["qweight"].cuda())
+        s.copy_(b["scales"].cuda())
+        z.copy_(b["scaled_zeros"].cuda())
+        x = a["x"][:4].contiguous()
+        check_forward(eng.gemv_forward_cuda_new(x.cuda(), qw, s, z, 4, N, K, 128).cpu(), x, b["q"], b["scales"], b["scaled_zeros"], torch.bfloat16)
+        assert eng.cdna4_restore(qw) is True
+        assert torch.equal(qw.cpu(), b["qweight"]), "restored to the reference interleave"
+        assert eng.cdna4_restore(qw) is False
+        # converted again on the next call; clearing the cache restores every live in-place entry
+        eng.gemv_forward_cuda_new(x.cuda(), qw, s, z, 4, N, K, 128)
+        assert not torch.equal(qw.cpu(), b["qweight"])
+        eng.cdna4_cache_clear()
+        assert torch.equal(qw.cpu(), b["qweight"])
+        eng.gemv_forward_cuda_new(x.cuda(), qw, s, z, 4, N, K, 128)
+        eng.cdna4_cache_enable(False)   # the reference-layout kernels will read it: must be v2 again
+        assert torch.equal(qw.cpu(), b["qweight"])
+        check_forward(eng.gemv_forward_cuda_new(x.cuda(), qw, s, z, 4, N, K, 128).cpu(), x, b["q"], b["scales"], b["scaled_zeros"], torch.bfloat16)
+        del v2
+    finally:
+        eng.cdna4_cache_enable(True)
+        eng.cdna4_cache_inplace(False)

@@ -108,3 +108,75 @@ def test_entry_rejects_bad_arguments():
         ops.mlp_gate_up_forward_cdna4(c["x"].cuda(), c4, szp, None, group_size=64)
     with pytest.raises((TypeError, _capi.AwqNativeError)):
         ops.mlp_gate_up_forward_cdna4(c["x"].cuda().float(), c4, szp, None)
+
+
+def test_one_launch_entry_is_not_in_the_product_library(monkeypatch):
+    """awq_w4a16_mlp_decode_cdna4 (QuantLlamaMLP.forward as ONE launch) measured slower than two launches
+    (profiles/r02_mlp_one_launch.txt) and exists in AWQ_PROBES builds only: a product library answers "shape not served" and
+    QuantLlamaMLP falls back to the two-launch path even when the opt-in is set."""
+    import torch.nn as nn
+    from llm_awq_amd.fused_mlp import make_fused_mlp
+    from llm_awq_amd.qmodule import WQLinear
+    H, F, dtype = 4096, 2048, torch.bfloat16
+    cg, cu, x, act = _pair(F, H, dtype, 5, 4)
+    cd = make_case(H, F, dtype, seed=7, M=1)
+
+    def lin(c, k, n):
+        m = WQLinear(4, 128, k, n, False, "cuda", dtype=dtype)
+        m.load_state_dict(dict(qweight=c["qweight"], scales=c["scales"], scaled_zeros=c["scaled_zeros"]))
+        return m
+
+    class LlamaMLP(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.gate_proj, self.up_proj, self.down_proj = lin(cg, H, F), lin(cu, H, F), lin(cd, F, H)
+
+    class Block(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.mlp = LlamaMLP()
+
+    mlp = make_fused_mlp(Block()).mlp
+    y2 = mlp(x.cuda()).cpu()
+    monkeypatch.setenv("AWQ_MLP_ONE_LAUNCH", "1")
+    y1 = mlp(x.cuda()).cpu()
+    # (an AWQ_PROBES build runs the one-launch kernel here: same roundings, another K split of down_proj)
+    from tests.helpers import assert_bits
+    assert_bits(y1, y2, 0.2, what="one-launch opt-in vs two launches")
+    check_forward(y2, mlp.our_llama_mlp(x.cuda()).cpu(), cd["q"], cd["scales"], cd["scaled_zeros"], dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_v2_gate_up_buffers_are_released_and_state_dict_round_trips(dtype):
+    """fused_mlp.py:19-27 registers the six v2 gate / up buffers: here they are released once the fused cdna4 stream exists (no second
+    copy of two thirds of the block's weights) and state_dict() / load_state_dict() still speak the reference's keys bit-exactly."""
+    import torch.nn as nn
+    from llm_awq_amd.fused_mlp import QuantLlamaMLP
+    from llm_awq_amd.qmodule import WQLinear
+    H, F = 1024, 1408
+    cg, cu, x, act = _pair(F, H, dtype, 31, 12)
+    cd = make_case(H, F, dtype, seed=33, M=1)
+
+    def lin(c, k, n):
+        m = WQLinear(4, 128, k, n, False, "cuda", dtype=dtype)
+        m.load_state_dict(dict(qweight=c["qweight"], scales=c["scales"], scaled_zeros=c["scaled_zeros"]))
+        return m
+
+    mlp = QuantLlamaMLP(lin(cg, H, F), lin(cd, F, H), lin(cu, H, F))
+    before = {k: v.clone() for k, v in mlp.state_dict().items()}
+    y0 = mlp(x.cuda()).cpu()
+    held = sum(getattr(mlp, n).numel() for n in ("gate_proj_qweight", "up_proj_qweight", "gate_proj_scales", "up_proj_scales",
+                                                 "gate_proj_scaled_zeros", "up_proj_scaled_zeros"))
+    assert held == 0, "the v2 copies are gone once the fused stream is built"
+    after = mlp.state_dict()
+    assert set(before) <= set(after)  # (+ down_proj's layout marker: QuantLlamaMLP moved it to the cdna4 interleave)
+    for k in before:
+        if not k.startswith("down_proj."):
+            assert after[k].shape == before[k].shape and torch.equal(after[k].cpu(), before[k].cpu()), k
+    # load into a fresh module, and back into the one whose buffers were released
+    fresh = QuantLlamaMLP(lin(cu, H, F), lin(cd, F, H), lin(cg, H, F))  # (gate / up swapped on purpose: the load must overwrite them)
+    fresh(x.cuda())
+    fresh.load_state_dict(after)
+    assert torch.equal(fresh(x.cuda()).cpu(), y0)
+    mlp.load_state_dict(before)
+    assert torch.equal(mlp(x.cuda()).cpu(), y0)

