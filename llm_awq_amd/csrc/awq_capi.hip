@@ -357,6 +357,10 @@ int awq_w4a16_moe_forward_cdna4(const void* x_sorted, const void* qweight, const
       awq::launch_moe_skinny_cdna4(x_sorted, qweight, sz_packed, expert_offsets, out, total_tokens, num_experts, n, k, dtype,
                                    (hipStream_t)stream) == 0)
     return finish_launch();
+  if (total_tokens >= 256 && awq::moe_v6_enabled() &&
+      awq::launch_moe_gemm_cdna4_v6(x_sorted, qweight, sz_packed, expert_offsets, out, total_tokens, num_experts, n, k, dtype,
+                                    (hipStream_t)stream) == 0)
+    return finish_launch();
   if (total_tokens >= 256 && awq::moe_v4_enabled() &&
       awq::launch_moe_gemm_cdna4_v4(x_sorted, qweight, sz_packed, expert_offsets, out, total_tokens, num_experts, n, k, dtype,
                                     (hipStream_t)stream) == 0)

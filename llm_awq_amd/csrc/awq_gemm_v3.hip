@@ -356,9 +356,14 @@ namespace {
 int g_moe_v4 = 1;  // grouped prefill GEMM on 256 x 256 tiles (awq_gemm_v4.hip); 0: the 128 x 128 grouped kernel
 }
 bool moe_v4_enabled() { return g_moe_v4 != 0; }
+namespace {
+int g_moe_v6 = 1;  // grouped prefill GEMM on the v6 tile (awq_gemm_v6.hip); 0: the v4 loop above
+}
+bool moe_v6_enabled() { return g_moe_v6 != 0; }
 
 int gemm_v3_tune_set(const char* key, int value) {
-  if (!strcmp(key, "gemm_v4")) g_v4 = value;
+  if (!strcmp(key, "moe_v6")) g_moe_v6 = value;
+  else if (!strcmp(key, "gemm_v4")) g_v4 = value;
   else if (!strcmp(key, "gemm_v6")) {  // units: 0 off, 1 = the 256-wide tiles, 2 = every tile; tens (probe builds): timing-only probe of the kernel
     g_v6 = value % 10;
     gemm_v6_set_probe(value / 10);

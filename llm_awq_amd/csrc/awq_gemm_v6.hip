@@ -75,40 +75,17 @@ __device__ __forceinline__ void v6_mfma(f32x4& acc, const V8& a, const u32x4& b)
 // NS = weight slabs (16 columns) per wave: 4 -> 256-column blocks; 3 -> 192-column blocks (accumulators 192 AGPRs) for matrices
 // whose 256-wide tile count leaves a partial round that 192-wide tiles fill (qkv of Llama-3-8B: 6144 = 32 x 192 -> 8 x 32 = 256 tiles
 // at M = 2048 instead of 192)
-template <typename DT, int BITS, int PROBE = 0, int DQ = 0, int NS = 4>
-__global__ __launch_bounds__(256) void gemm_cdna4_v6_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
-                                                            const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
-                                                            uint16_t* __restrict__ out, int M, int N, int K, int tiles_m, int tiles_n,
-                                                            int n_begin, int n_end, int epi) {
+template <typename DT, int BITS, int PROBE, int DQ, int NS>
+__device__ __forceinline__ void v6_tile(char* smem, const uint16_t* __restrict__ x, const u32* __restrict__ qw, const u32* __restrict__ szp,
+                                        const uint16_t* __restrict__ bias, uint16_t* __restrict__ out, int N, int K, int m0, int n0, int n_end,
+                                        int epi, int row_lo, int row_hi) {
+  // one 256 x (64 NS) output tile: rows [m0, m0 + 256) of x (all readable), weight rows [n0, ...) below n_end; rows outside
+  // [row_lo, row_hi) are computed but NOT stored (grouped GEMM: they belong to another expert's segment)
   using vec8 = typename DT::vec8;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
   const int nit = K >> 7;
-
-  // XCD-aware, two-row-band tile order (as awq_gemm_v4.hip)
-  const int T = tiles_m * tiles_n;
-  int tile;
-  {
-    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
-    const int q = T >> 3, r = T & 7;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  int tm, tn;
-  {
-    const int full = (tiles_m >> 1) * 2 * tiles_n;
-    if (tile < full) {
-      const int band = tile / (2 * tiles_n), rem = tile - band * 2 * tiles_n;
-      tn = rem >> 1;
-      tm = 2 * band + (rem & 1);
-    } else {
-      tn = tile - full;
-      tm = tiles_m - 1;
-    }
-  }
-  // the last row tile is shifted up to end at row M - 1 (M >= 256: the launcher's contract): no row index needs clamping or masking
   constexpr int TN = 64 * NS;  // columns per block
-  const int m0 = min(tm * V6_TM, M - V6_TM), n0 = n_begin + tn * TN;
 
   // ---- x staging: piece q (0..15) of this wave = rows 64 wv + 4 q .. + 3, one 16-byte granule per lane ----
   // LDS layout of a stage: row r (256 B = 16 granules of 8 k) stores logical granule p at slot p ^ (r & 15)
@@ -417,7 +394,7 @@ __global__ __launch_bounds__(256) void gemm_cdna4_v6_kernel(const uint16_t* __re
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const int m = m0 + 64 * wv + 4 * (it0 + b) + (lane >> 4);
-        if (ok) __builtin_nontemporal_store(silu_mul_octet<DT>(v[b], u[b]), reinterpret_cast<u32x4*>(out + (size_t)m * (N >> 1) + (nn >> 1)));
+        if (ok && m >= row_lo && m < row_hi) __builtin_nontemporal_store(silu_mul_octet<DT>(v[b], u[b]), reinterpret_cast<u32x4*>(out + (size_t)m * (N >> 1) + (nn >> 1)));
       }
     }
   } else {
@@ -447,10 +424,75 @@ __global__ __launch_bounds__(256) void gemm_cdna4_v6_kernel(const uint16_t* __re
           };
           o = u32x4{add2(o.x, bv.x), add2(o.y, bv.y), add2(o.z, bv.z), add2(o.w, bv.w)};
         }
-        if (ncol_ok) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(out + (size_t)m * N + nn));  // streamed: keep x / weight panels in L2
+        if (ncol_ok && m >= row_lo && m < row_hi) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(out + (size_t)m * N + nn));  // streamed: keep x / weight panels in L2
       }
     }
   }
+}
+
+template <typename DT, int BITS, int PROBE = 0, int DQ = 0, int NS = 4>
+__global__ __launch_bounds__(256) void gemm_cdna4_v6_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
+                                                            const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
+                                                            uint16_t* __restrict__ out, int M, int N, int K, int tiles_m, int tiles_n,
+                                                            int n_begin, int n_end, int epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // XCD-aware, two-row-band tile order (as awq_gemm_v4.hip)
+  const int T = tiles_m * tiles_n;
+  int tile;
+  {
+    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    const int q = T >> 3, r = T & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tm, tn;
+  {
+    const int full = (tiles_m >> 1) * 2 * tiles_n;
+    if (tile < full) {
+      const int band = tile / (2 * tiles_n), rem = tile - band * 2 * tiles_n;
+      tn = rem >> 1;
+      tm = 2 * band + (rem & 1);
+    } else {
+      tn = tile - full;
+      tm = tiles_m - 1;
+    }
+  }
+  // the last row tile is shifted up to end at row M - 1 (M >= 256: the launcher's contract): no row index needs clamping or masking
+  v6_tile<DT, BITS, PROBE, DQ, NS>(smem, x, qw, szp, bias, out, N, K, min(tm * V6_TM, M - V6_TM), n_begin + tn * (64 * NS), n_end, epi, 0, M);
+}
+
+// Grouped (per-expert) GEMM on the same tile: tokens sorted by expert, `offsets[e] .. offsets[e + 1]` = expert e's rows, stacked cdna4
+// weights [E][N/16][K/128] tiles + packed scales (Mixtral w1 / w3 / w2: SURVEY.md 8(e) MoE row; the reference has no grouped kernel --
+// tinychat loops over experts).  Row tile rt of expert e covers its rows [lo + 256 rt, min(.. + 256, hi)); the tile itself always reads
+// 256 in-range rows of x (shifted up at the end of the token list) and the epilogue stores only the segment's rows, so a short segment
+// costs one tile and never sees another expert's weights in its outputs.
+template <typename DT>
+__global__ __launch_bounds__(256) void moe_gemm_cdna4_v6_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
+                                                                const u32* __restrict__ szp, const int* __restrict__ offsets,
+                                                                uint16_t* __restrict__ out, int total, int experts, int N, int K,
+                                                                int row_tiles, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int T = row_tiles * tiles_n;
+  int tile;
+  {
+    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    const int q = T >> 3, r = T & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int rt = tile / tiles_n;
+  const int tn = tile - rt * tiles_n;
+  int e = 0, lo = 0, hi = 0;
+  for (; e < experts; ++e) {
+    lo = offsets[e];
+    hi = offsets[e + 1];
+    const int cnt = (hi - lo + V6_TM - 1) / V6_TM;
+    if (rt < cnt) break;
+    rt -= cnt;
+  }
+  if (e == experts) return;  // wave-uniform: no tile for this block
+  const int r_lo = lo + rt * V6_TM, r_hi = min(r_lo + V6_TM, hi);
+  const size_t ew = (size_t)(N >> 4) * (K >> 7);  // tiles per expert
+  v6_tile<DT, 4, 0, 0, 4>(smem, x, qw + (size_t)e * ew * 256, szp + (size_t)e * ew * 16, nullptr, out, N, K, min(r_lo, total - V6_TM), tn * V6_TN,
+                          N, 0, r_lo, r_hi);
 }
 
 namespace {
@@ -499,6 +541,23 @@ void launch_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, const 
   optin[a][b].ensure(reinterpret_cast<const void*>(kern), smem);
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp,
                      (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end, epi);
+}
+
+// grouped GEMM over sorted tokens with the v6 tile; needs total >= 256.  Returns -1 if unsupported.
+int launch_moe_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total, int experts,
+                             int n, int k, int dtype, hipStream_t st) {
+  if (total < V6_TM || experts < 1 || (n % 16) != 0 || (k % 128) != 0 || (size_t)total * (size_t)k >= (1ull << 31) ||
+      (size_t)n * (size_t)k / 8 >= (1ull << 31))
+    return -1;
+  constexpr int stage2 = 2 * kV6Stage, stg_epi = V6_TM * kV6Pitch;
+  constexpr int smem = stage2 > stg_epi ? stage2 : stg_epi;
+  static LdsOptIn optin[2];
+  auto kern = dtype == 0 ? moe_gemm_cdna4_v6_kernel<F16> : moe_gemm_cdna4_v6_kernel<BF16>;
+  optin[dtype == 0 ? 0 : 1].ensure(reinterpret_cast<const void*>(kern), smem);
+  const int row_tiles = total / V6_TM + experts, tiles_n = (n + V6_TN - 1) / V6_TN;
+  hipLaunchKernelGGL(kern, dim3(row_tiles * tiles_n), dim3(256), smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp,
+                     (const int*)offsets, (uint16_t*)out, total, experts, n, k, row_tiles, tiles_n);
+  return 0;
 }
 
 }  // namespace awq

@@ -96,6 +96,10 @@ size_t gemm_cdna4_v3_workspace_bytes_w3(int m, int n, int k);  // same rule for 
 int launch_moe_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total, int experts,
                              int n, int k, int dtype, hipStream_t st);
 bool moe_v4_enabled();
+// the same grouped GEMM on the v6 tile (awq_gemm_v6.hip: one pipelined wave per SIMD, weights in registers); total >= 256
+int launch_moe_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total, int experts,
+                             int n, int k, int dtype, hipStream_t st);
+bool moe_v6_enabled();  // knob moe_v6 (default on)
 // 256 x 256-tile prefill GEMM with the hand-scheduled K loop (awq_gemm_v4.hip): weight rows [n_begin, n_end), m >= 256
 void launch_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                           int n_begin, int n_end, int dtype, hipStream_t st, int bits = 4, int epi = 0);

@@ -138,12 +138,14 @@ def test_gpu_grouped_decode_and_module(counts):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("counts", [[300, 0, 1, 255], [256, 256], [1, 700, 3, 40], [0, 0, 0, 256], [511, 2, 257, 0, 90]])
-def test_gpu_grouped_prefill_v4(counts):
-    """>= 256 sorted rows: the grouped 256 x 256 kernel (awq_gemm_v4.hip; tiles straddling expert boundaries, the shifted
-    last tile, empty experts) is bit-identical to the 128 x 128 grouped kernel (knob moe_v4=0) and meets the oracle."""
+def test_gpu_grouped_prefill_v6_v4_and_128(counts, dtype):
+    """>= 256 sorted rows: the grouped kernel on the v6 tile (default; awq_gemm_v6.hip) and on the v4 loop (knob moe_v6=0;
+    awq_gemm_v4.hip) -- tiles straddling expert boundaries, the shifted last tile, empty experts, segments shorter than a tile --
+    against the per-expert oracle; the v4 loop is bit-identical to the 128 x 128 grouped kernel (knobs moe_v6=0, moe_v4=0), the v6
+    tile agrees with both up to the association inside one 32-k MFMA."""
     from llm_awq_amd import ops
-    dtype = torch.bfloat16
     E, N, K = len(counts), 400, 512
     mods, cases = _experts(E, N, K, dtype, seed=sum(counts) + 11)
     grp = MOE.GroupedWQLinear(mods).cuda().to_cdna4()
@@ -151,18 +153,48 @@ def test_gpu_grouped_prefill_v4(counts):
     g = Gen(T + 5)
     x = g.randn(T, K).to(dtype).cuda()
     off = torch.tensor([0] + list(np.cumsum(counts)), dtype=torch.int32).cuda()
-    y = grp(x, off)
-    ops._capi.tune(moe_v4=0)
+    y6 = grp(x, off)
     try:
+        ops._capi.tune(moe_v6=0)
+        y4 = grp(x, off)
+        ops._capi.tune(moe_v4=0)
         y_ref = grp(x, off)
     finally:
-        ops._capi.tune(moe_v4=1)
-    assert torch.equal(y, y_ref)
-    y, x = y.cpu(), x.cpu()
+        ops._capi.tune(moe_v4=1, moe_v6=1)
+    if dtype == torch.bfloat16:
+        assert torch.equal(y4, y_ref)
+    else:
+        assert_bits(y4, y_ref, 0.01)
+    assert_bits(y6, y4, 0.01, what="v6 tile vs v4 loop")
+    x = x.cpu()
+    for y in (y6.cpu(), y4.cpu()):
+        for e in range(E):
+            lo, hi = int(off[e]), int(off[e + 1])
+            if hi > lo:
+                check_forward(y[lo:hi], x[lo:hi], cases[e]["q"], cases[e]["scales"], cases[e]["scaled_zeros"], dtype)
+
+
+@pytest.mark.gpu
+def test_gpu_grouped_prefill_mixtral_shape_v6():
+    """Mixtral-8x7B w1 (4096 -> 14336), 8 experts, 1024 tokens x top-2 = 2048 sorted rows with a ragged split: the v6 grouped tile
+    against per-expert calls of the plain (dense, separately verified) prefill GEMM on the same buffers."""
+    from llm_awq_amd import ops, synth
+    E, H, F = 8, 4096, 14336
+    counts = [300, 212, 256, 1, 511, 0, 257, 511]
+    ws = [synth.random_wq(H, F, dtype=torch.bfloat16, seed=40 + e, keep_q=False) for e in range(E)]
+    c4 = torch.stack([ops.repack_v2_to_cdna4(w["qweight"]) for w in ws])
+    s = torch.stack([w["scales"] for w in ws])
+    z = torch.stack([w["scaled_zeros"] for w in ws])
+    szp = torch.stack([ops.pack_sz_cdna4(w["scales"], w["scaled_zeros"], H) for w in ws])
+    T = sum(counts)
+    x = torch.randn(T, H, device="cuda", generator=cuda_gen(3)).to(torch.bfloat16)
+    off = torch.tensor([0] + list(np.cumsum(counts)), dtype=torch.int32).cuda()
+    y = ops.moe_forward_cdna4(x, c4, s, z, szp, off)
     for e in range(E):
         lo, hi = int(off[e]), int(off[e + 1])
-        if hi > lo:
-            check_forward(y[lo:hi], x[lo:hi], cases[e]["q"], cases[e]["scales"], cases[e]["scaled_zeros"], dtype)
+        if hi - lo >= 1:
+            ref = ops.gemm_cdna4(x[lo:hi].contiguous(), c4[e], s[e], z[e], None, szp[e])
+            assert_bits(ref, y[lo:hi], 0.01, what=f"expert {e}")
 
 
 @pytest.mark.gpu

@@ -45,8 +45,9 @@ def rand_sz(K, N, dev="cuda"):
 
 def main():
     dt = torch.bfloat16
+    only_moe = "moe" in sys.argv[1:]
     print("== W3A16, Llama-2-7B shapes (w3c tiles, 0.375 B / weight) ==")
-    for (K, N) in [(4096, 12288), (4096, 4096), (4096, 22016), (11008, 4096)]:
+    for (K, N) in ([] if only_moe else [(4096, 12288), (4096, 4096), (4096, 22016), (11008, 4096)]):
         R = max(8, min(40, (900 << 20) // (N * K * 3 // 8)))
         items = []
         for i in range(R):
@@ -80,9 +81,13 @@ def main():
         order, off = sort_by_expert(ids, E)
         xs = torch.randn(2 * T, K, device="cuda").to(dt)
         szp = torch.stack([ops.pack_sz_cdna4(ss[e], zs[e], K) for e in range(E)])
-        for label, fn in (("128x128 grouped kernel", lambda _c: ops.moe_gemm(xs, qw, s, z, off, layout="cdna4")),
-                          ("256x256 grouped v4    ", lambda _c: ops.moe_forward_cdna4(xs, qw, s, z, szp, off))):
+        for label, knob, fn in (("128x128 grouped kernel", None, lambda _c: ops.moe_gemm(xs, qw, s, z, off, layout="cdna4")),
+                                ("256x256 grouped v4    ", 0, lambda _c: ops.moe_forward_cdna4(xs, qw, s, z, szp, off)),
+                                ("256x256 grouped v6    ", 1, lambda _c: ops.moe_forward_cdna4(xs, qw, s, z, szp, off))):
+            if knob is not None:
+                _capi.tune(moe_v6=knob)
             us = graph_time(fn, [0, 1, 2, 3])
+            _capi.tune(moe_v6=1)
             tf = 2.0 * 2 * T * N * K / us / 1e6
             print(f"{name:6s} K={K:6d} N={N:6d} rows={2 * T} {label} {us:8.1f} us  {tf:7.1f} TFLOP/s  {tf / 25:5.1f}% of 2.5 PF",
                   flush=True)
