@@ -160,6 +160,11 @@ int awq_w4a16_rmsnorm_forward_cdna4(const void* x, const void* gamma, float eps,
                                     const void* bias, void* out, int m, int n, int k, int group_size, int dtype,
                                     int fused_gate_up, void* stream);
 
+/* The norm alone, any row count (the prefill side of the same step; replaces layernorm_forward_cuda, awq/kernels/csrc/layernorm/
+ * layernorm.cu:39-89 as tinychat's FTLlamaRMSNorm calls it, fused_norm.py:7-21): out[m, k] = T((float(x) * rsqrtf(mean(x^2) + eps)) *
+ * float(gamma)), fp32 sum of squares, one rounding.  k % 8 == 0; x, gamma, out 16-byte aligned. */
+int awq_rmsnorm(const void* x, const void* gamma, float eps, void* out, int m, int k, int dtype, void* stream);
+
 /* OPTIONAL fp32 workspace of awq_w4a16_gemm_cdna4 / awq_w4a16_forward_cdna4 (0 = none useful).  Prompts of 256 .. ~1 k tokens
  * against narrow projections produce too few output tiles to fill the 256 CUs; given this many bytes (16-byte aligned) the
  * K loop is split over blocks and a second kernel adds the partial tiles in a fixed order -- the role of the reference's

@@ -279,6 +279,16 @@ int awq_w4a16_rmsnorm_forward_cdna4(const void* x, const void* gamma, float eps,
   return finish_launch();
 }
 
+int awq_rmsnorm(const void* x, const void* gamma, float eps, void* out, int m, int k, int dtype, void* stream) {
+  if (!x || !gamma || !out) return AWQ_ERR_NULL;
+  if (dtype != AWQ_F16 && dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
+  if (m < 1) return AWQ_ERR_BATCH;
+  if (k < 8 || (k % 8) != 0) return AWQ_ERR_SHAPE;
+  if (!aligned16(x) || !aligned16(gamma) || !aligned16(out)) return AWQ_ERR_ALIGN;
+  if (awq::launch_rmsnorm(x, gamma, eps, out, m, k, dtype, (hipStream_t)stream) != 0) return AWQ_ERR_SHAPE;
+  return finish_launch();
+}
+
 size_t awq_w4a16_forward_cdna4_workspace_bytes(int m, int n, int k) { return awq::gemm_cdna4_v3_workspace_bytes(m, n, k); }
 int awq_w4a16_gemm_cdna4_plan(int m, int n, int bits, int* mode, int* cols_main) { return awq::gemm_cdna4_v3_plan(m, n, bits, mode, cols_main); }
 

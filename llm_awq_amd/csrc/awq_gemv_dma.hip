@@ -305,7 +305,7 @@ struct DmaCfg {
   int waves, tx, d;
   size_t smem;
 };
-int g_dma_waves = 0, g_dma_d = 0, g_dma_probe = 0;
+int g_dma_waves = 0, g_dma_d = 0, g_dma_probe = 0, g_dma_four = 1;  // gemvd_four: four ring-7 blocks per CU where there are > 3 slabs per CU (rounds 4 + 3 instead of 3 + 3 + 1: +0.6 % decode tok/s, profiles/r03_gemvps.txt)
 
 size_t dma_smem(int waves, int d, int ns, int tx, int m) {
   const int txp = (tx + 3) & ~3;
@@ -323,7 +323,7 @@ bool pick_dma(int m, int n_rows, int k, int ns, DmaCfg& c) {
   if (g_dma_waves) waves = g_dma_waves;
   while (waves > 4 && waves > nit) waves >>= 1;  // (waves beyond the step count idle: their steps are clamped and skipped)
   int want = blocks_per_cu <= 1.0 ? 1 : (blocks_per_cu <= 2.0 ? 2 : (blocks_per_cu <= 3.0 ? 3 : 4));
-  if (waves == 4 && want > 3) want = 3;  // three deep-ring blocks per CU beat four shallow ones (gate/up: 14.8 vs 15.1 us)
+  if (waves == 4 && want > 3 && !g_dma_four) want = 3;  // (three ring-8 blocks beat four ring-4 ones: 14.8 vs 15.1 us; four ring-7 blocks beat both)
   // x staging is m * k * 2 bytes per block whatever the wave count: when it crowds out the ring, fewer, longer waves
   while (waves > 4 && dma_smem(waves, 1, ns, (nit + waves - 1) / waves, m) > 150 * 1024) waves >>= 1;
   const int tx = (nit + waves - 1) / waves;
@@ -335,7 +335,7 @@ bool pick_dma(int m, int n_rows, int k, int ns, DmaCfg& c) {
   while (d > 1 && dma_smem(waves, d, ns, tx, m) * want > 156 * 1024) --d;
   // compiled ring depths: 1, 2, 4, 8 (7 with 16 waves: K = 14336)
   if (d == 3) d = 2;
-  if (d == 5 || d == 6 || (d == 7 && waves != 16)) d = 4;
+  if (d == 5 || d == 6 || (d == 7 && waves == 8)) d = 4;
   if (d == 8 && waves == 16) d = 7;
   c = {waves, tx, d, dma_smem(waves, d, ns, tx, m)};
   return c.smem <= 160 * 1024 && tx >= d;
@@ -346,6 +346,7 @@ int gemv_dma_tune_set(const char* key, int value) {
   if (!strcmp(key, "gemvd_waves")) g_dma_waves = value;
   else if (!strcmp(key, "gemvd_d")) g_dma_d = value;
   else if (!strcmp(key, "gemvd_probe")) g_dma_probe = value;
+  else if (!strcmp(key, "gemvd_four")) g_dma_four = value;
   else return -1;
   return 0;
 }
@@ -373,7 +374,7 @@ static int launch_dma_dt(const void* x, const void* qw, const void* szp, const v
   }
   AWQ_DCASE(8, 1) AWQ_DCASE(8, 2) AWQ_DCASE(8, 4) AWQ_DCASE(8, 8)
   AWQ_DCASE(16, 1) AWQ_DCASE(16, 2) AWQ_DCASE(16, 4) AWQ_DCASE(16, 7)
-  AWQ_DCASE(4, 1) AWQ_DCASE(4, 2) AWQ_DCASE(4, 4) AWQ_DCASE(4, 8)
+  AWQ_DCASE(4, 1) AWQ_DCASE(4, 2) AWQ_DCASE(4, 4) AWQ_DCASE(4, 7) AWQ_DCASE(4, 8)
 #undef AWQ_DCASE
   return -1;
 }

@@ -114,6 +114,8 @@ int launch_mlp_decode(const void* x, const void* qw_gu, const void* szh_gu, cons
 void launch_gemm_cdna4_v5(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
                           int n_end, int dtype, hipStream_t st, int bits = 4, int mf = 16);
 int launch_bias_add(void* out, const void* bias, int m, int n, int dtype, hipStream_t st);
+// RMSNorm of m rows of k (awq_util.hip; layernorm.cu:39-61's arithmetic); -1 if k % 8 != 0
+int launch_rmsnorm(const void* x, const void* gamma, float eps, void* out, int m, int k, int dtype, hipStream_t st);
 int launch_unpack_v2(const void* qw, void* out_u8, int n, int k, hipStream_t st);
 int launch_dequant_v2(const void* qw, const void* s, const void* z, void* out, int n, int k, int dtype, hipStream_t st);
 int launch_pack_v2(const void* q_u8, void* qw, int n, int k, hipStream_t st);

@@ -313,6 +313,54 @@ int launch_dequant_cdna4(const void* qw, const void* s, const void* z, void* out
   return 0;
 }
 
+// RMSNorm of whole rows (prefill side of RMSNormWQLinear; decode rows are fused into the GEMV, awq_gemv_cdna4.hip NORM = 1): one 256-thread
+// block per row, 16-byte loads, fp32 sum of squares (lane -> wave -> block), rsqrtf(mean + eps), (x * rstd) * gamma with ONE rounding
+// to T -- layernorm.cu:48-60's arithmetic (generalT5LayerNorm: no mean subtraction, no bias).  k % 8 == 0.
+template <typename DT>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gamma,
+                                                      uint16_t* __restrict__ out, int K, float eps) {
+  __shared__ float part[4];
+  const uint16_t* xr = x + (size_t)blockIdx.x * K;
+  uint16_t* orow = out + (size_t)blockIdx.x * K;
+  const int ng = K >> 3;  // 16-byte granules per row
+  float ss = 0.f;
+  for (int gi = threadIdx.x; gi < ng; gi += 256) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(xr + (size_t)gi * 8);
+    const u32 w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float lo = DT::to_float((uint16_t)(w4[e] & 0xFFFFu)), hi = DT::to_float((uint16_t)(w4[e] >> 16));
+      ss = __builtin_fmaf(lo, lo, ss);
+      ss = __builtin_fmaf(hi, hi, ss);
+    }
+  }
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) ss += __shfl_xor(ss, d, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  const float tot = (part[0] + part[1]) + (part[2] + part[3]);
+  const float rstd = rsqrtf(tot / (float)K + eps);  // layernorm.cu:55
+  for (int gi = threadIdx.x; gi < ng; gi += 256) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(xr + (size_t)gi * 8), gv = *reinterpret_cast<const u32x4*>(gamma + (size_t)gi * 8);
+    const u32 w4[4] = {v.x, v.y, v.z, v.w}, g4[4] = {gv.x, gv.y, gv.z, gv.w};
+    u32 o4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {  // layernorm.cu:60: T((float(x) * s_variance) * float(gamma))
+      const float lo = (DT::to_float((uint16_t)(w4[e] & 0xFFFFu)) * rstd) * DT::to_float((uint16_t)(g4[e] & 0xFFFFu));
+      const float hi = (DT::to_float((uint16_t)(w4[e] >> 16)) * rstd) * DT::to_float((uint16_t)(g4[e] >> 16));
+      o4[e] = (u32)DT::from_float(lo) | ((u32)DT::from_float(hi) << 16);
+    }
+    *reinterpret_cast<u32x4*>(orow + (size_t)gi * 8) = u32x4{o4[0], o4[1], o4[2], o4[3]};
+  }
+}
+
+int launch_rmsnorm(const void* x, const void* gamma, float eps, void* out, int m, int k, int dtype, hipStream_t st) {
+  if (m < 1 || k < 8 || (k % 8) != 0) return -1;
+  if (dtype == 0) hipLaunchKernelGGL((rmsnorm_kernel<F16>), dim3(m), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)gamma, (uint16_t*)out, k, eps);
+  else hipLaunchKernelGGL((rmsnorm_kernel<BF16>), dim3(m), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)gamma, (uint16_t*)out, k, eps);
+  return 0;
+}
+
 int launch_bias_add(void* out, const void* bias, int m, int n, int dtype, hipStream_t st) {
   const size_t total = (size_t)m * n;
   if (dtype == 0)

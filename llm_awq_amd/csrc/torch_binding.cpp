@@ -494,6 +494,20 @@ torch::Tensor mlp_gate_up_cdna4(torch::Tensor in_feats, torch::Tensor kernel_gat
 
 // FTLlamaRMSNorm (tinychat/modules/fused_norm.py:7-21 -> layernorm.cu:39-61) fused in front of the decode GEMV: x is the
 // UN-normalised activation, gamma the norm weight [k]; <= 4 rows.  fused_gate_up: kernel = stacked [gate; up], out [.., n/2].
+// FTLlamaRMSNorm.forward for any row count (tinychat/modules/fused_norm.py:16-21 -> layernorm_forward_cuda): one launch
+torch::Tensor rmsnorm(torch::Tensor in_feats, torch::Tensor gamma, double eps) {
+  TORCH_CHECK(in_feats.is_cuda() && gamma.is_cuda() && in_feats.is_contiguous() && gamma.is_contiguous());
+  TORCH_CHECK((in_feats.scalar_type() == at::kBFloat16 || in_feats.scalar_type() == at::kHalf) && gamma.scalar_type() == in_feats.scalar_type());
+  const int64_t k = in_feats.size(-1);
+  TORCH_CHECK(k > 0 && gamma.numel() == k);
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(in_feats.device());
+  at::Tensor out = torch::empty_like(in_feats);
+  if (in_feats.numel() == 0) return out;
+  raise_on(awq_rmsnorm(in_feats.data_ptr(), gamma.data_ptr(), (float)eps, out.data_ptr(), (int)(in_feats.numel() / k), (int)k, dtype_code(in_feats),
+                       (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()));
+  return out;
+}
+
 torch::Tensor rmsnorm_forward_cdna4(torch::Tensor in_feats, torch::Tensor gamma, double eps, torch::Tensor kernel, torch::Tensor sz_packed,
                                     c10::optional<torch::Tensor> bias, bool fused_gate_up) {
   TORCH_CHECK(in_feats.is_cuda() && gamma.is_cuda() && kernel.is_cuda() && sz_packed.is_cuda());
@@ -667,6 +681,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("pack_szh_cdna4", &pack_szh_cdna4, "scales/scaled_zeros [Gpad,N] -> (sz_half int32 [N/16, K/128, 16], exact)");
   m.def("decode_cdna4", &decode_cdna4, "<= 8 rows on cdna4 weights + sz_half (LDS-DMA streaming kernel)", py::arg("in_feats"),
         py::arg("kernel"), py::arg("sz_half"), py::arg("bias") = py::none(), py::arg("epilogue") = 0);
+  m.def("rmsnorm", &rmsnorm, "RMSNorm of every row (layernorm_forward_cuda's arithmetic), one launch", py::arg("in_feats"), py::arg("gamma"), py::arg("eps"));
   m.def("rmsnorm_forward_cdna4", &rmsnorm_forward_cdna4, "RMSNorm fused in front of the decode GEMV (<= 4 rows)", py::arg("in_feats"),
         py::arg("gamma"), py::arg("eps"), py::arg("kernel"), py::arg("sz_packed"), py::arg("bias") = py::none(),
         py::arg("fused_gate_up") = false);

@@ -8,7 +8,7 @@ to T -- as one launch for decode rows (<= 4): every wave of the decode GEMV sums
 so the 8 KiB activation row never makes a round trip through HBM / L2.  Measured (profiles/r01_norm_fusion.txt): it costs what
 the separate norm launch costs for narrow projections and less for the gate/up pair, i.e. it removes a launch from the chain
 without removing time from it; it is offered for callers that want the launch count down, it is not the default of anything.
-Prefill rows run the norm with torch ops on the GPU (the reference's norm kernel is outside this repository's path).
+More rows run the norm as one launch of the same arithmetic (`awq_rmsnorm`, csrc/awq_util.hip), then the linear.
 """
 from __future__ import annotations
 
@@ -41,4 +41,7 @@ class RMSNormWQLinear(nn.Module):
                 lin.sz_cdna4 = load_engine().pack_sz_cdna4(lin.scales, lin.scaled_zeros, lin.in_features)
             return load_engine().rmsnorm_forward_cdna4(x.contiguous(), self.weight, float(self.variance_epsilon), lin.qweight,
                                                        lin.sz_cdna4, lin.bias, False)
+        if x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and self.weight.dtype == x.dtype and x.shape[-1] % 8 == 0:
+            # more rows: the norm as ONE launch of the same arithmetic (csrc/awq_util.hip rmsnorm_kernel), then the linear
+            return lin(load_engine().rmsnorm(x.contiguous(), self.weight.contiguous(), float(self.variance_epsilon)))
         return lin(rmsnorm_reference_semantics(x, self.weight, self.variance_epsilon))

@@ -283,6 +283,16 @@ def mlp_gate_up_forward_cdna4(x, qweight_interleaved, sz_packed, sz_half=None, g
     return out
 
 
+def rmsnorm(x, gamma, eps: float):
+    """C-ABI awq_rmsnorm: T((float(x) * rsqrt(mean(x^2) + eps)) * float(gamma)) for every row of x [.., k] (layernorm.cu:39-61)."""
+    _need_gpu(x, gamma)
+    k = x.shape[-1]
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _capi.check(_capi.lib().awq_rmsnorm(x.data_ptr(), gamma.data_ptr(), float(eps), out.data_ptr(), x.numel() // k, k, _dt(x), _stream(x)))
+    return out
+
+
 def rmsnorm_forward_cdna4(x, gamma, eps: float, qweight, sz_packed, bias=None, fused_gate_up: bool = False, group_size: int = 128):
     """C-ABI awq_w4a16_rmsnorm_forward_cdna4: T5/Llama RMSNorm (FTLlamaRMSNorm, fused_norm.py:7-21) fused in front of the
     quantised linear -- or, with fused_gate_up, of the gate/up pair + SiLU*mul.  x: un-normalised [.., K], 1 <= M <= 4."""

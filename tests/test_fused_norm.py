@@ -105,3 +105,22 @@ def test_module_matches_norm_then_linear(dtype):
         # on its hardware): where T(x * rstd * gamma) hangs on the last fp32 bits of rstd, one ulp of T of slack on that x
         unc = rmsnorm_uncertainty(x, gamma, eps)
         check_forward(mod(x.cuda()).cpu(), xn, c["q"], c["scales"], c["scaled_zeros"], dtype, bias=c["bias"], x_unc=unc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,K", [(1, 8), (3, 768), (5, 4096), (300, 4096), (17, 14336), (2, 11008)])
+def test_standalone_rmsnorm_vs_oracle(dtype, M, K):
+    """awq_rmsnorm (any row count; layernorm.cu:39-61's arithmetic) against the oracle: identical except where the rounding of
+    T(x * rstd * gamma) hangs on the last fp32 bits of rstd (hardware rsqrt, another order of the fp32 sum of squares)."""
+    from llm_awq_amd import ops
+    g = Gen(M * 7 + K)
+    x = (g.randn(M, K) * 3).to(dtype)
+    gamma = (1 + 0.2 * g.randn(K)).to(dtype)
+    eps = 1e-5
+    y = ops.rmsnorm(x.cuda(), gamma.cuda(), eps).cpu()
+    ref = O.rmsnorm(x, gamma, eps)
+    unc = rmsnorm_uncertainty(x, gamma, eps)
+    diff = (y.double() - ref.double()).abs()
+    assert (diff <= unc + 1e-30).all(), "a difference outside the elements whose rounding is undecided"
+    assert_bits(y, ref, 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -13, what="rmsnorm")
