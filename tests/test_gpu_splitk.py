@@ -6,6 +6,8 @@ split-K (gemm_cuda.cu:546-619) has the same property."""
 import pytest
 import torch
 
+from tests.helpers import assert_bits, cuda_gen
+
 pytestmark = pytest.mark.gpu
 
 SHAPES = [(4096, 4096), (14336, 4096), (1024, 1296), (4096, 6144), (8192, 1024)]

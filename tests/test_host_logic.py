@@ -1,5 +1,7 @@
 """not-gpu: the product's host-side mirror of the reference interface (llm_awq_amd.qmodule) against the
 golden vectors, the WQLinear buffer contract, and the 'no CPU fallback' rule."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -103,3 +105,14 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dp, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(dp, fn)
                 assert "awq_oracle" not in src, os.path.join(dp, fn)
+
+
+def test_no_undefined_names_in_the_python_sources():
+    """a static pass over tests/, the package, bench.py and the tools: a name that is loaded but never bound in its function or at
+    module level fails HERE (on the CPU), not in the one GPU test that reaches it (round 3: a missing import stopped `pytest -x -m gpu`)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_undefined_names.py")], cwd=root, capture_output=True, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if "undefined name" in ln and "__file__" not in ln]
+    assert not lines, lines
