@@ -305,11 +305,25 @@ struct DmaCfg {
   int waves, tx, d;
   size_t smem;
 };
+int g_dma_skinny_from = 0;  // knob decode_skinny_from: 0 = by shape (skinny_takes below), 1..8 = from that row count, 9 = never
 int g_dma_waves = 0, g_dma_d = 0, g_dma_probe = 0, g_dma_four = 1;  // gemvd_four: four ring-7 blocks per CU where there are > 3 slabs per CU (rounds 4 + 3 instead of 3 + 3 + 1: +0.6 % decode tok/s, profiles/r03_gemvps.txt)
 
 size_t dma_smem(int waves, int d, int ns, int tx, int m) {
   const int txp = (tx + 3) & ~3;
   return (size_t)waves * ((size_t)d * ns * 1024 + (size_t)ns * txp * 64 + (size_t)m * (txp * 256 + 16));
+}
+
+// Batched decode: this kernel stages m x K x 2 bytes of x per SLAB by LDS-DMA -- at m = 4 as many bytes as the slab's weights -- and the
+// staging region crowds the ring out of LDS (gate/up at m = 5: ring depth 1) or forces row chunks that re-stream the weights (K = 14336 at
+// m >= 6).  The skinny kernel (awq_skinny_cdna4.hip: x through registers, shared by a block's slabs, one weight pass for up to 16 rows)
+// costs the same for every m <= 8 and takes over where that staging exceeds ~128 KiB per CU (profiles/r03_decode_m_sweep.txt: gate/up
+// and down_proj from 5 rows, qkv at 8, o_proj never; a Llama-3-8B layer at m = 7: 56.0 -> 38.6 us).
+bool skinny_takes(int m, int n_rows, int k, int epi) {
+  if (epi == 1) return false;  // (the stacked [gate; up] form has no skinny epilogue)
+  if (g_dma_skinny_from) return m >= g_dma_skinny_from;
+  const double blocks_per_cu = (double)(n_rows / 16) / 256.0;
+  const int want = blocks_per_cu <= 1.0 ? 1 : (blocks_per_cu <= 2.0 ? 2 : (blocks_per_cu <= 3.0 ? 3 : 4));
+  return m >= 5 && (size_t)m * (size_t)k * 2 * want >= 128 * 1024;
 }
 
 // K split and ring depth: as many tiles in flight per CU as LDS allows (<= ~150 KiB per CU over the blocks that share it),
@@ -347,6 +361,7 @@ int gemv_dma_tune_set(const char* key, int value) {
   else if (!strcmp(key, "gemvd_d")) g_dma_d = value;
   else if (!strcmp(key, "gemvd_probe")) g_dma_probe = value;
   else if (!strcmp(key, "gemvd_four")) g_dma_four = value;
+  else if (!strcmp(key, "decode_skinny_from")) g_dma_skinny_from = value;
   else return -1;
   return 0;
 }
@@ -386,6 +401,7 @@ static int launch_dma_dt(const void* x, const void* qw, const void* szp, const v
 int launch_gemv_dma(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int epi,
                     int dtype, int szfmt, hipStream_t st) {
   if (m < 1 || m > 8 || (k % 128) != 0 || (n % (epi == 1 ? 32 : 16)) != 0) return -1;
+  if (skinny_takes(m, n, k, epi) && launch_skinny_decode(x, qw, szp, bias, out, m, n, k, epi, dtype, szfmt, st) == 0) return 0;
   DmaCfg probe_cfg;
   int mc = m;
   while (mc > 1 && !pick_dma(mc, n, k, epi == 1 ? 2 : 1, probe_cfg)) --mc;

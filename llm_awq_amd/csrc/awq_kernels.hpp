@@ -77,6 +77,9 @@ int gemm_variant_get();
 // skinny GEMM, 9 <= m <= 255 (row chunks of <= 64), cdna4 layout + packed sz (awq_skinny_cdna4.hip); bias may be nullptr; -1 if unsupported
 int launch_skinny_cdna4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                         int dtype, hipStream_t st);
+// batched decode on the same kernel (m <= 16; szfmt 1: szp = sz_half; epi 0 / 2 as launch_gemv_dma); -1 if unsupported
+int launch_skinny_decode(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int epi,
+                         int dtype, int szfmt, hipStream_t st);
 int launch_moe_gemm(const void* x, const void* qw, const void* s, const void* z, const void* offsets, void* out, int total_m,
                     int experts, int n, int k, int gpad, int dtype, int layout, hipStream_t st);
 int gemv_tune_set(const char* key, int value);

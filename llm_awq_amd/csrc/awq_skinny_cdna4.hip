@@ -15,7 +15,9 @@
 namespace awq {
 
 // the block's work for slab group `nb` on M <= 16 CB rows: shared by the plain kernel and the grouped (per-expert) kernel
-template <typename DT, int WAVES, int NS, int CB>
+// DQ 1: szp is the decode side buffer "sz_half" (f16-mantissa dequant form, Cdna4DequantH); EPI 2: QuantLlamaMLP's 8 + 8 interleaved
+// gate / up slabs, out[m, N / 2] = silu(gate) * up (batched decode of 5..8 rows arrives here from launch_gemv_dma)
+template <typename DT, int WAVES, int NS, int CB, int DQ = 0, int EPI = 0>
 __device__ __forceinline__ void skinny_cdna4_body(char* smem, const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                   const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
                                                   uint16_t* __restrict__ out, int M, int N, int K, int nb) {
@@ -43,7 +45,9 @@ __device__ __forceinline__ void skinny_cdna4_body(char* smem, const uint16_t* __
   }
 
   Cdna4DequantT<DT> cd;
-  cd.init(lane);
+  Cdna4DequantH<DT> ch;
+  if (DQ == 0) cd.init(lane);
+  else ch.init(lane);
   const int cnt = (nit - wv + WAVES - 1) / WAVES;  // this wave's steps: kg = wv + WAVES * t
 
   f32x4 acc[NS][CB];
@@ -89,7 +93,8 @@ __device__ __forceinline__ void skinny_cdna4_body(char* smem, const uint16_t* __
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       vec8 op[4];
-      cd.tile_packed(wc[s], szc[s], op);
+      if (DQ == 0) cd.tile_packed(wc[s], szc[s], op);
+      else ch.tile(wc[s], szc[s], op);
 #pragma unroll
       for (int a = 0; a < 4; ++a)  // a outer: consecutive MFMAs hit different accumulators
 #pragma unroll
@@ -119,9 +124,31 @@ __device__ __forceinline__ void skinny_cdna4_body(char* smem, const uint16_t* __
       for (int q = 0; q < WAVES; ++q) t += red[((q * NBLK + blk) * 4 + r) * 64 + lane];
       v[r] = t;
     }
-    if (slab < nslab && m < M) {
+    auto to_f = [](uint16_t b) { return DT::to_float(b); };
+    if (EPI == 2) {
+      // rows 0..7 of a slab are gate rows 8 slab .. + 7, rows 8..15 the matching up rows: lane (g < 2) pairs with lane + 32
+      // (fused_mlp.py:79-82: c = F.silu(gate_output) * up_output, every op rounded to T -- as the decode kernel's EPI 2)
+      float u[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < WAVES; ++q) t += red[((q * NBLK + blk) * 4 + r) * 64 + ((lane + 32) & 63)];
+        u[r] = t;
+      }
+      if (slab < nslab && m < M && g < 2) {
+        uint16_t o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float gt = to_f(DT::from_float(v[r])), up = to_f(DT::from_float(u[r]));
+          const float sl = to_f(DT::from_float(silu_f32(gt)));
+          o[r] = DT::from_float(sl * up);
+        }
+        *reinterpret_cast<u32x2*>(out + (size_t)m * (N >> 1) + slab * 8 + 4 * g) =
+            u32x2{(u32)o[0] | ((u32)o[1] << 16), (u32)o[2] | ((u32)o[3] << 16)};
+      }
+    } else if (slab < nslab && m < M) {
       const int nn = slab * 16 + 4 * g;
-      auto to_f = [](uint16_t b) { return DT::to_float(b); };
       uint16_t o[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -133,13 +160,13 @@ __device__ __forceinline__ void skinny_cdna4_body(char* smem, const uint16_t* __
   }
 }
 
-template <typename DT, int WAVES, int NS, int CB>
+template <typename DT, int WAVES, int NS, int CB, int DQ = 0, int EPI = 0>
 __global__ __launch_bounds__(64 * WAVES) void skinny_cdna4_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                                    const u32* __restrict__ szp,
                                                                    const uint16_t* __restrict__ bias,
                                                                    uint16_t* __restrict__ out, int M, int N, int K) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  skinny_cdna4_body<DT, WAVES, NS, CB>(smem, x, qw, szp, bias, out, M, N, K, blockIdx.x);
+  skinny_cdna4_body<DT, WAVES, NS, CB, DQ, EPI>(smem, x, qw, szp, bias, out, M, N, K, blockIdx.x);
 }
 
 // Grouped (per-expert) form for MoE batches between the grouped GEMV (<= 8 sorted rows) and the grouped prefill GEMM
@@ -161,12 +188,12 @@ __global__ __launch_bounds__(64 * WAVES) void moe_skinny_cdna4_kernel(const uint
   }
 }
 
-template <typename DT, int WAVES, int NS, int CB>
+template <typename DT, int WAVES, int NS, int CB, int DQ = 0, int EPI = 0>
 static void launch_skinny(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                           hipStream_t st) {
   const size_t xbytes = (size_t)WAVES * 16 * CB * 256, rbytes = (size_t)WAVES * NS * CB * 1024;
   const size_t smem = xbytes > rbytes ? xbytes : rbytes;
-  auto kern = skinny_cdna4_kernel<DT, WAVES, NS, CB>;
+  auto kern = skinny_cdna4_kernel<DT, WAVES, NS, CB, DQ, EPI>;
   static LdsOptIn optin;  // per (kernel instantiation, device)
   if (smem > 64 * 1024) optin.ensure(reinterpret_cast<const void*>(kern));
   const int nslab = n / 16;
@@ -202,6 +229,7 @@ static int launch_skinny_64(const void* x, const void* qw, const void* szp, cons
   const int nslab = n / 16;
   if (m <= 16) {
     if (nslab >= 1024) launch_skinny<DT, 8, 2, 1>(x, qw, szp, bias, out, m, n, k, st);
+    else if (k / 128 >= 96) launch_skinny<DT, 16, 1, 1>(x, qw, szp, bias, out, m, n, k, st);
     else launch_skinny<DT, 8, 1, 1>(x, qw, szp, bias, out, m, n, k, st);
   } else if (m <= 32) {
     if (nslab >= 512) launch_skinny<DT, 8, 2, 2>(x, qw, szp, bias, out, m, n, k, st);
@@ -214,6 +242,35 @@ static int launch_skinny_64(const void* x, const void* qw, const void* szp, cons
     else launch_skinny<DT, 8, 2, 4>(x, qw, szp, bias, out, m, n, k, st);
   }
   return 0;
+}
+
+// Batched decode (launch_gemv_dma hands over the row counts where one weight pass with x in registers beats its LDS-DMA staging of
+// m x K x 2 bytes per slab, profiles/r03_decode_m_sweep.txt): m <= 16 rows, one 16-row x block; szfmt 1 = szp is "sz_half";
+// epi 0 (bias fused) or 2 (8 + 8 interleaved gate / up pair -> silu(gate) * up, out [m, n / 2]).  Returns -1 if unsupported.
+int launch_skinny_decode(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int epi,
+                         int dtype, int szfmt, hipStream_t st) {
+  if (!szp || m < 1 || m > 16 || (n % 16) != 0 || (k % 128) != 0 || (epi != 0 && epi != 2) || (epi == 2 && bias)) return -1;
+  const bool wide = n / 16 >= 1024, deep = !wide && k / 128 >= 96;  // deep: 16 waves split a long K (down_proj: 112 steps)
+#define AWQ_SD(DT_, DQ_, EPI_)                                                                    \
+  {                                                                                               \
+    if (wide) launch_skinny<DT_, 8, 2, 1, DQ_, EPI_>(x, qw, szp, bias, out, m, n, k, st);          \
+    else if (deep) launch_skinny<DT_, 16, 1, 1, DQ_, EPI_>(x, qw, szp, bias, out, m, n, k, st);    \
+    else launch_skinny<DT_, 8, 1, 1, DQ_, EPI_>(x, qw, szp, bias, out, m, n, k, st);               \
+    return 0;                                                                                     \
+  }
+#define AWQ_SD_DT(DT_)                          \
+  if (szfmt == 1) {                             \
+    if (epi == 2) AWQ_SD(DT_, 1, 2)             \
+    AWQ_SD(DT_, 1, 0)                           \
+  }                                             \
+  if (epi == 2) AWQ_SD(DT_, 0, 2)               \
+  AWQ_SD(DT_, 0, 0)
+  if (dtype == 0) {
+    AWQ_SD_DT(F16)
+  }
+  AWQ_SD_DT(BF16)
+#undef AWQ_SD_DT
+#undef AWQ_SD
 }
 
 template <typename DT, int WAVES, int NS, int CB>

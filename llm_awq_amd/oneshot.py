@@ -163,9 +163,52 @@ def make_reducer(dist, group=None, max_bytes: int = 64 * 1024, device=None):
     world = dist.get_world_size(group)
     if world <= 1 or world > MAX_WORLD or not enabled_by_env() or not torch.cuda.is_available():
         return None
+    import sys
     try:
-        return OneShotAllReduce(group, max_bytes, device)  # (raises on EVERY rank or on none: see __init__)
+        red = OneShotAllReduce(group, max_bytes, device)  # (raises on EVERY rank or on none: see __init__)
     except Exception as e:  # noqa: BLE001 -- no fine-grained memory / hipIpc on this box: RCCL serves the messages
-        import sys
         print(f"[oneshot] rank {dist.get_rank(group)}: {e}; using RCCL for the small messages", file=sys.stderr)
         return None
+    why = validate_reducer(red, dist, group)
+    if why is not None:  # (agreed by all ranks: every rank drops the reducer or none does)
+        print(f"[oneshot] rank {dist.get_rank(group)}: self-check failed ({why}); using RCCL for the small messages", file=sys.stderr)
+        red.close()
+        return None
+    return red
+
+
+def validate_reducer(red, dist, group=None, rounds: int = 6):
+    """A few rounds of the one-shot reducer against dist.all_reduce on rank-dependent data (both message sizes the decode paths send and
+    a ragged one), then ONE collective agreement: returns None if every rank saw every round match (sums of small integers: exact in
+    T whatever the order) and no round timed out, else a reason string -- on EVERY rank.  The peer-mapped path has only ever run
+    between processes on one GPU in the test suite; a fabric where peer stores are not visible to a polling kernel shows up here as
+    a timeout / mismatch and costs the fallback, not the run."""
+    why = None
+    dev, rank = red.device, red.rank
+    cdev = torch.device("cpu") if dist.get_backend(group) == "gloo" else dev  # (the reference sum travels over the group's own backend)
+    for r in range(rounds):
+        n = (4096, 8192, 8 * (1 + r))[r % 3]
+        if 2 * n > red.max_bytes:
+            n = red.max_bytes // 2
+        dt = torch.bfloat16 if r & 1 else torch.float16
+        t = ((torch.arange(n, device=dev, dtype=torch.float32) % 7) + rank + r).to(dt)
+        ref = t.float().to(cdev)
+        dist.all_reduce(ref, group=group)  # (outside the try: every rank issues the same sequence of collectives whatever its one-shot rounds do)
+        ref = ref.to(dev).to(dt)
+        if why is not None:
+            continue
+        try:
+            got = red(t.clone())
+            torch.cuda.synchronize(dev)
+            if int(red.status.item()) != 0:
+                why = f"round {r}: a peer flag timed out"
+            elif not torch.equal(got, ref):
+                why = f"round {r}: {int((got != ref).sum().item())} of {n} elements differ from the group's all-reduce"
+        except Exception as e:  # noqa: BLE001
+            why = f"round {r}: {type(e).__name__}: {e}"
+    bad = torch.tensor([0 if why is None else 1], dtype=torch.int32,
+                       device="cpu" if dist.get_backend(group) == "gloo" else red.device)
+    dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+    if int(bad.item()) != 0:
+        return why or "another rank's self-check failed"
+    return None

@@ -46,7 +46,7 @@ def test_decode_ring_configurations(ops, knobs):
                 c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
                 szh, exact = ops.pack_szh_cdna4(c["scales"].cuda(), c["scaled_zeros"].cuda(), K)
                 assert exact
-                ops._capi.tune(**knobs)
+                ops._capi.tune(decode_skinny_from=9, **knobs)  # (9: every row count stays on the streaming kernel)
                 y = ops.decode_cdna4(c["x"].cuda(), c4, szh, c["bias"].cuda(), 0)
                 check_forward(y.cpu(), c["x"], c["q"], c["scales"], c["scaled_zeros"], torch.bfloat16, bias=c["bias"])
                 # the same kernel on the T-typed sz_packed (the fallback for layers whose scales are not f16-exact)
@@ -55,7 +55,7 @@ def test_decode_ring_configurations(ops, knobs):
                 check_forward(y2.cpu(), c["x"], c["q"], c["scales"], c["scaled_zeros"], torch.bfloat16, bias=c["bias"])
                 assert torch.equal(y, y2), "both dequant forms are exact: identical outputs"
     finally:
-        ops._capi.tune(gemvd_waves=0, gemvd_d=0)
+        ops._capi.tune(gemvd_waves=0, gemvd_d=0, decode_skinny_from=0)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -106,3 +106,54 @@ def test_inexact_scales_are_flagged(ops):
     szp = ops.pack_sz_cdna4(s.cuda(), sz.cuda(), 256)
     y = ops.gemm_cdna4(c["x"].cuda(), c4, s.cuda(), sz.cuda(), None, szp)
     check_forward(y.cpu(), c["x"], c["q"], s, sz, torch.bfloat16)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,K", [(16, 128), (48, 1280), (64, 11008), (4096, 512), (6144, 4096), (16400, 256)])
+def test_batched_decode_on_the_skinny_kernel(ops, dtype, N, K):
+    """the decode entry with its rows handed to the skinny kernel (x through registers, shared by a block's slabs; knob
+    decode_skinny_from): every row count, bias, both side-buffer forms, narrow and wide (two slabs per block, ragged last block)"""
+    c = make_case(N, K, dtype, seed=N + K + 3, M=8, bias=True)
+    c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
+    szh, exact = ops.pack_szh_cdna4(c["scales"].cuda(), c["scaled_zeros"].cuda(), K)
+    assert exact
+    try:
+        ops._capi.tune(decode_skinny_from=1)
+        for M in range(1, 9):
+            x = c["x"][:M].contiguous()
+            for b in (None, c["bias"]):
+                y = ops.decode_cdna4(x.cuda(), c4, szh, b.cuda() if b is not None else None, 0)
+                check_forward(y.cpu(), x, c["q"], c["scales"], c["scaled_zeros"], dtype, bias=b)
+    finally:
+        ops._capi.tune(decode_skinny_from=0)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [1, 5, 8])
+@pytest.mark.parametrize("F,K", [(256, 768), (1376, 512), (14336, 4096)])
+def test_fused_gate_up_on_the_skinny_kernel(ops, dtype, M, F, K):
+    """epilogue 2 (8 + 8 interleaved pair -> silu(gate) * up) on the skinny kernel == the streaming kernel's result up to the
+    split-K order, and == the reference's QuantLlamaMLP sequence (fused_mlp.py:36-83)"""
+    from llm_awq_amd.fused_mlp import interleave_gate_up
+    cg = make_case(F, K, dtype, seed=F + K + M, M=M)
+    cu = make_case(F, K, dtype, seed=F + K + M + 1, M=M)
+    x = cg["x"]
+    g = O.wqlinear_forward(x, None, cg["scales"], cg["scaled_zeros"], None, 128, q_int=cg["q"])
+    u = O.wqlinear_forward(x, None, cu["scales"], cu["scaled_zeros"], None, 128, q_int=cu["q"])
+    ref = torch.nn.functional.silu(g) * u
+    qi, si, zi = interleave_gate_up(cg["qweight"].cuda(), cu["qweight"].cuda(), cg["scales"].cuda(), cu["scales"].cuda(),
+                                    cg["scaled_zeros"].cuda(), cu["scaled_zeros"].cuda())
+    szh, exact = ops.pack_szh_cdna4(si, zi, K)
+    assert exact
+    c4 = ops.repack_v2_to_cdna4(qi)
+    try:
+        ops._capi.tune(decode_skinny_from=9)
+        y_dma = ops.decode_cdna4(x.cuda(), c4, szh, None, 2).cpu()
+        ops._capi.tune(decode_skinny_from=1)
+        y = ops.decode_cdna4(x.cuda(), c4, szh, None, 2).cpu()
+    finally:
+        ops._capi.tune(decode_skinny_from=0)
+    rel = ((y.float() - ref.float()).norm() / ref.float().norm()).item()
+    assert rel <= 3e-3, rel
+    assert_bits(y, ref, 0.05)
+    assert_bits(y, y_dma, 0.01)

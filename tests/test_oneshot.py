@@ -218,9 +218,14 @@ def _same_gpu_worker(rank, world, port, q):
                 torch.cuda.synchronize()
                 ok = ok and bool((y == float(3 + 2 * rep)).all())
         ar.check()
+        # the self-check make_reducer runs before it hands the reducer to the tensor-parallel modules (one-shot vs the group's own
+        # all-reduce on rank-dependent data, outcome agreed by all ranks)
+        from llm_awq_amd.oneshot import validate_reducer
+        why = validate_reducer(ar, dist)
+        ok = ok and why is None
         dist.barrier()
         ar.close()
-        q.put((rank, ok, ""))
+        q.put((rank, ok, why or ""))
         dist.destroy_process_group()
     except Exception as e:  # noqa: BLE001
         import traceback
