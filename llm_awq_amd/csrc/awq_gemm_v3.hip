@@ -39,8 +39,20 @@ void launch_wide(const void* x, const void* qw, const void* szp, const void* bia
   }
   launch_gemm_cdna4_v4(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, epi);
 }
+// knob gemm_v6_128 (default 1, round 3): the 128-wide tiles of m >= 256 that awq_gemm_v4n.hip would run UNSPLIT go to awq_gemm_v6.hip with
+// two slabs per wave (256 x 128 blocks on the one-wave-per-SIMD loop: +4.3 ... +6.8 % on the M = 2048 prefill pass, o_proj / down_proj /
+// the gate-up remainder, profiles/r03_v6_128.txt; bit-identical products and K order).  Split-K launches (short prompts that under-fill
+// the chip) and m < 256 (masked single row tile) stay on awq_gemm_v4n.hip, W3 tiles too.
+int g_v6_128 = 1;
 void launch_narrow(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
                    int n_end, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits, int epi) {
+  if (g_v6_128 && g_v6 && bits == 4 && m >= TM) {
+    const bool splits = g_splitk && ws != nullptr && epi == 0 && gemm_v4n_workspace_bytes(m, n_end - n_begin, k) > 0;
+    if (!splits) {
+      launch_gemm_cdna4_v6(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, epi, 0, 128);
+      return;
+    }
+  }
   launch_gemm_cdna4_v4n(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, g_splitk ? ws : nullptr, ws_bytes, st, bits, epi);
 }
 }  // namespace
@@ -70,6 +82,7 @@ int gemm_v3_tune_set(const char* key, int value) {
   else if (!strcmp(key, "gemm_tile_n")) g_tile_n = value;
   else if (!strcmp(key, "gemm_v6_szh")) g_v6_szh = value;
   else if (!strcmp(key, "gemm_v6_192")) g_v6_192 = value;
+  else if (!strcmp(key, "gemm_v6_128")) g_v6_128 = value;
   else if (!strcmp(key, "moe_v4")) g_moe_v4 = value;
   else if (!strcmp(key, "gemm_small_m")) g_small_m = value;
   else if (!strcmp(key, "gemm_splitk")) {  // 0 = off, 1 = auto, n > 1 = force n K ranges

@@ -72,7 +72,8 @@ __device__ __forceinline__ void v6_mfma(f32x4& acc, const V8& a, const u32x4& b)
 // DQ 1: szp is the "sz_half" side buffer and the dequant runs in its f16-mantissa form (Cdna4DequantH: one shift + four v_and_or per word
 // instead of three + four, two v_perm + one v_dot2 for the operands instead of perm / and / and / dot2c; exact for layers
 // awq_pack_szh_cdna4 reports exact; W4 tiles only)
-// NS = weight slabs (16 columns) per wave: 4 -> 256-column blocks; 3 -> 192-column blocks (accumulators 192 AGPRs) for matrices
+// NS = weight slabs (16 columns) per wave: 4 -> 256-column blocks; 2 -> 128-column blocks (knob gemm_v6_128: against awq_gemm_v4n.hip's
+// 256 x 128 tiles where 256-wide tiles would fill half the chip); 3 -> 192-column blocks (accumulators 192 AGPRs) for matrices
 // whose 256-wide tile count leaves a partial round that 192-wide tiles fill (qkv of Llama-3-8B: 6144 = 32 x 192 -> 8 x 32 = 256 tiles
 // at M = 2048 instead of 192)
 template <typename DT, int BITS, int PROBE, int DQ, int NS>
@@ -505,7 +506,7 @@ void launch_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, const 
                           int n_end, int dtype, hipStream_t st, int bits, int epi, int szfmt, int tile_n) {
   constexpr int stage2 = 2 * kV6Stage, stg_epi = V6_TM * kV6Pitch;
   constexpr int smem = stage2 > stg_epi ? stage2 : stg_epi;
-  const int tn_cols = tile_n == 192 ? 192 : V6_TN;
+  const int tn_cols = tile_n == 192 ? 192 : (tile_n == 128 ? 128 : V6_TN);
   const int tiles_m = (m + V6_TM - 1) / V6_TM, tiles_n = (n_end - n_begin + tn_cols - 1) / tn_cols;
   using Kern = void (*)(const uint16_t*, const u32*, const u32*, const uint16_t*, uint16_t*, int, int, int, int, int, int, int, int);
   static const Kern kerns[2][2] = {{gemm_cdna4_v6_kernel<F16, 4>, gemm_cdna4_v6_kernel<F16, 3>},
@@ -517,6 +518,15 @@ void launch_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, const 
     const int a3 = dtype == 0 ? 0 : 1;
     optin_3[a3].ensure(reinterpret_cast<const void*>(kerns_3[a3]), smem);
     hipLaunchKernelGGL(kerns_3[a3], dim3(tiles_m * tiles_n), dim3(256), smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp,
+                       (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end, epi);
+    return;
+  }
+  if (tn_cols == 128 && bits == 4) {  // 128-column blocks (two slabs per wave): o_proj / down_proj at M = 2048 fill the chip with 256 of them
+    static const Kern kerns_2[2] = {gemm_cdna4_v6_kernel<F16, 4, 0, 0, 2>, gemm_cdna4_v6_kernel<BF16, 4, 0, 0, 2>};
+    static LdsOptIn optin_2[2];
+    const int a2 = dtype == 0 ? 0 : 1;
+    optin_2[a2].ensure(reinterpret_cast<const void*>(kerns_2[a2]), smem);
+    hipLaunchKernelGGL(kerns_2[a2], dim3(tiles_m * tiles_n), dim3(256), smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp,
                        (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end, epi);
     return;
   }

@@ -152,3 +152,26 @@ def test_v6_192_wide_is_what_the_plan_picks_for_qkv(ops):
     finally:
         ops._capi.tune(gemm_v6_192=1)
     assert torch.equal(y, y256), "same products in the same K order: the block width only moves columns between waves"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_v6_128_wide_blocks_equal_the_default_plan(ops, dtype):
+    """two slabs per wave (knob gemm_v6_128, default on: the unsplit narrow tiles of m >= 256 on the v6 loop instead of
+    awq_gemm_v4n.hip): the same products in the same K order, so the two kernels agree bit for bit up to the association inside one
+    32-k MFMA (o_proj / down_proj shapes, ragged N and M, bias)"""
+    from llm_awq_amd import synth
+    for (K, N, M) in ((4096, 4096, 2048), (1024, 4096, 1024), (512, 1296, 1100), (256, 400, 300)):
+        w = synth.random_wq(K, N, dtype=dtype, seed=K + N, keep_q=False)
+        c4 = ops.repack_v2_to_cdna4(w["qweight"])
+        szp = ops.pack_sz_cdna4(w["scales"], w["scaled_zeros"], K)
+        x = torch.randn(M, K, device="cuda", generator=cuda_gen(M)).to(dtype)
+        b = (torch.randn(N, device="cuda", generator=cuda_gen(N)) * 0.02).to(dtype)
+        try:
+            ops._capi.tune(gemm_tile_n=128, gemm_splitk=0, gemm_v6_128=0)
+            y0 = ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], b, szp)   # awq_gemm_v4n.hip
+            ops._capi.tune(gemm_v6_128=1)
+            y = ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], b, szp)    # awq_gemm_v6.hip, NS = 2
+        finally:
+            ops._capi.tune(gemm_tile_n=0, gemm_splitk=1, gemm_v6_128=1)
+        assert_bits(y, y0, 0.001, what=str((K, N, M)))
+        assert ((y.float() - y0.float()).norm() / y0.float().norm()).item() < 1e-4
