@@ -11,7 +11,7 @@ tail -4 $O/pytest_gpu_seed0.log
 tail -1 $O/smoke.log
 ( timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 2>&1 | grep -E "metric|Error|error|Traceback" | tail -3 ) > $O/bench.log
 cut -c1-700 $O/bench.log
-( AWQ_BENCH_FORCE_TP=1 AWQ_BENCH_TP70B_LAYERS=2 timeout 200 python bench.py --steps 5 --warmup 2 --layers 8 2>&1 | tail -2 | cut -c1-1500 ) > $O/bench_tp_world1.log
+( RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 AWQ_BENCH_FORCE_TP=1 AWQ_BENCH_TP70B_LAYERS=2 timeout 200 python bench.py --steps 5 --warmup 2 --layers 8 2>&1 | tail -2 | cut -c1-1500 ) > $O/bench_tp_world1.log
 cut -c1-400 $O/bench_tp_world1.log
 ( timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_bench -o bench -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-dropin --no-batched-decode --no-graph --prefill-iters 1 2>&1 | tail -3 ) > $O/rocprof_bench.log
 python tools/rocpd_stats.py $O/prof_bench/bench_results.db $O/bench_kernel_stats.csv > $O/bench_kernel_stats.txt
