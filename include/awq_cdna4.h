@@ -175,6 +175,16 @@ size_t awq_w4a16_forward_cdna4_workspace_bytes(int m, int n, int k);
  * of thread blocks, 0 if the GEMM does not take this m (decode / skinny kernels do).  The counterpart of the reference's tile table,
  * gemm_cuda.cu:1155-1232. */
 int awq_w4a16_gemm_cdna4_plan(int m, int n, int bits, int* mode, int* cols_main);
+/* host-side query: which kernel runs the 256 x 128 blocks of such a launch over n_cols weight rows.  Returns 1 = awq_gemm_v6.hip (one wave
+ * per SIMD, two slabs per wave: every unsplit launch of W4 tiles at m >= 256), 0 = awq_gemm_v4n.hip unsplit (m < 256: masked single row
+ * tile; W3 tiles), ks >= 2 = awq_gemm_v4n.hip with the K loop split into ks ranges (needs the workspace and no fused SiLU*mul tail). */
+int awq_w4a16_gemm_cdna4_narrow_kernel(int m, int n_cols, int k, int bits, int has_workspace, int epilogue);
+/* host-side query: how awq_w4a16_decode_cdna4 / awq_w4a16_mlp_gate_up_forward_cdna4 serve m <= 8 rows of an [n, k] matrix.  *kernel: 0 =
+ * the LDS-DMA streaming kernel (awq_gemv_dma.hip; x staged per slab), 1 = the skinny kernel (awq_skinny_cdna4.hip; x through registers,
+ * one weight pass -- where the streaming kernel's staging of m x k x 2 bytes per slab would crowd its ring out of LDS).  Returns the number
+ * of weight passes (1; more when the streaming kernel serves the rows in chunks), 0 if the shape is not served.  The reference's GEMV
+ * handles its batch inside one pass, gemv_cuda.cu:187-208, 291-329. */
+int awq_w4a16_decode_cdna4_plan(int m, int n, int k, int epilogue, int* kernel);
 int awq_w4a16_gemm_cdna4(const void* x, const void* qweight_cdna4, const void* scales, const void* scaled_zeros,
                          const void* sz_packed, void* out, int m, int n, int k, int group_size, int dtype,
                          void* workspace, size_t workspace_bytes, void* stream);

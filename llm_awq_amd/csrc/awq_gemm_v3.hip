@@ -44,14 +44,17 @@ void launch_wide(const void* x, const void* qw, const void* szp, const void* bia
 // the gate-up remainder, profiles/r03_v6_128.txt; bit-identical products and K order).  Split-K launches (short prompts that under-fill
 // the chip) and m < 256 (masked single row tile) stay on awq_gemm_v4n.hip, W3 tiles too.
 int g_v6_128 = 1;
+// 1 = awq_gemm_v6.hip (NS = 2), 0 = awq_gemm_v4n.hip unsplit, ks >= 2 = awq_gemm_v4n.hip split into ks K ranges
+int narrow_kernel(int m, int n_cols, int k, int bits, bool has_ws, int epi) {
+  const size_t wsb = g_splitk && has_ws && epi == 0 ? gemm_v4n_workspace_bytes(m, n_cols, k) : 0;
+  if (wsb > 0) return (int)(wsb / ((size_t)((m + TM - 1) / TM) * ((n_cols + 127) / 128) * TM * 128 * 4));
+  return g_v6_128 && g_v6 && bits == 4 && m >= TM ? 1 : 0;
+}
 void launch_narrow(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
                    int n_end, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits, int epi) {
-  if (g_v6_128 && g_v6 && bits == 4 && m >= TM) {
-    const bool splits = g_splitk && ws != nullptr && epi == 0 && gemm_v4n_workspace_bytes(m, n_end - n_begin, k) > 0;
-    if (!splits) {
-      launch_gemm_cdna4_v6(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, epi, 0, 128);
-      return;
-    }
+  if (narrow_kernel(m, n_end - n_begin, k, bits, ws != nullptr, epi) == 1) {
+    launch_gemm_cdna4_v6(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, epi, 0, 128);
+    return;
   }
   launch_gemm_cdna4_v4n(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, g_splitk ? ws : nullptr, ws_bytes, st, bits, epi);
 }
@@ -168,6 +171,11 @@ int gemm_cdna4_v3_plan(int m, int n, int bits, int* mode, int* cols_main) {
   if (p.mode == 1) return (int)(tm * ((n + 127) / 128));
   if (p.mode == 3) return (int)(tm * ((n + 191) / 192));
   return (int)(tm * p.cols_main + tm * ((n - p.cols_main * 256 + 127) / 128));
+}
+
+int gemm_cdna4_v3_narrow_kernel(int m, int n_cols, int k, int bits, int has_workspace, int epi) {
+  if (m <= 8 || n_cols < 16 || (n_cols % 16) != 0 || k < 128 || (k % 128) != 0) return 0;
+  return narrow_kernel(m, n_cols, k, bits, has_workspace != 0, epi);
 }
 
 int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,

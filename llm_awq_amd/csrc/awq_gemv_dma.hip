@@ -394,6 +394,21 @@ static int launch_dma_dt(const void* x, const void* qw, const void* szp, const v
   return -1;
 }
 
+// host-side: how launch_gemv_dma serves the call (awq_w4a16_decode_cdna4_plan): weight passes, *kernel 0 streaming / 1 skinny
+int gemv_dma_plan(int m, int n, int k, int epi, int* kernel) {
+  if (m < 1 || m > 8 || k < 128 || (k % 128) != 0 || epi < 0 || epi > 2 || n < (epi == 1 ? 32 : 16) || (n % (epi == 1 ? 32 : 16)) != 0) return 0;
+  if (skinny_takes(m, n, k, epi)) {
+    if (kernel) *kernel = 1;
+    return 1;
+  }
+  if (kernel) *kernel = 0;
+  DmaCfg c;
+  int mc = m;
+  while (mc > 1 && !pick_dma(mc, n, k, epi == 1 ? 2 : 1, c)) --mc;
+  if (!pick_dma(mc, n, k, epi == 1 ? 2 : 1, c)) return 0;
+  return (m + mc - 1) / mc;
+}
+
 // epi as in the kernel header; returns -1 if the shape is not served.  The kernel stages every row's x slice in LDS up front
 // (m * k * 2 bytes per block): when m rows do not fit (m * k > ~50 k elements: batched decode against K >= 8 k) the rows are
 // served in chunks of as many rows as do fit, each chunk re-streaming the weights -- as the reference's GEMV does per row

@@ -94,6 +94,8 @@ extern int g_v4n_ksplit_force;  // knob gemm_splitk > 1
 bool gemm_cdna4_v3_takes(int m, int k);  // m >= 256, or a shorter prompt the 256-row tile still beats the skinny kernel on
 size_t gemm_cdna4_v3_workspace_bytes(int m, int n, int k);
 int gemm_cdna4_v3_plan(int m, int n, int bits, int* mode, int* cols_main);
+int gemm_cdna4_v3_narrow_kernel(int m, int n_cols, int k, int bits, int has_workspace, int epi);  // 1 v6 (NS = 2), 0 v4n unsplit, >= 2 v4n split-K ranges
+int gemv_dma_plan(int m, int n, int k, int epi, int* kernel);  // weight passes of the decode entry (0: not served); *kernel 0 streaming, 1 skinny
 size_t gemm_cdna4_v3_workspace_bytes_w3(int m, int n, int k);  // same rule for w3c tiles (every m > 8 takes the tile kernels)
 // grouped (MoE) GEMM with the same K loop: sorted rows, device expert offsets, stacked cdna4 weights + packed scales; total >= 256
 int launch_moe_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total, int experts,

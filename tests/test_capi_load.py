@@ -105,3 +105,48 @@ def test_prefill_tile_plan_for_the_llama3_shapes():
     assert plan(4096, 28672) == (16 * 112, 0, 0)  # seven full rounds of 256-wide
     assert plan(2048, 6144, bits=3)[1] != 3       # the 192-wide blocks are W4 only
     assert plan(100, 4096)[1] == 1 and plan(4, 4096)[0] == 0
+
+
+def test_batched_decode_routing_for_the_llama3_shapes():
+    """host-side query (no GPU): which kernel serves 1 .. 8 rows behind awq_w4a16_decode_cdna4 -- the streaming kernel up to 4 rows and on
+    narrow projections, the skinny kernel where the per-slab activation staging would crowd LDS (profiles/r03_decode_m_sweep.txt)"""
+    from llm_awq_amd import _capi
+    L = _capi.lib()
+
+    def plan(m, n, k, epi=0):
+        kern = ctypes.c_int(-1)
+        passes = L.awq_w4a16_decode_cdna4_plan(m, n, k, epi, ctypes.byref(kern))
+        return passes, kern.value
+
+    for m in (1, 2, 3, 4):
+        for (n, k, epi) in ((6144, 4096, 0), (4096, 4096, 0), (28672, 4096, 2), (4096, 14336, 0)):
+            assert plan(m, n, k, epi) == (1, 0), (m, n, k)
+    for m in (5, 6, 7, 8):
+        assert plan(m, 28672, 4096, 2) == (1, 1)          # gate/up pair: 7 slabs per CU
+        assert plan(m, 4096, 14336, 0) == (1, 1)          # down_proj: 28 KiB of x per row
+        assert plan(m, 4096, 4096, 0) == (1, 0)           # o_proj: one slab per CU, never
+        assert plan(m, 6144, 4096, 0) == (1, 1 if m == 8 else 0)
+    assert plan(8, 28672, 4096, 1)[1] == 0                # the stacked [gate; up] form has no skinny epilogue
+    assert plan(9, 4096, 4096)[0] == 0 and plan(4, 4100, 4096)[0] == 0 and plan(4, 4096, 4000)[0] == 0
+    try:  # forced / disabled (tests and sweeps)
+        _capi.tune(decode_skinny_from=9)
+        assert plan(7, 4096, 14336)[1] == 0 and plan(7, 4096, 14336)[0] >= 2   # the streaming kernel serves 7 rows of K = 14336 in chunks
+        _capi.tune(decode_skinny_from=1)
+        assert plan(1, 4096, 4096) == (1, 1)
+    finally:
+        _capi.tune(decode_skinny_from=0)
+
+
+def test_narrow_tile_kernel_choice():
+    """host-side query: the 256 x 128 blocks run on awq_gemm_v6.hip (two slabs per wave) whenever they are not split along K (round 3:
+    profiles/r03_v6_128.txt); short prompts that under-fill the chip keep awq_gemm_v4n.hip's split-K, m < 256 and W3 tiles its unsplit kernel"""
+    from llm_awq_amd import _capi
+    L = _capi.lib()
+    q = L.awq_w4a16_gemm_cdna4_narrow_kernel
+    assert q(2048, 4096, 4096, 4, 1, 0) == 1 and q(2048, 4096, 14336, 4, 1, 0) == 1      # o / down at M = 2048: 256 blocks, no split
+    assert q(2048, 4096, 4096, 4, 0, 0) == 1 and q(4096, 4096, 4096, 4, 1, 2) == 1
+    assert q(512, 4096, 4096, 4, 1, 0) >= 2 and q(512, 4096, 14336, 4, 1, 0) >= 2         # 64 tiles for 256 CUs: split-K (v4n)
+    assert q(512, 4096, 4096, 4, 0, 0) == 1                                              # ... but without a workspace: unsplit, v6
+    assert q(512, 4096, 4096, 4, 1, 2) == 1                                              # the fused SiLU*mul tail is not split either
+    assert q(200, 4096, 4096, 4, 0, 0) == 0 and q(2048, 4096, 4096, 3, 0, 0) == 0         # masked single row tile; W3 tiles
+    assert q(4, 4096, 4096, 4, 0, 0) == 0
