@@ -1,0 +1,111 @@
+"""CPU: the PLANNED 32-row interleave "cdna4w" (oracle/awq_oracle.py, DESIGN.md "Next steps after round 3") -- no kernel reads it yet.
+
+What is pinned here so that the kernel work starts from a verified layout:
+  * the index map is a bijection of the nibbles (pack / unpack round trip, a pure permutation of the cdna4 buffer's nibbles);
+  * a REGISTER-LEVEL emulation of the matrix-core dequant -- the same instruction sequence the shipped kernels run on cdna4 tiles
+    (extractions (w >> 4 i) & 0x000F000F, v_mfma_f32_4x4x4_16B with the per-block diagonal B operand, pack of the two results) --
+    lands, on cdna4w tiles, with lane (n = l % 32, kb = l / 32) holding k = 16 a + 8 kb + 0..7 of row n: the A operand of
+    v_mfma_f32_32x32x16.  The emulator is first held against the SHIPPED cdna4 layout (lane (n = l % 16, g = l / 16), k = 32 a + 8 g +
+    0..7: the 16x16x32 operand, which the GPU tests verify on hardware), so its model of the 4x4x4 blocks is the one the hardware has.
+"""
+import numpy as np
+import pytest
+
+from oracle import awq_oracle as O
+
+
+def _blocks_dequant(words, s_lane, c_lane):
+    """words u32 [64 lanes]; s_lane / c_lane float64 [64] (this lane's scale and offset).  Emulates, per 4-lane block of
+    v_mfma_f32_4x4x4_16B: A[m][kk] = lane m's four extracted values, B[kk][n] = s_n [kk == n] (the diagonal operand the kernels build
+    with v_perm / masks by lane % 4), C = c_n; D[m][n] lands in lane n, register m.  Returns [64 lanes][8] = pack8(d0, d1)."""
+    out = np.zeros((64, 8))
+    for half, shifts in enumerate(((0, 4), (8, 12))):          # a0 = extractions i = 0, 1; a1 = i = 2, 3
+        A = np.zeros((64, 4))
+        for e, sh in enumerate(shifts):
+            v = (words >> np.uint32(sh)) & np.uint32(0x000F000F)
+            A[:, 2 * e] = (v & 0xFFFF).astype(np.float64)       # low half of the register: nibble i
+            A[:, 2 * e + 1] = (v >> 16).astype(np.float64)      # high half: nibble i + 4
+        for b in range(16):
+            for n in range(4):                                  # output lane 4 b + n
+                for m in range(4):                              # its register m <- lane 4 b + m, element kk = n
+                    out[4 * b + n, 4 * half + m] = A[4 * b + m, n] * s_lane[4 * b + n] + c_lane[4 * b + n]
+    return out
+
+
+@pytest.mark.parametrize("N,K", [(32, 128), (64, 256), (96, 384)])
+def test_round_trip_and_permutation_of_the_cdna4_nibbles(N, K):
+    rng = np.random.default_rng(N + K)
+    q = rng.integers(0, 16, size=(N, K), dtype=np.uint8)
+    qw = O.pack_cdna4w(q)
+    assert qw.shape == (N // 4, K) and qw.dtype == np.int16
+    assert np.array_equal(O.unpack_cdna4w(qw), q)
+    # every (word, nibble) slot is hit exactly once
+    nn, kk = np.meshgrid(np.arange(N), np.arange(K), indexing="ij")
+    word, p = O.cdna4w_position(nn, kk, K)
+    slots = word.astype(np.int64) * 8 + p
+    assert np.unique(slots).size == N * K and slots.min() == 0 and slots.max() == N * K - 1
+    # a slab PAIR's K extent is one contiguous run of 1-KiB tiles (what a streaming decode kernel needs)
+    first = word[0:32].min() // 256, word[0:32].max() // 256
+    assert first == (0, K // 64 - 1)
+
+
+@pytest.mark.parametrize("layout", ["cdna4", "cdna4w"])
+def test_matrix_core_dequant_emits_the_product_operand(layout):
+    """register-level emulation on both layouts: cdna4 -> the 16x16x32 operand (what the hardware tests confirm), cdna4w -> 32x32x16"""
+    N, K = 64, 256
+    rng = np.random.default_rng(7)
+    q = rng.integers(0, 16, size=(N, K), dtype=np.uint8)
+    s = rng.uniform(0.004, 0.01, size=(N, K // 128))
+    z = -s * rng.integers(0, 16, size=(N, K // 128))
+    W = q * np.repeat(s, 128, axis=1) + np.repeat(z, 128, axis=1)          # [N, K] exact in float64
+    if layout == "cdna4":
+        buf = np.ascontiguousarray(O.pack_cdna4(q)).view(np.uint32).reshape(N // 16, K // 128, 64, 4)
+        rows, kspan = 16, 32      # operand: lane (n = l % 16, g = l / 16), word a covers k = 32 a + 8 g + 0..7
+    else:
+        buf = np.ascontiguousarray(O.pack_cdna4w(q)).view(np.uint32).reshape(N // 32, K // 64, 64, 4)
+        rows, kspan = 32, 16      # operand: lane (n = l % 32, kb = l / 32), word a covers k = 16 a + 8 kb + 0..7
+    lanes = np.arange(64)
+    for nb in range(buf.shape[0]):
+        for kt in range(buf.shape[1]):
+            k0 = kt * (128 if layout == "cdna4" else 64)
+            n_lane = nb * rows + lanes % rows
+            s_lane, c_lane = s[n_lane, k0 // 128], z[n_lane, k0 // 128]
+            for a in range(4):
+                got = _blocks_dequant(buf[nb, kt, :, a], s_lane, c_lane)   # (the kernels fold the magic / offset: q s + sz exactly)
+                kcol = k0 + kspan * a + 8 * (lanes // rows)
+                want = np.stack([W[n_lane, kcol + j] for j in range(8)], axis=1)
+                assert np.allclose(got, want, rtol=0, atol=1e-12), (layout, nb, kt, a)
+
+
+def test_product_mfma_32x32x16_on_the_emitted_operands():
+    """the emitted operands against activations in the B layout of v_mfma_f32_32x32x16 (lane (m = l % 32, kb = l / 32): 8 k of row m), D
+    in its accumulator layout (lane l, register r: weight row (r & 3) + 8 (r >> 2) + 4 (l / 32), activation row l % 32 -- the layout
+    awq_gemm_v4.hip's epilogue reads) == W x^T."""
+    N, K, M = 32, 128, 32
+    rng = np.random.default_rng(11)
+    q = rng.integers(0, 16, size=(N, K), dtype=np.uint8)
+    s = rng.uniform(0.004, 0.01, size=(N, 1))
+    z = -s * rng.integers(0, 16, size=(N, 1))
+    W = q * s + z
+    x = rng.standard_normal((M, K))
+    buf = np.ascontiguousarray(O.pack_cdna4w(q)).view(np.uint32).reshape(1, K // 64, 64, 4)
+    lanes = np.arange(64)
+    acc = np.zeros((64, 16))
+    for kt in range(K // 64):
+        for a in range(4):
+            A_l = _blocks_dequant(buf[0, kt, :, a], s[lanes % 32, 0], z[lanes % 32, 0])       # [lane][8]
+            kcol = 64 * kt + 16 * a + 8 * (lanes // 32)
+            B_l = np.stack([x[lanes % 32, kcol + j] for j in range(8)], axis=1)            # [lane][8]
+            Am = np.zeros((32, 16))
+            Bm = np.zeros((16, 32))
+            for lane in range(64):
+                Am[lane % 32, 8 * (lane // 32): 8 * (lane // 32) + 8] = A_l[lane]
+                Bm[8 * (lane // 32): 8 * (lane // 32) + 8, lane % 32] = B_l[lane]
+            D = Am @ Bm
+            for lane in range(64):
+                for r in range(16):
+                    acc[lane, r] += D[(r & 3) + 8 * (r >> 2) + 4 * (lane // 32), lane % 32]
+    ref = W @ x.T                                                                            # [n, m]
+    for lane in range(64):
+        for r in range(16):
+            assert abs(acc[lane, r] - ref[(r & 3) + 8 * (r >> 2) + 4 * (lane // 32), lane % 32]) < 1e-9
