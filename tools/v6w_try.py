@@ -1,0 +1,81 @@
+"""GPU experiment (AWQ_PROBES=1 build): the v6 prefill loop on the PLANNED 32-row interleave "cdna4w" (csrc/awq_gemm_v6w.hip; layout:
+oracle/awq_oracle.py::pack_cdna4w, pinned by tests/test_cdna4w_layout.py) against the product path on the same weights.
+  1. correctness: small shapes against the oracle forward (tests/helpers.check_forward), then full shapes against the product GEMM;
+  2. time per call at M = 2048 / 4096 on the Llama-3-8B shapes (the product path next to it).
+The cdna4w buffer is packed on the HOST by the oracle (this is an experiment: there is no device repacker yet).
+usage: AWQ_PROBES=1 python -c "import llm_awq_amd.build as b; b.build_all(force=True)";  AWQ_TUNING=1 python tools/v6w_try.py [quick]"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from llm_awq_amd import _capi, ops  # noqa: E402
+from oracle import awq_oracle as O  # noqa: E402  (experiment script: the oracle packs the planned layout and checks the result)
+
+
+def timeit(fn, it=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(it):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / it
+
+
+def main():
+    L = _capi.lib()
+    probe = getattr(L, "awq_probe_gemm_cdna4w", None)
+    if probe is None:
+        raise SystemExit("this library was not built with AWQ_PROBES=1")
+    probe.restype = ctypes.c_int
+    probe.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+    from tests.helpers import check_forward, make_case
+    quick = len(sys.argv) > 1
+
+    def run(x, qww, szp, bias, N, K):
+        out = torch.empty(x.shape[0], N, dtype=x.dtype, device="cuda")
+        _capi.check(probe(x.data_ptr(), qww.data_ptr(), szp.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(),
+                          x.shape[0], N, K, 0 if x.dtype == torch.float16 else 1, torch.cuda.current_stream().cuda_stream))
+        return out
+
+    # ---- 1. small shapes against the oracle ----
+    for dtype in (torch.bfloat16, torch.float16):
+        for (N, K, M) in ((256, 128, 256), (512, 1024, 300), (1280, 512, 777)):
+            c = make_case(N, K, dtype, seed=N + K + M, M=M, bias=True)
+            qww = torch.from_numpy(O.pack_cdna4w(c["q"])).cuda()
+            szp = ops.pack_sz_cdna4(c["scales"].cuda(), c["scaled_zeros"].cuda(), K)
+            for b in (None, c["bias"]):
+                y = run(c["x"].cuda(), qww, szp, b.cuda() if b is not None else None, N, K)
+                check_forward(y.cpu(), c["x"], c["q"], c["scales"], c["scaled_zeros"], dtype, bias=b)
+            print("oracle ok", dtype, (N, K, M), flush=True)
+
+    # ---- 2. Llama-3-8B shapes: equality with the product path + time ----
+    from llm_awq_amd import synth
+    print("# shape K N M  product_us  v6w_us  TF_product TF_v6w  identical_fraction")
+    for (name, K, N) in (("o", 4096, 4096), ("qkv", 4096, 6144), ("down", 14336, 4096)) + (() if quick else (("gate+up", 4096, 28672),)):
+        w = synth.random_wq(K, N, dtype=torch.bfloat16, seed=K + N, keep_q=True)
+        q = w["q"].cpu().numpy() if torch.is_tensor(w["q"]) else np.asarray(w["q"])
+        qww = torch.from_numpy(O.pack_cdna4w(q)).cuda()
+        c4 = ops.repack_v2_to_cdna4(w["qweight"])
+        szp = ops.pack_sz_cdna4(w["scales"], w["scaled_zeros"], K)
+        for M in (2048, 4096):
+            x = torch.randn(M, K, device="cuda").bfloat16()
+            y0 = ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], None, szp)
+            y1 = run(x, qww, szp, None, N, K)
+            same = (y0 == y1).float().mean().item()
+            rel = ((y0.float() - y1.float()).norm() / y0.float().norm()).item()
+            t0 = timeit(lambda: ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], None, szp))
+            t1 = timeit(lambda: run(x, qww, szp, None, N, K))
+            tf = lambda us: 2.0 * M * N * K / us / 1e6  # noqa: E731
+            print(f"{name:8s} {K:6d} {N:6d} {M:5d}  {t0:9.1f} {t1:9.1f}  {tf(t0):7.1f} {tf(t1):7.1f}  {same:.5f} rel {rel:.2e}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
