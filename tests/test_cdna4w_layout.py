@@ -109,3 +109,84 @@ def test_product_mfma_32x32x16_on_the_emitted_operands():
     for lane in range(64):
         for r in range(16):
             assert abs(acc[lane, r] - ref[(r & 3) + 8 * (r >> 2) + 4 * (lane // 32), lane % 32]) < 1e-9
+
+
+def test_index_model_of_the_v6w_experiment_kernel():
+    """The address arithmetic of csrc/awq_gemm_v6w.hip (AWQ_PROBES builds; not yet run on hardware) restated formula by formula -- x staging
+    writes (wpat), fragment reads (xa + f * 8192), weight / scale offsets (w_off, s_off, tile and word of a step), the operand the dequant
+    emits, the 32x32x16 product in its register layouts, the epilogue's staging writes and row-major read-back -- on one 256 x 256 block:
+    out == x W^T.  Scheduling and hazards are not modelled; a slip in an index expression shows up here before the kernel meets a GPU."""
+    M, N, K = 256, 256, 256
+    nit = K // 128
+    rng = np.random.default_rng(3)
+    q = rng.integers(0, 16, size=(N, K), dtype=np.uint8)
+    s = rng.uniform(0.004, 0.01, size=(N, nit))
+    z = -s * rng.integers(0, 16, size=(N, nit))
+    W = q * np.repeat(s, 128, axis=1) + np.repeat(z, 128, axis=1)
+    x = rng.standard_normal((M, K))
+    qw = np.ascontiguousarray(O.pack_cdna4w(q)).view(np.uint32).reshape(-1)             # flat u32 words
+    # sz_packed as the kernels read it: [N / 16][K / 128][16] -> here two float arrays with the same indexing
+    szs = s.reshape(N // 16, 16, nit).transpose(0, 2, 1).reshape(-1)
+    szz = z.reshape(N // 16, 16, nit).transpose(0, 2, 1).reshape(-1)
+    m0 = n0 = 0
+    pitch = 2 * 256 + 16
+    stage_out = np.zeros((256 * pitch // 2,))                                             # epilogue staging, in units of one T element
+    out = np.zeros((M, N))
+    lanes = np.arange(64)
+    l32, kb = lanes & 31, lanes >> 5
+    r4, p16 = lanes >> 4, lanes & 15
+    accs = {}
+    for wv in range(4):
+        acc = np.zeros((8, 2, 64, 16))
+        for t in range(nit):
+            # ---- x tile t in LDS as the staging writes lay it out (granule units of 8 elements) ----
+            lds = np.zeros((256 * 16, 8))                                                 # [row * 16 + slot][8 k]
+            for w2 in range(4):                                                           # all four waves stage their 64 rows
+                for qq in range(16):
+                    for ln in range(64):
+                        row_src = m0 + 64 * w2 + 4 * qq + r4[ln]                          # xw + 4 q K + r4 K
+                        kcol = t * 128 + p16[ln] * 8                                      # kt * 128 + p16 * 8
+                        wpat = (64 * w2) * 256 + r4[ln] * 256 + ((p16[ln] ^ (4 * (qq & 3) + r4[ln])) << 4)
+                        addr = wpat + qq * 1024                                           # bytes inside the stage
+                        lds[addr // 16] = x[row_src, kcol: kcol + 8]
+            for S in range(8):
+                for p in range(2):
+                    pc = (n0 >> 5) + 2 * wv + p
+                    TI, WI = S >> 2, S & 3
+                    w_off = pc * (2 * nit) * 256 + lanes * 4
+                    words = qw[(2 * t + TI) * 256 + w_off + WI]
+                    slab = 2 * pc + (l32 >> 4)
+                    s_off = slab * nit * 16 + (lanes & 15)
+                    A_l = _blocks_dequant(words, szs[t * 16 + s_off], szz[t * 16 + s_off])   # [lane][8]
+                    for f in range(8):
+                        xa = l32 * 256 + (((2 * S + kb) ^ (lanes & 15)) << 4)
+                        B_l = lds[(xa + f * 8192) // 16]                                  # [lane][8]
+                        Am = np.zeros((32, 16))
+                        Bm = np.zeros((16, 32))
+                        for ln in range(64):
+                            Am[ln % 32, 8 * (ln // 32): 8 * (ln // 32) + 8] = A_l[ln]
+                            Bm[8 * (ln // 32): 8 * (ln // 32) + 8, ln % 32] = B_l[ln]
+                        D = Am @ Bm
+                        for ln in range(64):
+                            for r in range(16):
+                                acc[f, p, ln, r] += D[(r & 3) + 8 * (r >> 2) + 4 * (ln // 32), ln % 32]
+        accs[wv] = acc
+    # ---- epilogue: staging writes of every wave, then the row-major read-back / store ----
+    for wv in range(4):
+        for f in range(8):
+            for p in range(2):
+                for rg in range(4):
+                    for ln in range(64):
+                        wbase = l32[ln] * pitch + (64 * wv + 4 * kb[ln]) * 2
+                        addr = wbase + f * (32 * pitch) + p * 64 + rg * 16                # bytes; four consecutive T elements
+                        for e in range(4):
+                            stage_out[addr // 2 + e] = accs[wv][f, p, ln, 4 * rg + e]
+    for wv in range(4):
+        for it in range(32):
+            for ln in range(64):
+                col = (ln & 31) * 8
+                row = 64 * wv + 2 * it + (ln >> 5)
+                ra = row * pitch + col * 2
+                out[m0 + row, n0 + col: n0 + col + 8] = stage_out[ra // 2: ra // 2 + 8]
+    ref = x @ W.T
+    assert np.allclose(out, ref, rtol=0, atol=1e-8), np.abs(out - ref).max()
