@@ -190,3 +190,46 @@ def test_index_model_of_the_v6w_experiment_kernel():
                 out[m0 + row, n0 + col: n0 + col + 8] = stage_out[ra // 2: ra // 2 + 8]
     ref = x @ W.T
     assert np.allclose(out, ref, rtol=0, atol=1e-8), np.abs(out - ref).max()
+
+
+def test_decode_kernels_can_read_cdna4w_at_slab_granularity():
+    """A 16-row slab is HALF of every pair tile (tile lanes 32 kb + 16 h + 0..15), so a decode block per slab -- the granularity that
+    gives N = 4096 projections one block per CU -- fetches, per 128-k step, the two halves of two adjacent pair tiles with ONE wave load
+    (per-lane offset tsel * 1024 + (32 kb + 16 h + l % 16) * 16, kb = (l / 16) & 1, tsel = l / 32): the 4-lane blocks of the dequant MFMA
+    see the same lane quads as inside the tile, and the result is the 16x16x32 A operand of row 16 h + l % 16 over the k set
+    {64 (2 st + tsel) + 16 a + 8 kb + 0..7}; with the activations read at the matching offsets the product is W x^T.  So the planned layout
+    costs the decode kernels three constants (lane offset of the weight load, lane offset of the x operand, nothing for sz), not their
+    block granularity."""
+    N, K, M = 64, 256, 5
+    rng = np.random.default_rng(19)
+    q = rng.integers(0, 16, size=(N, K), dtype=np.uint8)
+    s = rng.uniform(0.004, 0.01, size=(N, K // 128))
+    z = -s * rng.integers(0, 16, size=(N, K // 128))
+    W = q * np.repeat(s, 128, axis=1) + np.repeat(z, 128, axis=1)
+    x = rng.standard_normal((M, K))
+    buf = np.ascontiguousarray(O.pack_cdna4w(q)).view(np.uint8).reshape(-1)                # bytes, [pair][K / 64] tiles of 1 KiB
+    lanes = np.arange(64)
+    i16, g = lanes & 15, lanes >> 4
+    kbl, tsel = g & 1, g >> 1
+    ref = W @ x.T                                                                            # [n, m]
+    for slab in range(N // 16):
+        pair, h = slab >> 1, slab & 1
+        acc = np.zeros((16, 16))                                                            # [n in slab][m]  (16x16x32: D[i][j])
+        for st in range(K // 128):                                                          # one 128-k step = one wave load of 1 KiB
+            voff = tsel * 1024 + (32 * kbl + 16 * h + i16) * 16                             # per-lane constant
+            soff = (pair * (K // 64) + 2 * st) * 1024                                       # wave-uniform: pair tile 2 st (and 2 st + 1 behind it)
+            words = np.stack([np.array([int.from_bytes(bytes(buf[soff + v + 4 * a: soff + v + 4 * a + 4]), "little") for v in voff], dtype=np.uint32)
+                              for a in range(4)], axis=1)                                   # [lane][word a]: the lane's 16 bytes
+            n_lane = 16 * slab + i16
+            for a in range(4):
+                A_l = _blocks_dequant(words[:, a], s[n_lane, st], z[n_lane, st])            # [lane][8]: row n_lane, k = base + 0..7
+                kbase = 64 * (2 * st + tsel) + 16 * a + 8 * kbl
+                want = np.stack([W[n_lane, kbase + j] for j in range(8)], axis=1)
+                assert np.allclose(A_l, want, rtol=0, atol=1e-12), (slab, st, a)
+                # 16x16x32: A lane (i = l % 16, g = l / 16) holds 8 of the 32 k; B lane (j = l % 16, g) the same k of activation row j
+                B_l = np.stack([x[np.minimum(i16, M - 1), kbase + j] for j in range(8)], axis=1)
+                for gg in range(4):
+                    Ag = A_l[16 * gg: 16 * gg + 16]                                         # [i][8]
+                    Bg = B_l[16 * gg: 16 * gg + 16]                                         # [j][8]
+                    acc += Ag @ Bg.T
+        assert np.allclose(acc[:, :M], ref[16 * slab: 16 * slab + 16, :], rtol=0, atol=1e-9), slab
