@@ -368,21 +368,27 @@ def pack_cdna4w(q) -> np.ndarray:
     N, K = q.shape
     assert N % 32 == 0 and K % 128 == 0
     out = np.zeros(N * K // 8, dtype=np.uint32)
-    nn, kk = np.meshgrid(np.arange(N, dtype=np.int64), np.arange(K, dtype=np.int64), indexing="ij")
-    word, p = cdna4w_position(nn, kk, K)
-    val = (q.astype(np.uint32) & 0xF) << (4 * p).astype(np.uint32)
-    for j in range(8):
-        m = p == j
-        out[word[m]] |= val[m]
+    kk1 = np.arange(K, dtype=np.int64)
+    for n0, n1 in _row_chunks(N):  # (chunks are multiples of 32 rows: a pair's tiles only hold nibbles of its own rows)
+        nn, kk = np.meshgrid(np.arange(n0, n1, dtype=np.int64), kk1, indexing="ij")
+        word, p = cdna4w_position(nn, kk, K)
+        val = (q[n0:n1].astype(np.uint32) & 0xF) << (4 * p).astype(np.uint32)
+        for j in range(8):
+            m = p == j
+            out[word[m]] |= val[m]
     return out.view(np.int16).reshape(N // 4, K)
 
 
 def unpack_cdna4w(qweight) -> np.ndarray:
     w = np.ascontiguousarray(np.asarray(qweight)).view(np.uint32).reshape(-1)
     N, K = qweight.shape[0] * 4, qweight.shape[1]
-    nn, kk = np.meshgrid(np.arange(N, dtype=np.int64), np.arange(K, dtype=np.int64), indexing="ij")
-    word, p = cdna4w_position(nn, kk, K)
-    return ((w[word] >> (4 * p).astype(np.uint32)) & 0xF).astype(np.uint8)
+    out = np.empty((N, K), dtype=np.uint8)
+    kk1 = np.arange(K, dtype=np.int64)
+    for n0, n1 in _row_chunks(N):
+        nn, kk = np.meshgrid(np.arange(n0, n1, dtype=np.int64), kk1, indexing="ij")
+        word, p = cdna4w_position(nn, kk, K)
+        out[n0:n1] = ((w[word] >> (4 * p).astype(np.uint32)) & 0xF).astype(np.uint8)
+    return out
 
 
 def pack_sz_half(scales: torch.Tensor, scaled_zeros: torch.Tensor, K: int):

@@ -29,6 +29,30 @@ def timeit(fn, it=10):
     return e0.elapsed_time(e1) * 1e3 / it
 
 
+def pack_cdna4w_torch(q: torch.Tensor) -> torch.Tensor:
+    """oracle.cdna4w_position evaluated with torch on the device (the numpy oracle takes ~15 s per 4096 x 4096 on the host: too slow to hold
+    a GPU box for); checked against the oracle on a small matrix in main()."""
+    N, K = q.shape
+    dev = q.device
+    n = torch.arange(N, device=dev, dtype=torch.int64)[:, None]
+    k = torch.arange(K, device=dev, dtype=torch.int64)[None, :]
+    npair, c = n // 32, n % 32
+    nq, j = c // 4, c % 4
+    kt, kk = k // 64, k % 64
+    a, r16 = kk // 16, kk % 16
+    kb, e = r16 // 8, r16 % 8
+    th, rr = e // 4, e % 4
+    lane = 32 * kb + 4 * nq + rr
+    i = 2 * th + (j >> 1)
+    p = (i + 4 * (j & 1)).expand(N, K)
+    word = (((npair * (K // 64) + kt) * 64 + lane) * 4 + a).expand(N, K)
+    val = (q.to(torch.int64) & 0xF) << (4 * p)
+    out = torch.zeros(N * K // 8, dtype=torch.int64, device=dev)
+    out.index_put_((word.reshape(-1),), val.reshape(-1), accumulate=True)   # disjoint bit fields: the sum is the OR
+    out = torch.where(out >= 2 ** 31, out - 2 ** 32, out).to(torch.int32)
+    return out.view(torch.int16).reshape(N // 4, K)
+
+
 def main():
     L = _capi.lib()
     probe = getattr(L, "awq_probe_gemm_cdna4w", None)
@@ -45,11 +69,14 @@ def main():
                           x.shape[0], N, K, 0 if x.dtype == torch.float16 else 1, torch.cuda.current_stream().cuda_stream))
         return out
 
+    qs = torch.randint(0, 16, (96, 384), dtype=torch.uint8, device="cuda")
+    assert np.array_equal(pack_cdna4w_torch(qs).cpu().numpy(), O.pack_cdna4w(qs.cpu().numpy())), "device-side packer != oracle"
+
     # ---- 1. small shapes against the oracle ----
     for dtype in (torch.bfloat16, torch.float16):
         for (N, K, M) in ((256, 128, 256), (512, 1024, 300), (1280, 512, 777)):
             c = make_case(N, K, dtype, seed=N + K + M, M=M, bias=True)
-            qww = torch.from_numpy(O.pack_cdna4w(c["q"])).cuda()
+            qww = pack_cdna4w_torch(torch.from_numpy(c["q"]).cuda())
             szp = ops.pack_sz_cdna4(c["scales"].cuda(), c["scaled_zeros"].cuda(), K)
             for b in (None, c["bias"]):
                 y = run(c["x"].cuda(), qww, szp, b.cuda() if b is not None else None, N, K)
@@ -61,8 +88,7 @@ def main():
     print("# shape K N M  product_us  v6w_us  TF_product TF_v6w  identical_fraction")
     for (name, K, N) in (("o", 4096, 4096), ("qkv", 4096, 6144), ("down", 14336, 4096)) + (() if quick else (("gate+up", 4096, 28672),)):
         w = synth.random_wq(K, N, dtype=torch.bfloat16, seed=K + N, keep_q=True)
-        q = w["q"].cpu().numpy() if torch.is_tensor(w["q"]) else np.asarray(w["q"])
-        qww = torch.from_numpy(O.pack_cdna4w(q)).cuda()
+        qww = pack_cdna4w_torch(w["q"])
         c4 = ops.repack_v2_to_cdna4(w["qweight"])
         szp = ops.pack_sz_cdna4(w["scales"], w["scaled_zeros"], K)
         for M in (2048, 4096):
