@@ -337,6 +337,37 @@ __global__ __launch_bounds__(256) void gemm_cdna4w_v6_kernel(const uint16_t* __r
   v6w_tile<DT>(smem, x, qw, szp, bias, out, N, K, min(tm * W_TM, M - W_TM), tn * W_TN, N);
 }
 
+// v2 -> cdna4w (one thread per destination u32 word, as awq_util.hip's repack_v2_to_cdna4_kernel): destination word t = tile * 256 + lane * 4 + a
+// of tile (pair, kt); lane = 32 kb + 4 nq + r; nibble p (i = p & 3, hi = p >> 2) <- Q[32 pair + 4 nq + 2 (i & 1) + hi][64 kt + 16 a + 8 kb + 4 (i >> 1) + r]
+__global__ void repack_v2_to_cdna4w_kernel(const u32* __restrict__ src, u32* __restrict__ dst, int N, int K) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)N * K / 8) return;
+  const int a = (int)(t & 3), lane = (int)((t >> 2) & 63);
+  const size_t tile = t >> 8;
+  const int nt64 = K >> 6;
+  const int pair = (int)(tile / nt64), kt = (int)(tile % nt64);
+  const int kb = lane >> 5, nq = (lane >> 2) & 7, r = lane & 3;
+  u32 w = 0;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int i = p & 3, hi = p >> 2;
+    const int n = 32 * pair + 4 * nq + 2 * (i & 1) + hi;
+    const int k = 64 * kt + 16 * a + 8 * kb + 4 * (i >> 1) + r;
+    // the v2 read of awq_util.hip::v2_read_nibble
+    const int kl = k & 31;
+    const int wa = (kl & 7) >> 1, nib = (kl >> 3) + 4 * (kl & 1);
+    w |= ((src[v2_chunk_word(n, k >> 5, K) + wa] >> (4 * nib)) & 0xFu) << (4 * p);
+  }
+  dst[t] = w;
+}
+
+int launch_repack_v2_to_cdna4w(const void* src, void* dst, int n, int k, hipStream_t st) {
+  if ((n % 32) != 0 || (k % 128) != 0) return -1;
+  const size_t words = (size_t)n * k / 8;
+  hipLaunchKernelGGL(repack_v2_to_cdna4w_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, (const u32*)src, (u32*)dst, n, k);
+  return 0;
+}
+
 // qw: cdna4w-interleaved weights (tools/v6w_try.py packs them on the host); szp: the usual sz_packed [N / 16][K / 128][16].  m >= 256, n % 32 == 0, k % 128 == 0.
 int launch_gemm_cdna4w_v6(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int dtype,
                           hipStream_t st) {

@@ -71,6 +71,17 @@ def main():
 
     qs = torch.randint(0, 16, (96, 384), dtype=torch.uint8, device="cuda")
     assert np.array_equal(pack_cdna4w_torch(qs).cpu().numpy(), O.pack_cdna4w(qs.cpu().numpy())), "device-side packer != oracle"
+    # the HIP repacker v2 -> cdna4w (awq_probe_repack_v2_to_cdna4w) against both
+    rep = getattr(L, "awq_probe_repack_v2_to_cdna4w")
+    rep.restype = ctypes.c_int
+    rep.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    for (N, K) in ((96, 384), (4096, 4096)):
+        qv = torch.randint(0, 16, (N, K), dtype=torch.uint8, device="cuda")
+        v2 = ops.pack_v2(qv)
+        dst = torch.empty_like(v2)
+        _capi.check(rep(v2.data_ptr(), dst.data_ptr(), N, K, torch.cuda.current_stream().cuda_stream))
+        assert torch.equal(dst, pack_cdna4w_torch(qv)), ("HIP repacker != packer", N, K)
+    print("repack_v2_to_cdna4w ok", flush=True)
 
     # ---- 1. small shapes against the oracle ----
     for dtype in (torch.bfloat16, torch.float16):
