@@ -233,3 +233,21 @@ def test_decode_kernels_can_read_cdna4w_at_slab_granularity():
                     Bg = B_l[16 * gg: 16 * gg + 16]                                         # [j][8]
                     acc += Ag @ Bg.T
         assert np.allclose(acc[:, :M], ref[16 * slab: 16 * slab + 16, :], rtol=0, atol=1e-9), slab
+
+
+def test_forward_rule_of_the_device_repacker_inverts_the_index_map():
+    """csrc/awq_gemm_v6w.hip::repack_v2_to_cdna4w_kernel builds destination word t = tile * 256 + lane * 4 + a nibble by nibble from
+    (n, k) = (32 pair + 4 nq + 2 (i & 1) + hi, 64 kt + 16 a + 8 kb + 4 (i >> 1) + r): that rule, restated, is the inverse of
+    cdna4w_position for every (word, nibble)."""
+    N, K = 64, 256
+    nt64 = K // 64
+    for t in range(N * K // 8):
+        a, lane, tile = t & 3, (t >> 2) & 63, t >> 8
+        pair, kt = tile // nt64, tile % nt64
+        kb, nq, r = lane >> 5, (lane >> 2) & 7, lane & 3
+        for p in range(8):
+            i, hi = p & 3, p >> 2
+            n = 32 * pair + 4 * nq + 2 * (i & 1) + hi
+            k = 64 * kt + 16 * a + 8 * kb + 4 * (i >> 1) + r
+            word, pp = O.cdna4w_position(n, k, K)
+            assert (int(word), int(pp)) == (t, p), (t, p, n, k)
