@@ -383,6 +383,156 @@ int launch_gemm_cdna4w_v6(const void* x, const void* qw, const void* szp, const 
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Decode GEMV on cdna4w weights at SLAB granularity (EXPERIMENT; a reduced copy of awq_gemv_dma.hip's body: EPI 0, sz_half dequant form).
+// A 16-row slab nb is half h = nb & 1 of every tile of pair nb >> 1 (tile lanes 32 kb + 16 h + 0..15), so one 1-KiB wave load per 128-k
+// step fetches the two halves of two adjacent pair tiles: lane l = 16 g + i, kb = g & 1, tsel = g >> 1 reads 16 bytes at
+// tsel * 1024 + (32 kb + 16 h + i) * 16 behind the wave-uniform (pair * K / 64 + 2 step) * 1024.  The dequant then yields the 16x16x32
+// operand of row i over k = 128 step + 64 tsel + 16 a + 8 kb + 0..7, and the x operand is read at the matching offsets
+// (tests/test_cdna4w_layout.py::test_decode_kernels_can_read_cdna4w_at_slab_granularity).  Everything else -- K split over waves, ring,
+// counted vmcnt, sz staging, split-K reduction through LDS, bias -- is the product kernel's.
+// ---------------------------------------------------------------------------------------------------------------------------------
+#define DMAW_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+template <int SIZE, int AUX>
+__device__ __forceinline__ void dmaw_to_lds(const __amdgpu_buffer_rsrc_t& rsrc, char* dst, u32 voff, u32 soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (SIZE == 16 && AUX == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, DMAW_LDS_PTR(dst), 16, voff, soff, 0, 2);
+  if constexpr (SIZE == 16 && AUX == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, DMAW_LDS_PTR(dst), 16, voff, soff, 0, 0);
+  if constexpr (SIZE == 4 && AUX == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, DMAW_LDS_PTR(dst), 4, voff, soff, 0, 0);
+#endif
+}
+template <int N_>
+__device__ __forceinline__ void dmaw_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N_) : "memory");
+}
+template <int J, int E, class F>
+__device__ __forceinline__ void dmaw_static_for(F&& f) {
+  if constexpr (J < E) {
+    f(std::integral_constant<int, J>{});
+    dmaw_static_for<J + 1, E>(f);
+  }
+}
+
+template <typename DT, int WAVES, int D>
+__global__ __launch_bounds__(64 * WAVES) void gemv_dmaw_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
+                                                                const u32* __restrict__ szh, const uint16_t* __restrict__ bias,
+                                                                uint16_t* __restrict__ out, int M, int N, int K, int TX) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nb = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int kbl = g & 1, tsel = g >> 1;
+  const int nit = K >> 7;
+  const int TXp = (TX + 3) & ~3;
+  const int xrow = TXp * 256 + 16;
+  const int wave_bytes = D * 1024 + TXp * 64 + M * xrow;
+  char* wbase = smem + wv * wave_bytes;
+  char* ring = wbase;
+  char* szs = wbase + D * 1024;
+  char* xs = szs + TXp * 64;
+  const int s0 = wv * TX;
+
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(qw), 0, (N >> 4) * nit * 1024, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(szh), 0, (N >> 4) * nit * 64, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(x), 0, M * K * 2, 0x00020000);
+  const u32 pair_tile = (u32)(nb >> 1) * (u32)(2 * nit);                                 // pair tiles are [N / 32][K / 64]
+  const u32 wvoff = (u32)tsel * 1024u + (u32)(32 * kbl + 16 * (nb & 1) + i) * 16u;        // this lane's 16 bytes inside the two tiles of a step
+  const u32 slab_sz = (u32)nb * (u32)nit;                                                // sz_half stays [N / 16][K / 128][16]
+  const u32 lane16 = lane * 16u, lane4 = lane * 4u;
+  auto issue = [&](int t, int slot) {
+    const u32 kg = (u32)min(s0 + t, nit - 1);
+    dmaw_to_lds<16, 2>(rw, ring + slot * 1024, wvoff, (pair_tile + 2u * kg) * 1024u);
+  };
+  issue(0, 0);
+  for (int q = 0; q < TXp; q += 4) dmaw_to_lds<4, 0>(rs, szs + q * 64, lane4, (slab_sz + (u32)(s0 + q)) * 64u);
+  for (int r = 0; r < M; ++r)
+    for (int q = 0; q < TXp; q += 4) dmaw_to_lds<16, 0>(rx, xs + r * xrow + q * 256, lane16, ((u32)r * (u32)K + (u32)(s0 + q) * 128u) * 2u);
+#pragma unroll
+  for (int d = 1; d < D; ++d) issue(d, d);
+
+  using vec8 = typename DT::vec8;
+  Cdna4DequantH<DT> ch;
+  ch.init(lane);
+  const int mrow = min(i, M - 1);
+  const u32 lds0 = (u32)(size_t)(__attribute__((address_space(3))) char*)wbase;
+  const u32 ring_lane = lds0 + lane16;
+  const u32 sz_lane = lds0 + D * 1024 + i * 4;
+  const u32 x_lane = lds0 + D * 1024 + TXp * 64 + mrow * xrow + tsel * 128 + kbl * 16;   // k = 64 tsel + 16 a + 8 kb: a * 32 bytes apart
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int slot = 0;
+  auto step = [&](int t, auto vm_, auto reissue_) {
+    constexpr int VM = decltype(vm_)::value;
+    constexpr bool REISSUE = decltype(reissue_)::value;
+    u32x4 w, xo[4];
+    u32 sz;
+    const u32 ra = ring_lane + slot * 1024, sa = sz_lane + t * 64, xa = x_lane + t * 256;
+    dmaw_wait_vm<VM>();
+    asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(w) : "v"(ra) : "memory");
+    asm volatile("ds_read_b32 %0, %1" : "=v"(sz) : "v"(sa) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(xo[0]) : "v"(xa) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(xo[1]) : "v"(xa) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(xo[2]) : "v"(xa) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(xo[3]) : "v"(xa) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w), "+v"(sz), "+v"(xo[0]), "+v"(xo[1]), "+v"(xo[2]), "+v"(xo[3]) : : "memory");
+    if (REISSUE) issue(t + D, slot);
+    if (s0 + t < nit) {
+      vec8 op[4];
+      ch.tile(w, sz, op);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) acc = DT::mfma(op[a], __builtin_bit_cast(vec8, xo[a]), acc);
+    }
+    slot = slot + 1 == D ? 0 : slot + 1;
+  };
+  int t = 0;
+  for (; t < TX - D; ++t) step(t, std::integral_constant<int, D - 1>{}, std::true_type{});
+  dmaw_static_for<0, D>([&](auto j_) {
+    constexpr int J = decltype(j_)::value;
+    step(t + J, std::integral_constant<int, D - 1 - J>{}, std::false_type{});
+  });
+  // split-K reduction across the block's waves through each wave's own (now idle) first ring slot: acc[r] = C[n = 4 g + r][m = i]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) reinterpret_cast<float*>(wbase)[r * 64 + lane] = acc[r];
+  __syncthreads();
+  if (wv < 4 && i < M) {
+    const int r = wv;
+    float tsum = 0.f;
+#pragma unroll
+    for (int q = 0; q < WAVES; ++q) tsum += reinterpret_cast<const float*>(smem + q * wave_bytes)[r * 64 + lane];
+    const int nn = nb * 16 + 4 * g + r;
+    uint16_t o = DT::from_float(tsum);
+    if (bias != nullptr) o = DT::from_float(DT::to_float(o) + DT::to_float(bias[nn]));
+    out[(size_t)i * N + nn] = o;
+  }
+}
+
+// waves / d: the product's choice for the shape (8 / 2: one or two slabs per CU; 16 / 1: K >= 12288; 4 / 7: many slabs per CU).  m <= 8.
+int launch_gemv_dmaw(const void* x, const void* qw, const void* szh, const void* bias, void* out, int m, int n, int k, int dtype, int waves,
+                     int d, hipStream_t st) {
+  if (m < 1 || m > 8 || (k % 128) != 0 || (n % 32) != 0 || !szh) return -1;
+  const int nit = k / 128;
+  while (waves > 4 && waves > nit) waves >>= 1;
+  const int tx = (nit + waves - 1) / waves, txp = (tx + 3) & ~3;
+  if (d > tx) d = tx;
+  const size_t smem = (size_t)waves * ((size_t)d * 1024 + (size_t)txp * 64 + (size_t)m * (txp * 256 + 16));
+  if (smem > 160 * 1024) return -1;
+#define AWQ_DW(DT_, W_, D_)                                                                                                        \
+  if (waves == W_ && d == D_) {                                                                                                    \
+    auto kern = gemv_dmaw_kernel<DT_, W_, D_>;                                                                                     \
+    static LdsOptIn optin;                                                                                                         \
+    if (smem > 64 * 1024) optin.ensure(reinterpret_cast<const void*>(kern));                                                       \
+    hipLaunchKernelGGL(kern, dim3(n / 16), dim3(64 * W_), smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szh,           \
+                       (const uint16_t*)bias, (uint16_t*)out, m, n, k, tx);                                                        \
+    return 0;                                                                                                                      \
+  }
+  if (dtype == 0) {
+    AWQ_DW(F16, 8, 2) AWQ_DW(F16, 16, 1) AWQ_DW(F16, 4, 7) AWQ_DW(F16, 4, 4)
+  } else {
+    AWQ_DW(BF16, 8, 2) AWQ_DW(BF16, 16, 1) AWQ_DW(BF16, 4, 7) AWQ_DW(BF16, 4, 4)
+  }
+#undef AWQ_DW
+  return -1;
+}
+
 }  // namespace awq
 
 #endif  // AWQ_ENABLE_PROBES

@@ -94,6 +94,48 @@ def main():
                 check_forward(y.cpu(), c["x"], c["q"], c["scales"], c["scaled_zeros"], dtype, bias=b)
             print("oracle ok", dtype, (N, K, M), flush=True)
 
+    # ---- 1b. decode on the same weights at slab granularity (awq_probe_decode_cdna4w) against the oracle and the product decode ----
+    dec = getattr(L, "awq_probe_decode_cdna4w")
+    dec.restype = ctypes.c_int
+    dec.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 6 + [ctypes.c_void_p]
+
+    def run_dec(x, qww, szh, bias, N, K, waves, ring):
+        out = torch.empty(x.shape[0], N, dtype=x.dtype, device="cuda")
+        _capi.check(dec(x.data_ptr(), qww.data_ptr(), szh.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(),
+                        x.shape[0], N, K, 0 if x.dtype == torch.float16 else 1, waves, ring, torch.cuda.current_stream().cuda_stream))
+        return out
+
+    for dtype in (torch.bfloat16, torch.float16):
+        for (N, K, waves, ring) in ((64, 1280, 8, 2), (256, 4096, 8, 2), (64, 14336, 16, 1), (2048, 4096, 4, 7), (96, 11008, 4, 4)):
+            c = make_case(N, K, dtype, seed=N + K, M=8, bias=True)
+            qww = pack_cdna4w_torch(torch.from_numpy(c["q"]).cuda())
+            szh, exact = ops.pack_szh_cdna4(c["scales"].cuda(), c["scaled_zeros"].cuda(), K)
+            assert exact
+            for M in (1, 3, 8):
+                xx = c["x"][:M].contiguous()
+                for b in (None, c["bias"]):
+                    y = run_dec(xx.cuda(), qww, szh, b.cuda() if b is not None else None, N, K, waves, ring)
+                    check_forward(y.cpu(), xx, c["q"], c["scales"], c["scaled_zeros"], dtype, bias=b)
+            print("decode oracle ok", dtype, (N, K, waves, ring), flush=True)
+    from tools.gemvc_sweep import time_graph
+    from llm_awq_amd import synth as _synth
+    print("# decode M = 1, graph over rotating copies: shape  product_us  cdna4w_us")
+    for (name, K, N, waves, ring) in (("o", 4096, 4096, 8, 2), ("qkv", 4096, 6144, 8, 2), ("down", 14336, 4096, 16, 1)):
+        copies = []
+        for ci in range(max(10, min(40, (700 << 20) // (N * K // 2)))):
+            w = _synth.random_wq(K, N, dtype=torch.bfloat16, seed=ci, keep_q=True)
+            szh, exact = ops.pack_szh_cdna4(w["scales"], w["scaled_zeros"], K)
+            copies.append(dict(c4=ops.repack_v2_to_cdna4(w["qweight"]), cw=pack_cdna4w_torch(w["q"]), szh=szh))
+            del w
+        x1 = torch.randn(1, K, device="cuda").bfloat16()
+        o1 = torch.empty(1, N, device="cuda", dtype=torch.bfloat16)
+        st = lambda: torch.cuda.current_stream().cuda_stream  # noqa: E731
+        t_prod = time_graph(lambda c: _capi.check(L.awq_w4a16_decode_cdna4(x1.data_ptr(), c["c4"].data_ptr(), c["szh"].data_ptr(), None, o1.data_ptr(), 1, N, K, 128, 1, 0, st())), copies)
+        t_new = time_graph(lambda c: _capi.check(dec(x1.data_ptr(), c["cw"].data_ptr(), c["szh"].data_ptr(), None, o1.data_ptr(), 1, N, K, 1, waves, ring, st())), copies)
+        print(f"{name:6s} {K:6d} {N:6d}  {t_prod:7.2f} {t_new:7.2f}", flush=True)
+        del copies
+        torch.cuda.empty_cache()
+
     # ---- 2. Llama-3-8B shapes: equality with the product path + time ----
     from llm_awq_amd import synth
     print("# shape K N M  product_us  v6w_us  TF_product TF_v6w  identical_fraction")
