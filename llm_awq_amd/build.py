@@ -27,7 +27,7 @@ ARCH = "gfx950"
 
 HIP_SOURCES = ["awq_gemv.hip", "awq_gemv_cdna4.hip", "awq_gemv_dma.hip", "awq_gemv_v2fast.hip", "awq_gemm.hip", "awq_gemm_v3.hip", "awq_gemm_v4.hip", "awq_gemm_v4n.hip", "awq_gemm_v6.hip", "awq_skinny_cdna4.hip", "awq_skinny_v2.hip", "awq_util.hip", "awq_w3.hip", "awq_oneshot.hip", "awq_capi.hip"]
 # evaluated alternatives that only AWQ_PROBES=1 builds compile (knob-reachable there, absent from the product library)
-PROBE_SOURCES = ["awq_gemm_v5.hip", "awq_gemm_v6w.hip"]
+PROBE_SOURCES = ["awq_gemm_v5.hip"]
 HIP_DEPS = ["awq_device.hpp", "awq_kernels.hpp", os.path.join(ROOT, "include", "awq_cdna4.h")]
 
 

@@ -437,28 +437,6 @@ int awq_w3a16_forward(const void* x, const void* qweight_w3, const void* scales,
   return finish_launch();
 }
 
-#ifdef AWQ_ENABLE_PROBES
-// experiment builds only (not declared in include/awq_cdna4.h): the prefill GEMM on the planned "cdna4w" interleave, see awq_gemm_v6w.hip
-int awq_probe_gemm_cdna4w(const void* x, const void* qweight_cdna4w, const void* sz_packed, const void* bias, void* out, int m, int n, int k,
-                          int dtype, void* stream) {
-  if (!x || !qweight_cdna4w || !sz_packed || !out) return AWQ_ERR_NULL;
-  if (dtype != AWQ_F16 && dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
-  if (awq::launch_gemm_cdna4w_v6(x, qweight_cdna4w, sz_packed, bias, out, m, n, k, dtype, (hipStream_t)stream) != 0) return AWQ_ERR_SHAPE;
-  return finish_launch();
-}
-int awq_probe_decode_cdna4w(const void* x, const void* qweight_cdna4w, const void* sz_half, const void* bias, void* out, int m, int n, int k,
-                            int dtype, int waves, int ring, void* stream) {
-  if (!x || !qweight_cdna4w || !sz_half || !out) return AWQ_ERR_NULL;
-  if (awq::launch_gemv_dmaw(x, qweight_cdna4w, sz_half, bias, out, m, n, k, dtype, waves, ring, (hipStream_t)stream) != 0) return AWQ_ERR_SHAPE;
-  return finish_launch();
-}
-int awq_probe_repack_v2_to_cdna4w(const void* qweight_v2, void* qweight_cdna4w, int n, int k, void* stream) {
-  if (!qweight_v2 || !qweight_cdna4w) return AWQ_ERR_NULL;
-  if (awq::launch_repack_v2_to_cdna4w(qweight_v2, qweight_cdna4w, n, k, (hipStream_t)stream) != 0) return AWQ_ERR_SHAPE;
-  return finish_launch();
-}
-#endif
-
 int awq_tune_set(const char* key, int value) {
   if (!key) return AWQ_ERR_NULL;
   // the knobs select between shipped code paths (tests force each of them) or, in AWQ_PROBES builds, timing probes; all of them

@@ -113,12 +113,6 @@ void launch_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const 
 void launch_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
                           int n_end, int dtype, hipStream_t st, int bits = 4, int epi = 0, int szfmt = 0, int tile_n = 256);
 void gemm_v6_set_probe(int v);
-// AWQ_PROBES builds only (awq_gemm_v6w.hip): the v6 loop on the planned 32-row interleave "cdna4w"; m >= 256, n % 32 == 0; -1 if unsupported
-int launch_repack_v2_to_cdna4w(const void* src, void* dst, int n, int k, hipStream_t st);
-int launch_gemv_dmaw(const void* x, const void* qw_cdna4w, const void* szh, const void* bias, void* out, int m, int n, int k, int dtype, int waves,
-                     int d, hipStream_t st);
-int launch_gemm_cdna4w_v6(const void* x, const void* qw_cdna4w, const void* szp, const void* bias, void* out, int m, int n, int k, int dtype,
-                          hipStream_t st);
 // awq_gemv_dma.hip: QuantLlamaMLP.forward at decode (gate/up + SiLU * mul + down) in one launch; -1 if the shape is not served
 int launch_mlp_decode(const void* x, const void* qw_gu, const void* szh_gu, const void* qw_d, const void* szh_d, const void* bias_d,
                       void* h, void* out, int m, int hidden, int ffn, int n_out, int dtype, int* ctr, hipStream_t st);

@@ -332,65 +332,6 @@ def v2_to_cdna4(qweight_v2) -> np.ndarray:
     return pack_cdna4(unpack_v2(qweight_v2))
 
 
-# --------------------------------------------------------------------------------------
-# "cdna4w" interleave -- PLANNED (DESIGN.md "Next steps after round 3", item 1): the 32-row sibling of the cdna4 tile, so that the
-# matrix-core dequant emits the A operand of v_mfma_f32_32x32x16 (half the product-MFMA issue and operand reads of 16x16x32) directly.
-# No kernel reads it yet; the index map, its round trip and a register-level emulation of the dequant + product MFMAs are pinned by
-# tests/test_cdna4w_layout.py so that the kernel work starts from a verified layout.  Same size / dtype as v2 and cdna4:
-#   u32 words [N/32][K/64][64 lanes][4 words]; one 1-KiB tile = 32 rows x 64 k (half a quantisation group of a slab PAIR).
-#   lane = 32*kb + 4*nq + r (kb = k octet 0..1, nq = row quad 0..7), word a, nibble p (i = p & 3, hi = p >> 2) holds
-#       Q[n = 32*np + 4*nq + 2*(i & 1) + hi][k = 64*kt + 16*a + 8*kb + 4*(i >> 1) + r]
-# i.e. the cdna4 rule with the 16 blocks of the 4x4x4 MFMA assigned to (2 k octets x 8 row quads) instead of (4 x 4): the dequant
-# result lands with lane (n = l % 32, kb = l / 32) holding k = 16 a + 8 kb + 0..7 of row n -- the 32x32x16 A operand.
-# --------------------------------------------------------------------------------------
-
-
-def cdna4w_position(n, k, K):
-    """(word index into the flat u32 buffer, nibble index) of logical weight Q[n, k] in the planned 32-row interleave."""
-    n = np.asarray(n)
-    k = np.asarray(k)
-    npair, c = n // 32, n % 32
-    nq, j = c // 4, c % 4
-    kt, kk = k // 64, k % 64
-    a, r16 = kk // 16, kk % 16
-    kb, e = r16 // 8, r16 % 8
-    th, rr = e // 4, e % 4
-    lane = 32 * kb + 4 * nq + rr
-    i = 2 * th + (j >> 1)
-    p = i + 4 * (j & 1)
-    word = ((npair * (K // 64) + kt) * 64 + lane) * 4 + a
-    return word, p
-
-
-def pack_cdna4w(q) -> np.ndarray:
-    """Logical ints [N, K] (0..15) -> the planned cdna4w interleave, int16 [N/4, K] (same shape as v2 / cdna4)."""
-    q = np.asarray(q)
-    N, K = q.shape
-    assert N % 32 == 0 and K % 128 == 0
-    out = np.zeros(N * K // 8, dtype=np.uint32)
-    kk1 = np.arange(K, dtype=np.int64)
-    for n0, n1 in _row_chunks(N):  # (chunks are multiples of 32 rows: a pair's tiles only hold nibbles of its own rows)
-        nn, kk = np.meshgrid(np.arange(n0, n1, dtype=np.int64), kk1, indexing="ij")
-        word, p = cdna4w_position(nn, kk, K)
-        val = (q[n0:n1].astype(np.uint32) & 0xF) << (4 * p).astype(np.uint32)
-        for j in range(8):
-            m = p == j
-            out[word[m]] |= val[m]
-    return out.view(np.int16).reshape(N // 4, K)
-
-
-def unpack_cdna4w(qweight) -> np.ndarray:
-    w = np.ascontiguousarray(np.asarray(qweight)).view(np.uint32).reshape(-1)
-    N, K = qweight.shape[0] * 4, qweight.shape[1]
-    out = np.empty((N, K), dtype=np.uint8)
-    kk1 = np.arange(K, dtype=np.int64)
-    for n0, n1 in _row_chunks(N):
-        nn, kk = np.meshgrid(np.arange(n0, n1, dtype=np.int64), kk1, indexing="ij")
-        word, p = cdna4w_position(nn, kk, K)
-        out[n0:n1] = ((w[word] >> (4 * p).astype(np.uint32)) & 0xF).astype(np.uint8)
-    return out
-
-
 def pack_sz_half(scales: torch.Tensor, scaled_zeros: torch.Tensor, K: int):
     """THIS repository's "sz_half" side buffer of the decode kernels (no reference counterpart; DESIGN.md "f16-mantissa dequant"):
     u32 [N/16][K/128][16] = {f16(s') | f16(sz) << 16} with s' = s for rows n % 4 < 2 and s / 16 for the others.
