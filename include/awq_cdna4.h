@@ -227,6 +227,18 @@ int awq_w3a16_forward(const void* x, const void* qweight_w3, const void* scales,
                       const void* sz_packed, const void* bias, void* out, int m, int n, int k, int group_size, int dtype,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- Tensor-parallel row split (K-sharded WQLinear; SURVEY.md 8(e): new capability, the reference has no multi-GPU path for
+ * awq/quantize/qmodule.py:201-224).  Rank r holds the k range [k0, k1) of the cdna4 buffers and computes
+ *     out_f32[m, n] = x[:, k0:k1] . W[:, k0:k1]^T        fp32 accumulators, UNROUNDED, no bias
+ * with the same kernels as the unsharded forward (decode streaming / skinny / prefill tiles by m); the ranks' partials are summed in fp32
+ * (awq_oneshot_allreduce_f32 for the latency-class messages, RCCL on the float tensor above that) and rounded to T ONCE, then the bias
+ * is added in T -- what the single-device kernel does with its one accumulator, so the sharded output stays within the 1e-3 budget of
+ * the single-device result in bf16 as well (T-rounded partials: 2.6-2.9e-3).  sz_half is optional (NULL = read sz_packed). ---- */
+int awq_w4a16_partial_cdna4(const void* x, const void* qweight_cdna4, const void* sz_packed, const void* sz_half, float* out_f32, int m,
+                            int n, int k, int group_size, int dtype, void* stream);
+/* out[m, n] = T(in_f32[m, n]) (+ bias[n] in T; may be NULL): the single rounding after an RCCL sum of the partials.  n % 8 == 0. */
+int awq_round_bias_f32(const float* in_f32, const void* bias, void* out, int m, int n, int dtype, void* stream);
+
 /* ---- One-shot all-reduce (sum, fp32 accumulation in rank order, one rounding to T) for the latency-class messages of
  * K-sharded decode: M * N * 2 bytes = 8 .. 16 KiB after o_proj / down_proj (the reference has no multi-GPU path).
  * Every rank owns one exchange buffer (awq_oneshot_alloc: fine-grained device memory, awq_oneshot_buffer_bytes(world, max_bytes)
@@ -245,10 +257,19 @@ int awq_oneshot_ipc_open(const void* handle64, void** buffer);
 int awq_oneshot_ipc_close(void* buffer);
 int awq_oneshot_allreduce(void* const* peer_buffers, const void* in, void* out, int count, int dtype, int rank, int world,
                           unsigned round, int max_bytes, int* status_dev, void* stream);
+/* The same exchange on fp32 partials (count floats, count * 4 <= max_bytes): out = T(sum over ranks, fp32, rank order) (+ bias in T, bias_n =
+ * its length, count % bias_n == 0; NULL = none).  A communicator serves both forms; a call after *status_dev was set poisons its output. */
+int awq_oneshot_allreduce_f32(void* const* peer_buffers, const float* in_f32, const void* bias, int bias_n, void* out, int count, int dtype,
+                              int rank, int world, unsigned round, int max_bytes, int* status_dev, void* stream);
+/* Spin bound of the flag wait (polls of ~1 us; default 40 M: a peer may be tens of seconds late before the round is declared lost). */
+int awq_oneshot_set_spin_limit(unsigned spins);
 /* Single-GPU self-test of the device protocol: ONE launch of `world` co-resident blocks, block r playing rank r against the
  * others on `world` exchange buffers of the same device (in_all / out_all: [world][count]).  Tests only. */
 int awq_oneshot_allreduce_selftest(void* const* peer_buffers, const void* in_all, void* out_all, int count, int dtype, int world,
                                    unsigned round, int max_bytes, int* status_dev, void* stream);
+
+int awq_oneshot_allreduce_f32_selftest(void* const* peer_buffers, const float* in_all_f32, const void* bias, int bias_n, void* out_all, int count,
+                                       int dtype, int world, unsigned round, int max_bytes, int* status_dev, void* stream);
 
 /* Tuning hook for tests, experiments and benchmarks (not part of the reference surface): integer knobs that force one of the
  * shipped code paths ("gemm_variant", "gemm_splitk", "gemv_dma", "gemvd_waves", ...) so that tests can cover each of them; 0

@@ -340,6 +340,35 @@ int awq_w4a16_forward_cdna4(const void* x, const void* qweight, const void* scal
   return finish_launch();
 }
 
+// ---- tensor-parallel row split: the K shard's fp32 partial + the single rounding after the sum ----
+int awq_w4a16_partial_cdna4(const void* x, const void* qweight, const void* sz_packed, const void* sz_half, float* out_f32, int m, int n, int k,
+                            int group_size, int dtype, void* stream) {
+  if (!x || !qweight || !sz_packed || !out_f32) return AWQ_ERR_NULL;
+  if (dtype != AWQ_F16 && dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
+  if (group_size != 128) return AWQ_ERR_GROUP;
+  if (m < 1 || n < 16 || k < 128 || (n % 16) != 0 || (k % 128) != 0) return AWQ_ERR_SHAPE;
+  if (!aligned16(x) || !aligned16(qweight) || !aligned16(out_f32) || !aligned16(sz_packed) || !aligned16(sz_half)) return AWQ_ERR_ALIGN;
+  const hipStream_t st = (hipStream_t)stream;
+  if (m <= 8) {  // decode: the streaming kernel (or the skinny kernel where it takes the row count), f16-mantissa dequant when the layer allows it
+    if (awq::launch_gemv_dma(x, qweight, sz_half ? sz_half : sz_packed, nullptr, out_f32, m, n, k, 0, dtype, sz_half ? 1 : 0, st, 1) == 0) return finish_launch();
+    if (awq::launch_skinny_decode(x, qweight, sz_packed, nullptr, out_f32, m, n, k, 0, dtype, 0, st, 1) == 0) return finish_launch();
+    return AWQ_ERR_SHAPE;
+  }
+  if (m < 256 && !awq::gemm_cdna4_v3_takes(m, k)) {
+    if (awq::launch_skinny_cdna4(x, qweight, sz_packed, nullptr, out_f32, m, n, k, dtype, st, 1) == 0) return finish_launch();
+  }
+  if (awq::launch_gemm_cdna4_v3(x, qweight, sz_packed, nullptr, out_f32, m, n, k, 0, dtype, nullptr, 0, st, 4, 3) != 0) return AWQ_ERR_SHAPE;
+  return finish_launch();
+}
+
+int awq_round_bias_f32(const float* in_f32, const void* bias, void* out, int m, int n, int dtype, void* stream) {
+  if (!in_f32 || !out) return AWQ_ERR_NULL;
+  if (dtype != AWQ_F16 && dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
+  if (!aligned16(in_f32) || !aligned16(out) || !aligned16(bias)) return AWQ_ERR_ALIGN;
+  if (awq::launch_round_bias_f32(in_f32, bias, out, m, n, dtype, (hipStream_t)stream) != 0) return AWQ_ERR_SHAPE;
+  return finish_launch();
+}
+
 int awq_w4a16_moe_gemm(const void* x_sorted, const void* qweight, const void* scales, const void* scaled_zeros,
                        const void* expert_offsets, void* out, int total_tokens, int num_experts, int n, int k, int gpad,
                        int group_size, int dtype, int layout, void* stream) {

@@ -341,6 +341,21 @@ __global__ __launch_bounds__(512) void gemm_cdna4_v4n_kernel(const uint16_t* __r
             f32x4{acc[b][4 * j + 0], acc[b][4 * j + 1], acc[b][4 * j + 2], acc[b][4 * j + 3]};
     return;
   }
+  if (epi == 3) {
+    // K shard of a tensor-parallel row split (awq_w4a16_partial_cdna4): out is float [M, N], the fp32 accumulators unrounded, no bias
+    float* o32 = reinterpret_cast<float*>(out);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int m = m0 + wm * 128 + b * 32 + l32;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int nn = n0 + wn * WN + 8 * j + 4 * hk;
+        if (nn < n_end && m < M)
+          __builtin_nontemporal_store(f32x4{acc[b][4 * j + 0], acc[b][4 * j + 1], acc[b][4 * j + 2], acc[b][4 * j + 3]}, reinterpret_cast<f32x4*>(o32 + (size_t)m * N + nn));
+      }
+    }
+    return;
+  }
   // ---------------- epilogue through LDS: acc[b][r] = C[n = wn*32 + (r&3) + 8 (r>>2) + 4 hk][m = wm*128 + b*32 + l32] ----
   __syncthreads();
   char* eb = smem + wv * (128 * kEpiRow);

@@ -361,7 +361,23 @@ __device__ __forceinline__ void v6_tile(char* smem, const uint16_t* __restrict__
     cur = nxt;
   }
 
-  // ---------------- epilogue through LDS: acc[f][s][r] = C[n = n0 + 64 wv + 16 s + 4 g + r][m = m0 + 16 f + i], staged row-major ----
+  if (epi == 3) {
+    // K shard of a tensor-parallel row split (awq_w4a16_partial_cdna4): out is float [M, N] and takes the fp32 accumulators unrounded,
+    // no bias -- the ranks' partials are summed in fp32 and rounded to T once.  Straight from the registers: a lane holds four
+    // consecutive columns of one row (16 bytes), the four g-lanes of a row one 64-byte run
+    float* o32 = reinterpret_cast<float*>(out);
+#pragma unroll
+    for (int f = 0; f < 16; ++f) {
+      const int m = m0 + 16 * f + i;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int col = 16 * NS * wv + 16 * s + 4 * g, nn = n0 + col;
+        if (nn < n_end && m >= row_lo && m < row_hi) __builtin_nontemporal_store(acc[f][s], reinterpret_cast<f32x4*>(o32 + (size_t)m * N + nn));
+      }
+    }
+    return;
+  }
+  // ---------------- epilogue through LDS: acc[f][s][r] = C[n = n0 + 16 NS wv + 16 s + 4 g + r][m = m0 + 16 f + i], staged row-major ----
   asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
   __builtin_amdgcn_s_barrier();  // every wave is done with the x stages (the trailing reads of the unused stage have returned)
   {

@@ -43,10 +43,12 @@ __device__ __forceinline__ void dma_to_lds(const __amdgpu_buffer_rsrc_t& rsrc, c
 // timing probes (builds with AWQ_PROBES=1 only; wrong results): bit 0 = no math (stream only), bit 1 = no weight DMA and no
 // waits for it (math only, on whatever the ring holds)
 #ifdef AWQ_ENABLE_PROBES
-#define DMA_PROBE(p) (p)
+#define DMA_PROBE(p) ((p) & 0xFF)
 #else
 #define DMA_PROBE(p) 0
 #endif
+// bit 8 of the same kernel argument (every build): EPI 0 stores its fp32 sums to `out` as float [M, N] instead of rounding them to T
+constexpr int kDmaF32Out = 0x100;
 template <int N_>
 __device__ __forceinline__ void dma_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N_) : "memory");
@@ -215,7 +217,10 @@ __device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __rest
         v[s] = tsum;
       }
       const int nn = nb * 16 + 4 * g + r;
-      if (EPI == 0) {
+      if (EPI == 0 && (probe_ & kDmaF32Out)) {
+        // K shard of a tensor-parallel row split (awq_w4a16_partial_cdna4): the fp32 sum goes out unrounded, no bias
+        reinterpret_cast<float*>(out)[(size_t)i * N + nn] = v[0];
+      } else if (EPI == 0) {
         uint16_t o = DT::from_float(v[0]);
         if (bias != nullptr) o = DT::from_float(to_f(o) + to_f(bias[nn]));  // `out + self.bias` in T (qmodule.py:221)
         out[(size_t)i * N + nn] = o;
@@ -368,23 +373,23 @@ int gemv_dma_tune_set(const char* key, int value) {
 
 template <typename DT, int WAVES, int D, int DQ, int EPI>
 static void launch_dma_cfg(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                           const DmaCfg& c, hipStream_t st) {
+                           const DmaCfg& c, hipStream_t st, int f32out) {
   constexpr int NS = EPI == 1 ? 2 : 1;
   auto kern = gemv_dma_kernel<DT, WAVES, D, DQ, EPI>;
   static LdsOptIn optin;
   if (c.smem > 64 * 1024) optin.ensure(reinterpret_cast<const void*>(kern));
   hipLaunchKernelGGL(kern, dim3(n / 16 / NS), dim3(64 * WAVES), c.smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp,
-                     (const uint16_t*)bias, (uint16_t*)out, m, n, k, c.tx, g_dma_probe);
+                     (const uint16_t*)bias, (uint16_t*)out, m, n, k, c.tx, (g_dma_probe & 0xFF) | (f32out ? kDmaF32Out : 0));
 }
 
 template <typename DT, int EPI, int DQ>
 static int launch_dma_dt(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                         hipStream_t st) {
+                         hipStream_t st, int f32out) {
   DmaCfg c;
   if (!pick_dma(m, n, k, EPI == 1 ? 2 : 1, c)) return -1;
 #define AWQ_DCASE(W_, D_)                                                           \
   if (c.waves == W_ && c.d == D_) {                                                 \
-    launch_dma_cfg<DT, W_, D_, DQ, EPI>(x, qw, szp, bias, out, m, n, k, c, st);      \
+    launch_dma_cfg<DT, W_, D_, DQ, EPI>(x, qw, szp, bias, out, m, n, k, c, st, f32out); \
     return 0;                                                                       \
   }
   AWQ_DCASE(8, 1) AWQ_DCASE(8, 2) AWQ_DCASE(8, 4) AWQ_DCASE(8, 8)
@@ -414,9 +419,9 @@ int gemv_dma_plan(int m, int n, int k, int epi, int* kernel) {
 // served in chunks of as many rows as do fit, each chunk re-streaming the weights -- as the reference's GEMV does per row
 // (gemv_cuda.cu:187-208 loops over the batch inside one weight pass; here the LDS budget decides).
 int launch_gemv_dma(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int epi,
-                    int dtype, int szfmt, hipStream_t st) {
-  if (m < 1 || m > 8 || (k % 128) != 0 || (n % (epi == 1 ? 32 : 16)) != 0) return -1;
-  if (skinny_takes(m, n, k, epi) && launch_skinny_decode(x, qw, szp, bias, out, m, n, k, epi, dtype, szfmt, st) == 0) return 0;
+                    int dtype, int szfmt, hipStream_t st, int f32out) {
+  if (m < 1 || m > 8 || (k % 128) != 0 || (n % (epi == 1 ? 32 : 16)) != 0 || (f32out && (epi != 0 || bias != nullptr))) return -1;
+  if (skinny_takes(m, n, k, epi) && launch_skinny_decode(x, qw, szp, bias, out, m, n, k, epi, dtype, szfmt, st, f32out) == 0) return 0;
   DmaCfg probe_cfg;
   int mc = m;
   while (mc > 1 && !pick_dma(mc, n, k, epi == 1 ? 2 : 1, probe_cfg)) --mc;
@@ -425,16 +430,16 @@ int launch_gemv_dma(const void* x, const void* qw, const void* szp, const void* 
     const size_t ncols = epi ? (size_t)n / 2 : (size_t)n;
     for (int r = 0; r < m; r += mc) {
       const int rows = m - r < mc ? m - r : mc;
-      const int rc = launch_gemv_dma((const char*)x + (size_t)r * k * 2, qw, szp, bias, (char*)out + (size_t)r * ncols * 2, rows, n, k, epi,
-                                     dtype, szfmt, st);
+      const int rc = launch_gemv_dma((const char*)x + (size_t)r * k * 2, qw, szp, bias, (char*)out + (size_t)r * ncols * (f32out ? 4 : 2), rows, n, k,
+                                     epi, dtype, szfmt, st, f32out);
       if (rc != 0) return rc;
     }
     return 0;
   }
 #define AWQ_DDT(DT_, DQ_)                                                                   \
-  if (epi == 0) return launch_dma_dt<DT_, 0, DQ_>(x, qw, szp, bias, out, m, n, k, st);     \
-  if (epi == 1) return launch_dma_dt<DT_, 1, DQ_>(x, qw, szp, bias, out, m, n, k, st);     \
-  return launch_dma_dt<DT_, 2, DQ_>(x, qw, szp, bias, out, m, n, k, st);
+  if (epi == 0) return launch_dma_dt<DT_, 0, DQ_>(x, qw, szp, bias, out, m, n, k, st, f32out); \
+  if (epi == 1) return launch_dma_dt<DT_, 1, DQ_>(x, qw, szp, bias, out, m, n, k, st, 0);      \
+  return launch_dma_dt<DT_, 2, DQ_>(x, qw, szp, bias, out, m, n, k, st, 0);
   if (szfmt == 1) {
     if (dtype == 0) {
       AWQ_DDT(F16, 1)

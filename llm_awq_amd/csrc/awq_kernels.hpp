@@ -51,8 +51,9 @@ int gemv_cdna4_tune_set(const char* key, int value);
 // LDS-DMA streaming decode GEMV (awq_gemv_dma.hip): 1 <= m <= 8, cdna4 layout + packed sz.  epi 0: out[m,n] (+bias); epi 1: stacked
 // [gate; up]; epi 2: gate / up rows interleaved 8 + 8 per slab; both out[m, n/2] = silu(gate) * up.  -1 if the shape is not served.
 // szfmt 0: szp = sz_packed {s | sz << 16} in T;  szfmt 1: szp = sz_half (f16-mantissa dequant, awq_pack_szh_cdna4)
+// f32out (epi 0, no bias): out is float [m, n], the fp32 sums unrounded -- the K-shard partial of a tensor-parallel row split
 int launch_gemv_dma(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int epi,
-                    int dtype, int szfmt, hipStream_t st);
+                    int dtype, int szfmt, hipStream_t st, int f32out = 0);
 int gemv_dma_tune_set(const char* key, int value);
 int launch_moe_gemv_cdna4(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total_rows,
                           int experts, int n, int k, int dtype, hipStream_t st);
@@ -73,13 +74,14 @@ size_t gemm_workspace_bytes(int m, int n, int k);
 int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                          int tile_n, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits = 4, int epi = 0, const void* szh = nullptr);
 // epi 2: qw holds QuantLlamaMLP's 8 + 8 row-interleaved gate / up pair, out[m, n/2] = silu(gate) * up fused into the tile epilogue
+// epi 3: out is float [m, n]: the fp32 accumulators unrounded, no bias (K-shard partial of a tensor-parallel row split)
 int gemm_variant_get();
 // skinny GEMM, 9 <= m <= 255 (row chunks of <= 64), cdna4 layout + packed sz (awq_skinny_cdna4.hip); bias may be nullptr; -1 if unsupported
 int launch_skinny_cdna4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                        int dtype, hipStream_t st);
+                        int dtype, hipStream_t st, int f32out = 0);
 // batched decode on the same kernel (m <= 16; szfmt 1: szp = sz_half; epi 0 / 2 as launch_gemv_dma); -1 if unsupported
 int launch_skinny_decode(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int epi,
-                         int dtype, int szfmt, hipStream_t st);
+                         int dtype, int szfmt, hipStream_t st, int f32out = 0);
 int launch_moe_gemm(const void* x, const void* qw, const void* s, const void* z, const void* offsets, void* out, int total_m,
                     int experts, int n, int k, int gpad, int dtype, int layout, hipStream_t st);
 int gemv_tune_set(const char* key, int value);
@@ -119,6 +121,8 @@ int launch_mlp_decode(const void* x, const void* qw_gu, const void* szh_gu, cons
 void launch_gemm_cdna4_v5(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
                           int n_end, int dtype, hipStream_t st, int bits = 4, int mf = 16);
 int launch_bias_add(void* out, const void* bias, int m, int n, int dtype, hipStream_t st);
+// out[m, n] = T(in_f32) (+ bias in T); n % 8 == 0 (awq_util.hip)
+int launch_round_bias_f32(const void* in_f32, const void* bias, void* out, int m, int n, int dtype, hipStream_t st);
 // RMSNorm of m rows of k (awq_util.hip; layernorm.cu:39-61's arithmetic); -1 if k % 8 != 0
 int launch_rmsnorm(const void* x, const void* gamma, float eps, void* out, int m, int k, int dtype, hipStream_t st);
 int launch_unpack_v2(const void* qw, void* out_u8, int n, int k, hipStream_t st);

@@ -20,7 +20,7 @@ namespace awq {
 template <typename DT, int WAVES, int NS, int CB, int DQ = 0, int EPI = 0>
 __device__ __forceinline__ void skinny_cdna4_body(char* smem, const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                   const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
-                                                  uint16_t* __restrict__ out, int M, int N, int K, int nb) {
+                                                  uint16_t* __restrict__ out, int M, int N, int K, int nb, int f32out = 0) {
   using vec8 = typename DT::vec8;
   constexpr int XB = 4 * CB;            // staging pieces per step: 4 x rows (1 KiB) each
   constexpr int XBYTES = 16 * CB * 256; // wave-private x region: 16 CB rows x 256 B
@@ -147,6 +147,9 @@ __device__ __forceinline__ void skinny_cdna4_body(char* smem, const uint16_t* __
         *reinterpret_cast<u32x2*>(out + (size_t)m * (N >> 1) + slab * 8 + 4 * g) =
             u32x2{(u32)o[0] | ((u32)o[1] << 16), (u32)o[2] | ((u32)o[3] << 16)};
       }
+    } else if (f32out) {
+      // K shard of a tensor-parallel row split (awq_w4a16_partial_cdna4): fp32 sums, unrounded, no bias, out = float [M, N]
+      if (slab < nslab && m < M) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + (size_t)m * N + slab * 16 + 4 * g) = f32x4{v[0], v[1], v[2], v[3]};
     } else if (slab < nslab && m < M) {
       const int nn = slab * 16 + 4 * g;
       uint16_t o[4];
@@ -164,9 +167,9 @@ template <typename DT, int WAVES, int NS, int CB, int DQ = 0, int EPI = 0>
 __global__ __launch_bounds__(64 * WAVES) void skinny_cdna4_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                                    const u32* __restrict__ szp,
                                                                    const uint16_t* __restrict__ bias,
-                                                                   uint16_t* __restrict__ out, int M, int N, int K) {
+                                                                   uint16_t* __restrict__ out, int M, int N, int K, int f32out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  skinny_cdna4_body<DT, WAVES, NS, CB, DQ, EPI>(smem, x, qw, szp, bias, out, M, N, K, blockIdx.x);
+  skinny_cdna4_body<DT, WAVES, NS, CB, DQ, EPI>(smem, x, qw, szp, bias, out, M, N, K, blockIdx.x, EPI == 0 ? f32out : 0);
 }
 
 // Grouped (per-expert) form for MoE batches between the grouped GEMV (<= 8 sorted rows) and the grouped prefill GEMM
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(64 * WAVES) void moe_skinny_cdna4_kernel(const uint
 
 template <typename DT, int WAVES, int NS, int CB, int DQ = 0, int EPI = 0>
 static void launch_skinny(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                          hipStream_t st) {
+                          hipStream_t st, int f32out = 0) {
   const size_t xbytes = (size_t)WAVES * 16 * CB * 256, rbytes = (size_t)WAVES * NS * CB * 1024;
   const size_t smem = xbytes > rbytes ? xbytes : rbytes;
   auto kern = skinny_cdna4_kernel<DT, WAVES, NS, CB, DQ, EPI>;
@@ -198,48 +201,48 @@ static void launch_skinny(const void* x, const void* qw, const void* szp, const 
   if (smem > 64 * 1024) optin.ensure(reinterpret_cast<const void*>(kern));
   const int nslab = n / 16;
   hipLaunchKernelGGL(kern, dim3((nslab + NS - 1) / NS), dim3(64 * WAVES), smem, st, (const uint16_t*)x, (const u32*)qw,
-                     (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k);
+                     (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k, f32out);
 }
 
 template <typename DT>
 static int launch_skinny_64(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                            hipStream_t st);
+                            hipStream_t st, int f32out);
 
 // 9 <= m <= 255, cdna4 layout, packed sz required.  Returns -1 if unsupported.  65 <= m <= 255 (below the 256-row tile of
 // the prefill GEMM) runs as row chunks of <= 64: the weights are re-streamed per chunk, which still beats the 128 x 128
 // kernel's long serial K loop on one wave of tiles (measured: profiles/r01_skinny_sweep.txt) except for very wide N.
 int launch_skinny_cdna4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                        int dtype, hipStream_t st) {
-  if (!szp || m < 1 || m > 255 || (n % 16) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return -1;
+                        int dtype, hipStream_t st, int f32out) {
+  if (!szp || m < 1 || m > 255 || (n % 16) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31) || (f32out && bias)) return -1;
   if (m > 128 && n >= 16384) return -1;
   const int chunks = (m + 63) / 64, rows = (m + chunks - 1) / chunks;
   for (int r0 = 0; r0 < m; r0 += rows) {
     const int mr = m - r0 < rows ? m - r0 : rows;
     const uint16_t* xr = static_cast<const uint16_t*>(x) + (size_t)r0 * k;
-    uint16_t* orow = static_cast<uint16_t*>(out) + (size_t)r0 * n;
-    if (dtype == 0) launch_skinny_64<F16>(xr, qw, szp, bias, orow, mr, n, k, st);
-    else launch_skinny_64<BF16>(xr, qw, szp, bias, orow, mr, n, k, st);
+    void* orow = static_cast<char*>(out) + (size_t)r0 * n * (f32out ? 4 : 2);
+    if (dtype == 0) launch_skinny_64<F16>(xr, qw, szp, bias, orow, mr, n, k, st, f32out);
+    else launch_skinny_64<BF16>(xr, qw, szp, bias, orow, mr, n, k, st, f32out);
   }
   return 0;
 }
 
 template <typename DT>
 static int launch_skinny_64(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                            hipStream_t st) {
+                            hipStream_t st, int f32out) {
   const int nslab = n / 16;
   if (m <= 16) {
-    if (nslab >= 1024) launch_skinny<DT, 8, 2, 1>(x, qw, szp, bias, out, m, n, k, st);
-    else if (k / 128 >= 96) launch_skinny<DT, 16, 1, 1>(x, qw, szp, bias, out, m, n, k, st);
-    else launch_skinny<DT, 8, 1, 1>(x, qw, szp, bias, out, m, n, k, st);
+    if (nslab >= 1024) launch_skinny<DT, 8, 2, 1>(x, qw, szp, bias, out, m, n, k, st, f32out);
+    else if (k / 128 >= 96) launch_skinny<DT, 16, 1, 1>(x, qw, szp, bias, out, m, n, k, st, f32out);
+    else launch_skinny<DT, 8, 1, 1>(x, qw, szp, bias, out, m, n, k, st, f32out);
   } else if (m <= 32) {
-    if (nslab >= 512) launch_skinny<DT, 8, 2, 2>(x, qw, szp, bias, out, m, n, k, st);
-    else launch_skinny<DT, 8, 1, 2>(x, qw, szp, bias, out, m, n, k, st);
+    if (nslab >= 512) launch_skinny<DT, 8, 2, 2>(x, qw, szp, bias, out, m, n, k, st, f32out);
+    else launch_skinny<DT, 8, 1, 2>(x, qw, szp, bias, out, m, n, k, st, f32out);
   } else if (m <= 48) {
-    if (nslab >= 512) launch_skinny<DT, 4, 4, 3>(x, qw, szp, bias, out, m, n, k, st);
-    else launch_skinny<DT, 8, 2, 3>(x, qw, szp, bias, out, m, n, k, st);
+    if (nslab >= 512) launch_skinny<DT, 4, 4, 3>(x, qw, szp, bias, out, m, n, k, st, f32out);
+    else launch_skinny<DT, 8, 2, 3>(x, qw, szp, bias, out, m, n, k, st, f32out);
   } else {
-    if (nslab >= 512) launch_skinny<DT, 4, 4, 4>(x, qw, szp, bias, out, m, n, k, st);
-    else launch_skinny<DT, 8, 2, 4>(x, qw, szp, bias, out, m, n, k, st);
+    if (nslab >= 512) launch_skinny<DT, 4, 4, 4>(x, qw, szp, bias, out, m, n, k, st, f32out);
+    else launch_skinny<DT, 8, 2, 4>(x, qw, szp, bias, out, m, n, k, st, f32out);
   }
   return 0;
 }
@@ -248,14 +251,14 @@ static int launch_skinny_64(const void* x, const void* qw, const void* szp, cons
 // m x K x 2 bytes per slab, profiles/r03_decode_m_sweep.txt): m <= 16 rows, one 16-row x block; szfmt 1 = szp is "sz_half";
 // epi 0 (bias fused) or 2 (8 + 8 interleaved gate / up pair -> silu(gate) * up, out [m, n / 2]).  Returns -1 if unsupported.
 int launch_skinny_decode(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int epi,
-                         int dtype, int szfmt, hipStream_t st) {
-  if (!szp || m < 1 || m > 16 || (n % 16) != 0 || (k % 128) != 0 || (epi != 0 && epi != 2) || (epi == 2 && bias)) return -1;
+                         int dtype, int szfmt, hipStream_t st, int f32out) {
+  if (!szp || m < 1 || m > 16 || (n % 16) != 0 || (k % 128) != 0 || (epi != 0 && epi != 2) || (epi == 2 && bias) || (f32out && (epi || bias))) return -1;
   const bool wide = n / 16 >= 1024, deep = !wide && k / 128 >= 96;  // deep: 16 waves split a long K (down_proj: 112 steps)
 #define AWQ_SD(DT_, DQ_, EPI_)                                                                    \
   {                                                                                               \
-    if (wide) launch_skinny<DT_, 8, 2, 1, DQ_, EPI_>(x, qw, szp, bias, out, m, n, k, st);          \
-    else if (deep) launch_skinny<DT_, 16, 1, 1, DQ_, EPI_>(x, qw, szp, bias, out, m, n, k, st);    \
-    else launch_skinny<DT_, 8, 1, 1, DQ_, EPI_>(x, qw, szp, bias, out, m, n, k, st);               \
+    if (wide) launch_skinny<DT_, 8, 2, 1, DQ_, EPI_>(x, qw, szp, bias, out, m, n, k, st, f32out);       \
+    else if (deep) launch_skinny<DT_, 16, 1, 1, DQ_, EPI_>(x, qw, szp, bias, out, m, n, k, st, f32out); \
+    else launch_skinny<DT_, 8, 1, 1, DQ_, EPI_>(x, qw, szp, bias, out, m, n, k, st, f32out);            \
     return 0;                                                                                     \
   }
 #define AWQ_SD_DT(DT_)                          \

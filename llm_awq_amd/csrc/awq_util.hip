@@ -361,6 +361,35 @@ int launch_rmsnorm(const void* x, const void* gamma, float eps, void* out, int m
   return 0;
 }
 
+// out[m, n] = T(in_f32[m, n]) (+ bias in T): the single rounding of a tensor-parallel row split after its fp32 partials were summed
+// (by RCCL: the bandwidth-class messages; the latency-class ones are summed and rounded inside awq_oneshot_allreduce_f32)
+template <typename DT>
+__global__ __launch_bounds__(256) void round_bias_f32_kernel(const float* __restrict__ in, const uint16_t* __restrict__ bias, uint16_t* __restrict__ out,
+                                                             size_t octets, int n) {
+  for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < octets; o += (size_t)gridDim.x * 256) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(in + o * 8), b = *reinterpret_cast<const f32x4*>(in + o * 8 + 4);
+    uint16_t v[8] = {DT::from_float(a[0]), DT::from_float(a[1]), DT::from_float(a[2]), DT::from_float(a[3]),
+                     DT::from_float(b[0]), DT::from_float(b[1]), DT::from_float(b[2]), DT::from_float(b[3])};
+    if (bias != nullptr) {  // `out + self.bias` in T (qmodule.py:221)
+      const u32x4 bv = *reinterpret_cast<const u32x4*>(bias + (o * 8) % (size_t)n);
+      const u32 bw[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = DT::from_float(DT::to_float(v[e]) + DT::to_float((uint16_t)((bw[e >> 1] >> (16 * (e & 1))) & 0xFFFFu)));
+    }
+    *reinterpret_cast<u32x4*>(out + o * 8) = u32x4{(u32)v[0] | ((u32)v[1] << 16), (u32)v[2] | ((u32)v[3] << 16), (u32)v[4] | ((u32)v[5] << 16),
+                                                   (u32)v[6] | ((u32)v[7] << 16)};
+  }
+}
+
+int launch_round_bias_f32(const void* in_f32, const void* bias, void* out, int m, int n, int dtype, hipStream_t st) {
+  if (m < 1 || n < 8 || (n % 8) != 0) return -1;
+  const size_t octets = (size_t)m * n / 8;
+  const unsigned blocks = (unsigned)(octets + 255) / 256 > 4096u ? 4096u : (unsigned)((octets + 255) / 256);
+  if (dtype == 0) hipLaunchKernelGGL((round_bias_f32_kernel<F16>), dim3(blocks), dim3(256), 0, st, (const float*)in_f32, (const uint16_t*)bias, (uint16_t*)out, octets, n);
+  else hipLaunchKernelGGL((round_bias_f32_kernel<BF16>), dim3(blocks), dim3(256), 0, st, (const float*)in_f32, (const uint16_t*)bias, (uint16_t*)out, octets, n);
+  return 0;
+}
+
 int launch_bias_add(void* out, const void* bias, int m, int n, int dtype, hipStream_t st) {
   const size_t total = (size_t)m * n;
   if (dtype == 0)

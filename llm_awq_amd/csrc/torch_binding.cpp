@@ -136,12 +136,27 @@ void drop_entry(std::unordered_map<const void*, CacheEntry>::iterator it) {
   g_cache.erase(it);
 }
 
+// is this exact buffer (data pointer incl. storage offset) currently held converted in place?  (g_cache_mu held by the caller)
+bool inplace_converted_locked(const torch::Tensor& kernel) {
+  auto it = g_cache.find(kernel.data_ptr());
+  return it != g_cache.end() && it->second.inplace && it->second.c4.defined() && it->second.c4.storage().is_alias_of(kernel.storage());
+}
+// the reference-layout kernels must never read a buffer the cache converted where it lies: callers that cannot be served by the cdna4 path
+// (cache switched off, fp32 scales, a failed scale pack) get an error that names the way out instead of silently wrong products
+void refuse_if_converted(const torch::Tensor& kernel, const char* why) {
+  TORCH_CHECK(!inplace_converted_locked(kernel), "awq_inference_engine: this qweight was converted to the cdna4 interleave IN PLACE (AWQ_CDNA4_INPLACE=1) and ",
+              why, "; call awq_inference_engine.cdna4_restore(qweight) first");
+}
+
 // returns true and fills (c4, szp, szh) when the cdna4 kernels can serve this call (szh stays undefined if the scales are not f16-exact)
 bool cdna4_view(const torch::Tensor& kernel, const torch::Tensor& scales, const torch::Tensor& zeros, int64_t n, int64_t k,
                 hipStream_t stream, at::Tensor& c4, at::Tensor& szp, at::Tensor* szh = nullptr) {
   if (!cache_enabled() || kernel.scalar_type() != at::kShort ||
-      (scales.scalar_type() != at::kBFloat16 && scales.scalar_type() != at::kHalf))
+      (scales.scalar_type() != at::kBFloat16 && scales.scalar_type() != at::kHalf)) {
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    refuse_if_converted(kernel, "this call cannot run on the cdna4 kernels (cache disabled, or scales that are neither fp16 nor bf16)");
     return false;
+  }
   if (n % 16 != 0 || k % 128 != 0 || kernel.numel() != n / 4 * k) return false;
   // inside a hipGraph capture the weights are never re-packed (an entry built by an earlier warm-up call is used, a first call
   // falls back to the reference-layout kernels); the small scale buffers may be (torch's allocator is capture-safe)
@@ -153,9 +168,22 @@ bool cdna4_view(const torch::Tensor& kernel, const torch::Tensor& scales, const 
   if (it != g_cache.end()) {
     auto lw = it->second.w.lock();
     if (lw.get() != kernel.unsafeGetTensorImpl() || it->second.vw != tensor_version(kernel)) {  // address re-used or edited in place
-      if (capturing) return false;
-      drop_entry(it);
-      it = g_cache.end();
+      CacheEntry& old = it->second;
+      const bool same_bytes = old.inplace && old.c4.defined() && old.c4.storage().is_alias_of(kernel.storage());
+      if (same_bytes && lw.get() != kernel.unsafeGetTensorImpl()) {
+        // ANOTHER tensor over the converted bytes (a view, .detach(), .data, load_state_dict(assign=True) of an alias, a compile wrapper):
+        // the storage already holds the cdna4 interleave -- converting "again" would permute it twice.  The entry follows the caller
+        // (host-side only: legal inside a capture); a tensor whose version moved under the SAME impl was overwritten with new v2 data.
+        old.w = c10::weak_intrusive_ptr<c10::TensorImpl>(kernel.getIntrusivePtr());
+        old.vw = tensor_version(kernel);
+      } else {
+        TORCH_CHECK(!(capturing && same_bytes), "awq_inference_engine: an in-place converted qweight was modified during a graph capture");
+        if (capturing) return false;
+        // (same impl, new version: the caller wrote fresh v2 bytes over the buffer -- nothing to restore; a foreign tensor at a re-used
+        // address: the old entry's storage is not ours to touch either)
+        drop_entry(it);
+        it = g_cache.end();
+      }
     }
   }
   if (it == g_cache.end()) {
@@ -207,7 +235,10 @@ bool cdna4_view(const torch::Tensor& kernel, const torch::Tensor& scales, const 
     else if (e.slot[1].stamp < e.slot[0].stamp) victim = &e.slot[1];
     SzSlot& sl = *victim;
     at::Tensor nszp = torch::empty({n / 16, k / 128, 16}, scales.options().dtype(at::kInt));
-    if (awq_pack_sz_cdna4(scales.data_ptr(), zeros.data_ptr(), nszp.data_ptr(), (int)n, (int)k, (void*)stream) != AWQ_OK) return false;
+    if (awq_pack_sz_cdna4(scales.data_ptr(), zeros.data_ptr(), nszp.data_ptr(), (int)n, (int)k, (void*)stream) != AWQ_OK) {
+      refuse_if_converted(kernel, "its scales could not be packed for the cdna4 kernels");
+      return false;
+    }
     if (capturing) {
       // built while a graph is being captured: the pack kernel is only RECORDED, so the buffer must not be published (an eager call
       // could hit it before the first replay); it lives for this call's launch alone, decode uses the T-typed sz_packed
@@ -666,6 +697,16 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     drop_entry(it);
     return was;
   }, "undo an in-place conversion of this qweight (e.g. before saving a reference-layout checkpoint); true if it was converted");
+  m.def("decode_cdna4_plan", [](int m, int n, int k, int epilogue) {
+    int kernel = 0;
+    const int passes = awq_w4a16_decode_cdna4_plan(m, n, k, epilogue, &kernel);
+    return py::make_tuple(passes, kernel);
+  }, "host-side: (weight passes, kernel) of decode_cdna4 for this shape; passes == 0: the shape is not served (use forward_cdna4)");
+  m.def("cdna4_is_converted", [](torch::Tensor kernel) {
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    return kernel.is_cuda() && inplace_converted_locked(kernel);
+  }, "true while this qweight's storage holds the cdna4 interleave because the cache converted it in place (AWQ_CDNA4_INPLACE): the module's "
+     "`layout` attribute still says v2 -- format tools must cdna4_restore() it before they slice, repack or save it");
   // extras of the MI355X build (not part of the reference module)
   m.def("repack_v2_to_cdna4", &repack_v2_to_cdna4, "qweight v2 -> cdna4 interleave (same shape)");
   m.def("repack_cdna4_to_v2", &repack_cdna4_to_v2, "qweight cdna4 -> v2 interleave (same shape)");

@@ -96,6 +96,16 @@ class QuantLlamaMLP(nn.Module):
         self._register_state_dict_hook(QuantLlamaMLP._fill_state_dict)
         self._register_load_state_dict_pre_hook(self._rematerialise_v2)
 
+    _one_launch_available = None  # None = not probed yet; False = this library has no one-launch MLP kernel
+
+    def _apply(self, fn, *args, **kwargs):
+        """.to() / .cuda() / .half(): the fused stream is a plain tuple nn.Module does not move, and while the six reference-named buffers are
+        released it is the only copy -- they are rematerialised first, moved by nn.Module like any buffer, and the stream (with the device it
+        was pinned on) is dropped and rebuilt at the next forward."""
+        if self._fused is not None:
+            self._rematerialise_v2()
+        return super()._apply(fn, *args, **kwargs)
+
     # ---- the v2 buffers while they are released ----
     @torch.no_grad()
     def _v2_from_fused(self):
@@ -126,6 +136,10 @@ class QuantLlamaMLP(nn.Module):
             for name, t in self._v2_from_fused().items():
                 setattr(self, name, t if device is None else t.to(device))
             self._v2_released = False
+        if hasattr(eng, "cdna4_is_converted") and self.gate_proj_qweight.is_cuda and (
+                eng.cdna4_is_converted(self.gate_proj_qweight) or eng.cdna4_is_converted(self.up_proj_qweight)):
+            raise RuntimeError("QuantLlamaMLP: gate_proj / up_proj qweight was converted in place by the engine cache (AWQ_CDNA4_INPLACE); "
+                               "call awq_inference_engine.cdna4_restore(qweight) on both before the fused stream is built")
         q, s, z = interleave_gate_up(self.gate_proj_qweight, self.up_proj_qweight, self.gate_proj_scales, self.up_proj_scales,
                                      self.gate_proj_scaled_zeros, self.up_proj_scaled_zeros)
         c4 = eng.repack_v2_to_cdna4(q)
@@ -173,10 +187,19 @@ class QuantLlamaMLP(nn.Module):
             self._ctr = torch.zeros(4096, dtype=torch.int32, device=x.device)
         if not x.is_contiguous():
             x = x.contiguous()
-        try:
-            return eng.mlp_decode_cdna4(x, c4, szh, d.qweight, d.szh_cdna4, self._ctr, d.bias)
-        except RuntimeError:  # a product library does not carry the one-launch kernel (AWQ_PROBES builds only): two launches
+        if QuantLlamaMLP._one_launch_available is False:
             return None
+        try:
+            y = eng.mlp_decode_cdna4(x, c4, szh, d.qweight, d.szh_cdna4, self._ctr, d.bias)
+            QuantLlamaMLP._one_launch_available = True
+            return y
+        except RuntimeError as e:
+            # a product library does not carry the one-launch kernel (AWQ_PROBES builds only) and says "unsupported shape" for every call:
+            # remembered, so the probe is paid once; any OTHER error (a failed launch, an asynchronous HIP error) is the caller's to see
+            if QuantLlamaMLP._one_launch_available is None and "shape" in str(e).lower():
+                QuantLlamaMLP._one_launch_available = False
+                return None
+            raise
 
     @torch.no_grad()
     def our_llama_mlp(self, x):

@@ -18,13 +18,6 @@ import torch.nn as nn
 from . import load_engine
 
 
-def rmsnorm_reference_semantics(x: torch.Tensor, gamma: torch.Tensor, eps: float) -> torch.Tensor:
-    """layernorm.cu:48-60 (generalT5LayerNorm: no mean subtraction, no bias), torch ops on x's device."""
-    xf = x.float()
-    rstd = torch.rsqrt((xf * xf).sum(-1, keepdim=True) / xf.shape[-1] + eps)
-    return ((xf * rstd) * gamma.float()).to(x.dtype)
-
-
 class RMSNormWQLinear(nn.Module):
     def __init__(self, norm_weight: torch.Tensor, eps: float, linear):
         super().__init__()
@@ -41,7 +34,10 @@ class RMSNormWQLinear(nn.Module):
                 lin.sz_cdna4 = load_engine().pack_sz_cdna4(lin.scales, lin.scaled_zeros, lin.in_features)
             return load_engine().rmsnorm_forward_cdna4(x.contiguous(), self.weight, float(self.variance_epsilon), lin.qweight,
                                                        lin.sz_cdna4, lin.bias, False)
-        if x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and self.weight.dtype == x.dtype and x.shape[-1] % 8 == 0:
-            # more rows: the norm as ONE launch of the same arithmetic (csrc/awq_util.hip rmsnorm_kernel), then the linear
-            return lin(load_engine().rmsnorm(x.contiguous(), self.weight.contiguous(), float(self.variance_epsilon)))
-        return lin(rmsnorm_reference_semantics(x, self.weight, self.variance_epsilon))
+        # more rows: the norm as ONE launch of the same arithmetic (csrc/awq_util.hip rmsnorm_kernel), then the linear.  No torch
+        # arithmetic stands in for the kernel: what it does not take (CPU tensors, fp32 activations, a norm weight of another dtype,
+        # k % 8 != 0) raises, like every other entry of this package
+        if not (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and self.weight.dtype == x.dtype and x.shape[-1] % 8 == 0):
+            raise RuntimeError("RMSNormWQLinear runs the HIP kernels only: x must be a GPU fp16 / bf16 tensor, the norm weight of the same "
+                               "dtype, and the hidden size a multiple of 8 (there is no CPU / PyTorch fallback)")
+        return lin(load_engine().rmsnorm(x.contiguous(), self.weight.contiguous(), float(self.variance_epsilon)))

@@ -45,8 +45,11 @@ class HostMailbox:
         off = 2 * self.world * self.max_bytes
         return self.bufs[q][off: off + 64].view(np.uint32)
 
-    def all_reduce(self, x: torch.Tensor, timeout_s: float = 20.0) -> torch.Tensor:
-        """x: fp16 / bf16 CPU tensor; returns the sum over ranks (fp32 accumulation in rank order, one rounding)."""
+    def all_reduce(self, x: torch.Tensor, timeout_s: float = 20.0, out_dtype=None) -> torch.Tensor:
+        """x: fp16 / bf16 CPU tensor; returns the sum over ranks (fp32 accumulation in rank order, one rounding).
+        x float32 + out_dtype = T: the fp32 form (awq_oneshot_allreduce_f32): unrounded partials in, T(sum) out."""
+        if x.dtype == torch.float32:
+            return self._all_reduce_f32(x, timeout_s, out_dtype or torch.float32)
         self.round += 1
         e, half = self.round, self.round & 1
         raw = x.contiguous().view(torch.int16).numpy().view(np.uint8).reshape(-1)
@@ -67,6 +70,26 @@ class HostMailbox:
             acc += part.float()
         return acc.to(x.dtype).reshape(x.shape)
 
+    def _all_reduce_f32(self, x, timeout_s, out_dtype):
+        self.round += 1
+        e, half = self.round, self.round & 1
+        raw = x.contiguous().numpy().view(np.uint8).reshape(-1)
+        assert raw.size <= self.max_bytes
+        for q in range(self.world):
+            self._data(q, half, self.rank, raw.size)[:] = raw
+        for q in range(self.world):
+            self._flags(q)[half * self.world + self.rank] = e
+        mine = self._flags(self.rank)
+        t_end = time.time() + timeout_s
+        while not all(int(mine[half * self.world + q]) == e for q in range(self.world)):
+            if time.time() > t_end:
+                raise TimeoutError(f"rank {self.rank}: round {e} flags {mine[half * self.world: half * self.world + self.world]}")
+            time.sleep(0.0005)
+        acc = torch.zeros(x.numel(), dtype=torch.float32)
+        for q in range(self.world):                      # rank order, fp32
+            acc += torch.from_numpy(self._data(self.rank, half, q, raw.size).copy().view(np.float32))
+        return acc.to(out_dtype).reshape(x.shape)
+
 
 class OneShotAllReduce:
     """GPU side: one exchange buffer per rank, peers mapped through hipIpc.  `__call__(t)` returns the reduced tensor (new
@@ -77,6 +100,9 @@ class OneShotAllReduce:
         from . import _capi
         self.dist, self.group, self.L = dist, group, _capi.lib()
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        spin = os.environ.get("AWQ_ONESHOT_SPIN_LIMIT")  # polls (~1 us each) before a round is declared lost; default 40 M (library)
+        if spin:
+            _capi.check(self.L.awq_oneshot_set_spin_limit(int(spin)))
         assert self.world <= MAX_WORLD and max_bytes % 16 == 0
         self.max_bytes = max_bytes
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -125,10 +151,33 @@ class OneShotAllReduce:
             self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
         dist.barrier(group=group)  # every buffer is zeroed and mapped before the first round
 
+    def serves(self, t: torch.Tensor) -> bool:
+        """whether this reducer exchanges `t` itself (else the group's all-reduce does): size class, dtype, and the DEVICE its buffers
+        and launch stream live on (a tensor elsewhere has no ordering against that stream)"""
+        return (t.is_cuda and t.device == self.device and t.dtype in (torch.float16, torch.bfloat16, torch.float32) and t.is_contiguous()
+                and t.numel() % 8 == 0 and 0 < t.numel() * t.element_size() <= self.max_bytes and self.local is not None)
+
+    def reduce_f32(self, y32: torch.Tensor, out_dtype, bias=None) -> torch.Tensor:
+        """fp32 partials of a row split -> T(sum over ranks) (+ bias in T).  Latency-class messages go through the exchange buffers
+        (sum, rounding and bias inside the one kernel); larger ones are summed by the group's all-reduce ON THE FLOAT TENSOR and rounded
+        once by awq_round_bias_f32."""
+        from . import _capi, ops
+        if not self.serves(y32) or (bias is not None and (y32.numel() % bias.numel() or bias.numel() % 8)):
+            self.dist.all_reduce(y32, group=self.group)
+            return ops.round_bias_f32(y32, out_dtype, bias)
+        self.round += 1
+        out = torch.empty(y32.shape, dtype=out_dtype, device=y32.device)
+        with torch.cuda.device(self.device):
+            _capi.check(self.L.awq_oneshot_allreduce_f32(self.ptrs, y32.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                                         bias.numel() if bias is not None else 0, out.data_ptr(), y32.numel(),
+                                                         0 if out_dtype == torch.float16 else 1, self.rank, self.world,
+                                                         0 if self.device_epoch else self.round, self.max_bytes, self.status.data_ptr(),
+                                                         torch.cuda.current_stream(self.device).cuda_stream))
+        return out
+
     def __call__(self, t: torch.Tensor) -> torch.Tensor:
         from . import _capi
-        nbytes = t.numel() * t.element_size()
-        if t.dtype not in (torch.float16, torch.bfloat16) or nbytes > self.max_bytes or t.numel() % 8 or not t.is_contiguous():
+        if t.dtype == torch.float32 or not self.serves(t):
             self.dist.all_reduce(t, group=self.group)
             return t
         self.round += 1
@@ -160,6 +209,8 @@ def enabled_by_env() -> bool:
 def make_reducer(dist, group=None, max_bytes: int = 64 * 1024, device=None):
     """The default small-message reducer of a tensor-parallel group: a OneShotAllReduce if EVERY rank could build one, else None
     (= torch.distributed.all_reduce).  Collective: every rank of the group must call it."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
     world = dist.get_world_size(group)
     if world <= 1 or world > MAX_WORLD or not enabled_by_env() or not torch.cuda.is_available():
         return None
@@ -199,11 +250,14 @@ def validate_reducer(red, dist, group=None, rounds: int = 6):
             continue
         try:
             got = red(t.clone())
+            got32 = red.reduce_f32(t.float(), dt) if 4 * n <= red.max_bytes else ref  # the fp32-partial form the row splits send
             torch.cuda.synchronize(dev)
             if int(red.status.item()) != 0:
                 why = f"round {r}: a peer flag timed out"
             elif not torch.equal(got, ref):
                 why = f"round {r}: {int((got != ref).sum().item())} of {n} elements differ from the group's all-reduce"
+            elif not torch.equal(got32, ref):
+                why = f"round {r}: fp32 form: {int((got32 != ref).sum().item())} of {n} elements differ from the group's all-reduce"
         except Exception as e:  # noqa: BLE001
             why = f"round {r}: {type(e).__name__}: {e}"
     bad = torch.tensor([0 if why is None else 1], dtype=torch.int32,

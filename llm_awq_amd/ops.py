@@ -201,6 +201,38 @@ def decode_cdna4(x, qweight, sz_half, bias=None, epilogue: int = 0, group_size: 
     return out
 
 
+def partial_cdna4(x, qweight, sz_packed, sz_half=None, group_size: int = 128):
+    """C-ABI awq_w4a16_partial_cdna4: the K shard's product x . W^T as fp32 [..., N], unrounded, no bias (tensor-parallel row split)."""
+    _need_gpu(x, qweight, sz_packed, sz_half)
+    k = x.shape[-1]
+    m = x.numel() // k
+    n = qweight.shape[0] * 4
+    out = torch.empty(*x.shape[:-1], n, dtype=torch.float32, device=x.device)
+    if m == 0:
+        return out
+    with torch.cuda.device(x.device):
+        _capi.check(_capi.lib().awq_w4a16_partial_cdna4(x.data_ptr(), qweight.data_ptr(), sz_packed.data_ptr(),
+                                                         sz_half.data_ptr() if sz_half is not None else None, out.data_ptr(), m, n, k,
+                                                         group_size, _dt(x), _stream(x)))
+    return out
+
+
+def round_bias_f32(y32, dtype, bias=None):
+    """C-ABI awq_round_bias_f32: T(y32) (+ bias in T) -- the single rounding after the fp32 partials of a row split were summed."""
+    _need_gpu(y32, bias)
+    if y32.dtype != torch.float32:
+        raise TypeError("expected the float32 sum of the partials")
+    n = y32.shape[-1]
+    m = y32.numel() // n
+    out = torch.empty(y32.shape, dtype=dtype, device=y32.device)
+    if m == 0:
+        return out
+    with torch.cuda.device(y32.device):
+        _capi.check(_capi.lib().awq_round_bias_f32(y32.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), m, n,
+                                                    _dt(out), _stream(y32)))
+    return out
+
+
 def gemv_cdna4(x, qweight, scales, scaled_zeros, sz_packed=None, group_size: int = 128):
     _need_gpu(x, qweight, scales, scaled_zeros, sz_packed)
     k = x.shape[-1]
@@ -288,6 +320,8 @@ def rmsnorm(x, gamma, eps: float):
     _need_gpu(x, gamma)
     k = x.shape[-1]
     out = torch.empty_like(x)
+    if x.numel() == 0:  # (an empty batch: as the torch binding, nothing to launch)
+        return out
     with torch.cuda.device(x.device):
         _capi.check(_capi.lib().awq_rmsnorm(x.data_ptr(), gamma.data_ptr(), float(eps), out.data_ptr(), x.numel() // k, k, _dt(x), _stream(x)))
     return out

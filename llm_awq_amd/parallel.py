@@ -80,23 +80,39 @@ def shard_stacked_column_parallel(qweight, scales, scaled_zeros, world: int, ran
 
 
 class TPWQLinear(nn.Module):
-    """A WQLinear shard + its collective.  `matmul(x, qweight, scales, scaled_zeros)` defaults to the HIP
-    engine (WQLinear.forward's dispatch); tests on CPU inject the oracle instead."""
+    """A WQLinear shard + its collective.
+
+    Row mode (K-sharded, the north star's form): the shard computes its product as an UNROUNDED fp32 partial
+    (`awq_w4a16_partial_cdna4`: the same decode / skinny / prefill kernels with an fp32 epilogue), the partials are summed in fp32 --
+    `OneShotAllReduce.reduce_f32` for the latency-class messages, the group's all-reduce on the float tensor above that -- and the sum is
+    rounded to T ONCE, then the bias is added in T: what the single-device kernel does with its one accumulator.  (Rounding every rank's
+    partial to T first puts a bf16 output 2.6-2.9e-3 norm-wise from the single-device result, outside the 1e-3 budget of SURVEY.md 8(e);
+    fp32 partials: ~2e-6.)
+    Column mode (N-sharded): the shard is a plain WQLinear on its output rows; no communication.
+
+    `partial(x, qweight_v2, scales, scaled_zeros) -> float32` / `matmul(...) -> T` are TEST SEAMS: the CPU tests (no GPU in that container)
+    inject the oracle there; the product path never has them set and runs the HIP kernels."""
 
     def __init__(self, full: WQLinear, mode: str, group=None, world: Optional[int] = None, rank: Optional[int] = None,
-                 matmul: Optional[Callable] = None, reducer: Optional[Callable] = None):
+                 matmul: Optional[Callable] = None, reducer: Optional[Callable] = None, partial: Optional[Callable] = None):
         super().__init__()
         import torch.distributed as dist
 
         assert mode in ("row", "column")
         self.mode, self.group = mode, group
+        have_dist = dist.is_available() and dist.is_initialized()
+        if (world is None or rank is None) and not have_dist:
+            raise RuntimeError("TPWQLinear needs an initialised process group, or explicit world= and rank= (offline sharding)")
         self.world = world if world is not None else dist.get_world_size(group)
         self.rank = rank if rank is not None else dist.get_rank(group)
         self.in_features, self.out_features = full.in_features, full.out_features
         # the slicing below is defined on the REFERENCE (v2) interleave, where a K cut at a multiple of 64 / an N cut at a multiple
         # of 4 is a plain column / row slice of the int16 buffer; the cdna4 and w3c tilings permute across those cuts
         if getattr(full, "w_bit", 4) != 4:
-            raise NotImplementedError("tensor-parallel sharding is defined for w_bit = 4 (v2 buffers); shard before packing W3 tiles")
+            raise ValueError("tensor-parallel sharding slices v2 (w_bit = 4) buffers; a w3c module has no v2 form -- shard the "
+                             "integer weights before packing (llm_awq_amd.parallel.shard_bounds gives the cuts)")
+        if hasattr(full, "_refuse_converted"):
+            full._refuse_converted("TPWQLinear")
         relayout = getattr(full, "layout", "v2") == "cdna4"
         if relayout:
             full.to_v2()
@@ -108,54 +124,115 @@ class TPWQLinear(nn.Module):
         self.shard.qweight, self.shard.scales, self.shard.scaled_zeros = qw, s, z
         if relayout:
             full.to_cdna4()
-            if n_local % 16 == 0 and k_local % 128 == 0 and self.shard.group_size == 128:
+        cdna4_able = n_local % 16 == 0 and k_local % 128 == 0 and self.shard.group_size == 128 and s.dtype in (torch.float16, torch.bfloat16)
+        self._matmul, self._partial = matmul, partial
+        if qw.is_cuda and matmul is None and partial is None:
+            if mode == "row" and not cdna4_able:
+                raise ValueError("a K-sharded WQLinear runs the cdna4 kernels' fp32-partial epilogue: it needs out_features % 16 == 0, "
+                                 "group_size 128 and fp16 / bf16 scales")
+            if cdna4_able and (relayout or mode == "row"):
                 self.shard.to_cdna4()  # the shard runs the same kernels the unsharded module did
         if full.bias is None:
             self.bias = None
         else:
             self.bias = full.bias if mode == "row" else full.bias[self.bounds[0]: self.bounds[1]].contiguous()
-        self._matmul = matmul
-        # reducer(y) -> reduced y.  Default on GPUs with world > 1: the group's shared llm_awq_amd.oneshot.OneShotAllReduce for the
-        # 8 .. 64 KiB decode messages (it sends larger ones to RCCL itself; AWQ_ONESHOT=0 or a box without fine-grained memory /
-        # hipIpc -> None); None = torch.distributed.all_reduce (RCCL on GPUs, gloo in the CPU tests)
-        if reducer is None and mode == "row" and self.world > 1 and qw.is_cuda and matmul is None:
-            reducer = default_reducer(dist, group)
+        # reducer: an llm_awq_amd.oneshot.OneShotAllReduce (reduce_f32) or None = torch.distributed.all_reduce on the fp32 partial (RCCL on
+        # GPUs, gloo in the CPU tests).  Default on GPUs with world > 1: the group's shared one-shot reducer, built on the SHARD's device
+        # (AWQ_ONESHOT=0, a box without fine-grained memory / hipIpc, or a world that is not the group's -> None)
+        if (reducer is None and mode == "row" and self.world > 1 and qw.is_cuda and matmul is None and partial is None and have_dist
+                and self.world == dist.get_world_size(group)):
+            reducer = default_reducer(dist, group, qw.device)
         self._reducer = reducer
+
+    def _reduce_round(self, y32, dtype):
+        """fp32 partial -> T(sum over ranks) + bias"""
+        import torch.distributed as dist
+        if self._reducer is not None and hasattr(self._reducer, "reduce_f32"):
+            return self._reducer.reduce_f32(y32, dtype, self.bias)
+        if self.world > 1:
+            if self._reducer is not None:
+                y32 = self._reducer(y32)
+            else:
+                dist.all_reduce(y32, op=dist.ReduceOp.SUM, group=self.group)
+        if y32.is_cuda:
+            from . import ops
+            return ops.round_bias_f32(y32, dtype, self.bias)
+        y = y32.to(dtype)  # (CPU test seam only: the product path's rounding + bias is awq_round_bias_f32)
+        return y + self.bias if self.bias is not None else y
 
     @torch.no_grad()
     def forward(self, x, input_is_sharded: bool = False):
-        import torch.distributed as dist
+        if self.mode == "column":
+            y = self.shard(x) if self._matmul is None else self._matmul(x, self.shard.qweight, self.shard.scales, self.shard.scaled_zeros)
+            return y + self.bias if self.bias is not None else y
+        return self._reduce_round(self.partial(x, input_is_sharded), x.dtype)
 
-        if self.mode == "row" and not input_is_sharded:
+    @torch.no_grad()
+    def partial(self, x, input_is_sharded: bool = False):
+        """row mode: this rank's fp32 partial [..., N] of x . W^T (unrounded, no bias)"""
+        assert self.mode == "row"
+        if not input_is_sharded:
             x = x[..., self.bounds[0]: self.bounds[1]].contiguous()
-        if self._matmul is None:
-            y = self.shard(x)
+        if self._partial is not None:
+            y32 = self._partial(x, self.shard.qweight, self.shard.scales, self.shard.scaled_zeros)
+        elif self._matmul is not None:  # (legacy seam: T-rounded partials, the pre-round-4 numerics -- kept for the comparison test)
+            y32 = self._matmul(x, self.shard.qweight, self.shard.scales, self.shard.scaled_zeros).float()
         else:
-            y = self._matmul(x, self.shard.qweight, self.shard.scales, self.shard.scaled_zeros)
-        if self.mode == "row" and self.world > 1:
-            if self._reducer is not None:
-                y = self._reducer(y)
-            else:
-                dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
-        return y + self.bias if self.bias is not None else y
+            from . import ops
+            sh = self.shard
+            if not x.is_contiguous():
+                x = x.contiguous()
+            key = sh._side_key()
+            if sh.sz_cdna4 is None or getattr(sh, "_sz_key", None) != key:
+                sh.sz_cdna4 = ops.pack_sz_cdna4(sh.scales, sh.scaled_zeros, sh.in_features)
+                sh.szh_cdna4, sh._sz_key = None, key
+            if sh.szh_cdna4 is None and not torch.cuda.is_current_stream_capturing():
+                sh._build_szh(ops)
+            szh = sh.szh_cdna4 if (sh.szh_cdna4 is not None and sh.szh_cdna4 is not False) else None
+            y32 = ops.partial_cdna4(x, sh.qweight, sh.sz_cdna4, szh)
+        return y32
 
     def check(self):
-        """after a synchronize: raise if a one-shot round of this module's reducer timed out (its output was poisoned with NaNs)"""
+        """after a synchronize: raise if a one-shot round of this module's reducer timed out (its output was poisoned with NaNs; every
+        later call of that communicator poisons its output too).  forward() cannot poll the status word without a host sync: serving
+        loops call this at their own sync points (once per generated token is enough)."""
         if self._reducer is not None and hasattr(self._reducer, "check"):
             self._reducer.check()
 
 
-_REDUCERS = {}
+_REDUCERS = {}  # id(group) -> (weakref to the group or None, reducer): an entry whose group object died is rebuilt, never reused
 
 
-def default_reducer(dist, group=None):
-    """One OneShotAllReduce per process group, built at the first row-parallel module (a collective: every rank builds its modules
-    in the same order), or None where it is disabled / unavailable."""
-    key = id(group) if group is not None else 0
-    if key not in _REDUCERS:
-        from . import oneshot
-        _REDUCERS[key] = oneshot.make_reducer(dist, group)
-    return _REDUCERS[key]
+def default_reducer(dist, group=None, device=None):
+    """One OneShotAllReduce per (process group, device), built at the first row-parallel module (a collective: every rank builds its
+    modules in the same order), or None where it is disabled / unavailable."""
+    import weakref
+    key = (id(group) if group is not None else 0, str(device))
+    ent = _REDUCERS.get(key)
+    if ent is not None:
+        ref, red = ent
+        if (ref is None and group is None) or (ref is not None and ref() is group):
+            if red is None or red.local is not None:
+                return red
+        if red is not None:
+            red.close()
+        del _REDUCERS[key]
+    from . import oneshot
+    red = oneshot.make_reducer(dist, group, device=device)
+    try:
+        ref = weakref.ref(group) if group is not None else None
+    except TypeError:  # (a group object that cannot be weakly referenced: keyed by id only, closed reducers are still never reused)
+        ref = None if group is None else (lambda g=group: g)
+    _REDUCERS[key] = (ref, red)
+    return red
+
+
+def close_reducers():
+    """close every cached one-shot reducer (call before destroying the process group)"""
+    for _ref, red in list(_REDUCERS.values()):
+        if red is not None:
+            red.close()
+    _REDUCERS.clear()
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -189,22 +266,28 @@ def _build_shards(eng, block, layers, shard_world, rank, dev, dtype, seed0=0):
 
 
 def _make_pass(eng, shards, xs, reducer, dist, world):
+    from . import ops
+
     def run_pass():
         outs = []
         for (name, kl, nl, qw, s, sz, szp, mode, szh) in shards:
             x = xs[kl]
             m = x.numel() // kl
-            if name == "gate_up":  # the shard's rows are taken as QuantLlamaMLP's 8 + 8 interleaved gate / up pair (synthetic weights)
+            if mode == "row":
+                # K shard: fp32 partial -> sum over ranks in fp32 -> ONE rounding to T (TPWQLinear.forward's path, no module overhead)
+                y32 = ops.partial_cdna4(x, qw, szp, szh)
+                if reducer is not None:
+                    y = reducer.reduce_f32(y32, x.dtype)
+                else:
+                    if world > 1:
+                        dist.all_reduce(y32)
+                    y = ops.round_bias_f32(y32, x.dtype)
+            elif name == "gate_up":  # the shard's rows are taken as QuantLlamaMLP's 8 + 8 interleaved gate / up pair (synthetic weights)
                 y = eng.mlp_gate_up_forward_cdna4(x, qw, szp, szh)
             elif m <= 8 and szh is not None:
                 y = eng.decode_cdna4(x, qw, szh, None, 0)
             else:
                 y = eng.forward_cdna4(x, qw, s, sz, szp, None)
-            if mode == "row" and world > 1:
-                if reducer is not None:
-                    y = reducer(y)
-                else:
-                    dist.all_reduce(y)
             outs.append(y)
         return outs
     return run_pass
@@ -254,11 +337,13 @@ def _timed(run_pass, steps, warmup, dist, dev, use_graph, rank):
 
 
 def _allreduce_record(dist, reducer, dev, world, numel, dtype, iters=200):
-    """one message class on its own: microseconds per all-reduce (max over ranks), RCCL and -- where it serves the size -- one-shot"""
-    rec = {"bytes": numel * 2, "ranks": world}
+    """one message class on its own: microseconds per reduction of `numel` fp32 partials to T (max over ranks) -- the group's all-reduce on
+    the float tensor + the rounding kernel, and, where it serves the size, the one-shot exchange (sum + rounding in one kernel)"""
+    from . import ops
+    rec = {"bytes": numel * 4, "partials": "fp32 (rounded to T once, after the sum)", "ranks": world}
     if world <= 1:
         return rec
-    t = torch.ones(numel, device=dev, dtype=dtype)
+    t = torch.ones(numel, device=dev, dtype=torch.float32)
 
     def timeit(fn):
         for _ in range(5):
@@ -274,9 +359,13 @@ def _allreduce_record(dist, reducer, dev, world, numel, dtype, iters=200):
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         return dt.item() * 1e6 / iters
 
-    rec["rccl_us"] = round(timeit(lambda: dist.all_reduce(t.fill_(1.0))), 2)
-    if reducer is not None and numel * 2 <= reducer.max_bytes:
-        rec["oneshot_us"] = round(timeit(lambda: reducer(t)), 2)
+    def rccl():
+        dist.all_reduce(t.fill_(1.0))
+        return ops.round_bias_f32(t, dtype)
+
+    rec["rccl_us"] = round(timeit(rccl), 2)
+    if reducer is not None and numel * 4 <= reducer.max_bytes:
+        rec["oneshot_us"] = round(timeit(lambda: reducer.reduce_f32(t, dtype)), 2)
     return rec
 
 
@@ -330,11 +419,11 @@ def run_tp_bench(args, eng, dist, rank, world, dev, shapes, algo_bytes):
                     "layers_timed": L70,
                     "decode": {"m": 1, "ms_per_step_80_layers": round(d_ms * 80 / L70, 4), "tok_s": round(1e3 / (d_ms * 80 / L70), 2), "graph": d_graph,
                                "hbm_gbs_per_gpu": round(b70 / (d_ms * 1e-3) / 1e9, 1), "hbm_frac_per_gpu": round(b70 / (d_ms * 1e-3) / 1e9 / 8000.0, 4),
-                               "allreduce_bytes": 8192 * 2, "allreduces_per_token": 2 * 80},
+                               "allreduce_bytes": 8192 * 4, "allreduces_per_token": 2 * 80},
                     "prefill": {"m": Mp, "ms_per_pass_80_layers": round(p_ms * 80 / L70, 3), "tok_s": round(Mp / (p_ms * 80 / L70 * 1e-3), 1),
                                 "mfma_tflops_per_gpu": round(flops_rank / (p_ms * 1e-3) / 1e12, 1),
                                 "mfma_frac_per_gpu": round(flops_rank / (p_ms * 1e-3) / 1e12 / 2500.0, 4),
-                                "allreduce_bytes": Mp * 8192 * 2, "allreduces_per_pass": 2 * 80}}
+                                "allreduce_bytes": Mp * 8192 * 4, "allreduces_per_pass": 2 * 80}}
             del sh70
             torch.cuda.empty_cache()
 

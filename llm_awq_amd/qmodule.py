@@ -129,6 +129,7 @@ class WQLinear(nn.Module):
         self.layout = "v2" if w_bit == 4 else "w3c"
         self.sz_cdna4 = None
         self.szh_cdna4 = None  # decode side buffer ("sz_half"): None = not built yet, False = this layer's scales are not f16-exact
+        self._decode_served = {}  # rows -> does the streaming decode entry serve this (rows, N, K)?  (awq_w4a16_decode_cdna4_plan)
         assert self.in_features % self.group_size == 0
         assert out_features % 8 == 0  # 32 // w_bit for the reference's w_bit = 4 (qmodule.py:93)
         assert out_features % self.interleave == 0
@@ -175,6 +176,20 @@ class WQLinear(nn.Module):
         q.scaled_zeros = sz.transpose(1, 0).contiguous()
         return q
 
+    def engine_converted(self) -> bool:
+        """True while the engine's cache holds THIS qweight converted in place (AWQ_CDNA4_INPLACE=1: the reference entry points permuted the
+        bytes where they lie; `layout` still says "v2").  Format tools -- to_cdna4, tensor-parallel sharding, QuantLlamaMLP's stacking,
+        checkpoint writers -- must `awq_inference_engine.cdna4_restore(qweight)` first; they check this and raise."""
+        if not self.qweight.is_cuda or self.layout != "v2":
+            return False
+        eng = load_engine()
+        return bool(eng.cdna4_is_converted(self.qweight)) if hasattr(eng, "cdna4_is_converted") else False
+
+    def _refuse_converted(self, what: str):
+        if self.engine_converted():
+            raise RuntimeError(f"{what}: this module's qweight was converted in place by the engine cache (AWQ_CDNA4_INPLACE); call "
+                               "awq_inference_engine.cdna4_restore(module.qweight) first")
+
     # ---- MI355X-native layout (no reference counterpart; what llm_awq_amd.repacker emits) ----
     @torch.no_grad()
     def to_cdna4(self):
@@ -183,6 +198,7 @@ class WQLinear(nn.Module):
         group_size 128; buffers must live on the GPU.  Idempotent."""
         if self.layout in ("cdna4", "w3c"):
             return self
+        self._refuse_converted("to_cdna4")
         if self.scales.dtype not in (torch.bfloat16, torch.float16):
             raise TypeError("the cdna4 interleave (matrix-core dequant) is defined for bfloat16 / float16 WQLinear only")
         if self.out_features % 16 or self.group_size != 128:
@@ -254,11 +270,13 @@ class WQLinear(nn.Module):
                 if self.szh_cdna4 is None and not (x.is_cuda and torch.cuda.is_current_stream_capturing()):
                     self._build_szh(eng)
                 if self.szh_cdna4 is not None and self.szh_cdna4 is not False:
-                    try:
+                    rows = x.numel() // x.shape[-1]
+                    # (host-side plan query, decided once per row count: a shape the streaming kernel does not serve goes to the general entry)
+                    served = self._decode_served.get(rows)
+                    if served is None:
+                        served = self._decode_served[rows] = rows >= 1 and eng.decode_cdna4_plan(rows, self.out_features, self.in_features, 0)[0] > 0
+                    if served:
                         return eng.decode_cdna4(x, self.qweight, self.szh_cdna4, self.bias, 0)
-                    except RuntimeError as e:  # a shape the streaming kernel does not serve: the general entry takes every shape
-                        if "shape" not in str(e).lower():
-                            raise
             fwd = eng.forward_cdna4 if self.layout == "cdna4" else eng.forward_w3
             return fwd(x, self.qweight, self.scales, self.scaled_zeros, self.sz_cdna4, self.bias)
         rows = x.numel() // x.shape[-1]

@@ -249,6 +249,18 @@ def wqlinear_forward(x: torch.Tensor, qweight, scales, scaled_zeros, bias=None, 
     return y
 
 
+def wqlinear_partial_f32(x: torch.Tensor, qweight, scales, scaled_zeros, group_size: int = 128, q_int=None) -> torch.Tensor:
+    """The K shard's product of a tensor-parallel row split, as THIS repository defines it (the reference has no multi-GPU path for
+    qmodule.py:201-224): the same contraction as `wqlinear_forward` on the shard's k range, left in fp32 -- not rounded to
+    T, no bias.  The ranks' partials are summed in fp32 and rounded once, so the sharded layer reproduces the single-device forward to fp32
+    reassociation error."""
+    if q_int is None:
+        q_int = unpack_v2(qweight.numpy() if isinstance(qweight, torch.Tensor) else qweight)
+    W = dequant_weight(q_int, scales, scaled_zeros, group_size)
+    K = x.shape[-1]
+    return (x.reshape(-1, K).float() @ W.float().t()).reshape(*x.shape[:-1], W.shape[0])
+
+
 def wqlinear_forward_f64(x, q_int, scales, scaled_zeros, group_size=128):
     """Same contraction in float64 on the T-rounded weights: the 'exact' value the fp32
     accumulations approximate (used to size tolerances)."""

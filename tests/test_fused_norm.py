@@ -124,3 +124,13 @@ def test_standalone_rmsnorm_vs_oracle(dtype, M, K):
     diff = (y.double() - ref.double()).abs()
     assert (diff <= unc + 1e-30).all(), "a difference outside the elements whose rounding is undecided"
     assert_bits(y, ref, 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -13, what="rmsnorm")
+
+
+def test_module_has_no_torch_fallback():
+    """what the HIP norm does not take raises (CPU tensors here): nothing under llm_awq_amd/ computes the step in torch"""
+    from llm_awq_amd.fused_norm import RMSNormWQLinear
+    import llm_awq_amd.fused_norm as FN
+    assert not hasattr(FN, "rmsnorm_reference_semantics")
+    mod = RMSNormWQLinear(torch.ones(128, dtype=torch.bfloat16), 1e-5, torch.nn.Identity())
+    with pytest.raises(RuntimeError, match="no CPU / PyTorch fallback"):
+        mod(torch.zeros(9, 128, dtype=torch.bfloat16))

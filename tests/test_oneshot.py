@@ -31,6 +31,15 @@ def _host_worker(rank, world, port, names, nbytes, rounds, q):
         dist.all_gather(parts, x)
         want = sum(p.float() for p in parts).to(dtype)   # rank order, fp32, one rounding
         ok = ok and torch.equal(got, want)
+        # the fp32 form (row splits send unrounded partials): fp32 sum in rank order, one rounding to T
+        x32 = g.randn(min(n, nbytes // 4))
+        got32 = box.all_reduce(x32, out_dtype=dtype)
+        parts32 = [torch.empty_like(x32) for _ in range(world)]
+        dist.all_gather(parts32, x32)
+        acc = torch.zeros_like(x32)
+        for p32 in parts32:
+            acc += p32
+        ok = ok and got32.dtype == dtype and torch.equal(got32, acc.to(dtype))
     q.put((rank, ok))
     dist.barrier()
     for s in shms:
@@ -94,6 +103,105 @@ def test_kernel_ranks_as_coresident_blocks(dtype, world):
             for r in range(world):
                 assert torch.equal(outs[r], want), (rnd, r)
     finally:
+        for b in bufs:
+            L.awq_oneshot_free(b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_kernel_fp32_partials_rounded_once(dtype, world):
+    """awq_oneshot_allreduce_f32: `world` co-resident blocks exchange UNROUNDED fp32 partials; out = T(fp32 sum in rank order) (+ bias in T).
+    Same buffers serve the T form in between (a communicator carries both)."""
+    import ctypes
+    from llm_awq_amd import _capi
+    L = _capi.lib()
+    max_bytes = 65536
+    bufs = [ctypes.c_void_p() for _ in range(world)]
+    for b in bufs:
+        _capi.check(L.awq_oneshot_alloc(ctypes.byref(b), world, max_bytes))
+    try:
+        ptrs = (ctypes.c_void_p * 8)(*[bufs[q % world].value for q in range(8)])
+        status = torch.zeros(1, dtype=torch.int32, device="cuda")
+        g = cuda_gen(13)
+        st = lambda: torch.cuda.current_stream().cuda_stream  # noqa: E731
+        dt = 0 if dtype == torch.float16 else 1
+        rnd = 0
+        for (m, n) in ((1, 4096), (1, 8192), (3, 4096), (2, 8), (1, 16384)):
+            cnt = m * n
+            xs = torch.randn(world, cnt, device="cuda", generator=g)
+            bias = (torch.randn(n, device="cuda", generator=g) * 0.1).to(dtype)
+            for b in (None, bias):
+                rnd += 1
+                outs = torch.empty(world, cnt, device="cuda", dtype=dtype)
+                _capi.check(L.awq_oneshot_allreduce_f32_selftest(ptrs, xs.data_ptr(), b.data_ptr() if b is not None else None, n if b is not None else 0,
+                                                                 outs.data_ptr(), cnt, dt, world, rnd, max_bytes, status.data_ptr(), st()))
+                torch.cuda.synchronize()
+                assert int(status.item()) == 0
+                acc = torch.zeros(cnt, device="cuda")
+                for r in range(world):
+                    acc += xs[r]
+                want = acc.to(dtype)
+                if b is not None:
+                    want = (want.view(m, n) + b).view(-1)
+                for r in range(world):
+                    assert torch.equal(outs[r], want), (m, n, r, b is not None)
+            # a T-form round on the same buffers
+            rnd += 1
+            xt = torch.randn(world, 1024, device="cuda", generator=g).to(dtype)
+            ot = torch.empty_like(xt)
+            _capi.check(L.awq_oneshot_allreduce_selftest(ptrs, xt.data_ptr(), ot.data_ptr(), 1024, dt, world, rnd, max_bytes, status.data_ptr(), st()))
+            torch.cuda.synchronize()
+            acc = torch.zeros(1024, device="cuda")
+            for r in range(world):
+                acc += xt[r].float()
+            assert torch.equal(ot[0], acc.to(dtype))
+        # a message above max_bytes is refused (the caller's RCCL class)
+        big = torch.zeros(world, max_bytes // 4 + 8, device="cuda")
+        assert L.awq_oneshot_allreduce_f32_selftest(ptrs, big.data_ptr(), None, 0, big.data_ptr(), max_bytes // 4 + 8, dt, world, rnd + 1, max_bytes,
+                                                    status.data_ptr(), st()) == -4
+    finally:
+        for b in bufs:
+            L.awq_oneshot_free(b)
+
+
+@pytest.mark.gpu
+def test_lost_round_kills_the_communicator():
+    """a rank whose peer never shows up: the round times out (small spin bound), the output is NaN, the status word is sticky, and EVERY later
+    call on that communicator poisons its output at entry instead of summing whatever late flags of the lost round would match"""
+    import ctypes
+    from llm_awq_amd import _capi
+    L = _capi.lib()
+    world, max_bytes, n = 2, 16384, 1024
+    bufs = [ctypes.c_void_p() for _ in range(world)]
+    for b in bufs:
+        _capi.check(L.awq_oneshot_alloc(ctypes.byref(b), world, max_bytes))
+    try:
+        _capi.check(L.awq_oneshot_set_spin_limit(2000))
+        ptrs = (ctypes.c_void_p * 8)(*[bufs[q % world].value for q in range(8)])
+        status = torch.zeros(1, dtype=torch.int32, device="cuda")
+        x = torch.ones(n, device="cuda", dtype=torch.bfloat16)
+        out = torch.zeros_like(x)
+        st = torch.cuda.current_stream().cuda_stream
+        # ONE block plays rank 0 of a two-rank group: rank 1 never arrives
+        _capi.check(L.awq_oneshot_allreduce(ptrs, x.data_ptr(), out.data_ptr(), n, 1, 0, world, 0, max_bytes, status.data_ptr(), st))
+        torch.cuda.synchronize()
+        assert int(status.item()) == 1 and bool(torch.isnan(out.float()).all())
+        # now rank 1's block DOES play the lost round (its flags land late) ...
+        o1 = torch.zeros_like(x)
+        s1 = torch.zeros(1, dtype=torch.int32, device="cuda")
+        _capi.check(L.awq_oneshot_allreduce(ptrs, x.data_ptr(), o1.data_ptr(), n, 1, 1, world, 0, max_bytes, s1.data_ptr(), st))
+        torch.cuda.synchronize()
+        # ... and rank 0's next call, whose device epoch still names that round, must NOT hand back the stale sum
+        out.zero_()
+        _capi.check(L.awq_oneshot_allreduce(ptrs, x.data_ptr(), out.data_ptr(), n, 1, 0, world, 0, max_bytes, status.data_ptr(), st))
+        x32 = torch.ones(n, device="cuda")
+        o32 = torch.zeros(n, device="cuda", dtype=torch.bfloat16)
+        _capi.check(L.awq_oneshot_allreduce_f32(ptrs, x32.data_ptr(), None, 0, o32.data_ptr(), n, 1, 0, world, 0, max_bytes, status.data_ptr(), st))
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(out.float()).all()) and bool(torch.isnan(o32.float()).all())
+    finally:
+        L.awq_oneshot_set_spin_limit(40000000)
         for b in bufs:
             L.awq_oneshot_free(b)
 
@@ -201,6 +309,12 @@ def _same_gpu_worker(rank, world, port, q):
             y = ar(xs[rank])
             torch.cuda.synchronize()
             ok = ok and torch.equal(y, (xs[0].float() + xs[1].float()).to(torch.bfloat16))
+            if r % 10 == 0:  # the fp32-partial form of the row splits on the same communicator (sum + one rounding + bias in the kernel)
+                x32 = [xs[q].float() * 1.001 for q in range(world)]
+                bias = torch.full((n,), 0.5, device="cuda", dtype=torch.bfloat16)
+                y32 = ar.reduce_f32(x32[rank].contiguous(), torch.bfloat16, bias)
+                torch.cuda.synchronize()
+                ok = ok and torch.equal(y32, (x32[0] + x32[1]).to(torch.bfloat16) + bias)
         # graph replay: the kernel arguments are frozen, the epoch lives in the exchange buffer
         x = torch.zeros(n, device="cuda", dtype=torch.bfloat16)
         side = torch.cuda.Stream()

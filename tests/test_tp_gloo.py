@@ -1,7 +1,8 @@
 """not-gpu: the N > 1 path (llm_awq_amd.parallel) on CPU with the gloo backend, world_size 2.
 The shard matmul is the ORACLE here (there is no GPU in this container, and the product never falls back
-to it: TPWQLinear takes the matmul as an injected test seam); what is under test is the sharding of the v2
-buffers, the collective, and bias-after-reduce."""
+to it: TPWQLinear takes the shard product as an injected test seam -- `partial=` the fp32 partial of a row split,
+`matmul=` the T output of a column split); what is under test is the sharding of the v2 buffers, the fp32 sum over
+ranks, the single rounding to T and bias-after-reduce, against the SINGLE-DEVICE ORACLE within SURVEY.md 8(e)'s 1e-3."""
 import os
 import socket
 
@@ -42,9 +43,16 @@ def _worker(rank, world, port, dtype_name, result_q):
         def oracle_mm(xs, qw, s, z):
             return O.wqlinear_forward(xs, qw, s, z, None, 128)
 
+        def oracle_partial(xs, qw, s, z):
+            return O.wqlinear_partial_f32(xs, qw, s, z, 128)
+
         ref = O.wqlinear_forward(x, d["qweight"], d["scales"], d["scaled_zeros"], full.bias, 128).float()
-        row = P.TPWQLinear(full, "row", matmul=oracle_mm)
-        y_row = row(x).float()
+        row = P.TPWQLinear(full, "row", partial=oracle_partial)
+        y_row_t = row(x)
+        assert y_row_t.dtype == dtype
+        y_row = y_row_t.float()
+        # the pre-round-4 numerics (every partial rounded to T before the sum) through the legacy seam: what the fp32 partials fix
+        y_old = P.TPWQLinear(full, "row", matmul=oracle_mm)(x).float()
         col = P.TPWQLinear(full, "column", matmul=oracle_mm)
         y_col_local = col(x)
         parts = [torch.empty_like(y_col_local) for _ in range(world)]
@@ -56,7 +64,8 @@ def _worker(rank, world, port, dtype_name, result_q):
         n0, n1 = col.bounds
         assert (O.unpack_v2(col.shard.qweight.numpy()) == d["intweight"].numpy()[n0:n1]).all()
         assert row.shard.scales.shape[0] == 8 and torch.equal(row.shard.scales[: (k1 - k0) // 128], d["scales"][k0 // 128: k1 // 128])
-        result_q.put((rank, ((y_row - ref).norm() / ref.norm()).item(), torch.equal(y_col, ref), (k0, k1), (n0, n1)))
+        result_q.put((rank, ((y_row - ref).norm() / ref.norm()).item(), torch.equal(y_col, ref), (k0, k1), (n0, n1),
+                      ((y_old - ref).norm() / ref.norm()).item(), int((y_row != ref).sum().item()), y_row.numel()))
     finally:
         dist.destroy_process_group()
 
@@ -76,10 +85,13 @@ def test_tp2_row_and_column_parallel_gloo(dtype_name):
     res.sort()
     assert res[0][3] == (0, 640) and res[1][3] == (640, 1280)
     assert res[0][4] == (0, 48) and res[1][4] == (48, 96)
-    for _rank, rel, col_exact, _kb, _nb in res:
+    for _rank, rel, col_exact, _kb, _nb, rel_old, flips, numel in res:
         assert col_exact  # column-parallel is a pure partition of the outputs: bit exact
-        # row-parallel adds one rounding to T per partial before the sum
-        assert rel < (1e-3 if dtype_name == "float16" else 4e-3), rel
+        # row-parallel: fp32 partials, fp32 sum, ONE rounding -> the single-device oracle up to fp32 reassociation (a handful of
+        # elements on a rounding boundary of T flip by one ulp); SURVEY.md 8(e)'s budget is 1e-3 for fp16 AND bf16
+        assert rel < 1e-3, rel
+        assert flips <= max(3, numel // 50), (flips, numel)
+        assert rel <= rel_old + 1e-7, (rel, rel_old)  # never worse than T-rounded partials
 
 
 def test_shard_bounds():
@@ -117,3 +129,36 @@ def test_stacked_gate_up_column_shards_pair_matching_rows():
         h = y.shape[1] // 2
         outs.append(torch.nn.functional.silu(y[:, :h]) * y[:, h:])
     assert torch.equal(torch.cat(outs, 1), ref)
+
+
+@pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_row_split_fp32_partials_match_the_single_device_oracle(dtype_name, world):
+    """every rank of a `world`-way row split, one after the other in ONE process (explicit world= / rank=, no process group): the fp32 sum
+    of the oracle partials rounded once is within 1e-3 of the single-device oracle (bf16 with T-rounded partials: 2.6-2.9e-3)"""
+    from llm_awq_amd.qmodule import WQLinear
+    from oracle import awq_oracle as O
+    from tests.helpers import Gen
+    dtype = getattr(torch, dtype_name)
+    K, N, M = 2048, 64, 6
+    g = Gen(23 + world)
+    d = O.quantize_linear(g.randn(N, K) * 0.02, dtype=dtype)
+    full = WQLinear(4, 128, K, N, True, "cpu", dtype=dtype)
+    full.qweight, full.scales, full.scaled_zeros = d["qweight"], d["scales"], d["scaled_zeros"]
+    full.bias = (g.randn(N) * 0.02).to(dtype)
+    x = g.randn(M, K).to(dtype)
+    ref = O.wqlinear_forward(x, d["qweight"], d["scales"], d["scaled_zeros"], full.bias, 128).float()
+    acc32 = torch.zeros(M, N)
+    acc_t = torch.zeros(M, N)
+    for r in range(world):
+        tp = P.TPWQLinear(full, "row", world=world, rank=r, partial=lambda xs, qw, s, z: O.wqlinear_partial_f32(xs, qw, s, z, 128))
+        k0, k1 = tp.bounds
+        p32 = tp._partial(x[:, k0:k1].contiguous(), tp.shard.qweight, tp.shard.scales, tp.shard.scaled_zeros)
+        acc32 += p32
+        acc_t += p32.to(dtype).float()
+    y = acc32.to(dtype) + full.bias
+    rel = ((y.float() - ref).norm() / ref.norm()).item()
+    rel_t = (((acc_t.to(dtype) + full.bias).float() - ref).norm() / ref.norm()).item()
+    assert rel < 1e-3, (rel, rel_t)
+    if dtype_name == "bfloat16":
+        assert rel < rel_t  # what the T-rounded partials cost
