@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--prefill-m", type=int, default=2048, help="prefill rows of the headline GEMM figure (SURVEY.md 8(d) / BASELINE.md quote M = 2048)")
     ap.add_argument("--prefill-m2", type=int, default=4096, help="second prefill size reported beside it (0 = skip)")
     ap.add_argument("--prefill-m3", type=int, default=512, help="a short prompt (split-K territory) reported beside them (0 = skip)")
-    ap.add_argument("--prefill-iters", type=int, default=3)
+    ap.add_argument("--prefill-iters", type=int, default=10, help="timed prefill passes per size (after two untimed ones); median and min are reported")
     ap.add_argument("--no-prefill", action="store_true")
     ap.add_argument("--no-dropin", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -277,20 +277,72 @@ def main():
         return wall_ms, ev_ms, graph is not None
 
     def timed_prefill(run_pass, M, n_lin):
+        """two untimed passes (lazy init, clock ramp: the first timed leg of a run used to read 3 % slow), then --prefill-iters passes each
+        bracketed by its own pair of events on the launch stream: median (the reported figure) and min"""
         xsm = make_x(M)
+        iters = max(1, args.prefill_iters)
         with torch.cuda.stream(side):
-            run_pass(xsm)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(side)
-            for _ in range(args.prefill_iters):
+            for _ in range(2):
                 run_pass(xsm)
-            e1.record(side)
             torch.cuda.synchronize()
-            pms = e0.elapsed_time(e1) / args.prefill_iters
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+            for (e0, e1) in evs:
+                e0.record(side)
+                run_pass(xsm)
+                e1.record(side)
+            torch.cuda.synchronize()
+            ts = sorted(e0.elapsed_time(e1) for (e0, e1) in evs)
+        pms, pmin = ts[len(ts) // 2], ts[0]
         flops = sum(2.0 * M * K * N for (_nm, K, N) in SHAPES) * L
         tfl = flops / (pms * 1e-3) / 1e12
-        return pms, tfl
+        return pms, tfl, pmin, flops / (pmin * 1e-3) / 1e12
+
+    def per_kernel_decode(steps, warmup):
+        """the decode launch kinds one by one (events, graph replay of that kind's L launches, every layer its own weights): where the
+        token's time goes.  Each kind alone re-reads L x its bytes per replay (o_proj: 285 MB, just above the 256 MB Infinity Cache)."""
+        xs1 = make_x(1)
+        kinds = []
+        for (name, *_r) in nat:
+            if name not in kinds:
+                kinds.append(name)
+        res = {}
+        for kind in kinds:
+            sub = [t for t in nat if t[0] == kind]
+
+            def run_kind():
+                outs = []
+                for (name, K, N, qw, s, z, szp, szh, epi) in sub:
+                    if epi == 2:
+                        outs.append(eng.mlp_gate_up_forward_cdna4(xs1[K], qw, szp, szh))
+                    elif szh is not None:
+                        outs.append(eng.decode_cdna4(xs1[K], qw, szh, None, epi))
+                    elif epi == 1:
+                        outs.append(eng.mlp_gate_up_cdna4(xs1[K], qw, szp))
+                    else:
+                        outs.append(eng.forward_cdna4(xs1[K], qw, s, z, szp, None))
+                return outs
+
+            with torch.cuda.stream(side):
+                run_kind()
+                torch.cuda.synchronize()
+                gk = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gk, stream=side):
+                    keep = run_kind()  # noqa: F841
+                for _ in range(warmup):
+                    gk.replay()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(side)
+                for _ in range(steps):
+                    gk.replay()
+                e1.record(side)
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / (steps * len(sub))
+            (_nm, K, N, *_r2, epi) = sub[0]
+            b = algo_bytes(1, K, N) - ((N // 2) * 2 if epi else 0)
+            res[kind] = {"k": K, "n": N, "algorithmic_bytes": b, "avg_launch_us": round(us, 3), "frac": round(b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+            del gk
+        return res
 
     native_leg = args.layout == "cdna4"
     run_main = run_native if native_leg else run_dropin
@@ -307,6 +359,8 @@ def main():
                 "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_us": round(avg_launch_us, 3), "algorithmic_bytes_per_launch": bytes_step // launches,
                 "launches_per_step": launches, "timing": "hip events on the launch stream over the timed region"}
+    if native_leg and graphed and not one_launch_mlp and not probe_streams and args.repeat_layers == 1:
+        roofline["per_kernel"] = per_kernel_decode(max(5, args.steps // 2), max(2, args.warmup // 2))
     tok_s = 1e3 / ms_per_step * (L * args.repeat_layers / LAYERS)  # tokens/s of a full 32-layer model
 
     out = {"metric": "W4A16 decode+prefill tok/s, Llama-3-8B; achieved %HBM (GEMV) / %MFMA (GEMM)",
@@ -339,11 +393,12 @@ def main():
 
     # ---------------- prefill leg ----------------
     def prefill(M, run_pass, kernel):
-        pms, tfl = timed_prefill(run_pass, M, launches)
+        pms, tfl, pmin, tfl_best = timed_prefill(run_pass, M, launches)
         ptraffic, psrc = pmc_traffic(["awq::gemm_cdna4_v6", "awq::gemm_cdna4_v4"]) if M == 2048 else (None, None)
-        return {"m": M, "ms_per_pass": round(pms, 3), "tok_s": round(M / (pms * 1e-3) * (LAYERS / L), 1),
+        return {"m": M, "ms_per_pass": round(pms, 3), "ms_per_pass_min": round(pmin, 3), "passes_timed": max(1, args.prefill_iters), "statistic": "median",
+                "tok_s": round(M / (pms * 1e-3) * (LAYERS / L), 1),
                 "roofline": {"bound": "mfma", "kernel": kernel, "achieved": round(tfl, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(tfl / MFMA_PEAK_TFLOPS, 4), "traffic": ptraffic,
+                             "frac": round(tfl / MFMA_PEAK_TFLOPS, 4), "frac_best_pass": round(tfl_best / MFMA_PEAK_TFLOPS, 4), "traffic": ptraffic,
                              **({"traffic_source": psrc, "traffic_note": "HBM bytes per launch, averaged over the tile-kernel launches of the M = 2048 pass (the PMC passes run with --prefill-m2 0 --prefill-m3 0)"} if ptraffic else {})}}
 
     pk = "gemm_cdna4_v6_kernel (256-wide tiles) + gemm_cdna4_v4n_kernel (128-wide tiles / remainder)"
@@ -355,20 +410,31 @@ def main():
 
     # ---------------- the same work through the reference's entry points on raw v2 buffers ----------------
     if native_leg and raw:
-        # the engine converts the reference-layout qweights WHERE THEY LIE (AWQ_CDNA4_INPLACE; `raw` is this leg's own copy): no second
-        # copy of the weights -- cache.bytes reports what the cache holds beside them
-        eng.cdna4_cache_inplace(os.environ.get("AWQ_CDNA4_INPLACE", "1") != "0")
-        d_wall, d_ev, _g = timed_decode(run_dropin, args.steps, args.warmup, not args.no_graph)
-        d_bytes = sum(algo_bytes(1, K, N) for (_n, K, N, *_r) in raw)
-        d_gbs = d_bytes * args.steps / (d_ev * 1e-3) / 1e9
+        def dropin_leg(with_prefill):
+            d_wall, d_ev, _g = timed_decode(run_dropin, args.steps, args.warmup, not args.no_graph)
+            d_bytes = sum(algo_bytes(1, K, N) for (_n, K, N, *_r) in raw)
+            d_gbs = d_bytes * args.steps / (d_ev * 1e-3) / 1e9
+            d = {"launches_per_token": len(raw), "decode_tok_s": round(1e3 / (d_wall / args.steps) * (L / LAYERS), 2),
+                 "decode_vs_native": round((1e3 / (d_wall / args.steps)) / (1e3 / ms_per_step), 4),
+                 "roofline": {"bound": "hbm", "achieved": round(d_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(d_gbs / HBM_PEAK_GBS, 4),
+                              "avg_launch_us": round(d_ev * 1e3 / (args.steps * len(raw)), 3)},
+                 "cache": {k: int(v) for k, v in eng.cdna4_cache_info().items()}}
+            if with_prefill:
+                d["prefill_m%d" % args.prefill_m] = prefill(args.prefill_m, run_dropin, pk + " via gemm_forward_cuda_new")
+            return d
+
+        # DEFAULT cache mode (the product default, SURVEY.md 8(b) "no in-place mutation of inputs"): the engine keeps a cdna4 COPY of every
+        # qweight it has seen (cache.bytes = that second copy); the caller's v2 buffers are untouched
+        eng.cdna4_cache_inplace(False)
         drop = {"entry_points": "awq_inference_engine.gemv_forward_cuda_new / gemm_forward_cuda_new on reference-layout (v2) buffers, engine repack cache on",
-                "launches_per_token": len(raw), "decode_tok_s": round(1e3 / (d_wall / args.steps) * (L / LAYERS), 2),
-                "decode_vs_native": round((1e3 / (d_wall / args.steps)) / (1e3 / ms_per_step), 4),
-                "roofline": {"bound": "hbm", "achieved": round(d_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(d_gbs / HBM_PEAK_GBS, 4),
-                             "avg_launch_us": round(d_ev * 1e3 / (args.steps * len(raw)), 3)},
-                "cache": {k: int(v) for k, v in eng.cdna4_cache_info().items()}}
-        if not args.no_prefill:
-            drop["prefill_m%d" % args.prefill_m] = prefill(args.prefill_m, run_dropin, pk + " via gemm_forward_cuda_new")
+                "cache_mode": "default: a cdna4 copy beside the caller's untouched v2 buffers", **dropin_leg(not args.no_prefill)}
+        # OPT-IN mode beside it (AWQ_CDNA4_INPLACE=1): the first call converts the caller's qweight where it lies -- no second copy of the
+        # weights (cache.bytes 0), but the module's buffer then holds the cdna4 interleave until cdna4_restore(); `raw` is this leg's own copy
+        if os.environ.get("AWQ_BENCH_DROPIN_INPLACE", "1") != "0":
+            eng.cdna4_cache_inplace(True)
+            drop["inplace_opt_in"] = {"cache_mode": "AWQ_CDNA4_INPLACE=1 (opt-in): the caller's qweight is permuted in place, restored by cdna4_restore()",
+                                      **dropin_leg(False)}
+            eng.cdna4_cache_inplace(False)  # (clears the cache: every qweight gets its v2 interleave back)
         out["dropin"] = drop
 
     # ---------------- CPU baseline (reference's pseudo-quant Linear on the host cores) ----------------

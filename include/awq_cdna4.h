@@ -208,6 +208,20 @@ int awq_w4a16_moe_forward_cdna4(const void* x_sorted, const void* qweight, const
                                 const void* sz_packed, const void* expert_offsets, void* out, int total_tokens,
                                 int num_experts, int n, int k, int gpad, int group_size, int dtype, void* stream);
 
+/* out = T(T(silu(gate)) * up) elementwise over `count` values (count % 8 == 0): the activation step between the projections where it is not
+ * fused into a kernel epilogue (tinychat/modules/fused_mlp.py:79-82: c = F.silu(gate_output) * up_output, every op rounded to T). */
+int awq_silu_mul(const void* gate, const void* up, void* out, size_t count, int dtype, void* stream);
+/* The expert MLP's first half in ONE grouped launch: every expert's w1 (gate) and w3 (up) rows interleaved 8 + 8 inside each 16-row slab
+ * (n2 = 2 x ffn rows per expert: qweight int16 [E, n2/4, k], sz_packed int32 [E, n2/16, k/128, 16], scales / scaled_zeros T [E, gpad, n2] of
+ * the same interleaved rows), out[T, n2/2] = T(T(silu(x . W1^T)) * T(x . W3^T)) -- the dense pair's epilogue (tinychat/modules/
+ * fused_mlp.py:36-83) generalised to sorted tokens; the reference has no MoE path.  >= 256 sorted rows: fused into the grouped tile's
+ * epilogue, the [T, n2] intermediate is never written (scratch may be NULL).  Fewer rows: the grouped GEMV / skinny kernels write the pair's
+ * product to `scratch` (>= total_tokens * n2 * 2 bytes, 16-byte aligned; AWQ_ERR_WORKSPACE otherwise) and the SiLU * mul tail runs as its own
+ * launch.  scales / scaled_zeros are only read by the fallback kernels of that small-batch path. */
+int awq_w4a16_moe_mlp_gate_up_cdna4(const void* x_sorted, const void* qweight_interleaved, const void* scales, const void* scaled_zeros,
+                                    const void* sz_packed, const void* expert_offsets, void* out, void* scratch, size_t scratch_bytes,
+                                    int total_tokens, int num_experts, int n2, int k, int gpad, int group_size, int dtype, void* stream);
+
 /* ---- W3A16 ("w3c" tiles): BASELINE.json's INT3 configuration.  The reference has NO packed 3-bit format
  * (awq/quantize/qmodule.py:82-83 raises for w_bit != 4; INT3 exists only as pseudo-quantisation,
  * awq/quantize/quantizer.py:61-103 with n_bit = 3), so the format is this repository's: per 16-row x 128-k tile

@@ -413,6 +413,38 @@ int awq_w4a16_moe_forward_cdna4(const void* x_sorted, const void* qweight, const
   return finish_launch();
 }
 
+int awq_silu_mul(const void* gate, const void* up, void* out, size_t count, int dtype, void* stream) {
+  if (!gate || !up || !out) return AWQ_ERR_NULL;
+  if (dtype != AWQ_F16 && dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
+  if (!aligned16(gate) || !aligned16(up) || !aligned16(out)) return AWQ_ERR_ALIGN;
+  if (count == 0) return AWQ_OK;
+  if (awq::launch_silu_mul(gate, up, out, count, dtype, (hipStream_t)stream) != 0) return AWQ_ERR_SHAPE;
+  return finish_launch();
+}
+
+int awq_w4a16_moe_mlp_gate_up_cdna4(const void* x_sorted, const void* qweight_interleaved, const void* scales, const void* scaled_zeros,
+                                    const void* sz_packed, const void* expert_offsets, void* out, void* scratch, size_t scratch_bytes,
+                                    int total_tokens, int num_experts, int n2, int k, int gpad, int group_size, int dtype, void* stream) {
+  if (!expert_offsets || !sz_packed || !x_sorted || !qweight_interleaved || !out) return AWQ_ERR_NULL;
+  if (dtype != AWQ_F16 && dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
+  if (group_size != 128) return AWQ_ERR_GROUP;
+  if (num_experts < 1 || total_tokens < 0 || n2 < 32 || (n2 % 32) != 0 || k < 128 || (k % 128) != 0) return AWQ_ERR_SHAPE;
+  if (total_tokens == 0) return AWQ_OK;
+  if (!aligned16(x_sorted) || !aligned16(qweight_interleaved) || !aligned16(out) || !aligned16(sz_packed) || !aligned16(scratch)) return AWQ_ERR_ALIGN;
+  const hipStream_t st = (hipStream_t)stream;
+  if (total_tokens >= 256 && awq::moe_v6_enabled() &&
+      awq::launch_moe_gemm_cdna4_v6(x_sorted, qweight_interleaved, sz_packed, expert_offsets, out, total_tokens, num_experts, n2, k, dtype, st, 2) == 0)
+    return finish_launch();
+  // fewer than 256 sorted rows (grouped GEMV / grouped skinny kernel) -- or the v6 tile switched off: the pair's [total, n2] product goes
+  // through the caller's scratch, then the SiLU * mul tail as its own launch
+  if (!scratch || scratch_bytes < (size_t)total_tokens * n2 * 2) return AWQ_ERR_WORKSPACE;
+  const int rc = awq_w4a16_moe_forward_cdna4(x_sorted, qweight_interleaved, scales, scaled_zeros, sz_packed, expert_offsets, scratch, total_tokens,
+                                             num_experts, n2, k, gpad, group_size, dtype, stream);
+  if (rc != AWQ_OK) return rc;
+  if (awq::launch_silu_mul_interleaved(scratch, out, total_tokens, n2, dtype, st) != 0) return AWQ_ERR_SHAPE;
+  return finish_launch();
+}
+
 // ---- W3 ("w3c") : the repository's 3-bit format (bf16 only; no reference counterpart) ----
 static int check_w3_shape(int n, int k) { return (n < 16 || (n % 16) != 0 || k < 128 || (k % 128) != 0) ? AWQ_ERR_SHAPE : AWQ_OK; }
 

@@ -486,7 +486,7 @@ template <typename DT>
 __global__ __launch_bounds__(256) void moe_gemm_cdna4_v6_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                                 const u32* __restrict__ szp, const int* __restrict__ offsets,
                                                                 uint16_t* __restrict__ out, int total, int experts, int N, int K,
-                                                                int row_tiles, int tiles_n) {
+                                                                int row_tiles, int tiles_n, int epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int T = row_tiles * tiles_n;
   int tile;
@@ -508,8 +508,9 @@ __global__ __launch_bounds__(256) void moe_gemm_cdna4_v6_kernel(const uint16_t* 
   if (e == experts) return;  // wave-uniform: no tile for this block
   const int r_lo = lo + rt * V6_TM, r_hi = min(r_lo + V6_TM, hi);
   const size_t ew = (size_t)(N >> 4) * (K >> 7);  // tiles per expert
+  // epi 2: every expert's rows are its w1 / w3 pair interleaved 8 + 8 per 16-row slab (N = 2 x ffn): out [total, N / 2] = silu(w1 x) * (w3 x)
   v6_tile<DT, 4, 0, 0, 4>(smem, x, qw + (size_t)e * ew * 256, szp + (size_t)e * ew * 16, nullptr, out, N, K, min(r_lo, total - V6_TM), tn * V6_TN,
-                          N, 0, r_lo, r_hi);
+                          N, epi, r_lo, r_hi);
 }
 
 namespace {
@@ -571,7 +572,8 @@ void launch_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, const 
 
 // grouped GEMM over sorted tokens with the v6 tile; needs total >= 256.  Returns -1 if unsupported.
 int launch_moe_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total, int experts,
-                             int n, int k, int dtype, hipStream_t st) {
+                             int n, int k, int dtype, hipStream_t st, int epi) {
+  if ((epi != 0 && epi != 2) || (epi == 2 && (n % 32) != 0)) return -1;
   if (total < V6_TM || experts < 1 || (n % 16) != 0 || (k % 128) != 0 || (size_t)total * (size_t)k >= (1ull << 31) ||
       (size_t)n * (size_t)k / 8 >= (1ull << 31))
     return -1;
@@ -582,7 +584,7 @@ int launch_moe_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, con
   optin[dtype == 0 ? 0 : 1].ensure(reinterpret_cast<const void*>(kern), smem);
   const int row_tiles = total / V6_TM + experts, tiles_n = (n + V6_TN - 1) / V6_TN;
   hipLaunchKernelGGL(kern, dim3(row_tiles * tiles_n), dim3(256), smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp,
-                     (const int*)offsets, (uint16_t*)out, total, experts, n, k, row_tiles, tiles_n);
+                     (const int*)offsets, (uint16_t*)out, total, experts, n, k, row_tiles, tiles_n, epi);
   return 0;
 }
 

@@ -104,8 +104,12 @@ int launch_moe_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, con
                              int n, int k, int dtype, hipStream_t st);
 bool moe_v4_enabled();
 // the same grouped GEMM on the v6 tile (awq_gemm_v6.hip: one pipelined wave per SIMD, weights in registers); total >= 256
+// epi 2: per-expert w1 / w3 pair interleaved 8 + 8 per slab (n = 2 x ffn), out [total, n / 2] = silu(w1 x) * (w3 x) fused into the tile epilogue
 int launch_moe_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total, int experts,
-                             int n, int k, int dtype, hipStream_t st);
+                             int n, int k, int dtype, hipStream_t st, int epi = 0);
+// out[t, 8 j + c] = T(T(silu(in[t, 16 j + c])) * in[t, 16 j + 8 + c]): the SiLU * mul tail on an [m, n2] result of the 8 + 8 interleaved pair
+int launch_silu_mul_interleaved(const void* in, void* out, int m, int n2, int dtype, hipStream_t st);
+int launch_silu_mul(const void* gate, const void* up, void* out, size_t count, int dtype, hipStream_t st);  // out = T(T(silu(gate)) * up), count % 8 == 0
 bool moe_v6_enabled();  // knob moe_v6 (default on)
 // 256 x 256-tile prefill GEMM with the hand-scheduled K loop (awq_gemm_v4.hip): weight rows [n_begin, n_end), m >= 256
 void launch_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,

@@ -361,6 +361,43 @@ int launch_rmsnorm(const void* x, const void* gamma, float eps, void* out, int m
   return 0;
 }
 
+// the SiLU * mul tail (tinychat/modules/fused_mlp.py:79-82: c = F.silu(gate_output) * up_output, every op rounded to T) on a matmul result whose
+// columns are the 8 + 8 interleaved gate / up pair: one thread = one output octet (reads 2 x 16 B, writes 16 B)
+template <typename DT>
+__global__ __launch_bounds__(256) void silu_mul_interleaved_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, size_t octets, int half_octets) {
+  for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < octets; o += (size_t)gridDim.x * 256) {
+    const size_t row = o / (size_t)half_octets, j = o - row * (size_t)half_octets;
+    const uint16_t* src = in + (row * (size_t)half_octets * 2 + j * 2) * 8;
+    const u32x4 g = *reinterpret_cast<const u32x4*>(src), u = *reinterpret_cast<const u32x4*>(src + 8);
+    *reinterpret_cast<u32x4*>(out + o * 8) = silu_mul_octet<DT>(g, u);
+  }
+}
+
+template <typename DT>
+__global__ __launch_bounds__(256) void silu_mul_kernel(const uint16_t* __restrict__ gate, const uint16_t* __restrict__ up, uint16_t* __restrict__ out, size_t octets) {
+  for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < octets; o += (size_t)gridDim.x * 256)
+    *reinterpret_cast<u32x4*>(out + o * 8) = silu_mul_octet<DT>(*reinterpret_cast<const u32x4*>(gate + o * 8), *reinterpret_cast<const u32x4*>(up + o * 8));
+}
+
+// out = T(T(silu(gate)) * up), elementwise over `count` values (count % 8 == 0)
+int launch_silu_mul(const void* gate, const void* up, void* out, size_t count, int dtype, hipStream_t st) {
+  if (count == 0 || (count % 8) != 0) return -1;
+  const size_t octets = count / 8;
+  const unsigned blocks = (octets + 255) / 256 > 8192u ? 8192u : (unsigned)((octets + 255) / 256);
+  if (dtype == 0) hipLaunchKernelGGL((silu_mul_kernel<F16>), dim3(blocks), dim3(256), 0, st, (const uint16_t*)gate, (const uint16_t*)up, (uint16_t*)out, octets);
+  else hipLaunchKernelGGL((silu_mul_kernel<BF16>), dim3(blocks), dim3(256), 0, st, (const uint16_t*)gate, (const uint16_t*)up, (uint16_t*)out, octets);
+  return 0;
+}
+
+int launch_silu_mul_interleaved(const void* in, void* out, int m, int n2, int dtype, hipStream_t st) {
+  if (m < 1 || n2 < 16 || (n2 % 16) != 0) return -1;
+  const size_t octets = (size_t)m * (n2 / 16);
+  const unsigned blocks = (octets + 255) / 256 > 8192u ? 8192u : (unsigned)((octets + 255) / 256);
+  if (dtype == 0) hipLaunchKernelGGL((silu_mul_interleaved_kernel<F16>), dim3(blocks), dim3(256), 0, st, (const uint16_t*)in, (uint16_t*)out, octets, n2 / 16);
+  else hipLaunchKernelGGL((silu_mul_interleaved_kernel<BF16>), dim3(blocks), dim3(256), 0, st, (const uint16_t*)in, (uint16_t*)out, octets, n2 / 16);
+  return 0;
+}
+
 // out[m, n] = T(in_f32[m, n]) (+ bias in T): the single rounding of a tensor-parallel row split after its fp32 partials were summed
 // (by RCCL: the bandwidth-class messages; the latency-class ones are summed and rounded inside awq_oneshot_allreduce_f32)
 template <typename DT>

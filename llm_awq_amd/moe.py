@@ -68,12 +68,75 @@ class GroupedWQLinear(nn.Module):
         return eng.moe_gemm_forward(x_sorted.contiguous(), self.qweight, self.scales, self.scaled_zeros, expert_offsets, False)
 
 
+class GroupedGateUp(nn.Module):
+    """The expert MLP's first half as ONE grouped launch: every expert's w1 (gate) and w3 (up) WQLinear stacked with their rows interleaved
+    8 + 8 per 16-row slab -- the layout `llm_awq_amd.fused_mlp.QuantLlamaMLP` gives the dense pair (tinychat/modules/fused_mlp.py:36-83) --
+    so that `silu(w1 x) * (w3 x)` is the epilogue of the grouped tile (`awq_w4a16_moe_mlp_gate_up_cdna4`): the [T, 2F] intermediate is never
+    written and the block's w1 / w3 / F.silu * mul launches become one.  Built from v2 (reference layout) experts."""
+
+    def __init__(self, w1: Sequence[WQLinear], w3: Sequence[WQLinear]):
+        super().__init__()
+        from .fused_mlp import interleave_gate_up
+        assert len(w1) == len(w3) and len(w1) >= 1
+        e0 = w1[0]
+        assert all(e.w_bit == 4 and e.layout == "v2" and e.bias is None and e.group_size == 128 for e in list(w1) + list(w3)), \
+            "GroupedGateUp is built from v2 (reference layout) 4-bit experts without bias, group size 128"
+        assert all((e.in_features, e.out_features) == (e0.in_features, e0.out_features) for e in list(w1) + list(w3))
+        assert e0.out_features % 8 == 0
+        self.num_experts, self.in_features, self.out_features = len(w1), e0.in_features, e0.out_features
+        qs, ss, zs = [], [], []
+        for g, u in zip(w1, w3):
+            q, s, z = interleave_gate_up(g.qweight, u.qweight, g.scales, u.scales, g.scaled_zeros, u.scaled_zeros)
+            qs.append(q)
+            ss.append(s)
+            zs.append(z)
+        self.register_buffer("qweight", torch.stack(qs).contiguous())        # int16 [E, 2F/4, K], v2 interleave until the first GPU forward
+        self.register_buffer("scales", torch.stack(ss).contiguous())          # T [E, Gpad, 2F]
+        self.register_buffer("scaled_zeros", torch.stack(zs).contiguous())
+        self.layout = "v2"
+        self.sz_cdna4 = None
+
+    @torch.no_grad()
+    def _to_cdna4(self):
+        from . import ops
+        self.qweight = torch.stack([ops.repack_v2_to_cdna4(self.qweight[e].contiguous()) for e in range(self.num_experts)])
+        self.sz_cdna4 = torch.stack([ops.pack_sz_cdna4(self.scales[e].contiguous(), self.scaled_zeros[e].contiguous(), self.in_features)
+                                     for e in range(self.num_experts)])
+        self.layout = "cdna4"
+
+    @torch.no_grad()
+    def forward(self, x_sorted: torch.Tensor, expert_offsets: torch.Tensor) -> torch.Tensor:
+        from . import ops
+        if self.layout != "cdna4" or self.sz_cdna4 is None or self.sz_cdna4.device != self.qweight.device:
+            if self.layout == "cdna4":
+                self.layout = "v2"
+                self.qweight = torch.stack([ops.repack_cdna4_to_v2(self.qweight[e].contiguous()) for e in range(self.num_experts)])
+            self._to_cdna4()
+        return ops.moe_mlp_gate_up_cdna4(x_sorted.contiguous(), self.qweight, self.scales, self.scaled_zeros, self.sz_cdna4, expert_offsets)
+
+
 class SparseMoeMLP(nn.Module):
     """Mixtral-style block: y = sum_k p_k * w2_e( silu(w1_e x) * w3_e x ) over each token's top-k experts."""
 
-    def __init__(self, w1: GroupedWQLinear, w3: GroupedWQLinear, w2: GroupedWQLinear, top_k: int = 2):
+    def __init__(self, w1, w3, w2: GroupedWQLinear, top_k: int = 2, gate_up: Optional[GroupedGateUp] = None):
+        """w1 / w3: GroupedWQLinear modules (two grouped launches + the SiLU * mul tail as a third), or None with `gate_up` = a
+        GroupedGateUp built from the same experts (ONE grouped launch for h: `SparseMoeMLP.fused(w1_experts, w3_experts, w2, top_k)`)."""
         super().__init__()
-        self.w1, self.w3, self.w2, self.top_k = w1, w3, w2, top_k
+        self.w1, self.w3, self.w2, self.top_k, self.gate_up = w1, w3, w2, top_k, gate_up
+        assert gate_up is not None or (w1 is not None and w3 is not None)
+
+    @classmethod
+    def fused(cls, w1_experts: Sequence[WQLinear], w3_experts: Sequence[WQLinear], w2: GroupedWQLinear, top_k: int = 2):
+        return cls(None, None, w2, top_k, GroupedGateUp(w1_experts, w3_experts))
+
+    def _h(self, xs, offsets):
+        if self.gate_up is not None:
+            return self.gate_up(xs, offsets)
+        a, b = self.w1(xs, offsets), self.w3(xs, offsets)
+        if a.is_cuda:  # the SiLU * mul tail as the HIP kernel of the dense path's epilogue (no torch arithmetic on the hot path)
+            from . import ops
+            return ops.silu_mul(a, b)
+        return torch.nn.functional.silu(a) * b  # (CPU: only reachable with injected oracle matmuls -- the tests' seam)
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor, router_logits: torch.Tensor) -> torch.Tensor:
@@ -83,7 +146,7 @@ class SparseMoeMLP(nn.Module):
         w = (w / w.sum(-1, keepdim=True)).to(x.dtype)
         order, offsets = sort_by_expert(ids, self.w1.num_experts)
         xs = x[order // self.top_k]
-        h = torch.nn.functional.silu(self.w1(xs, offsets)) * self.w3(xs, offsets)
+        h = self._h(xs, offsets)
         ys = self.w2(h, offsets)
         out = torch.zeros(T * self.top_k, ys.shape[1], dtype=ys.dtype, device=ys.device)
         out[order] = ys

@@ -423,3 +423,30 @@ def moe_forward_cdna4(x_sorted, qweight, scales, scaled_zeros, sz_packed, expert
                                                              expert_offsets.data_ptr(), out.data_ptr(), t, e, n, k,
                                                              scales.shape[1], group_size, _dt(x_sorted), _stream(x_sorted)))
     return out
+
+
+def moe_mlp_gate_up_cdna4(x_sorted, qweight_interleaved, scales, scaled_zeros, sz_packed, expert_offsets, group_size: int = 128):
+    """C-ABI awq_w4a16_moe_mlp_gate_up_cdna4: silu(x . W1_e^T) * (x . W3_e^T) for tokens sorted by expert, every expert's w1 / w3 rows
+    interleaved 8 + 8 per slab (qweight int16 [E, 2F/4, K]); out [T, F].  One grouped launch from 256 sorted rows on."""
+    _need_gpu(x_sorted, qweight_interleaved, scales, scaled_zeros, sz_packed, expert_offsets)
+    e, n2, k = qweight_interleaved.shape[0], qweight_interleaved.shape[1] * 4, qweight_interleaved.shape[2]
+    t = x_sorted.shape[0]
+    out = torch.empty(t, n2 // 2, dtype=x_sorted.dtype, device=x_sorted.device)
+    scratch = torch.empty(t, n2, dtype=x_sorted.dtype, device=x_sorted.device) if 0 < t < 256 else None
+    with torch.cuda.device(x_sorted.device):
+        _capi.check(_capi.lib().awq_w4a16_moe_mlp_gate_up_cdna4(
+            x_sorted.data_ptr(), qweight_interleaved.data_ptr(), scales.data_ptr(), scaled_zeros.data_ptr(), sz_packed.data_ptr(),
+            expert_offsets.data_ptr(), out.data_ptr(), scratch.data_ptr() if scratch is not None else None,
+            scratch.numel() * 2 if scratch is not None else 0, t, e, n2, k, scales.shape[1], group_size, _dt(x_sorted), _stream(x_sorted)))
+    return out
+
+
+def silu_mul(gate, up):
+    """C-ABI awq_silu_mul: T(T(silu(gate)) * up), elementwise (fused_mlp.py:79-82)."""
+    _need_gpu(gate, up)
+    if gate.shape != up.shape or gate.dtype != up.dtype or gate.numel() % 8:
+        raise ValueError("silu_mul: gate and up must have the same shape / dtype and a multiple of 8 elements")
+    out = torch.empty_like(gate)
+    with torch.cuda.device(gate.device):
+        _capi.check(_capi.lib().awq_silu_mul(gate.data_ptr(), up.data_ptr(), out.data_ptr(), gate.numel(), _dt(gate), _stream(gate)))
+    return out

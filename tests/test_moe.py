@@ -224,3 +224,73 @@ def test_gpu_grouped_skinny(counts, dtype):
         lo, hi = int(off[e]), int(off[e + 1])
         if hi > lo:
             check_forward(y[lo:hi], x[lo:hi], cases[e]["q"], cases[e]["scales"], cases[e]["scaled_zeros"], dtype)
+
+
+def _fused_ref(x, c1, c3, dtype):
+    """per-expert oracle of the fused half: T(T(silu(T(x W1^T))) * T(x W3^T)) (fused_mlp.py:79-82, every op rounded to T)"""
+    a = O.wqlinear_forward(x, None, c1["scales"], c1["scaled_zeros"], None, 128, q_int=c1["q"])
+    b = O.wqlinear_forward(x, None, c3["scales"], c3["scaled_zeros"], None, 128, q_int=c3["q"])
+    return torch.nn.functional.silu(a) * b
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("counts", [[300, 0, 1, 255], [256, 256], [1, 700, 3, 40], [3, 2, 0, 2], [64, 64, 64, 63], [0, 5, 0, 0]])
+def test_gpu_fused_gate_up_grouped(counts, dtype):
+    """GroupedGateUp (awq_w4a16_moe_mlp_gate_up_cdna4): w1 / w3 interleaved 8 + 8 per expert, SiLU * mul in the grouped tile's epilogue from 256
+    sorted rows on (ragged segments, empty experts, the shifted last tile), through scratch + the tail kernel below -- against the per-expert
+    oracle SEQUENCE w1 -> w3 -> silu * mul, and against the unfused module path (two grouped launches + awq_silu_mul)."""
+    E, F, K = len(counts), 272, 512
+    m1, c1 = _experts(E, F, K, dtype, seed=sum(counts) + 101)
+    m3, c3 = _experts(E, F, K, dtype, seed=sum(counts) + 202)
+    gu = MOE.GroupedGateUp(m1, m3).cuda()
+    T = sum(counts)
+    x = Gen(T + 31).randn(T, K).to(dtype)
+    off = torch.tensor([0] + list(np.cumsum(counts)), dtype=torch.int32)
+    h = gu(x.cuda(), off.cuda()).cpu()
+    assert h.shape == (T, F) and h.dtype == dtype
+    w1 = MOE.GroupedWQLinear(m1).cuda().to_cdna4()
+    w3 = MOE.GroupedWQLinear(m3).cuda().to_cdna4()
+    blk = MOE.SparseMoeMLP(w1, w3, w1, 2)
+    h_unfused = blk._h(x.cuda(), off.cuda()).cpu()
+    assert_bits(h, h_unfused, 0.03, "fused grouped gate/up vs two grouped launches + tail")
+    for e in range(E):
+        lo, hi = int(off[e]), int(off[e + 1])
+        if hi > lo:
+            ref = _fused_ref(x[lo:hi], c1[e], c3[e], dtype)
+            # gate / up are each within the forward bound of the oracle; the tail is computed from T-rounded values on both sides: a flipped
+            # rounding of gate or up moves h by ~1 ulp, so bit-equality is statistical and the hard bound is a few ulps of T
+            assert_bits(h[lo:hi], ref, 0.03, f"expert {e}", ulps=4, dtype=dtype)
+            rel = ((h[lo:hi].float() - ref.float()).norm() / ref.float().norm()).item()
+            assert rel < 1e-3, (e, rel)
+
+
+@pytest.mark.gpu
+def test_gpu_silu_mul_kernel():
+    from llm_awq_amd import ops
+    for dtype in (torch.bfloat16, torch.float16):
+        g = cuda_gen(9)
+        a = (torch.randn(37, 264, device="cuda", generator=g) * 3).to(dtype)
+        b = (torch.randn(37, 264, device="cuda", generator=g) * 3).to(dtype)
+        ref = (torch.nn.functional.silu(a.float()).to(dtype).float() * b.float()).to(dtype)
+        # (the device silu is x / (1 + exp(-x)) with the hardware exp / rcp: the rounding of T(silu) flips on a few boundary cases)
+        assert_bits(ops.silu_mul(a, b), ref, 0.01, "silu * mul", ulps=2, dtype=dtype)
+
+
+@pytest.mark.gpu
+def test_gpu_sparse_moe_block_fused_equals_unfused():
+    """SparseMoeMLP.fused (one grouped launch for h) against SparseMoeMLP on separate w1 / w3 modules: same routing, same experts"""
+    dtype, E, H, F, T = torch.bfloat16, 4, 256, 512, 300
+    m1, _ = _experts(E, F, H, dtype, 310)
+    m3, _ = _experts(E, F, H, dtype, 320)
+    m2, _ = _experts(E, H, F, dtype, 330)
+    w2 = MOE.GroupedWQLinear(m2).cuda().to_cdna4()
+    fused = MOE.SparseMoeMLP.fused(m1, m3, w2, 2)
+    fused.gate_up.cuda()
+    plain = MOE.SparseMoeMLP(MOE.GroupedWQLinear(m1).cuda().to_cdna4(), MOE.GroupedWQLinear(m3).cuda().to_cdna4(), w2, 2)
+    g = Gen(5)
+    x = g.randn(T, H).to(dtype).cuda()
+    logits = g.randn(T, E).cuda()
+    y_f, y_p = fused(x, logits), plain(x, logits)
+    assert y_f.shape == (T, H)
+    assert ((y_f.float() - y_p.float()).norm() / y_p.float().norm()).item() < 2e-3

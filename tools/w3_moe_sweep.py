@@ -91,6 +91,26 @@ def main():
             tf = 2.0 * 2 * T * N * K / us / 1e6
             print(f"{name:6s} K={K:6d} N={N:6d} rows={2 * T} {label} {us:8.1f} us  {tf:7.1f} TFLOP/s  {tf / 25:5.1f}% of 2.5 PF",
                   flush=True)
+        if name == "w1/w3":  # the pair as ONE grouped launch (w1 / w3 interleaved 8 + 8 per expert, SiLU * mul in the tile epilogue)
+            from llm_awq_amd.fused_mlp import interleave_gate_up
+            qi, si, zi = [], [], []
+            for e in range(E):
+                q2 = torch.randint(0, 16, (N, K), dtype=torch.uint8, device="cuda")
+                s2, z2 = rand_sz(K, N)
+                qq, sq, zq = interleave_gate_up(ops.repack_cdna4_to_v2(qw[e]), ops.pack_v2(q2), ss[e], s2, zs[e], z2)
+                qi.append(ops.repack_v2_to_cdna4(qq))
+                si.append(sq)
+                zi.append(zq)
+                del q2
+            qwi, sI, zI = torch.stack(qi), torch.stack(si), torch.stack(zi)
+            szpi = torch.stack([ops.pack_sz_cdna4(si[e], zi[e], K) for e in range(E)])
+            del qi
+            us_f = graph_time(lambda _c: ops.moe_mlp_gate_up_cdna4(xs, qwi, sI, zI, szpi, off), [0, 1, 2, 3])
+            tf = 2.0 * 2 * T * (2 * N) * K / us_f / 1e6
+            us_2 = graph_time(lambda _c: ops.silu_mul(ops.moe_forward_cdna4(xs, qw, s, z, szp, off), ops.moe_forward_cdna4(xs, qw, s, z, szp, off)), [0, 1, 2, 3])
+            print(f"w1+w3  K={K:6d} N=2x{N:5d} rows={2 * T} FUSED grouped v6 (one launch, SiLU*mul epilogue) {us_f:8.1f} us  {tf:7.1f} TFLOP/s  {tf / 25:5.1f}% of 2.5 PF"
+                  f"   | two grouped launches + tail kernel {us_2:8.1f} us ({2.0 * 2 * T * (2 * N) * K / us_2 / 1e6 / 25:5.1f}%)", flush=True)
+            del qwi, sI, zI, szpi
         for tokens in (8, 32, 96):  # batched decode: top-2 -> 2 x tokens sorted rows
             idd = torch.stack([torch.randperm(E, device="cuda")[:2] for _ in range(tokens)])
             _o, offd = sort_by_expert(idd, E)
