@@ -25,9 +25,9 @@ EXT_PATH = os.path.join(EXT_DIR, "awq_inference_engine" + EXT_SUFFIX)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["awq_gemv.hip", "awq_gemv_cdna4.hip", "awq_gemv_dma.hip", "awq_gemv_v2fast.hip", "awq_gemm.hip", "awq_gemm_v3.hip", "awq_gemm_v4.hip", "awq_gemm_v4n.hip", "awq_gemm_v6.hip", "awq_skinny_cdna4.hip", "awq_skinny_v2.hip", "awq_util.hip", "awq_w3.hip", "awq_oneshot.hip", "awq_capi.hip"]
-# evaluated alternatives that only AWQ_PROBES=1 builds compile (knob-reachable there, absent from the product library)
-PROBE_SOURCES = ["awq_gemm_v5.hip"]
+HIP_SOURCES = ["awq_gemv.hip", "awq_gemv_cdna4.hip", "awq_gemv_dma.hip", "awq_v2_kernels.hip", "awq_gemm.hip", "awq_gemm_plan.hip", "awq_gemm_v4n.hip", "awq_gemm_v6.hip", "awq_skinny_cdna4.hip", "awq_util.hip", "awq_oneshot.hip", "awq_capi.hip"]
+# (round 4: the experiment kernels that AWQ_PROBES=1 builds once compiled -- v5, v6w -- live as records under tools/experiments)
+PROBE_SOURCES = []
 HIP_DEPS = ["awq_device.hpp", "awq_kernels.hpp", os.path.join(ROOT, "include", "awq_cdna4.h")]
 
 
@@ -59,7 +59,7 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
              # (the AGPR form costs one v_accvgpr_read per value)
              "-mllvm", "-amdgpu-mfma-vgpr-form",
              # AWQ_PROBES=1: compile the timing-only probes (linear-read / null kernels, GEMM v4 no-DMA / no-epilogue)
-             # behind the gemv_probe / gemm_v4_probe knobs; a default build has no knob that changes results
+             # behind the gemv_probe / gemm_v6 (tens digit) knobs; a default build has no knob that changes results
              *(["-DAWQ_ENABLE_PROBES"] if os.environ.get("AWQ_PROBES") == "1" else []),
              # the command processor preloads the first 16 kernel-argument dwords into SGPRs at dispatch (gfx950): the waves of a
              # decode launch issue their first loads without waiting for an s_load of the arguments -- +2.5 % decode tok/s

@@ -400,12 +400,8 @@ int awq_w4a16_moe_forward_cdna4(const void* x_sorted, const void* qweight, const
       awq::launch_moe_skinny_cdna4(x_sorted, qweight, sz_packed, expert_offsets, out, total_tokens, num_experts, n, k, dtype,
                                    (hipStream_t)stream) == 0)
     return finish_launch();
-  if (total_tokens >= 256 && awq::moe_v6_enabled() &&
+  if (total_tokens >= 256 && awq::moe_v6_enabled() && awq::moe_v4_enabled() &&
       awq::launch_moe_gemm_cdna4_v6(x_sorted, qweight, sz_packed, expert_offsets, out, total_tokens, num_experts, n, k, dtype,
-                                    (hipStream_t)stream) == 0)
-    return finish_launch();
-  if (total_tokens >= 256 && awq::moe_v4_enabled() &&
-      awq::launch_moe_gemm_cdna4_v4(x_sorted, qweight, sz_packed, expert_offsets, out, total_tokens, num_experts, n, k, dtype,
                                     (hipStream_t)stream) == 0)
     return finish_launch();
   awq::launch_moe_gemm(x_sorted, qweight, scales, scaled_zeros, expert_offsets, out, total_tokens, num_experts, n, k, gpad, dtype, 1,

@@ -1,8 +1,7 @@
 // Prefill GEMM on cdna4-interleaved weights: the TILE PLAN and the launch dispatch (bf16 and fp16, gfx950).
 // Replaces the tile table + dispatch of gemm_forward_cuda_new (reference awq/kernels/csrc/quantization_new/gemm/gemm_cuda.cu:1126-1236)
 // for the layout the rewritten repacker emits.  The kernels live in awq_gemm_v6.hip (256 x 256 / 256 x 192 tiles of prompts with >= 256
-// rows), awq_gemm_v4n.hip (256 x 128 tiles, masked single row tile, split-K) and awq_gemm_v4.hip (the 256 x 256 tile of w3c weights and of
-// knob gemm_v6 = 0).  (Round 1's own K loop of this file -- a compiler-scheduled 256 x (128 NSL) tile -- was retired in round 3: v4 / v4n
+// rows, W4 and w3c) and awq_gemm_v4n.hip (256 x 128 tiles, masked single row tile, split-K; knob gemm_v6 = 0).  (Round 1's own K loop of this file -- a compiler-scheduled 256 x (128 NSL) tile -- was retired in round 3: v4 / v4n
 // issue the same products in the same order and were bit-identical to it in every test.)
 #include <string.h>
 
@@ -18,26 +17,21 @@ constexpr int TM = 256;
 constexpr double kNarrowRate = 0.80;  // 256 x 128 tiles (awq_gemm_v4n.hip) vs 256 x 256 (awq_gemm_v6.hip) at equal chip fill (0.83 against awq_gemm_v4.hip, profiles/r01_gemm_v4.txt)
 int g_small_m = 1;  // knob gemm_small_m: 0 = the prefill GEMM only takes m >= 256 (see gemm_cdna4_v3_takes)
 int g_splitk = 1;  // narrow tiles: split K over blocks when the tiles fill less than half of the chip and a workspace is given
-int g_v5 = 0;  // 1: 256-wide tiles run awq_gemm_v5.hip (weights never touch LDS); knob gemm_v5
-int g_v6 = 1;  // 1 (default): 256-wide tiles of m >= 256 run awq_gemm_v6.hip (one software-pipelined wave per SIMD); 0: awq_gemm_v4.hip
+int g_v6 = 1;  // 1 (default): 256-wide tiles of m >= 256 run awq_gemm_v6.hip (one software-pipelined wave per SIMD); 0 (tests): awq_gemm_v4n.hip's 128-wide tiles
 int g_tile_n = 0;  // knob gemm_tile_n: 128 / 256 force one tile width for callers that pass tile_n = 0 (tests of a specific kernel)
 int g_v6_192 = 1;  // knob gemm_v6_192: 0 = no 192-wide blocks in the tile plan
 int g_v6_szh = 0;  // knob gemm_v6_szh: 1 = v6 dequantises in the f16-mantissa form when the caller hands its sz_half buffer (-40 VALU per K tile; measured neutral, profiles/r02_gemm_v6.txt)
 int g_v4 = 1;  // knob gemm_v4: 0 = the tile kernels take no m below 256 (the skinny kernel serves 9 .. 255 rows); the loop it once selected is gone
 void launch_wide(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
                  int n_end, int dtype, hipStream_t st, int bits, int epi, const void* szh = nullptr, int tile_n = 256) {
-#ifdef AWQ_ENABLE_PROBES  // awq_gemm_v5.hip is an evaluated alternative (profiles/r02_gemm_v5_sweep.txt), not a product path
-  if (g_v5) {
-    launch_gemm_cdna4_v5(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, g_v5 == 3 ? 8 : (g_v5 == 4 ? 17 : 16));
-    return;
-  }
-#endif
   if (g_v6 && m >= 256) {  // (szh: the caller's sz_half side buffer, reported exact for this layer -> the f16-mantissa dequant form)
     if (szh != nullptr && bits == 4 && g_v6_szh) launch_gemm_cdna4_v6(x, qw, szh, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, epi, 1);
     else launch_gemm_cdna4_v6(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, epi, 0, tile_n);
     return;
   }
-  launch_gemm_cdna4_v4(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, epi);
+  // knob gemm_v6 = 0 (tests: the second implementation v6 is held against): the same columns on awq_gemm_v4n.hip's 256 x 128 tiles -- the same
+  // products in the same K order.  (Round 2's 256 x 256 tile of that loop, awq_gemm_v4.hip, was removed in round 4.)
+  launch_gemm_cdna4_v4n(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, nullptr, 0, st, bits, epi);
 }
 // knob gemm_v6_128 (default 1, round 3): the 128-wide tiles of m >= 256 that awq_gemm_v4n.hip would run UNSPLIT go to awq_gemm_v6.hip with
 // two slabs per wave (256 x 128 blocks on the one-wave-per-SIMD loop: +4.3 ... +6.8 % on the M = 2048 prefill pass, o_proj / down_proj /
@@ -61,11 +55,11 @@ void launch_narrow(const void* x, const void* qw, const void* szp, const void* b
 }  // namespace
 
 namespace {
-int g_moe_v4 = 1;  // grouped prefill GEMM on 256 x 256 tiles (awq_gemm_v4.hip); 0: the 128 x 128 grouped kernel
+int g_moe_v4 = 1;  // knob moe_v4: 0 = every grouped batch above 8 rows on the 128 x 128 grouped kernel (tests: the second implementation of the grouped skinny / v6 kernels)
 }
 bool moe_v4_enabled() { return g_moe_v4 != 0; }
 namespace {
-int g_moe_v6 = 1;  // grouped prefill GEMM on the v6 tile (awq_gemm_v6.hip); 0: the v4 loop above
+int g_moe_v6 = 1;  // grouped prefill GEMM (>= 256 sorted rows) on the v6 tile (awq_gemm_v6.hip); 0: the 128 x 128 grouped kernel
 }
 bool moe_v6_enabled() { return g_moe_v6 != 0; }
 
@@ -76,12 +70,6 @@ int gemm_v3_tune_set(const char* key, int value) {
     g_v6 = value % 10;
     gemm_v6_set_probe(value / 10);
   }
-#ifdef AWQ_ENABLE_PROBES
-  else if (!strcmp(key, "gemm_v5")) g_v5 = value;
-#endif
-#ifdef AWQ_ENABLE_PROBES
-  else if (!strcmp(key, "gemm_v4_probe")) gemm_v4_set_probe(value);
-#endif
   else if (!strcmp(key, "gemm_tile_n")) g_tile_n = value;
   else if (!strcmp(key, "gemm_v6_szh")) g_v6_szh = value;
   else if (!strcmp(key, "gemm_v6_192")) g_v6_192 = value;
@@ -184,7 +172,7 @@ int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, const v
   if (!szp || !(gemm_cdna4_v3_takes(m, k) || ((bits == 3 || epi) && m > 8)) || (n % 16) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return -1;
   const bool allow192 = g_v6 != 0 && g_v6_192 != 0 && bits == 4 && m >= TM;
   Plan p = m < TM ? Plan{1, 0} : plan_tiles(m, n, tile_n ? tile_n : g_tile_n, allow192);  // m < 256: only the narrow-tile kernel masks rows
-  if (g_v5 >= 2 || g_v6 >= 2) p = Plan{0, 0};                            // experiments: every tile through awq_gemm_v5.hip (it masks rows itself)
+  if (g_v6 >= 2) p = Plan{0, 0};  // experiments: every tile 256-wide
   if (p.mode == 3) {
     launch_wide(x, qw, szp, bias, out, m, n, k, 0, n, dtype, st, bits, epi, nullptr, 192);
   } else if (p.mode == 2) {

@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256) void gemm_cdna4_v6_kernel(const uint16_t* __re
                                                             uint16_t* __restrict__ out, int M, int N, int K, int tiles_m, int tiles_n,
                                                             int n_begin, int n_end, int epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // XCD-aware, two-row-band tile order (as awq_gemm_v4.hip)
+  // XCD-aware, two-row-band tile order (as awq_gemm_v4n.hip)
   const int T = tiles_m * tiles_n;
   int tile;
   {

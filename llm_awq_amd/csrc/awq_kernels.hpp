@@ -86,8 +86,7 @@ int launch_moe_gemm(const void* x, const void* qw, const void* s, const void* z,
                     int experts, int n, int k, int gpad, int dtype, int layout, hipStream_t st);
 int gemv_tune_set(const char* key, int value);
 int gemm_tune_set(const char* key, int value);
-int gemm_v3_tune_set(const char* key, int value);  // gemm_v4, gemm_v4_probe
-void gemm_v4_set_probe(int v);
+int gemm_v3_tune_set(const char* key, int value);  // tile-plan / dispatch knobs (awq_gemm_plan.hip)
 // 256 x 128 tiles with the same hand-scheduled K loop (awq_gemm_v4n.hip)
 void launch_gemm_cdna4_v4n(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                            int n_begin, int n_end, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits = 4, int epi = 0);
@@ -99,10 +98,7 @@ int gemm_cdna4_v3_plan(int m, int n, int bits, int* mode, int* cols_main);
 int gemm_cdna4_v3_narrow_kernel(int m, int n_cols, int k, int bits, int has_workspace, int epi);  // 1 v6 (NS = 2), 0 v4n unsplit, >= 2 v4n split-K ranges
 int gemv_dma_plan(int m, int n, int k, int epi, int* kernel);  // weight passes of the decode entry (0: not served); *kernel 0 streaming, 1 skinny
 size_t gemm_cdna4_v3_workspace_bytes_w3(int m, int n, int k);  // same rule for w3c tiles (every m > 8 takes the tile kernels)
-// grouped (MoE) GEMM with the same K loop: sorted rows, device expert offsets, stacked cdna4 weights + packed scales; total >= 256
-int launch_moe_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total, int experts,
-                             int n, int k, int dtype, hipStream_t st);
-bool moe_v4_enabled();
+bool moe_v4_enabled();  // knob moe_v4 (default on): the grouped skinny / tile kernels; 0 = the 128 x 128 grouped kernel for every batch above 8 rows
 // the same grouped GEMM on the v6 tile (awq_gemm_v6.hip: one pipelined wave per SIMD, weights in registers); total >= 256
 // epi 2: per-expert w1 / w3 pair interleaved 8 + 8 per slab (n = 2 x ffn), out [total, n / 2] = silu(w1 x) * (w3 x) fused into the tile epilogue
 int launch_moe_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total, int experts,
@@ -111,10 +107,6 @@ int launch_moe_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, con
 int launch_silu_mul_interleaved(const void* in, void* out, int m, int n2, int dtype, hipStream_t st);
 int launch_silu_mul(const void* gate, const void* up, void* out, size_t count, int dtype, hipStream_t st);  // out = T(T(silu(gate)) * up), count % 8 == 0
 bool moe_v6_enabled();  // knob moe_v6 (default on)
-// 256 x 256-tile prefill GEMM with the hand-scheduled K loop (awq_gemm_v4.hip): weight rows [n_begin, n_end), m >= 256
-void launch_gemm_cdna4_v4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                          int n_begin, int n_end, int dtype, hipStream_t st, int bits = 4, int epi = 0);
-// 256 x 256 blocks, weights streamed straight into registers per wave (awq_gemm_v5.hip); any m >= 1
 // awq_gemm_v6.hip: 256 x 256 blocks of four software-pipelined waves (256 x 64 per wave, weights in registers, x through ds_write)
 void launch_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
                           int n_end, int dtype, hipStream_t st, int bits = 4, int epi = 0, int szfmt = 0, int tile_n = 256);
@@ -122,8 +114,6 @@ void gemm_v6_set_probe(int v);
 // awq_gemv_dma.hip: QuantLlamaMLP.forward at decode (gate/up + SiLU * mul + down) in one launch; -1 if the shape is not served
 int launch_mlp_decode(const void* x, const void* qw_gu, const void* szh_gu, const void* qw_d, const void* szh_d, const void* bias_d,
                       void* h, void* out, int m, int hidden, int ffn, int n_out, int dtype, int* ctr, hipStream_t st);
-void launch_gemm_cdna4_v5(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
-                          int n_end, int dtype, hipStream_t st, int bits = 4, int mf = 16);
 int launch_bias_add(void* out, const void* bias, int m, int n, int dtype, hipStream_t st);
 // out[m, n] = T(in_f32) (+ bias in T); n % 8 == 0 (awq_util.hip)
 int launch_round_bias_f32(const void* in_f32, const void* bias, void* out, int m, int n, int dtype, hipStream_t st);

@@ -1,5 +1,5 @@
 // Skinny GEMM on cdna4-interleaved weights, 9 <= M <= 64 per pass, bf16 and fp16 (gfx950): short prompts / chunk prefill / batched decode --
-// the M range between the decode GEMV (awq_gemv_cdna4.hip) and the tiled prefill GEMM (awq_gemm_v3.hip), which the
+// the M range between the decode GEMV (awq_gemv_cdna4.hip) and the tiled prefill GEMM (awq_gemm_plan.hip), which the
 // reference serves with gemm_w4a16_T1's 16/32-row tiles + split-K (gemm_cuda.cu:1155-1193).
 //
 // Still weight-stream bound (every packed byte is read once), but the activations are no longer negligible: a block

@@ -144,7 +144,7 @@ class SparseMoeMLP(nn.Module):
         probs = torch.softmax(router_logits.float(), dim=-1)
         w, ids = torch.topk(probs, self.top_k, dim=-1)
         w = (w / w.sum(-1, keepdim=True)).to(x.dtype)
-        order, offsets = sort_by_expert(ids, self.w1.num_experts)
+        order, offsets = sort_by_expert(ids, self.w2.num_experts)
         xs = x[order // self.top_k]
         h = self._h(xs, offsets)
         ys = self.w2(h, offsets)

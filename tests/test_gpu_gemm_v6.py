@@ -2,8 +2,9 @@
 weights dequantised into registers, x staged through ds_write).  Knob gemm_variant=4 forces 256-wide tiles for every shape, so
 ragged column tiles (N % 256 != 0), the shifted last row tile (M % 256 != 0), bias, both dtypes, the W3 tiles and the SiLU * mul
 epilogue all run through it; the checker is the oracle (tests/helpers.check_forward) and, for sizes the oracle does not take,
-awq_gemm_v4.hip (same products, fp32 accumulation in the same K order; the two differ only in the association inside one 32-k
-MFMA: 16x16x32 against two 32x32x16)."""
+awq_gemm_v4n.hip's 256 x 128 tiles (knob gemm_v6 = 0: same products, fp32 accumulation in the same K order; the two differ only in the
+association inside one 32-k MFMA: 16x16x32 against two 32x32x16).  (Round 2's 256 x 256 tile of that loop, awq_gemm_v4.hip, was the second
+implementation here until round 4 removed it from the library.)"""
 import pytest
 import torch
 
@@ -49,7 +50,7 @@ def test_v6_against_the_oracle(ops, dtype, bias, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_v6_full_shapes_against_v4(ops, dtype):
+def test_v6_full_shapes_against_v4n(ops, dtype):
     from llm_awq_amd import synth
     for (K, N) in ((4096, 6144), (14336, 4096)):
         w = synth.random_wq(K, N, dtype=dtype, seed=K + N, keep_q=False)

@@ -77,7 +77,7 @@ def test_gemv_vs_oracle(ops, dtype, M, N, K):
 @pytest.mark.parametrize("M", [1, 4, 5, 8])
 @pytest.mark.parametrize("N,K", [(768, 768), (1024, 4096), (512, 14336)])
 def test_gemv_reference_layout_kernels_agree(ops, dtype, M, N, K):
-    """The pipelined reference-layout decode kernel (awq_gemv_v2fast.hip, default for M <= 8, N % 16 == 0) and the older
+    """The pipelined reference-layout decode kernel (awq_v2_kernels.hip part 1, default for M <= 8, N % 16 == 0) and the older
     kernel of awq_gemv.hip (knob gemv_v2fast=0) both meet the oracle; they differ only in fp32 summation order."""
     c = make_case(N, K, dtype, seed=M + N + K, M=M)
     args = (c["x"].cuda(), c["qweight"].cuda(), c["scales"].cuda(), c["scaled_zeros"].cuda())

@@ -140,11 +140,10 @@ def test_gpu_grouped_decode_and_module(counts):
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("counts", [[300, 0, 1, 255], [256, 256], [1, 700, 3, 40], [0, 0, 0, 256], [511, 2, 257, 0, 90]])
-def test_gpu_grouped_prefill_v6_v4_and_128(counts, dtype):
-    """>= 256 sorted rows: the grouped kernel on the v6 tile (default; awq_gemm_v6.hip) and on the v4 loop (knob moe_v6=0;
-    awq_gemm_v4.hip) -- tiles straddling expert boundaries, the shifted last tile, empty experts, segments shorter than a tile --
-    against the per-expert oracle; the v4 loop is bit-identical to the 128 x 128 grouped kernel (knobs moe_v6=0, moe_v4=0), the v6
-    tile agrees with both up to the association inside one 32-k MFMA."""
+def test_gpu_grouped_prefill_v6_and_128(counts, dtype):
+    """>= 256 sorted rows: the grouped kernel on the v6 tile (default; awq_gemm_v6.hip) -- tiles straddling expert boundaries, the shifted
+    last tile, empty experts, segments shorter than a tile -- against the per-expert oracle and against the 128 x 128 grouped kernel (knob
+    moe_v6=0), with which it agrees up to the association inside one 32-k MFMA."""
     from llm_awq_amd import ops
     E, N, K = len(counts), 400, 512
     mods, cases = _experts(E, N, K, dtype, seed=sum(counts) + 11)
@@ -156,18 +155,12 @@ def test_gpu_grouped_prefill_v6_v4_and_128(counts, dtype):
     y6 = grp(x, off)
     try:
         ops._capi.tune(moe_v6=0)
-        y4 = grp(x, off)
-        ops._capi.tune(moe_v4=0)
         y_ref = grp(x, off)
     finally:
-        ops._capi.tune(moe_v4=1, moe_v6=1)
-    if dtype == torch.bfloat16:
-        assert torch.equal(y4, y_ref)
-    else:
-        assert_bits(y4, y_ref, 0.01)
-    assert_bits(y6, y4, 0.01, what="v6 tile vs v4 loop")
+        ops._capi.tune(moe_v6=1)
+    assert_bits(y6, y_ref, 0.01, what="v6 tile vs 128 x 128 grouped kernel")
     x = x.cpu()
-    for y in (y6.cpu(), y4.cpu()):
+    for y in (y6.cpu(), y_ref.cpu()):
         for e in range(E):
             lo, hi = int(off[e]), int(off[e + 1])
             if hi > lo:
