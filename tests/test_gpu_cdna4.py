@@ -65,7 +65,7 @@ def test_matrix_core_dequant_adversarial_scales(ops, dtype, emin, emax):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 7, 8, 13, 16])
+@pytest.mark.parametrize("M", [1, 2, 4, 5, 8, 13, 16])
 @pytest.mark.parametrize("N,K", [(768, 768), (3072, 768), (768, 3072), (256, 4096), (1040, 1280), (64, 11008)])
 def test_gemv_cdna4_vs_oracle(ops, dtype, M, N, K):
     c = make_case(N, K, dtype, seed=M * 131 + N + K, M=M)
@@ -111,8 +111,7 @@ def test_gemv_knobs_do_not_change_results(ops, knobs):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("variant", [0, 1, 2])
-@pytest.mark.parametrize("M", [17, 64, 128, 200, 512, 777])
+@pytest.mark.parametrize("variant,M", [(0, m) for m in (17, 64, 128, 200, 512, 777)] + [(v, m) for v in (1, 2) for m in (17, 128, 777)])
 @pytest.mark.parametrize("N,K", [(768, 768), (3072, 768), (768, 3072), (144, 1280)])
 def test_gemm_cdna4_vs_oracle(ops, dtype, variant, M, N, K):
     c = make_case(N, K, dtype, seed=M * 17 + N + K, M=M, bias=(M == 64))
@@ -169,7 +168,7 @@ def test_fused_gate_up_silu_mul(ops, dtype, M, F, K):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("M", [9, 16, 17, 31, 32, 33, 48, 49, 63, 64, 65, 100, 129, 200, 255])
+@pytest.mark.parametrize("M", [9, 16, 17, 32, 33, 48, 49, 64, 65, 129, 200, 255])
 @pytest.mark.parametrize("N,K", [(768, 768), (1040, 1280), (64, 11008), (8192, 512), (16400, 256)])
 def test_skinny_gemm_vs_oracle(ops, dtype, M, N, K):
     """9 <= M <= 255 (short prompts / batched decode; above 64 rows in chunks): the skinny kernel, every column-block count, slab counts that do not

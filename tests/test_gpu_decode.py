@@ -113,7 +113,7 @@ def test_inexact_scales_are_flagged(ops):
 def test_batched_decode_on_the_skinny_kernel(ops, dtype, N, K):
     """the decode entry with its rows handed to the skinny kernel (x through registers, shared by a block's slabs; knob
     decode_skinny_from): every row count, bias, both side-buffer forms, narrow and wide (two slabs per block, ragged last block)"""
-    c = make_case(N, K, dtype, seed=N + K + 3, M=8, bias=True)
+    c = make_case(N, K, dtype, seed=N + K + 2, M=8, bias=True)  # (the parity of N + K: shares the full-size oracle case of the test above)
     c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
     szh, exact = ops.pack_szh_cdna4(c["scales"].cuda(), c["scaled_zeros"].cuda(), K)
     assert exact

@@ -65,7 +65,7 @@ def test_dequant_adversarial_scales(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 6, 7, 8, 13, 16])
+@pytest.mark.parametrize("M", [1, 2, 4, 5, 7, 8, 13, 16])
 @pytest.mark.parametrize("N,K", [(768, 768), (3072, 768), (768, 3072), (256, 4096), (1032, 1280)])
 def test_gemv_vs_oracle(ops, dtype, M, N, K):
     c = make_case(N, K, dtype, seed=M * 131 + N + K, M=M)
@@ -96,7 +96,7 @@ def test_gemv_reference_layout_kernels_agree(ops, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M", [9, 16, 17, 33, 48, 64, 65, 130, 255])
+@pytest.mark.parametrize("M", [9, 17, 33, 48, 64, 65, 255])
 @pytest.mark.parametrize("N,K", [(768, 768), (1040, 1280), (64, 11008), (8192, 512)])
 def test_skinny_reference_layout_vs_oracle(ops, dtype, M, N, K):
     """9 <= M <= 255 on un-repacked buffers (fp16 and bf16): the v2-layout skinny kernel behind gemm_forward_cuda_new / forward,
@@ -111,8 +111,8 @@ def test_skinny_reference_layout_vs_oracle(ops, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("variant", [0, 1, 2])  # auto / force 128x128 / force 256x256
-@pytest.mark.parametrize("M", [8, 17, 64, 100, 128, 129, 200, 512, 777])
+@pytest.mark.parametrize("variant,M", [(0, m) for m in (8, 17, 64, 100, 128, 129, 200, 512, 777)] +   # auto: every row count
+                         [(v, m) for v in (1, 2) for m in (17, 128, 129, 777)])                       # forced 128x128 / 256x256 tiles
 @pytest.mark.parametrize("N,K", [(768, 768), (3072, 768), (768, 3072), (136, 1280)])
 def test_gemm_vs_oracle(ops, dtype, variant, M, N, K):
     c = make_case(N, K, dtype, seed=M * 17 + N + K, M=M)
