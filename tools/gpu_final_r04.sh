@@ -10,9 +10,9 @@ export TMPDIR=/tmp
 tail -1 $O/smoke.log
 ( timeout 300 python bench.py 2>$O/bench.err | tail -1 ) > $O/bench.json
 cut -c1-600 $O/bench.json
-( RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 AWQ_BENCH_FORCE_TP=1 AWQ_BENCH_TP70B_LAYERS=2 timeout 200 python bench.py --steps 5 --warmup 2 --layers 8 2>&1 | tail -1 ) > $O/bench_tp_world1.json
+( RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 AWQ_BENCH_FORCE_TP=1 AWQ_BENCH_TP70B_LAYERS=2 timeout 200 python bench.py --steps 5 --warmup 2 --layers 8 2>$O/bench_tp_world1.err | grep '"metric"' | tail -1 ) > $O/bench_tp_world1.json
 cut -c1-400 $O/bench_tp_world1.json
-( RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29534 AWQ_BENCH_FORCE_TP=1 AWQ_BENCH_SHARD_WORLD=8 AWQ_BENCH_TP70B_LAYERS=4 timeout 200 python bench.py --steps 5 --warmup 2 --layers 8 2>&1 | tail -1 ) > $O/bench_tp_shard8.json
+( RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29534 AWQ_BENCH_FORCE_TP=1 AWQ_BENCH_SHARD_WORLD=8 AWQ_BENCH_TP70B_LAYERS=4 timeout 200 python bench.py --steps 5 --warmup 2 --layers 8 2>$O/bench_tp_shard8.err | grep '"metric"' | tail -1 ) > $O/bench_tp_shard8.json
 cut -c1-300 $O/bench_tp_shard8.json
 ( timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_bench -o bench -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-dropin --no-batched-decode --no-graph --prefill-iters 1 2>&1 | tail -3 ) > $O/rocprof_bench.log
 python tools/rocpd_stats.py $O/prof_bench/bench_results.db $O/bench_kernel_stats.csv > $O/bench_kernel_stats.txt
