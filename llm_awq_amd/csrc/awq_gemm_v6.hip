@@ -488,24 +488,34 @@ __global__ __launch_bounds__(256) void moe_gemm_cdna4_v6_kernel(const uint16_t* 
                                                                 uint16_t* __restrict__ out, int total, int experts, int N, int K,
                                                                 int row_tiles, int tiles_n, int epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int T = row_tiles * tiles_n;
+  // Tile walk (round 4).  The launch is sized for the host's upper bound (total / 256 + experts row tiles); the REAL count depends on the device-side
+  // offsets, so every block first adds it up (experts + 1 scalar loads) and the eight XCDs split the real tiles into eight contiguous chunks -- the
+  // phantom blocks end up as the tail of EVERY chunk instead of being one XCD's whole share (with 21 real row tiles of a bound of 24 the old walk
+  // left XCD 7 idle).  Inside a chunk the order is expert-major, then column tile, then the expert's row tiles: the two or three row tiles of an
+  // expert that share a weight column tile run back to back on one XCD (the dense kernel's two-row band), so only the first of them misses its L2.
+  int R = 0;
+  for (int e2 = 0; e2 < experts; ++e2) R += (offsets[e2 + 1] - offsets[e2] + V6_TM - 1) / V6_TM;
+  const int T = R * tiles_n;
   int tile;
   {
     const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
     const int q = T >> 3, r = T & 7;
+    if (idx >= q + (xcd < r ? 1 : 0)) return;  // wave-uniform: a phantom block of this XCD's chunk
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  int rt = tile / tiles_n;
-  const int tn = tile - rt * tiles_n;
-  int e = 0, lo = 0, hi = 0;
+  int e = 0, lo = 0, hi = 0, rt = 0, tn = 0;
   for (; e < experts; ++e) {
     lo = offsets[e];
     hi = offsets[e + 1];
     const int cnt = (hi - lo + V6_TM - 1) / V6_TM;
-    if (rt < cnt) break;
-    rt -= cnt;
+    if (tile < cnt * tiles_n) {
+      tn = tile / cnt;  // (row-tile major inside the expert measured equal on the plain launch and 5 % slower on the fused w1 / w3 one: profiles/r04_moe_sweep.txt)
+      rt = tile - tn * cnt;
+      break;
+    }
+    tile -= cnt * tiles_n;
   }
-  if (e == experts) return;  // wave-uniform: no tile for this block
+  if (e == experts) return;  // (cannot happen: tile < T)
   const int r_lo = lo + rt * V6_TM, r_hi = min(r_lo + V6_TM, hi);
   const size_t ew = (size_t)(N >> 4) * (K >> 7);  // tiles per expert
   // epi 2: every expert's rows are its w1 / w3 pair interleaved 8 + 8 per 16-row slab (N = 2 x ffn): out [total, N / 2] = silu(w1 x) * (w3 x)

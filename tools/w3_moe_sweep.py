@@ -77,15 +77,16 @@ def main():
             zs.append(z)
             del q
         qw, s, z = torch.stack(qws), torch.stack(ss), torch.stack(zs)
-        ids = torch.stack([torch.randperm(E, device="cuda")[:2] for _ in range(T)])
+        gen = torch.Generator(device="cuda").manual_seed(1234)  # (the same routing in every run: rows per expert are printed below)
+        ids = torch.stack([torch.randperm(E, device="cuda", generator=gen)[:2] for _ in range(T)])
         order, off = sort_by_expert(ids, E)
+        cnts = (off[1:] - off[:-1]).tolist()
+        print(f"# rows per expert {cnts}: 256-row tiles {sum((c + 255) // 256 for c in cnts)} (ideal {2 * T / 256:.0f})")
         xs = torch.randn(2 * T, K, device="cuda").to(dt)
         szp = torch.stack([ops.pack_sz_cdna4(ss[e], zs[e], K) for e in range(E)])
-        for label, knob, fn in (("128x128 grouped kernel", None, lambda _c: ops.moe_gemm(xs, qw, s, z, off, layout="cdna4")),
-                                ("256x256 grouped v4    ", 0, lambda _c: ops.moe_forward_cdna4(xs, qw, s, z, szp, off)),
+        for label, knob, fn in (("128x128 grouped kernel", 0, lambda _c: ops.moe_forward_cdna4(xs, qw, s, z, szp, off)),
                                 ("256x256 grouped v6    ", 1, lambda _c: ops.moe_forward_cdna4(xs, qw, s, z, szp, off))):
-            if knob is not None:
-                _capi.tune(moe_v6=knob)
+            _capi.tune(moe_v6=knob)
             us = graph_time(fn, [0, 1, 2, 3])
             _capi.tune(moe_v6=1)
             tf = 2.0 * 2 * T * N * K / us / 1e6
