@@ -115,8 +115,8 @@ bool cache_enabled() {
 // call would take the permuted bytes for v2 data and permute them again
 void restore_inplace(CacheEntry& e) {
   if (!e.inplace || !e.c4.defined()) return;
-  auto lw = e.w.lock();
-  if (!lw) return;
+  // (not tied to the tensor the entry last followed: that may have been a temporary alias -- `.detach()`, a view -- that is gone, while the
+  // module's own tensor over the same storage is alive; e.c4 holds the storage)
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(e.c4.device());
   hipStream_t st = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
   if (e.built && st != e.build_stream) (void)hipStreamWaitEvent(st, e.built, 0);
@@ -193,6 +193,9 @@ bool cdna4_view(const torch::Tensor& kernel, const torch::Tensor& scales, const 
       auto cur = i2++;
       auto lw = cur->second.w.lock();
       // (the key is the tensor's data pointer INCLUDING its storage offset: sharded / flattened parameter buffers are views)
+      // an in-place entry lives as long as anybody else holds the converted storage: the tensor it last followed may have been a temporary
+      // alias, and forgetting the entry while the module's own tensor is alive would have the next call permute the bytes a second time
+      if (cur->second.inplace && cur->second.c4.defined() && (cur->second.c4.use_count() > 1 || cur->second.c4.storage().use_count() > 1)) continue;  // (c4 IS the caller's tensor: its own handle counts once)
       if (!lw || lw->data() != cur->first) drop_entry(cur);
     }
     const int64_t need = (int64_t)kernel.nbytes();

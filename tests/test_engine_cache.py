@@ -171,3 +171,51 @@ def test_in_place_conversion_keeps_no_second_copy_and_can_be_undone(eng):
     finally:
         eng.cdna4_cache_enable(True)
         eng.cdna4_cache_inplace(False)
+
+
+def test_in_place_entry_follows_aliases_and_refuses_what_it_cannot_serve(eng):
+    """with the in-place mode on, ANOTHER tensor over the converted bytes (`.detach()`, `.data`, a view of the whole buffer) must
+    hit the same entry -- not be taken for v2 data and permuted a second time -- `cdna4_is_converted` / `WQLinear.engine_converted()` report
+    the state to format tools (which raise), a call the cdna4 kernels cannot serve (fp32 scales) raises instead of running the v2 kernels
+    on permuted bytes, and the restore puts the reference interleave back whatever alias it is called through."""
+    import numpy as np
+    from oracle import awq_oracle as O
+    from llm_awq_amd.parallel import TPWQLinear
+    from llm_awq_amd.qmodule import WQLinear
+    N, K = 256, 1280
+    c = make_case(N, K, torch.bfloat16, seed=31, M=8)
+    try:
+        eng.cdna4_cache_inplace(True)
+        qw, s, z = _dev(c)
+        x = c["x"][:4].contiguous().cuda()
+        assert eng.cdna4_is_converted(qw) is False
+        builds0 = eng.cdna4_cache_info()["builds"]
+        y0 = eng.gemv_forward_cuda_new(x, qw, s, z, 4, N, K, 128)
+        assert eng.cdna4_is_converted(qw) is True
+        c4 = O.pack_cdna4(c["q"])
+        for alias in (qw.detach(), qw.data, qw.view(N // 4, K), qw[:]):
+            y = eng.gemv_forward_cuda_new(x, alias, s, z, 4, N, K, 128)
+            assert torch.equal(y, y0)
+            assert np.array_equal(qw.cpu().numpy(), c4), "permuted exactly once"
+            assert eng.cdna4_is_converted(alias) is True
+        check_forward(y0.cpu(), c["x"][:4], c["q"], c["scales"], c["scaled_zeros"], torch.bfloat16)
+        assert eng.cdna4_cache_info()["builds"] == builds0 + 1
+        # a module over these buffers: the format tools refuse them while they are converted
+        lin = WQLinear(4, 128, K, N, False, "cuda", dtype=torch.bfloat16)
+        lin.qweight, lin.scales, lin.scaled_zeros = qw, s, z
+        assert lin.engine_converted()
+        with pytest.raises(RuntimeError, match="cdna4_restore"):
+            lin.to_cdna4()
+        with pytest.raises(RuntimeError, match="cdna4_restore"):
+            TPWQLinear(lin, "row", world=2, rank=0)
+        # fp32 scales cannot run on the cdna4 kernels: an error, not the v2 kernels on permuted bytes
+        with pytest.raises(RuntimeError, match="cdna4_restore"):
+            eng.gemm_forward_cuda_new(x.float().repeat(3, 1), qw, s.float(), z.float())
+        # restore through an alias
+        assert eng.cdna4_restore(qw.detach()) is True
+        assert torch.equal(qw.cpu(), c["qweight"]) and not lin.engine_converted()
+        lin.to_cdna4()
+        check_forward(lin(x).cpu(), c["x"][:4], c["q"], c["scales"], c["scaled_zeros"], torch.bfloat16)
+    finally:
+        eng.cdna4_cache_enable(True)
+        eng.cdna4_cache_inplace(False)
