@@ -28,7 +28,24 @@ def sort_by_expert(topk_ids: torch.Tensor, num_experts: int):
     return order, offsets
 
 
-class GroupedWQLinear(nn.Module):
+class _LayoutMarker:
+    """state_dict contract of the stacked modules: `qweight` holds the reference (v2) interleave unless the dict carries `qweight_layout` = 1
+    (the cdna4 interleave, as WQLinear's native checkpoints do) -- a module that was converted on its first GPU forward saves the marker, and a
+    fresh module that loads such a dict takes the layout over instead of permuting the bytes a second time."""
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        if self.layout == "cdna4":
+            destination[prefix + "qweight_layout"] = torch.tensor(1, dtype=torch.uint8)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        marker = state_dict.pop(prefix + "qweight_layout", None)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+        self.layout = "cdna4" if (marker is not None and int(marker) == 1) else "v2"
+        self.sz_cdna4 = None  # rebuilt from the loaded scales at the next forward
+
+
+class GroupedWQLinear(_LayoutMarker, nn.Module):
     """E stacked WQLinear experts with one grouped launch.  `matmul(x_sorted, qweight, scales, scaled_zeros, offsets)`
     defaults to the HIP engine; CPU tests inject the oracle."""
 
@@ -68,7 +85,7 @@ class GroupedWQLinear(nn.Module):
         return eng.moe_gemm_forward(x_sorted.contiguous(), self.qweight, self.scales, self.scaled_zeros, expert_offsets, False)
 
 
-class GroupedGateUp(nn.Module):
+class GroupedGateUp(_LayoutMarker, nn.Module):
     """The expert MLP's first half as ONE grouped launch: every expert's w1 (gate) and w3 (up) WQLinear stacked with their rows interleaved
     8 + 8 per 16-row slab -- the layout `llm_awq_amd.fused_mlp.QuantLlamaMLP` gives the dense pair (tinychat/modules/fused_mlp.py:36-83) --
     so that `silu(w1 x) * (w3 x)` is the epilogue of the grouped tile (`awq_w4a16_moe_mlp_gate_up_cdna4`): the [T, 2F] intermediate is never
@@ -107,11 +124,11 @@ class GroupedGateUp(nn.Module):
     @torch.no_grad()
     def forward(self, x_sorted: torch.Tensor, expert_offsets: torch.Tensor) -> torch.Tensor:
         from . import ops
-        if self.layout != "cdna4" or self.sz_cdna4 is None or self.sz_cdna4.device != self.qweight.device:
-            if self.layout == "cdna4":
-                self.layout = "v2"
-                self.qweight = torch.stack([ops.repack_cdna4_to_v2(self.qweight[e].contiguous()) for e in range(self.num_experts)])
+        if self.layout != "cdna4":
             self._to_cdna4()
+        elif self.sz_cdna4 is None or self.sz_cdna4.device != self.qweight.device:  # (a loaded cdna4 checkpoint, or the module moved: only the side buffer)
+            self.sz_cdna4 = torch.stack([ops.pack_sz_cdna4(self.scales[e].contiguous(), self.scaled_zeros[e].contiguous(), self.in_features)
+                                         for e in range(self.num_experts)])
         return ops.moe_mlp_gate_up_cdna4(x_sorted.contiguous(), self.qweight, self.scales, self.scaled_zeros, self.sz_cdna4, expert_offsets)
 
 

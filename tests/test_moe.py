@@ -287,3 +287,23 @@ def test_gpu_sparse_moe_block_fused_equals_unfused():
     y_f, y_p = fused(x, logits), plain(x, logits)
     assert y_f.shape == (T, H)
     assert ((y_f.float() - y_p.float()).norm() / y_p.float().norm()).item() < 2e-3
+
+
+def test_stacked_modules_mark_their_layout_in_the_state_dict():
+    """a stacked module that holds the cdna4 interleave says so in its state_dict (`qweight_layout`, as WQLinear's native checkpoints do); a fresh
+    module that loads it takes the layout over, a v2 dict resets it"""
+    dtype, E, F, K = torch.bfloat16, 2, 64, 128
+    m1, _ = _experts(E, F, K, dtype, 5)
+    m3, _ = _experts(E, F, K, dtype, 6)
+    for make in (lambda: MOE.GroupedWQLinear(m1), lambda: MOE.GroupedGateUp(m1, m3)):
+        a, b = make(), make()
+        sd = a.state_dict()
+        assert "qweight_layout" not in sd and set(sd) == {"qweight", "scales", "scaled_zeros"}
+        a.layout = "cdna4"  # (what the first GPU forward / to_cdna4 leaves behind)
+        sd = a.state_dict()
+        assert int(sd["qweight_layout"]) == 1
+        b.load_state_dict(sd)
+        assert b.layout == "cdna4" and b.sz_cdna4 is None
+        sd.pop("qweight_layout")
+        b.load_state_dict(sd)
+        assert b.layout == "v2"
