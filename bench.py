@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--tune", action="append", default=[], help="experiments only: awq_tune_set knobs as key=value")
     ap.add_argument("--layout", default="cdna4", choices=["cdna4", "v2"], help="cdna4 = what the rewritten repacker emits (default); v2 = reference checkpoint layout through gemv/gemm_forward_cuda_new only")
     ap.add_argument("--mlp-decode", default="two", choices=["one", "two"],
-                    help="decode, --mlp interleaved: QuantLlamaMLP.forward as the fused gate/up launch followed by down_proj's (default: faster), or as ONE launch (awq_w4a16_mlp_decode_cdna4; measured slower: profiles/r02_mlp_one_launch.txt)")
+                    help="decode, --mlp interleaved: QuantLlamaMLP.forward as the fused gate/up launch followed by down_proj's (default: faster), or as ONE launch (awq_w4a16_mlp_decode_cdna4, granule hand-over of h; measured slower: profiles/r04_mlp_one_launch.txt)")
     ap.add_argument("--overlap-probe", type=int, default=0, help="experiments (NOT a valid decode figure): issue the decode launches round-robin on this many streams inside the graph, i.e. drop the dependency between consecutive linears -- the upper bound of what cross-launch overlap could give")
     ap.add_argument("--repeat-layers", type=int, default=1, help="experiments: run the --layers layers this many times per step (with --layers 1/2 the weights stay in the 256 MB Infinity Cache)")
     ap.add_argument("--mlp", default="interleaved", choices=["interleaved", "stacked", "unfused"],
@@ -181,7 +181,8 @@ def main():
 
     probe_streams = [torch.cuda.Stream(device=dev) for _ in range(args.overlap_probe)] if args.overlap_probe > 1 else []
     one_launch_mlp = args.layout == "cdna4" and args.mlp == "interleaved" and args.mlp_decode == "one" and args.sz == "half"
-    mlp_ctr = torch.zeros(4096, dtype=torch.int32, device=dev)  # device counters of the one-launch MLP (zero between calls)
+    # state of the one-launch MLP (epoch + the granule array of h): launches on one stream are ordered, so the layers share it
+    mlp_state = torch.zeros((eng.mlp_decode_state_bytes(1, 14336) + 3) // 4, dtype=torch.int32, device=dev) if one_launch_mlp else None
 
     def run_native(xs):
         outs = []
@@ -198,9 +199,9 @@ def main():
             if skip:  # down_proj: done inside the one-launch MLP
                 skip = False
                 continue
-            if decode and one_launch_mlp and not probe_streams and epi == 2 and szh is not None and seq[li + 1][0] == "down" and seq[li + 1][7] is not None:
+            if one_launch_mlp and xs[K].numel() == K and not probe_streams and epi == 2 and szh is not None and seq[li + 1][0] == "down" and seq[li + 1][7] is not None:
                 dn = seq[li + 1]
-                outs.append(eng.mlp_decode_cdna4(xs[K], qw, szh, dn[3], dn[7], mlp_ctr, None))   # QuantLlamaMLP.forward, <= 8 rows
+                outs.append(eng.mlp_decode_cdna4(xs[K], qw, szh, dn[3], dn[7], mlp_state, None))   # QuantLlamaMLP.forward, one row
                 skip = True
                 continue
             if probe_streams and decode:

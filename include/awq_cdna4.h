@@ -129,16 +129,19 @@ int awq_w4a16_mlp_gate_up_cdna4(const void* x, const void* qweight_gate_up, cons
                                 int n2, int k, int group_size, int dtype, void* stream);
 
 /* QuantLlamaMLP.forward at decode (tinychat/modules/fused_mlp.py:33-83: two gemv_forward_cuda_new + F.silu + multiply, then
- * down_proj's gemv_forward_cuda_new) in ONE launch, m <= 8: the gate/up slabs (8 + 8 interleaved pair, n2 = 2 * ffn rows, K = hidden) store
- * h = T(T(silu(gate)) * up) to h_scratch [m, ffn]; down_proj's slabs (K = ffn, n_out rows) are dispatched behind them, stream their weights
- * while the gate/up tail drains, wait for a device-side count of finished gate/up blocks and then read h.  Both weights with their sz_half
- * side buffers (awq_pack_szh_cdna4 must have reported them exact).  counters: AWQ_MLP_DECODE_COUNTER_BYTES of device memory, zero before the
- * first call and left zero by every call (int32 [2] is a sticky error flag: a consumer gave up waiting).  AWQ_ERR_SHAPE for shapes it does not serve
- * (hidden < 4096, ffn < 2048, more than 160 KiB of staging): callers then issue the two launches separately. */
+ * down_proj's gemv_forward_cuda_new) in ONE launch, m = 1: the gate/up slabs (8 + 8 interleaved pair, n2 = 2 * ffn rows, K = hidden) publish
+ * h = T(T(silu(gate)) * up) as 8-byte {2 x T, tag} granules, one write-through store each; down_proj's slabs (K = ffn, n_out rows) are dispatched
+ * behind them, stream the head of their weights while the gate/up tail drains, and every wave gathers its own k range of h (a sentinel poll, then a sweep
+ * re-tried until every tag carries this launch's epoch) -- no flag, no counter, no fence on the path.  Both weights with their sz_half side buffers
+ * (awq_pack_szh_cdna4 must have reported them exact).  `state`: awq_w4a16_mlp_decode_cdna4_state_bytes(m, ffn) bytes of device memory, ZERO before the
+ * first call, owned by one (module, stream) at a time and never written by the caller afterwards (it carries the epoch between calls: replayed graphs
+ * work); int32 [2] of it is a sticky error flag (a consumer gave up waiting).  AWQ_ERR_SHAPE for shapes it does not serve (m != 1, hidden != 4096,
+ * ffn outside 4096 .. 16384): callers then issue the two launches separately. */
 #define AWQ_MLP_DECODE_COUNTER_BYTES 16384
+size_t awq_w4a16_mlp_decode_cdna4_state_bytes(int m, int ffn);
 int awq_w4a16_mlp_decode_cdna4(const void* x, const void* gate_up_qweight, const void* gate_up_sz_half, const void* down_qweight,
-                               const void* down_sz_half, const void* down_bias, void* h_scratch, void* out, int m, int hidden, int ffn,
-                               int n_out, int group_size, int dtype, void* counters, void* stream);
+                               const void* down_sz_half, const void* down_bias, void* out, int m, int hidden, int ffn, int n_out,
+                               int group_size, int dtype, void* state, void* stream);
 
 /* QuantLlamaMLP.our_llama_mlp for ANY row count (tinychat/modules/fused_mlp.py:36-83: decode = two gemv_forward_cuda_new + F.silu +
  * multiply, prefill = two gemm_forward_cuda_new + F.silu + multiply) on the pair as llm_awq_amd.fused_mlp stacks it: gate and up

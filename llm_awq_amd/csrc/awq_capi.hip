@@ -225,18 +225,20 @@ int awq_w4a16_mlp_gate_up_cdna4(const void* x, const void* qweight_gate_up, cons
   return finish_launch();
 }
 
+size_t awq_w4a16_mlp_decode_cdna4_state_bytes(int m, int ffn) { return m >= 1 && ffn >= 1 ? awq::mlp_decode_state_bytes(m, ffn) : 0; }
+
 int awq_w4a16_mlp_decode_cdna4(const void* x, const void* gate_up_qweight, const void* gate_up_sz_half, const void* down_qweight,
-                               const void* down_sz_half, const void* down_bias, void* h_scratch, void* out, int m, int hidden, int ffn,
-                               int n_out, int group_size, int dtype, void* counters, void* stream) {
-  if (!x || !gate_up_qweight || !gate_up_sz_half || !down_qweight || !down_sz_half || !h_scratch || !out || !counters) return AWQ_ERR_NULL;
+                               const void* down_sz_half, const void* down_bias, void* out, int m, int hidden, int ffn, int n_out, int group_size,
+                               int dtype, void* state, void* stream) {
+  if (!x || !gate_up_qweight || !gate_up_sz_half || !down_qweight || !down_sz_half || !out || !state) return AWQ_ERR_NULL;
   if (group_size != 128) return AWQ_ERR_GROUP;
   if (dtype != AWQ_F16 && dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
   if (m < 1 || m > 8) return AWQ_ERR_BATCH;
   if (!aligned16(x) || !aligned16(gate_up_qweight) || !aligned16(down_qweight) || !aligned16(gate_up_sz_half) || !aligned16(down_sz_half) ||
-      !aligned16(h_scratch) || !aligned16(out))
+      !aligned16(state) || !aligned16(out) || !aligned16(down_bias))
     return AWQ_ERR_ALIGN;
-  if (awq::launch_mlp_decode(x, gate_up_qweight, gate_up_sz_half, down_qweight, down_sz_half, down_bias, h_scratch, out, m, hidden, ffn, n_out,
-                             dtype, (int*)counters, (hipStream_t)stream) != 0)
+  if (awq::launch_mlp_decode(x, gate_up_qweight, gate_up_sz_half, down_qweight, down_sz_half, down_bias, out, m, hidden, ffn, n_out, dtype, (int*)state,
+                             (hipStream_t)stream) != 0)
     return AWQ_ERR_SHAPE;
   return finish_launch();
 }

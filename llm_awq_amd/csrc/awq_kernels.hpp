@@ -111,9 +111,10 @@ bool moe_v6_enabled();  // knob moe_v6 (default on)
 void launch_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
                           int n_end, int dtype, hipStream_t st, int bits = 4, int epi = 0, int szfmt = 0, int tile_n = 256);
 void gemm_v6_set_probe(int v);
-// awq_gemv_dma.hip: QuantLlamaMLP.forward at decode (gate/up + SiLU * mul + down) in one launch; -1 if the shape is not served
-int launch_mlp_decode(const void* x, const void* qw_gu, const void* szh_gu, const void* qw_d, const void* szh_d, const void* bias_d,
-                      void* h, void* out, int m, int hidden, int ffn, int n_out, int dtype, int* ctr, hipStream_t st);
+// awq_gemv_dma.hip: QuantLlamaMLP.forward at decode (gate/up + SiLU * mul + down) in one launch, m = 1; -1 if the shape is not served
+int launch_mlp_decode(const void* x, const void* qw_gu, const void* szh_gu, const void* qw_d, const void* szh_d, const void* bias_d, void* out, int m,
+                      int hidden, int ffn, int n_out, int dtype, int* state, hipStream_t st);
+size_t mlp_decode_state_bytes(int m, int ffn);
 int launch_bias_add(void* out, const void* bias, int m, int n, int dtype, hipStream_t st);
 // out[m, n] = T(in_f32) (+ bias in T); n % 8 == 0 (awq_util.hip)
 int launch_round_bias_f32(const void* in_f32, const void* bias, void* out, int m, int n, int dtype, hipStream_t st);

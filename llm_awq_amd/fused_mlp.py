@@ -9,10 +9,11 @@ The reference module keeps gate_proj / up_proj as raw v2 buffers, issues two `ge
     two streams (896: 3.5 per CU, so half the CUs carried 4 blocks and the rest 3);
   * decode (<= 8 rows): `decode_cdna4(..., epilogue=2)` -- gate, up, SiLU and the multiply in one launch, every intermediate
     rounded to T exactly like the reference's separate ops (fused_mlp.py:39-61, :79-82) -- then down_proj's launch.  With
-    AWQ_MLP_ONE_LAUNCH=1 the WHOLE module is one launch (`mlp_decode_cdna4`: down_proj's blocks sit behind the gate/up blocks in
-    the same grid, stream their first weight tiles while the gate/up tail drains and wait on a device-side count for h); it is
-    correct and measured SLOWER (profiles/r02_mlp_one_launch.txt: the device-side hand-over costs more than the launch gap it
-    removes), so it is opt-in;
+    AWQ_MLP_ONE_LAUNCH=1 a single row is served by ONE launch for the whole module (`mlp_decode_cdna4`: down_proj's blocks sit
+    behind the gate/up blocks in the same grid, stream their first weight tiles while the gate/up tail drains and gather h from
+    8-byte {data, tag} granules the gate/up blocks publish -- no flag, no counter); it is correct, graph-replayable and measured
+    SLOWER (profiles/r04_mlp_one_launch.txt: 27.6-28.3 us against 22.4-23.6 us; what follows the last gate/up block -- hop, gather,
+    the rest of down_proj's stream on eight waves -- is as long as a second launch), so it is opt-in;
   * prefill (>= 8 rows): one GEMM over the interleaved weight (x is read once for both projections) whose tile epilogue pairs
     column n with column n + 8 and stores silu(gate) * up directly -- the [rows, 2 * ffn] intermediate of the reference's two
     GEMMs + F.silu + multiply is never written.
@@ -90,13 +91,11 @@ class QuantLlamaMLP(nn.Module):
         self.down_proj = down_proj
         self.split_k_iters = down_proj.split_k_iters
         self._fused = None  # (qweight cdna4, scales, scaled_zeros, sz_packed, sz_half or None): built on the first GPU forward
-        self._ctr = None    # device counters of the one-launch decode path (AWQ_PROBES builds)
+        self._state = None  # epoch + granule array of the one-launch decode path (opt-in), per device
         self._v2_released = False
         self._v2_meta = None  # (shape, dtype) of the six released buffers
         self._register_state_dict_hook(QuantLlamaMLP._fill_state_dict)
         self._register_load_state_dict_pre_hook(self._rematerialise_v2)
-
-    _one_launch_available = None  # None = not probed yet; False = this library has no one-launch MLP kernel
 
     def _apply(self, fn, *args, **kwargs):
         """.to() / .cuda() / .half(): the fused stream is a plain tuple nn.Module does not move, and while the six reference-named buffers are
@@ -157,47 +156,40 @@ class QuantLlamaMLP(nn.Module):
     @torch.no_grad()
     def forward(self, x):
         rows = x.numel() // x.shape[-1]
-        if rows <= 8 and x.is_cuda and os.environ.get("AWQ_MLP_ONE_LAUNCH") == "1":  # opt-in: measured slower than two launches
+        if rows == 1 and x.is_cuda and os.environ.get("AWQ_MLP_ONE_LAUNCH") == "1":  # opt-in: measured slower than two launches
             y = self._decode_one_launch(x)
             if y is not None:
                 return y
         return self.down_proj(self.our_llama_mlp(x))
 
     def _decode_one_launch(self, x):
-        """gate/up + SiLU * mul + down_proj in ONE launch (`awq_w4a16_mlp_decode_cdna4`): down_proj's blocks stream their weights while
-        the gate/up tail drains and wait on a device-side count for h.  None when this layer cannot take it (scales not f16-exact,
-        down_proj not in the cdna4 layout, shape outside the kernel's range)."""
+        """gate/up + SiLU * mul + down_proj in ONE launch (`awq_w4a16_mlp_decode_cdna4`, one row): down_proj's blocks stream the head of their
+        weights while the gate/up tail drains and gather h from the tagged granules the gate/up blocks publish.  None when this layer cannot
+        take it (more than one row, scales not f16-exact, down_proj not in the cdna4 layout, shape outside the kernel's range)."""
         eng = load_engine()
+        if x.numel() != x.shape[-1]:
+            return None
         if self._fused is None or self._fused[0].device != x.device:
             self._build(x.device)
         c4, s, z, szp, szh = self._fused
         d = self.down_proj
-        if szh is None or getattr(d, "layout", None) != "cdna4" or d.w_bit != 4 or self.in_features < 4096 or self.intermediate_size < 2048:
-            return None
-        # the down blocks stage their K slice of h for every row: 8 waves x (ring 2 KiB + scales + rows x slice) must fit in 160 KiB
-        txp = (((self.intermediate_size // 128 + 7) // 8) + 3) & ~3
-        rows = x.numel() // x.shape[-1]
-        if 8 * (2 * 1024 + txp * 64 + rows * (txp * 256 + 16)) > 160 * 1024:
+        if szh is None or getattr(d, "layout", None) != "cdna4" or d.w_bit != 4:
             return None
         if d.szh_cdna4 is None:
             d._build_szh(eng)
         if d.szh_cdna4 is False:
             return None
-        if self._ctr is None or self._ctr.device != x.device:
-            self._ctr = torch.zeros(4096, dtype=torch.int32, device=x.device)
+        if self._state is None or self._state.device != x.device:
+            # (one state per module: calls on one stream are ordered; it carries the hand-over epoch from call to call, graph replays included)
+            self._state = torch.zeros((eng.mlp_decode_state_bytes(1, self.intermediate_size) + 3) // 4, dtype=torch.int32, device=x.device)
         if not x.is_contiguous():
             x = x.contiguous()
-        if QuantLlamaMLP._one_launch_available is False:
-            return None
         try:
-            y = eng.mlp_decode_cdna4(x, c4, szh, d.qweight, d.szh_cdna4, self._ctr, d.bias)
-            QuantLlamaMLP._one_launch_available = True
-            return y
+            return eng.mlp_decode_cdna4(x, c4, szh, d.qweight, d.szh_cdna4, self._state, d.bias)
         except RuntimeError as e:
-            # a product library does not carry the one-launch kernel (AWQ_PROBES builds only) and says "unsupported shape" for every call:
-            # remembered, so the probe is paid once; any OTHER error (a failed launch, an asynchronous HIP error) is the caller's to see
-            if QuantLlamaMLP._one_launch_available is None and "shape" in str(e).lower():
-                QuantLlamaMLP._one_launch_available = False
+            # "unsupported shape": the kernel serves hidden = 4096 with 4096 <= ffn <= 16384 -- the two launches take over; any OTHER error (a
+            # failed launch, an asynchronous HIP error) is the caller's to see
+            if "shape" in str(e).lower():
                 return None
             raise
 

@@ -110,16 +110,10 @@ def test_entry_rejects_bad_arguments():
         ops.mlp_gate_up_forward_cdna4(c["x"].cuda().float(), c4, szp, None)
 
 
-def test_one_launch_entry_is_not_in_the_product_library(monkeypatch):
-    """awq_w4a16_mlp_decode_cdna4 (QuantLlamaMLP.forward as ONE launch) measured slower than two launches
-    (profiles/r02_mlp_one_launch.txt) and exists in AWQ_PROBES builds only: a product library answers "shape not served" and
-    QuantLlamaMLP falls back to the two-launch path even when the opt-in is set."""
+def _fused_block(cg, cu, cd, H, F, dtype):
     import torch.nn as nn
     from llm_awq_amd.fused_mlp import make_fused_mlp
     from llm_awq_amd.qmodule import WQLinear
-    H, F, dtype = 4096, 2048, torch.bfloat16
-    cg, cu, x, act = _pair(F, H, dtype, 5, 4)
-    cd = make_case(H, F, dtype, seed=7, M=1)
 
     def lin(c, k, n):
         m = WQLinear(4, 128, k, n, False, "cuda", dtype=dtype)
@@ -136,14 +130,91 @@ def test_one_launch_entry_is_not_in_the_product_library(monkeypatch):
             super().__init__()
             self.mlp = LlamaMLP()
 
-    mlp = make_fused_mlp(Block()).mlp
+    return make_fused_mlp(Block()).mlp
+
+
+def _granule_h(state, F, dtype):
+    """the activations the one-launch kernel handed over: data halves of the {2 x T, tag} granules behind the counter block of its state"""
+    from llm_awq_amd import ops
+    g = state[ops._capi.AWQ_MLP_DECODE_COUNTER_BYTES // 4:][: F].view(F // 2, 2)
+    return g[:, 0].contiguous().view(torch.int16).view(dtype).reshape(1, F).cpu(), g[:, 1].cpu()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("F", [4096, 11008])
+def test_one_launch_mlp_against_two_launches_and_the_oracle(monkeypatch, dtype, F):
+    """AWQ_MLP_ONE_LAUNCH=1: QuantLlamaMLP.forward for one row as ONE launch (awq_w4a16_mlp_decode_cdna4; fused_mlp.py:33-83).  The gate/up blocks hand h to
+    the down_proj blocks of the same launch as tagged granules: h itself (read back from the granule array) against the two-launch path and the oracle,
+    the output against the oracle's down_proj on that h, the epoch / error words of the state, three calls in a row and a row count it does not serve."""
+    H = 4096
+    cg, cu, x, act = _pair(F, H, dtype, 5, 1)
+    cd = make_case(H, F, dtype, seed=7, M=1)
+    mlp = _fused_block(cg, cu, cd, H, F, dtype)
     y2 = mlp(x.cuda()).cpu()
+    h2 = mlp.our_llama_mlp(x.cuda()).cpu()
     monkeypatch.setenv("AWQ_MLP_ONE_LAUNCH", "1")
-    y1 = mlp(x.cuda()).cpu()
-    # (an AWQ_PROBES build runs the one-launch kernel here: same roundings, another K split of down_proj)
-    from tests.helpers import assert_bits
-    assert_bits(y1, y2, 0.2, what="one-launch opt-in vs two launches")
-    check_forward(y2, mlp.our_llama_mlp(x.cuda()).cpu(), cd["q"], cd["scales"], cd["scaled_zeros"], dtype)
+    for call in range(3):
+        y1 = mlp(x.cuda()).cpu()
+        st = mlp._state.cpu()
+        assert st[0].item() == call + 1 and st[1].item() == 0 and st[2].item() == 0, st[:3]  # the kernel ran (no silent two-launch route), nobody gave up
+        h1, tags = _granule_h(mlp._state, F, dtype)
+        assert bool((tags == call + 1).all())
+        # F = 11008: 1376 slabs = 5.4 per CU -> the stand-alone launch also runs four waves per slab: the same sums in the same order
+        assert_bits(h1, h2, 0.0 if F == 11008 else 0.05, what="h through the granules")
+        assert_bits(h1, act, 0.05)
+        check_forward(y1, h1, cd["q"], cd["scales"], cd["scaled_zeros"], dtype)
+        assert_bits(y1, y2, 0.2, what="one launch vs two")  # (eight waves per down_proj slab instead of sixteen: another fp32 order)
+    # two rows: the module issues the two launches (the kernel is the single-row specialisation) and the state is not touched
+    x2 = torch.cat([x, x * 0.5]).cuda()
+    y = mlp(x2).cpu()
+    assert mlp._state[0].item() == 3
+    assert torch.equal(y[:1], y2)
+
+
+def test_one_launch_mlp_replays_from_a_graph_and_declines_other_shapes(monkeypatch):
+    from llm_awq_amd import ops, synth
+    from llm_awq_amd.fused_mlp import interleave_gate_up
+    dtype = torch.bfloat16
+
+    def build(hidden, ffn, n_out, seed):
+        g = synth.random_wq(hidden, ffn, dtype=dtype, seed=seed, keep_q=False)
+        u = synth.random_wq(hidden, ffn, dtype=dtype, seed=seed + 1, keep_q=False)
+        d = synth.random_wq(ffn, n_out, dtype=dtype, seed=seed + 2, keep_q=False)
+        qi, si, zi = interleave_gate_up(g["qweight"], u["qweight"], g["scales"], u["scales"], g["scaled_zeros"], u["scaled_zeros"])
+        gu_szh, e1 = ops.pack_szh_cdna4(si, zi, hidden)
+        d_szh, e2 = ops.pack_szh_cdna4(d["scales"], d["scaled_zeros"], ffn)
+        assert e1 and e2
+        return dict(gu=ops.repack_v2_to_cdna4(qi), gu_szp=ops.pack_sz_cdna4(si, zi, hidden), gu_szh=gu_szh, d=ops.repack_v2_to_cdna4(d["qweight"]),
+                    d_szh=d_szh, state=ops.mlp_decode_state(1, ffn, "cuda"))
+
+    def two(c, x):
+        return ops.decode_cdna4(ops.mlp_gate_up_forward_cdna4(x, c["gu"], c["gu_szp"], c["gu_szh"]), c["d"], c["d_szh"], None, 0)
+
+    c = build(4096, 14336, 4096, 3)
+    xs = [torch.zeros(1, 4096, device="cuda", dtype=dtype) for _ in range(3)]
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        gph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gph, stream=side):
+            ys = [ops.mlp_decode_cdna4(xx, c["gu"], c["gu_szh"], c["d"], c["d_szh"], c["state"]) for xx in xs]  # three launches sharing one state
+        for rep in range(3):
+            for xx in xs:
+                xx.copy_(torch.randn(1, 4096, device="cuda").to(dtype))
+            gph.replay()
+            torch.cuda.synchronize()
+            for xx, yy in zip(xs, ys):
+                ref = two(c, xx)
+                assert_bits(yy, ref, 0.2, what="replay %d" % rep)
+                assert ((yy.float() - ref.float()).norm() / ref.float().norm()).item() < 2e-3
+    st = c["state"][:3].cpu()
+    assert st[0].item() == 9 and st[1].item() == 0 and st[2].item() == 0, st
+    # shapes outside the specialisation: "unsupported shape", nothing launched
+    small = build(2048, 4096, 256, 9)
+    with pytest.raises(ops._capi.AwqNativeError):
+        ops.mlp_decode_cdna4(torch.zeros(1, 2048, device="cuda", dtype=dtype), small["gu"], small["gu_szh"], small["d"], small["d_szh"], small["state"])
+    with pytest.raises((AssertionError, ops._capi.AwqNativeError)):
+        ops.mlp_decode_cdna4(torch.zeros(2, 4096, device="cuda", dtype=dtype), c["gu"], c["gu_szh"], c["d"], c["d_szh"], c["state"])
+    assert c["state"][0].item() == 9
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
