@@ -139,6 +139,8 @@ int awq_w4a16_mlp_gate_up_cdna4(const void* x, const void* qweight_gate_up, cons
  * ffn outside 4096 .. 16384): callers then issue the two launches separately. */
 #define AWQ_MLP_DECODE_COUNTER_BYTES 16384
 size_t awq_w4a16_mlp_decode_cdna4_state_bytes(int m, int ffn);
+/* host-side, no launch: 1 if awq_w4a16_mlp_decode_cdna4 serves the shape, 0 if the caller issues the two launches */
+int awq_w4a16_mlp_decode_cdna4_plan(int m, int hidden, int ffn, int n_out);
 int awq_w4a16_mlp_decode_cdna4(const void* x, const void* gate_up_qweight, const void* gate_up_sz_half, const void* down_qweight,
                                const void* down_sz_half, const void* down_bias, void* out, int m, int hidden, int ffn, int n_out,
                                int group_size, int dtype, void* state, void* stream);

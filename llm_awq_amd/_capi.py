@@ -38,6 +38,7 @@ SIGNATURES = {
     "awq_w4a16_gemv_cdna4": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "awq_w4a16_mlp_gate_up_cdna4": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "awq_w4a16_mlp_decode_cdna4_state_bytes": (_sz, [_i, _i]),
+    "awq_w4a16_mlp_decode_cdna4_plan": (_i, [_i, _i, _i, _i]),
     "awq_w4a16_mlp_decode_cdna4": (_i, [_vp] * 7 + [_i] * 6 + [_vp, _vp]),
     "awq_w4a16_mlp_gate_up_forward_cdna4": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "awq_w4a16_rmsnorm_forward_cdna4": (_i, [_vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -225,6 +225,7 @@ int awq_w4a16_mlp_gate_up_cdna4(const void* x, const void* qweight_gate_up, cons
   return finish_launch();
 }
 
+int awq_w4a16_mlp_decode_cdna4_plan(int m, int hidden, int ffn, int n_out) { return awq::mlp_decode_plan(m, hidden, ffn, n_out); }
 size_t awq_w4a16_mlp_decode_cdna4_state_bytes(int m, int ffn) { return m >= 1 && ffn >= 1 ? awq::mlp_decode_state_bytes(m, ffn) : 0; }
 
 int awq_w4a16_mlp_decode_cdna4(const void* x, const void* gate_up_qweight, const void* gate_up_sz_half, const void* down_qweight,

@@ -503,16 +503,28 @@ int launch_gemv_dma(const void* x, const void* qw, const void* szp, const void* 
 // shape is not served (the caller issues the two launches): m != 1, hidden != 4 x 8 x 128 (a gate/up slab = four waves x eight k-steps on a ring of 7),
 // ffn beyond sixteen 128-k steps per down_proj wave, or more LDS than lets two blocks share a CU.
 size_t mlp_decode_state_bytes(int m, int ffn) { return (size_t)AWQ_MLP_DECODE_COUNTER_BYTES + (size_t)m * ffn * 4; }
+// host-side: is (m, hidden, ffn, n_out) served?  On success the two K splits and the LDS per block
+static bool mlp_decode_cfg(int m, int hidden, int ffn, int n_out, int& txa, int& txb, size_t& group, size_t& smem) {
+  if (m != 1 || hidden < 128 || ffn < 128 || n_out < 16 || (hidden % 128) != 0 || (ffn % 128) != 0 || (n_out % 16) != 0) return false;
+  const int nita = hidden / kGroup, nitb = ffn / kGroup;
+  txa = (nita + 3) / 4;
+  txb = (nitb + 7) / 8;
+  if (txa != 8 || txb < 4 || txb > 16) return false;  // compiled for rings of 7 / 4 tiles: hidden = 4096, 4096 <= ffn <= 16384
+  group = dma_smem(4, 7, 1, txa, m);
+  const size_t smem_a = 2 * group, smem_b = dma_smem(8, 4, 1, txb, m);
+  smem = smem_a > smem_b ? smem_a : smem_b;
+  return smem <= 78 * 1024;  // two blocks per CU
+}
+int mlp_decode_plan(int m, int hidden, int ffn, int n_out) {
+  int txa, txb;
+  size_t group, smem;
+  return mlp_decode_cfg(m, hidden, ffn, n_out, txa, txb, group, smem) ? 1 : 0;
+}
 int launch_mlp_decode(const void* x, const void* qw_gu, const void* szh_gu, const void* qw_d, const void* szh_d, const void* bias_d,
                       void* out, int m, int hidden, int ffn, int n_out, int dtype, int* state, hipStream_t st) {
-  if (m != 1 || (hidden % 128) != 0 || (ffn % 128) != 0 || (n_out % 16) != 0 || (ffn % 16) != 0) return -1;
-  const int nita = hidden / kGroup, nitb = ffn / kGroup;
-  const int txa = (nita + 3) / 4, txb = (nitb + 7) / 8;
-  if (txa != 8 || txb < 4 || txb > 16) return -1;  // compiled for rings of 7 / 4 tiles: hidden = 4096, 4096 <= ffn <= 16384
-  const size_t group = dma_smem(4, 7, 1, txa, m);
-  const size_t smem_a = 2 * group, smem_b = dma_smem(8, 4, 1, txb, m);
-  const size_t smem = smem_a > smem_b ? smem_a : smem_b;
-  if (smem > 78 * 1024) return -1;  // two blocks per CU
+  int txa, txb;
+  size_t group, smem;
+  if (!mlp_decode_cfg(m, hidden, ffn, n_out, txa, txb, group, smem)) return -1;
   const int blocks = ffn / 16 + n_out / 16;
 #define AWQ_MLPD(DT_)                                                                                                              \
   {                                                                                                                                \

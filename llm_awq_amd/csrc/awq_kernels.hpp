@@ -115,6 +115,7 @@ void gemm_v6_set_probe(int v);
 int launch_mlp_decode(const void* x, const void* qw_gu, const void* szh_gu, const void* qw_d, const void* szh_d, const void* bias_d, void* out, int m,
                       int hidden, int ffn, int n_out, int dtype, int* state, hipStream_t st);
 size_t mlp_decode_state_bytes(int m, int ffn);
+int mlp_decode_plan(int m, int hidden, int ffn, int n_out);  // 1 = launch_mlp_decode serves the shape (host-side, no launch)
 int launch_bias_add(void* out, const void* bias, int m, int n, int dtype, hipStream_t st);
 // out[m, n] = T(in_f32) (+ bias in T); n % 8 == 0 (awq_util.hip)
 int launch_round_bias_f32(const void* in_f32, const void* bias, void* out, int m, int n, int dtype, hipStream_t st);

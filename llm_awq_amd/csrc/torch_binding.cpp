@@ -734,6 +734,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("mlp_decode_cdna4", &mlp_decode_cdna4, "QuantLlamaMLP.forward for one row in ONE launch (granule hand-over of h inside the launch)",
         py::arg("in_feats"), py::arg("gate_up_kernel"), py::arg("gate_up_sz_half"), py::arg("down_kernel"), py::arg("down_sz_half"),
         py::arg("state"), py::arg("down_bias") = py::none());
+  m.def("mlp_decode_plan", [](int m, int hidden, int ffn, int n_out) { return awq_w4a16_mlp_decode_cdna4_plan(m, hidden, ffn, n_out) != 0; },
+        "host-side: does mlp_decode_cdna4 serve (m, hidden, ffn, n_out)?");
   m.def("mlp_decode_state_bytes", &mlp_decode_state_bytes, "bytes of zero-initialised int32 state mlp_decode_cdna4 needs (per module and stream)");
   m.def("mlp_gate_up_forward_cdna4", &mlp_gate_up_forward_cdna4, "silu(x Wg^T) * (x Wu^T) for any row count on the 8 + 8 interleaved gate/up pair",
         py::arg("in_feats"), py::arg("kernel"), py::arg("sz_packed"), py::arg("sz_half") = py::none());

@@ -167,8 +167,8 @@ class QuantLlamaMLP(nn.Module):
         weights while the gate/up tail drains and gather h from the tagged granules the gate/up blocks publish.  None when this layer cannot
         take it (more than one row, scales not f16-exact, down_proj not in the cdna4 layout, shape outside the kernel's range)."""
         eng = load_engine()
-        if x.numel() != x.shape[-1]:
-            return None
+        if x.numel() != x.shape[-1] or not eng.mlp_decode_plan(1, self.in_features, self.intermediate_size, self.out_features):
+            return None  # (host-side plan query: the kernel serves one row, hidden = 4096, 4096 <= ffn <= 16384)
         if self._fused is None or self._fused[0].device != x.device:
             self._build(x.device)
         c4, s, z, szp, szh = self._fused
@@ -184,14 +184,7 @@ class QuantLlamaMLP(nn.Module):
             self._state = torch.zeros((eng.mlp_decode_state_bytes(1, self.intermediate_size) + 3) // 4, dtype=torch.int32, device=x.device)
         if not x.is_contiguous():
             x = x.contiguous()
-        try:
-            return eng.mlp_decode_cdna4(x, c4, szh, d.qweight, d.szh_cdna4, self._state, d.bias)
-        except RuntimeError as e:
-            # "unsupported shape": the kernel serves hidden = 4096 with 4096 <= ffn <= 16384 -- the two launches take over; any OTHER error (a
-            # failed launch, an asynchronous HIP error) is the caller's to see
-            if "shape" in str(e).lower():
-                return None
-            raise
+        return eng.mlp_decode_cdna4(x, c4, szh, d.qweight, d.szh_cdna4, self._state, d.bias)
 
     @torch.no_grad()
     def our_llama_mlp(self, x):
