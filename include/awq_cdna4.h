@@ -135,7 +135,7 @@ int awq_w4a16_mlp_gate_up_cdna4(const void* x, const void* qweight_gate_up, cons
  * re-tried until every tag carries this launch's epoch) -- no flag, no counter, no fence on the path.  Both weights with their sz_half side buffers
  * (awq_pack_szh_cdna4 must have reported them exact).  `state`: awq_w4a16_mlp_decode_cdna4_state_bytes(m, ffn) bytes of device memory, ZERO before the
  * first call, owned by one (module, stream) at a time and never written by the caller afterwards (it carries the epoch between calls: replayed graphs
- * work); int32 [2] of it is a sticky error flag (a consumer gave up waiting).  AWQ_ERR_SHAPE for shapes it does not serve (m != 1, hidden != 4096,
+ * work); int32 [2] of it is a sticky error flag (a consumer gave up waiting -- bounded spin -- and its block's outputs are NaN).  AWQ_ERR_SHAPE for shapes it does not serve (m != 1, hidden != 4096,
  * ffn outside 4096 .. 16384): callers then issue the two launches separately. */
 #define AWQ_MLP_DECODE_COUNTER_BYTES 16384
 size_t awq_w4a16_mlp_decode_cdna4_state_bytes(int m, int ffn);

@@ -117,13 +117,14 @@ __device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __rest
   }
 #pragma unroll
   for (int d = 1; d < D; ++d) issue(d, d);
+  bool gave_up = false;  // (fused MLP launch only) this wave's activations never arrived: its partial sums are poisoned, the block's outputs read NaN
   if (gate != nullptr) {
     // Fused MLP launch, down_proj side (round 4).  The ring is in flight; h arrives as 8-byte {2 x T, tag} granules the gate/up blocks of the SAME launch
     // publish with one sc1 store each (no flag, no counter, no fence: tools/ubench/handoff_ubench.hip measured the hop at ~1.3 us).  `x` is the granule
     // array [M][K / 2] x 8 B, gate_target this launch's epoch.  A wave gathers ITS OWN k range: lane 0 first watches the range's LAST granule (the
     // producers finish roughly in dispatch order; one 8-byte load per poll keeps the waiting waves off the memory system), then the whole range is
     // swept (TX dwordx2 sc1 loads per lane and row) and re-swept until every tag carries the epoch; the data halves go to the wave's x slice in LDS.
-    // Bounded: a lost producer turns into a flagged error (gate[2]), not a hung queue.
+    // Bounded: a lost producer turns into a flagged error (gate[2]) and NaN outputs of the waiting block, not a hung queue or a plausible number.
     const uint64_t* gsrc = reinterpret_cast<const uint64_t*>(x);
     const u32 epoch = (u32)gate_target;
     const int gper = K >> 1;                                   // granules per row
@@ -137,6 +138,7 @@ __device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __rest
         if (__builtin_amdgcn_readfirstlane(sg.y) == epoch) break;
         if (++spins > 400000) {
           if (lane == 0) __hip_atomic_store(gate + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          gave_up = true;
           break;
         }
         __builtin_amdgcn_s_sleep(16);
@@ -168,6 +170,7 @@ __device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __rest
           }
           if (++spins > 400000) {
             if (lane == 0) __hip_atomic_store(gate + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gave_up = true;
             break;
           }
           __builtin_amdgcn_s_sleep(4);
@@ -191,6 +194,11 @@ __device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __rest
   f32x4 acc[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (gave_up) {
+    const float bad = __builtin_nanf("");
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = f32x4{bad, bad, bad, bad};
+  }
 
   int slot = 0;
   auto step = [&](int t, auto vm_, auto reissue_) {
