@@ -20,7 +20,7 @@ int g_splitk = 1;  // narrow tiles: split K over blocks when the tiles fill less
 int g_v6 = 1;  // 1 (default): 256-wide tiles of m >= 256 run awq_gemm_v6.hip (one software-pipelined wave per SIMD); 0 (tests): awq_gemm_v4n.hip's 128-wide tiles
 int g_tile_n = 0;  // knob gemm_tile_n: 128 / 256 force one tile width for callers that pass tile_n = 0 (tests of a specific kernel)
 int g_v6_192 = 1;  // knob gemm_v6_192: 0 = no 192-wide blocks in the tile plan
-int g_v6_szh = 0;  // knob gemm_v6_szh: 1 = v6 dequantises in the f16-mantissa form when the caller hands its sz_half buffer (-40 VALU per K tile; measured neutral, profiles/r02_gemm_v6.txt)
+int g_v6_szh = 1;  // knob gemm_v6_szh: 1 = v6 dequantises in the f16-mantissa form when the caller hands its sz_half buffer (QuantLlamaMLP's gate/up launch): -40 VALU per K tile; neutral in round 2, +0.1-0.3 % at M = 2048 / +0.5-1.2 % at M = 4096 on the power-limited round-4 loop (profiles/r04_v6_szh_ab.txt)
 int g_v4 = 1;  // knob gemm_v4: 0 = the tile kernels take no m below 256 (the skinny kernel serves 9 .. 255 rows); the loop it once selected is gone
 void launch_wide(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
                  int n_end, int dtype, hipStream_t st, int bits, int epi, const void* szh = nullptr, int tile_n = 256) {
