@@ -173,13 +173,20 @@ int awq_rmsnorm(const void* x, const void* gamma, float eps, void* out, int m, i
 /* OPTIONAL fp32 workspace of awq_w4a16_gemm_cdna4 / awq_w4a16_forward_cdna4 (0 = none useful).  Prompts of 256 .. ~1 k tokens
  * against narrow projections produce too few output tiles to fill the 256 CUs; given this many bytes (16-byte aligned) the
  * K loop is split over blocks and a second kernel adds the partial tiles in a fixed order -- the role of the reference's
- * split_k_iters + semaphore (gemm_cuda.cu:546-619).  Without a workspace the call runs unsplit (slower, same contract). */
+ * split_k_iters + semaphore (gemm_cuda.cu:546-619); for awq_w4a16_gemm_cdna4_pair_plan's shapes the two halves of K meet inside
+ * ONE launch (64-byte aligned workspace, any contents; one launch at a time per workspace).  Without a workspace the call runs
+ * unsplit (slower, same contract). */
 size_t awq_w4a16_forward_cdna4_workspace_bytes(int m, int n, int k);
 /* host-side query (no GPU work): the tiles the prefill GEMM launches for an [m, n] output of a 3- or 4-bit matrix.  *mode: 0 = 256 x 256
  * blocks, 1 = 256 x 128, 2 = 256 x 256 for the first *cols_main column tiles and 256 x 128 for the rest, 3 = 256 x 192; returns the number
  * of thread blocks, 0 if the GEMM does not take this m (decode / skinny kernels do).  The counterpart of the reference's tile table,
  * gemm_cuda.cu:1155-1232. */
 int awq_w4a16_gemm_cdna4_plan(int m, int n, int bits, int* mode, int* cols_main);
+/* host-side query: 1 if a W4 prefill call of this shape, GIVEN its workspace, runs as pairs of 256 x 256 blocks that each sum half of K and
+ * combine inside the launch (tiles that fill at most half the chip and K >= 8192: down_proj of Llama-3-8B at 1536 .. 2048 rows) -- the role
+ * of the reference's split_k_iters + Semaphore, gemm_cuda.cu:546-619, without a second kernel; 0 = the tiles awq_w4a16_gemm_cdna4_plan names.
+ * The two halves' fp32 sums are added once (lower K range + upper K range): another association than the unsplit kernels', same products. */
+int awq_w4a16_gemm_cdna4_pair_plan(int m, int n, int k);
 /* host-side query: which kernel runs the 256 x 128 blocks of such a launch over n_cols weight rows.  Returns 1 = awq_gemm_v6.hip (one wave
  * per SIMD, two slabs per wave: every unsplit launch of W4 tiles at m >= 256), 0 = awq_gemm_v4n.hip unsplit (m < 256: masked single row
  * tile; W3 tiles), ks >= 2 = awq_gemm_v4n.hip with the K loop split into ks ranges (needs the workspace and no fused SiLU*mul tail). */

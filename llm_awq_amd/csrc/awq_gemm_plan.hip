@@ -20,6 +20,7 @@ int g_splitk = 1;  // narrow tiles: split K over blocks when the tiles fill less
 int g_v6 = 1;  // 1 (default): 256-wide tiles of m >= 256 run awq_gemm_v6.hip (one software-pipelined wave per SIMD); 0 (tests): awq_gemm_v4n.hip's 128-wide tiles
 int g_tile_n = 0;  // knob gemm_tile_n: 128 / 256 force one tile width for callers that pass tile_n = 0 (tests of a specific kernel)
 int g_v6_192 = 1;  // knob gemm_v6_192: 0 = no 192-wide blocks in the tile plan
+int g_v6_pair = 1;  // knob gemm_v6_pair: K split over pairs of 256 x 256 blocks where the 256-wide tiles fill at most half the chip (needs the workspace)
 int g_v6_szh = 1;  // knob gemm_v6_szh: 1 = v6 dequantises in the f16-mantissa form when the caller hands its sz_half buffer (QuantLlamaMLP's gate/up launch): -40 VALU per K tile; neutral in round 2, +0.1-0.3 % at M = 2048 / +0.5-1.2 % at M = 4096 on the power-limited round-4 loop (profiles/r04_v6_szh_ab.txt)
 int g_v4 = 1;  // knob gemm_v4: 0 = the tile kernels take no m below 256 (the skinny kernel serves 9 .. 255 rows); the loop it once selected is gone
 void launch_wide(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
@@ -72,6 +73,9 @@ int gemm_v3_tune_set(const char* key, int value) {
   }
   else if (!strcmp(key, "gemm_tile_n")) g_tile_n = value;
   else if (!strcmp(key, "gemm_v6_szh")) g_v6_szh = value;
+  else if (!strcmp(key, "gemm_v6_pair")) g_v6_pair = value;
+  else if (!strcmp(key, "gemm_v6_pair_lead")) gemm_v6_set_pair_lead(value);
+  else if (!strcmp(key, "gemm_v6_pair_min_nit")) gemm_v6_set_pair_min_nit(value);
   else if (!strcmp(key, "gemm_v6_192")) g_v6_192 = value;
   else if (!strcmp(key, "gemm_v6_128")) g_v6_128 = value;
   else if (!strcmp(key, "moe_v4")) g_moe_v4 = value;
@@ -130,12 +134,16 @@ bool gemm_cdna4_v3_takes(int m, int k) {
 // fp32 workspace the call below can use to split K when its tiles under-fill the chip (0 = none needed)
 size_t gemm_cdna4_v3_workspace_bytes(int m, int n, int k) {
   if (!gemm_cdna4_v3_takes(m, k) || (n % 16) != 0 || (k % 128) != 0 || !g_v4 || !g_splitk) return 0;
+  if (gemm_cdna4_v3_pair_plan(m, n, k)) return gemm_v6_pair_workspace_bytes(m, n, k);
   if (m < TM) return gemm_v4n_workspace_bytes(m, n, k);
   const Plan p = plan_tiles(m, n, 0);
   if (p.mode == 1) return gemm_v4n_workspace_bytes(m, n, k);
   if (p.mode == 2) return gemm_v4n_workspace_bytes(m, n - (int)(p.cols_main * 256), k);
   return 0;
 }
+
+// 1 = a W4 call WITH its workspace runs as pairs of 256 x 256 blocks, each summing half of K (awq_gemm_v6.hip: gemm_cdna4_v6_pair_kernel)
+int gemm_cdna4_v3_pair_plan(int m, int n, int k) { return g_v6 && g_v6_pair && g_splitk && !g_tile_n && gemm_v6_pair_takes(m, n, k) ? 1 : 0; }
 
 size_t gemm_cdna4_v3_workspace_bytes_w3(int m, int n, int k) {
   if (m <= 8 || (n % 16) != 0 || (k % 128) != 0 || !g_splitk) return 0;
@@ -170,6 +178,10 @@ int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, const v
                          int tile_n, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits, int epi, const void* szh) {
   // (w3c tiles have no skinny kernel: the masked single-row-tile path of the narrow kernel serves every m > 8)
   if (!szp || !(gemm_cdna4_v3_takes(m, k) || ((bits == 3 || epi) && m > 8)) || (n % 16) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return -1;
+  // tiles that fill at most half the chip and a long K: pairs of 256 x 256 blocks, each half of K, combined inside the launch (needs the workspace)
+  if (g_v6 && g_v6_pair && g_splitk && bits == 4 && epi == 0 && !tile_n && !g_tile_n && ws != nullptr &&
+      launch_gemm_cdna4_v6_pair(x, qw, szp, bias, out, m, n, k, dtype, ws, ws_bytes, st) == 0)
+    return 0;
   const bool allow192 = g_v6 != 0 && g_v6_192 != 0 && bits == 4 && m >= TM;
   Plan p = m < TM ? Plan{1, 0} : plan_tiles(m, n, tile_n ? tile_n : g_tile_n, allow192);  // m < 256: only the narrow-tile kernel masks rows
   if (g_v6 >= 2) p = Plan{0, 0};  // experiments: every tile 256-wide

@@ -24,6 +24,7 @@
 // Register budget (one wave per SIMD: 256 VGPRs + 256 AGPRs): accumulators 256 AGPRs; fragments 32, operands 32, weights of two
 // groups 40, staging 32 VGPRs.
 // Numerics: products and fp32 accumulation order along K are v5's (= v4's up to the association inside one 32-k MFMA).
+#include <atomic>
 #include <type_traits>
 
 #include "awq_device.hpp"
@@ -76,16 +77,20 @@ __device__ __forceinline__ void v6_mfma(f32x4& acc, const V8& a, const u32x4& b)
 // 256 x 128 tiles where 256-wide tiles would fill half the chip); 3 -> 192-column blocks (accumulators 192 AGPRs) for matrices
 // whose 256-wide tile count leaves a partial round that 192-wide tiles fill (qkv of Llama-3-8B: 6144 = 32 x 192 -> 8 x 32 = 256 tiles
 // at M = 2048 instead of 192)
-template <typename DT, int BITS, int PROBE, int DQ, int NS>
+template <typename DT, int BITS, int PROBE, int DQ, int NS, int ROLE = 0>
 __device__ __forceinline__ void v6_tile(char* smem, const uint16_t* __restrict__ x, const u32* __restrict__ qw, const u32* __restrict__ szp,
                                         const uint16_t* __restrict__ bias, uint16_t* __restrict__ out, int N, int K, int m0, int n0, int n_end,
-                                        int epi, int row_lo, int row_hi) {
+                                        int epi, int row_lo, int row_hi, int g0 = 0, int nit_range = -1,
+                                        float* __restrict__ part = nullptr, u32x2* flag = nullptr, u32 token = 0) {
   // one 256 x (64 NS) output tile: rows [m0, m0 + 256) of x (all readable), weight rows [n0, ...) below n_end; rows outside
-  // [row_lo, row_hi) are computed but NOT stored (grouped GEMM: they belong to another expert's segment)
+  // [row_lo, row_hi) are computed but NOT stored (grouped GEMM: they belong to another expert's segment).
+  // K split over a PAIR of blocks (gemm_cdna4_v6_pair_kernel; nit_range >= 0: only the quantisation groups [g0, g0 + nit_range) are summed):
+  // ROLE 1 = the upper K range: its fp32 accumulators go to `part` in register order (1 KiB per wave store, write-through), then `flag` takes the
+  // launch's token; ROLE 2 = the lower K range: waits for the token, adds the partner's partials to its own accumulators, runs the epilogue.
   using vec8 = typename DT::vec8;
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
-  const int nit = K >> 7;
+  const int nit_all = K >> 7, nit = nit_range < 0 ? nit_all : nit_range;  // nit_all: tile stride of a slab; nit: this block's K tiles
   constexpr int TN = 64 * NS;  // columns per block
 
   // ---- x staging: piece q (0..15) of this wave = rows 64 wv + 4 q .. + 3, one 16-byte granule per lane ----
@@ -99,7 +104,7 @@ __device__ __forceinline__ void v6_tile(char* smem, const uint16_t* __restrict__
   const uint16_t* xw = x + (size_t)(m0 + 64 * wv) * (size_t)K;
   const u32 xlane_b = ((u32)r4 * (u32)K + (u32)p16 * 8u) * 2u;  // bytes, < 2^32: (SGPR base + 32-bit VGPR offset) is one instruction
   auto load_piece = [&](int kt, int q) {
-    const uint16_t* base = xw + (size_t)kt * V6_TK + (size_t)(4 * q) * (size_t)K;
+    const uint16_t* base = xw + (size_t)(g0 + kt) * V6_TK + (size_t)(4 * q) * (size_t)K;
     return *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(base) + xlane_b);
   };
 
@@ -110,8 +115,8 @@ __device__ __forceinline__ void v6_tile(char* smem, const uint16_t* __restrict__
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int slc = min((n0 >> 4) + NS * wv + s, slab_end - 1);
-    w_off[s] = (u32)slc * (u32)nit * kTileWords + lane * kLaneWords;
-    s_off[s] = (u32)slc * (u32)nit * 16 + i;
+    w_off[s] = ((u32)slc * (u32)nit_all + (u32)g0) * kTileWords + lane * kLaneWords;
+    s_off[s] = ((u32)slc * (u32)nit_all + (u32)g0) * 16 + i;
   }
   struct WG {
     u32x4 w[NS];
@@ -361,6 +366,69 @@ __device__ __forceinline__ void v6_tile(char* smem, const uint16_t* __restrict__
     cur = nxt;
   }
 
+  if constexpr (ROLE == 1) {
+    // upper K range of a block pair: fp32 partials in register order, write-through (the partner may sit behind another XCD's L2), every store
+    // acknowledged, then the flag.  (The last product MFMAs are opaque asm: let them retire before their accumulators are read.)
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : : : "memory");
+    float* pw = part + (size_t)wv * (16 * NS * 256) + lane * 4;
+#pragma unroll
+    for (int f = 0; f < 16; ++f)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const f32x4 v = acc[f][s];
+        const float* dst = pw + (f * NS + s) * 256;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+      }
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+    __builtin_amdgcn_s_barrier();
+    if (tid == 0) {
+      const u32x2 fv = {token, token ^ 0xA5A5A5A5u};
+      asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(flag), "v"(fv) : "memory");
+    }
+    return;
+  }
+  if constexpr (ROLE == 2) {
+    // lower K range: the partner's partials, added in fp32 (acc = lower + upper), then the ordinary epilogue.  Bounded wait: a lost partner turns
+    // into NaN outputs and the sticky error word behind the flags, not a hung queue
+    bool lost = false;
+    for (int spins = 0;; ++spins) {
+      u32x2 fv;
+      asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(fv) : "v"(flag) : "memory");
+      if ((u32)__builtin_amdgcn_readfirstlane(fv.x) == token && (u32)__builtin_amdgcn_readfirstlane(fv.y) == (token ^ 0xA5A5A5A5u)) break;
+      if (spins > (1 << 22)) {
+        lost = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : : : "memory");
+    const float* pw = part + (size_t)wv * (16 * NS * 256) + lane * 4;
+#pragma unroll
+    for (int f0 = 0; f0 < 16; f0 += 4) {
+      f32x4 pv[4 * NS];
+#pragma unroll
+      for (int j = 0; j < 4 * NS; ++j) {
+        const float* src = pw + ((f0 + j / NS) * NS + (j % NS)) * 256;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(pv[j]) : "v"(src) : "memory");
+      }
+      static_assert(NS == 4, "pair split: 256-wide blocks");
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]), "+v"(pv[6]), "+v"(pv[7]), "+v"(pv[8]), "+v"(pv[9]),
+                     "+v"(pv[10]), "+v"(pv[11]), "+v"(pv[12]), "+v"(pv[13]), "+v"(pv[14]), "+v"(pv[15])
+                   :
+                   : "memory");
+#pragma unroll
+      for (int j = 0; j < 4 * NS; ++j) acc[f0 + j / NS][j % NS] = acc[f0 + j / NS][j % NS] + pv[j];
+    }
+    if (lost) {
+      const float bad = __builtin_nanf("");
+#pragma unroll
+      for (int f = 0; f < 16; ++f)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[f][s] = f32x4{bad, bad, bad, bad};
+      if (tid == 0) flag[7].x = 1u;  // (word 14 of the pair's 64-byte flag line: sticky)
+    }
+  }
   if (epi == 3) {
     // K shard of a tensor-parallel row split (awq_w4a16_partial_cdna4): out is float [M, N] and takes the fp32 accumulators unrounded,
     // no bias -- the ranks' partials are summed in fp32 and rounded to T once.  Straight from the registers: a lane holds four
@@ -380,6 +448,10 @@ __device__ __forceinline__ void v6_tile(char* smem, const uint16_t* __restrict__
   // ---------------- epilogue through LDS: acc[f][s][r] = C[n = n0 + 16 NS wv + 16 s + 4 g + r][m = m0 + 16 f + i], staged row-major ----
   asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
   __builtin_amdgcn_s_barrier();  // every wave is done with the x stages (the trailing reads of the unused stage have returned)
+  if (ROLE == 2 && tid == 0) {  // (every wave of the block has seen the token: the flag is free for the next launch / the next replay of a graph)
+    const u32x2 z = {0u, 0u};
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(flag), "v"(z) : "memory");
+  }
   {
     const u32 wbase = lds0 + i * kV6Pitch + (16 * NS * wv + 4 * g) * 2;
 #pragma unroll
@@ -523,10 +595,83 @@ __global__ __launch_bounds__(256) void moe_gemm_cdna4_v6_kernel(const uint16_t* 
                           N, epi, r_lo, r_hi);
 }
 
+// K split over a PAIR of 256 x 256 blocks (round 4).  A matrix whose 256-wide tiles fill at most half the chip (down_proj of Llama-3-8B at 2048 rows: 8 x 16 =
+// 128 tiles) used to run as 256 x 128 blocks -- two slabs per wave: twice the x-fragment reads and twice the x staging per MFMA, 0.42 of the MFMA peak against
+// 0.51 for the four-slab block (profiles/r04_f_pmc_mfma_m2048.txt).  Here every tile is two four-slab blocks on the SAME XCD (block index mod 8), each summing
+// half of K: the upper half hands its fp32 accumulators to the lower half through the workspace (write-through stores, one flag per pair carrying the launch's
+// token; the reader resets it, so a captured launch replays), which adds them and runs the epilogue -- the role of the reference's split_k_iters + Semaphore
+// (gemm_cuda.cu:546-619) inside one launch, no second kernel.  The producers have the LOWER block indices of an XCD's share (dispatched first: a waiting
+// consumer can never keep its producer off the chip) and `lead` fewer K tiles, so their partials are on the way while the consumers finish.
+template <typename DT>
+__global__ __launch_bounds__(256) void gemm_cdna4_v6_pair_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw, const u32* __restrict__ szp,
+                                                                 const uint16_t* __restrict__ bias, uint16_t* __restrict__ out, int M, int N, int K,
+                                                                 int tiles_m, int tiles_n, int lead, float* __restrict__ ws, u32 token) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int T = tiles_m * tiles_n, per = T >> 3;  // T % 8 == 0 (launcher)
+  const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+  const bool producer = idx < per;
+  const int tile = xcd * per + (producer ? idx : idx - per);
+  int tm, tn;
+  {
+    const int full = (tiles_m >> 1) * 2 * tiles_n;
+    if (tile < full) {
+      const int band = tile / (2 * tiles_n), rem = tile - band * 2 * tiles_n;
+      tn = rem >> 1;
+      tm = 2 * band + (rem & 1);
+    } else {
+      tn = tile - full;
+      tm = tiles_m - 1;
+    }
+  }
+  const int nit_all = K >> 7, n_up = (nit_all >> 1) - lead, n_lo = nit_all - n_up;
+  float* part = ws + (size_t)tile * (size_t)(V6_TM * V6_TN);
+  u32x2* flag = reinterpret_cast<u32x2*>(ws + (size_t)T * (size_t)(V6_TM * V6_TN)) + (size_t)tile * 8;  // one 64-byte line per pair
+  const int m0 = min(tm * V6_TM, M - V6_TM), n0 = tn * V6_TN;
+  if (producer) v6_tile<DT, 4, 0, 0, 4, 1>(smem, x, qw, szp, nullptr, out, N, K, m0, n0, N, 0, 0, M, n_lo, n_up, part, flag, token);
+  else v6_tile<DT, 4, 0, 0, 4, 2>(smem, x, qw, szp, bias, out, N, K, m0, n0, N, 0, 0, M, 0, n_lo, part, flag, token);
+}
+
 namespace {
 int g_v6_probe = 0;
+int g_v6_pair_min_nit = 64;  // knob gemm_v6_pair_min_nit (experiments)
+int g_v6_pair_lead = 1;  // knob gemm_v6_pair_lead: K tiles the producer half of a block pair runs less than half of K
 }
 void gemm_v6_set_probe(int v) { g_v6_probe = v; }
+void gemm_v6_set_pair_lead(int v) { g_v6_pair_lead = v < 0 ? 0 : v; }
+void gemm_v6_set_pair_min_nit(int v) { g_v6_pair_min_nit = v < 8 ? 8 : v; }
+
+// Does the block-pair K split serve [m, n] x K?  W4, no fused tail; the 256-wide tiles fill between 3/8 and 1/2 of the 256 CUs (so the pairs fill 3/4 .. all
+// of it in ONE round), whole XCD shares, and a K loop long enough to pay for the hand-over (>= 64 groups: down_proj; o_proj's 32 measured no gain on paper:
+// 16 K tiles of ~3.4 us against ~7 us of hand-over and epilogue)
+bool gemm_v6_pair_takes(int m, int n, int k) {
+  if (m < V6_TM || (n % V6_TN) != 0 || (k % 128) != 0 || (k >> 7) < g_v6_pair_min_nit) return false;
+  const long tiles = (long)((m + V6_TM - 1) / V6_TM) * (n / V6_TN);
+  return tiles >= 96 && tiles <= 128 && (tiles % 8) == 0 && (size_t)m * (size_t)k < (1ull << 31);
+}
+size_t gemm_v6_pair_workspace_bytes(int m, int n, int k) {
+  if (!gemm_v6_pair_takes(m, n, k)) return 0;
+  const size_t tiles = (size_t)((m + V6_TM - 1) / V6_TM) * (n / V6_TN);
+  return tiles * (size_t)(V6_TM * V6_TN * 4) + tiles * 64;
+}
+// returns -1 if it does not serve the call (shape, workspace): the caller runs the 256 x 128 blocks
+int launch_gemm_cdna4_v6_pair(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int dtype, void* ws,
+                              size_t ws_bytes, hipStream_t st) {
+  const size_t need = gemm_v6_pair_workspace_bytes(m, n, k);
+  if (need == 0 || ws == nullptr || ws_bytes < need || (reinterpret_cast<uintptr_t>(ws) & 63) != 0) return -1;
+  constexpr int stage2 = 2 * kV6Stage, stg_epi = V6_TM * kV6Pitch;
+  constexpr int smem = stage2 > stg_epi ? stage2 : stg_epi;
+  const int tiles_m = (m + V6_TM - 1) / V6_TM, tiles_n = n / V6_TN;
+  static std::atomic<u32> counter{0};
+  const u32 token = (counter.fetch_add(1, std::memory_order_relaxed) % 0x7FFFFFFEu) + 1u;  // never 0 (= the reset value of a flag)
+  static LdsOptIn optin[2];
+  const int a = dtype == 0 ? 0 : 1;
+  auto kern = dtype == 0 ? gemm_cdna4_v6_pair_kernel<F16> : gemm_cdna4_v6_pair_kernel<BF16>;
+  optin[a].ensure(reinterpret_cast<const void*>(kern), smem);
+  const int lead = g_v6_pair_lead < (k >> 8) ? g_v6_pair_lead : 0;
+  hipLaunchKernelGGL(kern, dim3(2 * tiles_m * tiles_n), dim3(256), smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp, (const uint16_t*)bias,
+                     (uint16_t*)out, m, n, k, tiles_m, tiles_n, lead, (float*)ws, token);
+  return 0;
+}
 
 // weight rows [n_begin, n_end) with 256 x 256 blocks; any m >= 1 (rows past m are clamped / not stored)
 void launch_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,

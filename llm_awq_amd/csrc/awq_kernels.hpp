@@ -111,6 +111,14 @@ bool moe_v6_enabled();  // knob moe_v6 (default on)
 void launch_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
                           int n_end, int dtype, hipStream_t st, int bits = 4, int epi = 0, int szfmt = 0, int tile_n = 256);
 void gemm_v6_set_probe(int v);
+// K split over pairs of 256 x 256 blocks inside one launch (tiles that fill at most half the chip, long K: down_proj at 2048 rows); -1 = not served
+bool gemm_v6_pair_takes(int m, int n, int k);
+int gemm_cdna4_v3_pair_plan(int m, int n, int k);  // awq_gemm_plan.hip: 1 = the prefill call (with its workspace) takes the block-pair K split
+size_t gemm_v6_pair_workspace_bytes(int m, int n, int k);
+int launch_gemm_cdna4_v6_pair(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int dtype, void* ws,
+                              size_t ws_bytes, hipStream_t st);
+void gemm_v6_set_pair_lead(int v);
+void gemm_v6_set_pair_min_nit(int v);
 // awq_gemv_dma.hip: QuantLlamaMLP.forward at decode (gate/up + SiLU * mul + down) in one launch, m = 1; -1 if the shape is not served
 int launch_mlp_decode(const void* x, const void* qw_gu, const void* szh_gu, const void* qw_d, const void* szh_d, const void* bias_d, void* out, int m,
                       int hidden, int ffn, int n_out, int dtype, int* state, hipStream_t st);

@@ -107,6 +107,20 @@ def test_prefill_tile_plan_for_the_llama3_shapes():
     assert plan(100, 4096)[1] == 1 and plan(4, 4096)[0] == 0
 
 
+def test_block_pair_k_split_routing():
+    """host-side query (no GPU): the prefill shapes that run as pairs of 256 x 256 blocks, each summing half of K (awq_gemm_v6.hip) -- 256-wide tiles filling
+    3/8 .. 1/2 of the chip in whole XCD shares and K >= 8192; their workspace = one fp32 tile + one 64-byte flag line per pair"""
+    from llm_awq_amd import _capi
+    L = _capi.lib()
+    assert L.awq_w4a16_gemm_cdna4_pair_plan(2048, 4096, 14336) == 1 and L.awq_w4a16_gemm_cdna4_pair_plan(1536, 4096, 14336) == 1
+    assert L.awq_w4a16_gemm_cdna4_pair_plan(2048, 4096, 11008) == 1                      # Llama-2-7B down_proj
+    assert L.awq_w4a16_gemm_cdna4_pair_plan(1024, 8192, 28672) == 1                      # Llama-3-70B down_proj at 1024 rows: 4 x 32 tiles
+    assert L.awq_w4a16_gemm_cdna4_pair_plan(2048, 4096, 4096) == 0                       # o_proj: 16 K tiles per half do not pay for the hand-over
+    assert L.awq_w4a16_gemm_cdna4_pair_plan(4096, 4096, 14336) == 0 and L.awq_w4a16_gemm_cdna4_pair_plan(1024, 4096, 14336) == 0
+    assert L.awq_w4a16_gemm_cdna4_pair_plan(255, 4096 * 32, 14336) == 0
+    assert L.awq_w4a16_forward_cdna4_workspace_bytes(2048, 4096, 14336) == 128 * (256 * 256 * 4 + 64)
+
+
 def test_one_launch_mlp_plan_and_state_size():
     """host-side queries of awq_w4a16_mlp_decode_cdna4 (QuantLlamaMLP.forward for one row in ONE launch, opt-in): which shapes it serves and how
     much state (epoch / counters + one 8-byte {2 x T, tag} granule per pair of activations) the caller keeps"""

@@ -176,3 +176,83 @@ def test_v6_128_wide_blocks_equal_the_default_plan(ops, dtype):
             ops._capi.tune(gemm_tile_n=0, gemm_splitk=1, gemm_v6_128=1)
         assert_bits(y, y0, 0.001, what=str((K, N, M)))
         assert ((y.float() - y0.float()).norm() / y0.float().norm()).item() < 1e-4
+
+
+# ---------------- K split over pairs of 256 x 256 blocks inside one launch (gemm_cdna4_v6_pair_kernel) ----------------
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,lead,bias", [(1536, 1, False), (2000, 0, True), (2048, 3, False)])
+def test_v6_block_pair_k_split_against_the_oracle(ops, dtype, M, lead, bias):
+    """Tiles that fill at most half the chip run as block PAIRS, each summing half of K; the upper half hands its fp32 accumulators over inside the
+    launch (the reference's split_k_iters + Semaphore, gemm_cuda.cu:546-619, in one kernel).  Oracle check on a K the oracle takes (the knob lowers the
+    K >= 8192 rule), every lead (K tiles the producer half runs less), a shifted last row tile and the bias epilogue; against the unsplit kernels the
+    result differs only by the association of one fp32 add."""
+    N, K = 4096, 1024
+    c = make_case(N, K, dtype, seed=N + K + M, M=M, bias=bias)
+    c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
+    s, z = c["scales"].cuda(), c["scaled_zeros"].cuda()
+    szp = ops.pack_sz_cdna4(s, z, K)
+    b = c["bias"].cuda() if bias else None
+    L = ops._capi.lib()
+    try:
+        ops._capi.tune(gemm_v6_pair_min_nit=8, gemm_v6_pair_lead=lead)
+        assert L.awq_w4a16_gemm_cdna4_pair_plan(M, N, K) == 1 and L.awq_w4a16_forward_cdna4_workspace_bytes(M, N, K) >= (M + 255) // 256 * 16 * 256 * 256 * 4
+        ys = [ops.gemm_cdna4(c["x"].cuda(), c4, s, z, b, szp) for _ in range(3)]  # (the same cached workspace block three times: the flags were reset)
+        ops._capi.tune(gemm_v6_pair=0)
+        assert L.awq_w4a16_gemm_cdna4_pair_plan(M, N, K) == 0
+        y0 = ops.gemm_cdna4(c["x"].cuda(), c4, s, z, b, szp)
+    finally:
+        ops._capi.tune(gemm_v6_pair=1, gemm_v6_pair_min_nit=64, gemm_v6_pair_lead=1)
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])  # deterministic: lower K range + upper K range, always in that order
+    check_forward(ys[0].cpu(), c["x"], c["q"], c["scales"], c["scaled_zeros"], dtype, bias=c["bias"])
+    assert_bits(ys[0], y0, 0.01)
+
+
+def test_v6_block_pair_down_proj_full_size_graph_replay_and_routing(ops):
+    """Llama-3-8B down_proj (14336 -> 4096) at 1536 .. 2048 rows is the shape the pair split exists for: routing (host-side query), agreement with
+    the 256 x 128 blocks it replaces, a workspace full of garbage, and three captured launches sharing one workspace replayed with new inputs."""
+    from llm_awq_amd import synth
+    L = ops._capi.lib()
+    K, N, dtype = 14336, 4096, torch.bfloat16
+    plan = lambda m, n, k: L.awq_w4a16_gemm_cdna4_pair_plan(m, n, k)  # noqa: E731
+    assert [plan(m, N, K) for m in (1024, 1280, 1536, 1792, 2048, 2049, 4096)] == [0, 0, 1, 1, 1, 0, 0]  # 96 .. 128 tiles of 256 x 256, whole XCD shares
+    assert plan(2048, 4096, 4096) == 0 and plan(2048, 6144, 14336) == 0 and plan(2048, 4100, 14336) == 0   # short K (o_proj) / too many tiles / ragged N
+    w = synth.random_wq(K, N, dtype=dtype, seed=77, keep_q=False)
+    c4 = ops.repack_v2_to_cdna4(w["qweight"])
+    szp = ops.pack_sz_cdna4(w["scales"], w["scaled_zeros"], K)
+    g = cuda_gen(5)
+
+    def call(x, ws):
+        out = torch.empty(x.shape[0], N, device="cuda", dtype=dtype)
+        ops._capi.check(L.awq_w4a16_forward_cdna4(x.data_ptr(), c4.data_ptr(), w["scales"].data_ptr(), w["scaled_zeros"].data_ptr(), szp.data_ptr(), None,
+                                                  out.data_ptr(), x.shape[0], N, K, 128, 1, ws.data_ptr() if ws is not None else None,
+                                                  ws.numel() * 4 if ws is not None else 0, torch.cuda.current_stream().cuda_stream))
+        return out
+
+    for M in (1536, 2048):
+        x = torch.randn(M, K, device="cuda", generator=g).to(dtype)
+        y0 = call(x, None)                                   # no workspace: the 256 x 128 blocks
+        wsb = L.awq_w4a16_forward_cdna4_workspace_bytes(M, N, K)
+        ws = torch.randint(-2 ** 31, 2 ** 31 - 1, (wsb // 4,), device="cuda", dtype=torch.int32, generator=g).view(torch.float32)  # garbage, flags included
+        y1 = call(x, ws)
+        assert bool(torch.isfinite(y1.float()).all())
+        assert ((y1.float() - y0.float()).norm() / y0.float().norm()).item() < 2e-4
+        assert_bits(y1, y0, 0.01)
+        assert torch.equal(call(x, ws), y1)
+    # graph: three launches on ONE workspace, replayed
+    M = 2048
+    ws = torch.empty(L.awq_w4a16_forward_cdna4_workspace_bytes(M, N, K) // 4, device="cuda", dtype=torch.float32)
+    xs = [torch.zeros(M, K, device="cuda", dtype=dtype) for _ in range(3)]
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        call(xs[0], ws)
+        torch.cuda.synchronize()
+        gph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gph, stream=side):
+            ys = [call(xx, ws) for xx in xs]
+        for rep in range(3):
+            for xx in xs:
+                xx.copy_(torch.randn(M, K, device="cuda", generator=g).to(dtype))
+            gph.replay()
+            torch.cuda.synchronize()
+            for xx, yy in zip(xs, ys):
+                assert torch.equal(yy, call(xx, ws)), rep
