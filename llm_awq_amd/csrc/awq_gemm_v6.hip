@@ -377,7 +377,7 @@ __device__ __forceinline__ void v6_tile(char* smem, const uint16_t* __restrict__
       for (int s = 0; s < NS; ++s) {
         const f32x4 v = acc[f][s];
         const float* dst = pw + (f * NS + s) * 256;
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");  // (sc1 nt measured no different: profiles/r04_v6_pair.txt)
       }
     asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
     __builtin_amdgcn_s_barrier();
@@ -407,7 +407,7 @@ __device__ __forceinline__ void v6_tile(char* smem, const uint16_t* __restrict__
     for (int f0 = 0; f0 < 16; f0 += 4) {
       f32x4 pv[4 * NS];
 #pragma unroll
-      for (int j = 0; j < 4 * NS; ++j) {
+      for (int j = 0; j < 4 * NS; ++j) {  // (unconditional loads, one wait naming every destination: the compiler does not see the asynchronous writes)
         const float* src = pw + ((f0 + j / NS) * NS + (j % NS)) * 256;
         asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(pv[j]) : "v"(src) : "memory");
       }
