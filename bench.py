@@ -402,7 +402,7 @@ def main():
                              "frac": round(tfl / MFMA_PEAK_TFLOPS, 4), "frac_best_pass": round(tfl_best / MFMA_PEAK_TFLOPS, 4), "traffic": ptraffic,
                              **({"traffic_source": psrc, "traffic_note": "HBM bytes per launch, averaged over the tile-kernel launches of the M = 2048 pass (the PMC passes run with --prefill-m2 0 --prefill-m3 0)"} if ptraffic else {})}}
 
-    pk = "gemm_cdna4_v6_kernel (256-wide tiles) + gemm_cdna4_v4n_kernel (128-wide tiles / remainder)"
+    pk = "gemm_cdna4_v6_kernel (256- / 192- / 128-wide blocks) + gemm_cdna4_v6_pair_kernel (down_proj at <= 2048 rows: pairs of 256-wide blocks, half of K each) + gemm_cdna4_v4n_kernel (split-K launches of short prompts)"
     if not args.no_prefill:
         out["prefill"] = prefill(args.prefill_m, run_main, pk)
         for extra in (args.prefill_m2, args.prefill_m3):
