@@ -147,6 +147,7 @@ int gemm_cdna4_v3_pair_plan(int m, int n, int k) { return g_v6 && g_v6_pair && g
 
 size_t gemm_cdna4_v3_workspace_bytes_w3(int m, int n, int k) {
   if (m <= 8 || (n % 16) != 0 || (k % 128) != 0 || !g_splitk) return 0;
+  if (gemm_cdna4_v3_pair_plan(m, n, k)) return gemm_v6_pair_workspace_bytes(m, n, k);
   if (m < TM) return gemm_v4n_workspace_bytes(m, n, k);
   const Plan p = plan_tiles(m, n, 0);
   if (p.mode == 1) return gemm_v4n_workspace_bytes(m, n, k);
@@ -179,8 +180,8 @@ int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, const v
   // (w3c tiles have no skinny kernel: the masked single-row-tile path of the narrow kernel serves every m > 8)
   if (!szp || !(gemm_cdna4_v3_takes(m, k) || ((bits == 3 || epi) && m > 8)) || (n % 16) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return -1;
   // tiles that fill at most half the chip and a long K: pairs of 256 x 256 blocks, each half of K, combined inside the launch (needs the workspace)
-  if (g_v6 && g_v6_pair && g_splitk && bits == 4 && epi == 0 && !tile_n && !g_tile_n && ws != nullptr &&
-      launch_gemm_cdna4_v6_pair(x, qw, szp, bias, out, m, n, k, dtype, ws, ws_bytes, st) == 0)
+  if (g_v6 && g_v6_pair && g_splitk && (bits == 4 || bits == 3) && epi == 0 && !tile_n && !g_tile_n && ws != nullptr &&
+      launch_gemm_cdna4_v6_pair(x, qw, szp, bias, out, m, n, k, dtype, ws, ws_bytes, st, bits) == 0)
     return 0;
   const bool allow192 = g_v6 != 0 && g_v6_192 != 0 && bits == 4 && m >= TM;
   Plan p = m < TM ? Plan{1, 0} : plan_tiles(m, n, tile_n ? tile_n : g_tile_n, allow192);  // m < 256: only the narrow-tile kernel masks rows

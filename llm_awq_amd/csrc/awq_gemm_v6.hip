@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256) void moe_gemm_cdna4_v6_kernel(const uint16_t* 
 // token; the reader resets it, so a captured launch replays), which adds them and runs the epilogue -- the role of the reference's split_k_iters + Semaphore
 // (gemm_cuda.cu:546-619) inside one launch, no second kernel.  The producers have the LOWER block indices of an XCD's share (dispatched first: a waiting
 // consumer can never keep its producer off the chip) and `lead` fewer K tiles, so their partials are on the way while the consumers finish.
-template <typename DT>
+template <typename DT, int BITS>
 __global__ __launch_bounds__(256) void gemm_cdna4_v6_pair_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw, const u32* __restrict__ szp,
                                                                  const uint16_t* __restrict__ bias, uint16_t* __restrict__ out, int M, int N, int K,
                                                                  int tiles_m, int tiles_n, int lead, float* __restrict__ ws, u32 token) {
@@ -627,8 +627,8 @@ __global__ __launch_bounds__(256) void gemm_cdna4_v6_pair_kernel(const uint16_t*
   float* part = ws + (size_t)tile * (size_t)(V6_TM * V6_TN);
   u32x2* flag = reinterpret_cast<u32x2*>(ws + (size_t)T * (size_t)(V6_TM * V6_TN)) + (size_t)tile * 8;  // one 64-byte line per pair
   const int m0 = min(tm * V6_TM, M - V6_TM), n0 = tn * V6_TN;
-  if (producer) v6_tile<DT, 4, 0, 0, 4, 1>(smem, x, qw, szp, nullptr, out, N, K, m0, n0, N, 0, 0, M, n_lo, n_up, part, flag, token);
-  else v6_tile<DT, 4, 0, 0, 4, 2>(smem, x, qw, szp, bias, out, N, K, m0, n0, N, 0, 0, M, 0, n_lo, part, flag, token);
+  if (producer) v6_tile<DT, BITS, 0, 0, 4, 1>(smem, x, qw, szp, nullptr, out, N, K, m0, n0, N, 0, 0, M, n_lo, n_up, part, flag, token);
+  else v6_tile<DT, BITS, 0, 0, 4, 2>(smem, x, qw, szp, bias, out, N, K, m0, n0, N, 0, 0, M, 0, n_lo, part, flag, token);
 }
 
 namespace {
@@ -640,7 +640,7 @@ void gemm_v6_set_probe(int v) { g_v6_probe = v; }
 void gemm_v6_set_pair_lead(int v) { g_v6_pair_lead = v < 0 ? 0 : v; }
 void gemm_v6_set_pair_min_nit(int v) { g_v6_pair_min_nit = v < 8 ? 8 : v; }
 
-// Does the block-pair K split serve [m, n] x K?  W4, no fused tail; the 256-wide tiles fill between 3/8 and 1/2 of the 256 CUs (so the pairs fill 3/4 .. all
+// Does the block-pair K split serve [m, n] x K?  W4 or W3 tiles, no fused tail; the 256-wide tiles fill between 3/8 and 1/2 of the 256 CUs (so the pairs fill 3/4 .. all
 // of it in ONE round), whole XCD shares, and a K loop long enough to pay for the hand-over (>= 64 groups: down_proj; o_proj's 32 measured no gain on paper:
 // 16 K tiles of ~3.4 us against ~7 us of hand-over and epilogue)
 bool gemm_v6_pair_takes(int m, int n, int k) {
@@ -655,7 +655,7 @@ size_t gemm_v6_pair_workspace_bytes(int m, int n, int k) {
 }
 // returns -1 if it does not serve the call (shape, workspace): the caller runs the 256 x 128 blocks
 int launch_gemm_cdna4_v6_pair(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int dtype, void* ws,
-                              size_t ws_bytes, hipStream_t st) {
+                              size_t ws_bytes, hipStream_t st, int bits) {
   const size_t need = gemm_v6_pair_workspace_bytes(m, n, k);
   if (need == 0 || ws == nullptr || ws_bytes < need || (reinterpret_cast<uintptr_t>(ws) & 63) != 0) return -1;
   constexpr int stage2 = 2 * kV6Stage, stg_epi = V6_TM * kV6Pitch;
@@ -663,10 +663,13 @@ int launch_gemm_cdna4_v6_pair(const void* x, const void* qw, const void* szp, co
   const int tiles_m = (m + V6_TM - 1) / V6_TM, tiles_n = n / V6_TN;
   static std::atomic<u32> counter{0};
   const u32 token = (counter.fetch_add(1, std::memory_order_relaxed) % 0x7FFFFFFEu) + 1u;  // never 0 (= the reset value of a flag)
-  static LdsOptIn optin[2];
-  const int a = dtype == 0 ? 0 : 1;
-  auto kern = dtype == 0 ? gemm_cdna4_v6_pair_kernel<F16> : gemm_cdna4_v6_pair_kernel<BF16>;
-  optin[a].ensure(reinterpret_cast<const void*>(kern), smem);
+  using Kern = void (*)(const uint16_t*, const u32*, const u32*, const uint16_t*, uint16_t*, int, int, int, int, int, int, float*, u32);
+  static const Kern kerns[2][2] = {{gemm_cdna4_v6_pair_kernel<F16, 4>, gemm_cdna4_v6_pair_kernel<F16, 3>},
+                                   {gemm_cdna4_v6_pair_kernel<BF16, 4>, gemm_cdna4_v6_pair_kernel<BF16, 3>}};
+  static LdsOptIn optin[2][2];
+  const int a = dtype == 0 ? 0 : 1, b3 = bits == 3 ? 1 : 0;
+  const Kern kern = kerns[a][b3];
+  optin[a][b3].ensure(reinterpret_cast<const void*>(kern), smem);
   const int lead = g_v6_pair_lead < (k >> 8) ? g_v6_pair_lead : 0;
   hipLaunchKernelGGL(kern, dim3(2 * tiles_m * tiles_n), dim3(256), smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp, (const uint16_t*)bias,
                      (uint16_t*)out, m, n, k, tiles_m, tiles_n, lead, (float*)ws, token);

@@ -116,7 +116,7 @@ bool gemm_v6_pair_takes(int m, int n, int k);
 int gemm_cdna4_v3_pair_plan(int m, int n, int k);  // awq_gemm_plan.hip: 1 = the prefill call (with its workspace) takes the block-pair K split
 size_t gemm_v6_pair_workspace_bytes(int m, int n, int k);
 int launch_gemm_cdna4_v6_pair(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int dtype, void* ws,
-                              size_t ws_bytes, hipStream_t st);
+                              size_t ws_bytes, hipStream_t st, int bits = 4);
 void gemm_v6_set_pair_lead(int v);
 void gemm_v6_set_pair_min_nit(int v);
 // awq_gemv_dma.hip: QuantLlamaMLP.forward at decode (gate/up + SiLU * mul + down) in one launch, m = 1; -1 if the shape is not served

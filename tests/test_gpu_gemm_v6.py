@@ -256,3 +256,33 @@ def test_v6_block_pair_down_proj_full_size_graph_replay_and_routing(ops):
             torch.cuda.synchronize()
             for xx, yy in zip(xs, ys):
                 assert torch.equal(yy, call(xx, ws)), rep
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_v6_block_pair_k_split_w3_tiles(ops, dtype):
+    """the same block-pair K split on the 3-bit tiles (awq_w3a16_forward; BASELINE.json config 3: Llama-2-7B W3A16, down_proj 11008 -> 4096 at 2048 rows)"""
+    K, N, M = 1024, 4096, 1536
+    g = cuda_gen(9)
+    q = torch.randint(0, 8, (N, K), dtype=torch.uint8, device="cuda", generator=g)
+    qw = ops.pack_w3(q)
+    s = ((5.2 + 0.8 * torch.rand(K // 128, N, device="cuda", generator=g)) * 0.02 / 7).to(dtype)
+    z = -(s * torch.randint(2, 6, (K // 128, N), device="cuda", generator=g).float()).to(dtype)
+    szp = ops.pack_sz_cdna4(s, z, K)
+    W = ops.dequant_w3(qw, s, z).float()   # bit exact vs the oracle: tests/test_w3.py, tests/test_gpu_oracle_fullsize.py
+    x = torch.randn(M, K, device="cuda", generator=g).to(dtype)
+    bias = (torch.randn(N, device="cuda", generator=g) * 0.02).to(dtype)
+    L = ops._capi.lib()
+    try:
+        ops._capi.tune(gemm_v6_pair_min_nit=8)
+        assert L.awq_w3a16_forward_workspace_bytes(M, N, K) == 96 * (256 * 256 * 4 + 64)
+        y = ops.forward_w3(x, qw, s, z, szp, bias)
+        assert torch.equal(y, ops.forward_w3(x, qw, s, z, szp, bias))
+        ops._capi.tune(gemm_v6_pair=0)
+        y0 = ops.forward_w3(x, qw, s, z, szp, bias)
+    finally:
+        ops._capi.tune(gemm_v6_pair=1, gemm_v6_pair_min_nit=64)
+    ref = (x.float() @ W.t()).to(dtype) + bias
+    assert ((y.float() - ref.float()).norm() / ref.float().norm()).item() < (2.5e-3 if dtype == torch.bfloat16 else 4e-4)
+    assert_bits(ref, y, 0.03)
+    assert_bits(y, y0, 0.01)
+    assert ops._capi.lib().awq_w4a16_gemm_cdna4_pair_plan(2048, 4096, 11008) == 1  # (the Llama-2-7B down_proj shape itself)
