@@ -293,6 +293,9 @@ def _make_pass(eng, shards, xs, reducer, dist, world):
     return run_pass
 
 
+_CLOCK_RAMP_STEPS = 60  # untimed steps before the timed region, the W warmup steps included (every rank runs the same count: the collectives stay matched)
+
+
 def _timed(run_pass, steps, warmup, dist, dev, use_graph, rank):
     """K timed steps bracketed by barrier + synchronize on both sides, max over ranks; returns (ms_per_step, graphed)"""
     side = torch.cuda.Stream(device=dev)
@@ -319,6 +322,8 @@ def _timed(run_pass, steps, warmup, dist, dev, use_graph, rank):
         if flag.item() == 0:
             graph = None
         step = (lambda: graph.replay()) if graph is not None else run_pass
+        for _ in range(max(0, _CLOCK_RAMP_STEPS - warmup)):  # (untimed, as in bench.py's single-GPU leg: a --warmup 5 ends before the chip has left its idle clocks)
+            step()
         for _ in range(warmup):
             step()
         torch.cuda.synchronize()
