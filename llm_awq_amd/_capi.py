@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libawq_cdna4.so")
 
 AWQ_F16, AWQ_BF16 = 0, 1
+AWQ_ERR_WORKSPACE = -7  # include/awq_cdna4.h
 AWQ_MLP_DECODE_COUNTER_BYTES = 16384  # include/awq_cdna4.h: the granule array of awq_w4a16_mlp_decode_cdna4's state starts here
 _lib = None
 

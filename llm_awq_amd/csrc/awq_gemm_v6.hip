@@ -645,6 +645,7 @@ void gemm_v6_set_pair_min_nit(int v) { g_v6_pair_min_nit = v < 8 ? 8 : v; }
 // 16 K tiles of ~3.4 us against ~7 us of hand-over and epilogue)
 bool gemm_v6_pair_takes(int m, int n, int k) {
   if (m < V6_TM || (n % V6_TN) != 0 || (k % 128) != 0 || (k >> 7) < g_v6_pair_min_nit) return false;
+  if (device_cu_count() != 256) return false;  // the one-round co-residency of a pair (and its XCD = blockIdx & 7 placement) is the whole MI355X's
   const long tiles = (long)((m + V6_TM - 1) / V6_TM) * (n / V6_TN);
   return tiles >= 96 && tiles <= 128 && (tiles % 8) == 0 && (size_t)m * (size_t)k < (1ull << 31);
 }

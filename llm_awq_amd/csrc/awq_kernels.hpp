@@ -23,6 +23,21 @@ struct LdsOptIn {
     w.fetch_or(bit, std::memory_order_release);
   }
 };
+// Compute units of the current device (cached per ordinal).  The plans that assume ONE residency round on the whole MI355X (the block-pair
+// K split: 256 blocks, pair partners on one XCD) ask it: a partitioned (CPX / NPS), CU-masked or other part falls back to plans that do
+// not depend on co-residency.  Without a device (host-side plan queries in CPU tests) the answer is the MI355X's 256.
+inline int device_cu_count() {
+  static std::atomic<int> cached[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  std::atomic<int>& c = cached[dev & 63];
+  int v = c.load(std::memory_order_relaxed);
+  if (v == 0) {
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    c.store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
 // layout: 0 = reference v2 interleave, 1 = cdna4 interleave (bf16 only)
 // szp: optional packed {scale | scaled_zero << 16} u32 [N/16][K/128][16] (cdna4 layout only), else nullptr
 int launch_gemv(const void* x, const void* qw, const void* s, const void* z, const void* szp, void* out, int m, int n,

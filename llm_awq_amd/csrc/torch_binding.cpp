@@ -84,6 +84,10 @@ struct CacheEntry {
   hipStream_t build_stream = nullptr;
   bool settled = false;
   bool inplace = false;  // AWQ_CDNA4_INPLACE=1: c4 IS the caller's qweight storage, converted where it lies (no second copy)
+  uint32_t vc4 = 0;      // in-place entries: c4's version counter at conversion.  c4 is the module's own tensor, and `.detach()` / `.data` / view aliases
+                         // share its counter: a later value means the caller wrote fresh v2 bytes over the converted ones (copy_, load_state_dict)
+  // the converted bytes are still what the cache put there (false: overwritten since -- nothing to restore, nothing to follow)
+  bool inplace_intact() const { return inplace && c4.defined() && tensor_version(c4) == vc4; }
   explicit CacheEntry(const torch::Tensor& tw) : w(tw.getIntrusivePtr()), vw(tensor_version(tw)) {}
 };
 std::mutex g_cache_mu;
@@ -115,6 +119,11 @@ bool cache_enabled() {
 // call would take the permuted bytes for v2 data and permute them again
 void restore_inplace(CacheEntry& e) {
   if (!e.inplace || !e.c4.defined()) return;
+  if (!e.inplace_intact()) {  // overwritten with fresh v2 bytes since the conversion: running the cdna4 -> v2 permutation over them would corrupt them
+    e.inplace = false;
+    e.c4 = at::Tensor();
+    return;
+  }
   // (not tied to the tensor the entry last followed: that may have been a temporary alias -- `.detach()`, a view -- that is gone, while the
   // module's own tensor over the same storage is alive; e.c4 holds the storage)
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(e.c4.device());
@@ -139,7 +148,7 @@ void drop_entry(std::unordered_map<const void*, CacheEntry>::iterator it) {
 // is this exact buffer (data pointer incl. storage offset) currently held converted in place?  (g_cache_mu held by the caller)
 bool inplace_converted_locked(const torch::Tensor& kernel) {
   auto it = g_cache.find(kernel.data_ptr());
-  return it != g_cache.end() && it->second.inplace && it->second.c4.defined() && it->second.c4.storage().is_alias_of(kernel.storage());
+  return it != g_cache.end() && it->second.inplace_intact() && it->second.c4.storage().is_alias_of(kernel.storage());
 }
 // the reference-layout kernels must never read a buffer the cache converted where it lies: callers that cannot be served by the cdna4 path
 // (cache switched off, fp32 scales, a failed scale pack) get an error that names the way out instead of silently wrong products
@@ -167,9 +176,11 @@ bool cdna4_view(const torch::Tensor& kernel, const torch::Tensor& scales, const 
   auto it = g_cache.find(key);
   if (it != g_cache.end()) {
     auto lw = it->second.w.lock();
-    if (lw.get() != kernel.unsafeGetTensorImpl() || it->second.vw != tensor_version(kernel)) {  // address re-used or edited in place
+    // an in-place entry whose storage was overwritten since the conversion (the shared version counter moved) is stale whichever alias asks
+    const bool overwritten = it->second.inplace && it->second.c4.defined() && !it->second.inplace_intact();
+    if (overwritten || lw.get() != kernel.unsafeGetTensorImpl() || it->second.vw != tensor_version(kernel)) {  // address re-used or edited in place
       CacheEntry& old = it->second;
-      const bool same_bytes = old.inplace && old.c4.defined() && old.c4.storage().is_alias_of(kernel.storage());
+      const bool same_bytes = old.inplace_intact() && old.c4.storage().is_alias_of(kernel.storage());
       if (same_bytes && lw.get() != kernel.unsafeGetTensorImpl()) {
         // ANOTHER tensor over the converted bytes (a view, .detach(), .data, load_state_dict(assign=True) of an alias, a compile wrapper):
         // the storage already holds the cdna4 interleave -- converting "again" would permute it twice.  The entry follows the caller
@@ -177,7 +188,7 @@ bool cdna4_view(const torch::Tensor& kernel, const torch::Tensor& scales, const 
         old.w = c10::weak_intrusive_ptr<c10::TensorImpl>(kernel.getIntrusivePtr());
         old.vw = tensor_version(kernel);
       } else {
-        TORCH_CHECK(!(capturing && same_bytes), "awq_inference_engine: an in-place converted qweight was modified during a graph capture");
+        TORCH_CHECK(!(capturing && (same_bytes || overwritten)), "awq_inference_engine: an in-place converted qweight was modified during a graph capture");
         if (capturing) return false;
         // (same impl, new version: the caller wrote fresh v2 bytes over the buffer -- nothing to restore; a foreign tensor at a re-used
         // address: the old entry's storage is not ours to touch either)
@@ -195,7 +206,17 @@ bool cdna4_view(const torch::Tensor& kernel, const torch::Tensor& scales, const 
       // (the key is the tensor's data pointer INCLUDING its storage offset: sharded / flattened parameter buffers are views)
       // an in-place entry lives as long as anybody else holds the converted storage: the tensor it last followed may have been a temporary
       // alias, and forgetting the entry while the module's own tensor is alive would have the next call permute the bytes a second time
-      if (cur->second.inplace && cur->second.c4.defined() && (cur->second.c4.use_count() > 1 || cur->second.c4.storage().use_count() > 1)) continue;  // (c4 IS the caller's tensor: its own handle counts once)
+      if (cur->second.inplace && cur->second.c4.defined()) {
+        // c4 IS the caller's tensor: the entry's own handle counts once, and so does the temporary `lw` when the entry still follows that tensor.
+        // Anybody else (the module, an alias over the storage) keeps the entry alive; with nobody left the converted bytes are unreachable:
+        // drop without restoring, the storage goes back to the allocator
+        const size_t own = 1 + ((lw && lw.get() == cur->second.c4.unsafeGetTensorImpl()) ? 1 : 0);
+        const size_t impls = 1 + ((lw && lw.get() != cur->second.c4.unsafeGetTensorImpl() && lw->storage().is_alias_of(cur->second.c4.storage())) ? 1 : 0);
+        if (cur->second.c4.use_count() > own || cur->second.c4.storage().use_count() > impls) continue;
+        lw.reset();
+        drop_entry(cur);
+        continue;
+      }
       if (!lw || lw->data() != cur->first) drop_entry(cur);
     }
     const int64_t need = (int64_t)kernel.nbytes();
@@ -207,6 +228,7 @@ bool cdna4_view(const torch::Tensor& kernel, const torch::Tensor& scales, const 
       if (hipMemcpyAsync(kernel.data_ptr(), tmp.data_ptr(), kernel.nbytes(), hipMemcpyDeviceToDevice, stream) != hipSuccess) return false;
       e.c4 = kernel;  // (a raw copy: the tensor's version counter does not move, so the entry stays valid)
       e.inplace = true;
+      e.vc4 = tensor_version(kernel);
     } else {
       e.c4 = torch::empty_like(kernel);
       if (awq_repack_v2_to_cdna4(kernel.data_ptr(), e.c4.data_ptr(), (int)n, (int)k, (void*)stream) != AWQ_OK) return false;
@@ -697,7 +719,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     std::lock_guard<std::mutex> lock(g_cache_mu);
     auto it = g_cache.find(kernel.data_ptr());
     if (it == g_cache.end()) return false;
-    const bool was = it->second.inplace;
+    const bool was = it->second.inplace_intact();  // (overwritten since the conversion: the buffer holds v2 data, nothing is restored)
     restore_inplace(it->second);
     drop_entry(it);
     return was;

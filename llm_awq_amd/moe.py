@@ -9,7 +9,7 @@ ranges go to the kernel as a device int32 [E + 1] offsets array.
 """
 from __future__ import annotations
 
-from typing import Callable, Optional, Sequence
+from typing import Optional, Sequence
 
 import torch
 import torch.nn as nn
@@ -40,16 +40,20 @@ class _LayoutMarker:
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
         marker = state_dict.pop(prefix + "qweight_layout", None)
+        had_qweight = (prefix + "qweight") in state_dict
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
-        self.layout = "cdna4" if (marker is not None and int(marker) == 1) else "v2"
-        self.sz_cdna4 = None  # rebuilt from the loaded scales at the next forward
+        # the layout follows the qweight bytes: a partial load (strict=False, a dict that only carries scales) leaves them -- and the layout
+        # they are in -- untouched; resetting it would have an already converted module permute its bytes a second time
+        if had_qweight:
+            self.layout = "cdna4" if (marker is not None and int(marker) == 1) else "v2"
+        self.sz_cdna4 = None  # rebuilt from the (possibly new) scales at the next forward
 
 
 class GroupedWQLinear(_LayoutMarker, nn.Module):
-    """E stacked WQLinear experts with one grouped launch.  `matmul(x_sorted, qweight, scales, scaled_zeros, offsets)`
-    defaults to the HIP engine; CPU tests inject the oracle."""
+    """E stacked WQLinear experts with one grouped launch on the HIP engine (no other arithmetic path: the CPU tests of the routing glue
+    subclass this in tests/helpers.py and override `forward` with the oracle)."""
 
-    def __init__(self, experts: Sequence[WQLinear], matmul: Optional[Callable] = None):
+    def __init__(self, experts: Sequence[WQLinear]):
         super().__init__()
         e0 = experts[0]
         assert all(e.w_bit == 4 and e.layout == e0.layout and e.bias is None for e in experts)
@@ -59,7 +63,6 @@ class GroupedWQLinear(_LayoutMarker, nn.Module):
         self.register_buffer("qweight", torch.stack([e.qweight for e in experts]).contiguous())
         self.register_buffer("scales", torch.stack([e.scales for e in experts]).contiguous())
         self.register_buffer("scaled_zeros", torch.stack([e.scaled_zeros for e in experts]).contiguous())
-        self._matmul = matmul
         self.sz_cdna4 = None  # stacked packed scales int32 [E, N/16, K/128, 16], built lazily for the cdna4 layout
 
     @torch.no_grad()
@@ -73,8 +76,6 @@ class GroupedWQLinear(_LayoutMarker, nn.Module):
 
     @torch.no_grad()
     def forward(self, x_sorted: torch.Tensor, expert_offsets: torch.Tensor) -> torch.Tensor:
-        if self._matmul is not None:
-            return self._matmul(x_sorted, self.qweight, self.scales, self.scaled_zeros, expert_offsets)
         eng = load_engine()
         if self.layout == "cdna4":
             if self.sz_cdna4 is None or self.sz_cdna4.device != self.scales.device:
@@ -149,11 +150,13 @@ class SparseMoeMLP(nn.Module):
     def _h(self, xs, offsets):
         if self.gate_up is not None:
             return self.gate_up(xs, offsets)
-        a, b = self.w1(xs, offsets), self.w3(xs, offsets)
-        if a.is_cuda:  # the SiLU * mul tail as the HIP kernel of the dense path's epilogue (no torch arithmetic on the hot path)
-            from . import ops
-            return ops.silu_mul(a, b)
-        return torch.nn.functional.silu(a) * b  # (CPU: only reachable with injected oracle matmuls -- the tests' seam)
+        return self._silu_mul(self.w1(xs, offsets), self.w3(xs, offsets))
+
+    @staticmethod
+    def _silu_mul(a, b):
+        """the SiLU * mul tail as the HIP kernel of the dense path's epilogue (no torch arithmetic on the hot path; raises without a GPU)"""
+        from . import ops
+        return ops.silu_mul(a, b)
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor, router_logits: torch.Tensor) -> torch.Tensor:

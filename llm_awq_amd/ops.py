@@ -436,12 +436,20 @@ def moe_mlp_gate_up_cdna4(x_sorted, qweight_interleaved, scales, scaled_zeros, s
     e, n2, k = qweight_interleaved.shape[0], qweight_interleaved.shape[1] * 4, qweight_interleaved.shape[2]
     t = x_sorted.shape[0]
     out = torch.empty(t, n2 // 2, dtype=x_sorted.dtype, device=x_sorted.device)
+    # the fused grouped launch serves >= 256 sorted rows and needs no scratch; below that -- and whenever the launch declines a large call
+    # (t * k or n * k / 8 beyond 2^31, knob moe_v6 = 0: AWQ_ERR_WORKSPACE) -- the unfused route wants a [T, 2F] buffer: allocate and retry once
     scratch = torch.empty(t, n2, dtype=x_sorted.dtype, device=x_sorted.device) if 0 < t < 256 else None
     with torch.cuda.device(x_sorted.device):
-        _capi.check(_capi.lib().awq_w4a16_moe_mlp_gate_up_cdna4(
-            x_sorted.data_ptr(), qweight_interleaved.data_ptr(), scales.data_ptr(), scaled_zeros.data_ptr(), sz_packed.data_ptr(),
-            expert_offsets.data_ptr(), out.data_ptr(), scratch.data_ptr() if scratch is not None else None,
-            scratch.numel() * 2 if scratch is not None else 0, t, e, n2, k, scales.shape[1], group_size, _dt(x_sorted), _stream(x_sorted)))
+        for attempt in (0, 1):
+            rc = _capi.lib().awq_w4a16_moe_mlp_gate_up_cdna4(
+                x_sorted.data_ptr(), qweight_interleaved.data_ptr(), scales.data_ptr(), scaled_zeros.data_ptr(), sz_packed.data_ptr(),
+                expert_offsets.data_ptr(), out.data_ptr(), scratch.data_ptr() if scratch is not None else None,
+                scratch.numel() * 2 if scratch is not None else 0, t, e, n2, k, scales.shape[1], group_size, _dt(x_sorted), _stream(x_sorted))
+            if rc == _capi.AWQ_ERR_WORKSPACE and scratch is None and attempt == 0 and t > 0:
+                scratch = torch.empty(t, n2, dtype=x_sorted.dtype, device=x_sorted.device)
+                continue
+            _capi.check(rc)
+            break
     return out
 
 

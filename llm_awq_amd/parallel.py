@@ -90,11 +90,12 @@ class TPWQLinear(nn.Module):
     fp32 partials: ~2e-6.)
     Column mode (N-sharded): the shard is a plain WQLinear on its output rows; no communication.
 
-    `partial(x, qweight_v2, scales, scaled_zeros) -> float32` / `matmul(...) -> T` are TEST SEAMS: the CPU tests (no GPU in that container)
-    inject the oracle there; the product path never has them set and runs the HIP kernels."""
+    The arithmetic hooks `_shard_product` (column mode: T output of the shard), `_shard_partial` (row mode: fp32 partial) and `_round_bias`
+    run the HIP kernels and nothing else; the CPU tests of the sharding / collective logic (no GPU in that container) override them with the
+    oracle in a subclass that lives in tests/helpers.py, not here."""
 
     def __init__(self, full: WQLinear, mode: str, group=None, world: Optional[int] = None, rank: Optional[int] = None,
-                 matmul: Optional[Callable] = None, reducer: Optional[Callable] = None, partial: Optional[Callable] = None):
+                 reducer: Optional[Callable] = None):
         super().__init__()
         import torch.distributed as dist
 
@@ -125,8 +126,7 @@ class TPWQLinear(nn.Module):
         if relayout:
             full.to_cdna4()
         cdna4_able = n_local % 16 == 0 and k_local % 128 == 0 and self.shard.group_size == 128 and s.dtype in (torch.float16, torch.bfloat16)
-        self._matmul, self._partial = matmul, partial
-        if qw.is_cuda and matmul is None and partial is None:
+        if qw.is_cuda:
             if mode == "row" and not cdna4_able:
                 raise ValueError("a K-sharded WQLinear runs the cdna4 kernels' fp32-partial epilogue: it needs out_features % 16 == 0, "
                                  "group_size 128 and fp16 / bf16 scales")
@@ -139,7 +139,7 @@ class TPWQLinear(nn.Module):
         # reducer: an llm_awq_amd.oneshot.OneShotAllReduce (reduce_f32) or None = torch.distributed.all_reduce on the fp32 partial (RCCL on
         # GPUs, gloo in the CPU tests).  Default on GPUs with world > 1: the group's shared one-shot reducer, built on the SHARD's device
         # (AWQ_ONESHOT=0, a box without fine-grained memory / hipIpc, or a world that is not the group's -> None)
-        if (reducer is None and mode == "row" and self.world > 1 and qw.is_cuda and matmul is None and partial is None and have_dist
+        if (reducer is None and mode == "row" and self.world > 1 and qw.is_cuda and have_dist
                 and self.world == dist.get_world_size(group)):
             reducer = default_reducer(dist, group, qw.device)
         self._reducer = reducer
@@ -154,16 +154,21 @@ class TPWQLinear(nn.Module):
                 y32 = self._reducer(y32)
             else:
                 dist.all_reduce(y32, op=dist.ReduceOp.SUM, group=self.group)
-        if y32.is_cuda:
-            from . import ops
-            return ops.round_bias_f32(y32, dtype, self.bias)
-        y = y32.to(dtype)  # (CPU test seam only: the product path's rounding + bias is awq_round_bias_f32)
-        return y + self.bias if self.bias is not None else y
+        return self._round_bias(y32, dtype)
+
+    def _round_bias(self, y32, dtype):
+        """T(fp32 sum) + bias in T: awq_round_bias_f32"""
+        from . import ops
+        return ops.round_bias_f32(y32, dtype, self.bias)
+
+    def _shard_product(self, x):
+        """column mode: the shard's T output (a plain WQLinear on its output rows)"""
+        return self.shard(x)
 
     @torch.no_grad()
     def forward(self, x, input_is_sharded: bool = False):
         if self.mode == "column":
-            y = self.shard(x) if self._matmul is None else self._matmul(x, self.shard.qweight, self.shard.scales, self.shard.scaled_zeros)
+            y = self._shard_product(x)
             return y + self.bias if self.bias is not None else y
         return self._reduce_round(self.partial(x, input_is_sharded), x.dtype)
 
@@ -173,24 +178,22 @@ class TPWQLinear(nn.Module):
         assert self.mode == "row"
         if not input_is_sharded:
             x = x[..., self.bounds[0]: self.bounds[1]].contiguous()
-        if self._partial is not None:
-            y32 = self._partial(x, self.shard.qweight, self.shard.scales, self.shard.scaled_zeros)
-        elif self._matmul is not None:  # (legacy seam: T-rounded partials, the pre-round-4 numerics -- kept for the comparison test)
-            y32 = self._matmul(x, self.shard.qweight, self.shard.scales, self.shard.scaled_zeros).float()
-        else:
-            from . import ops
-            sh = self.shard
-            if not x.is_contiguous():
-                x = x.contiguous()
-            key = sh._side_key()
-            if sh.sz_cdna4 is None or getattr(sh, "_sz_key", None) != key:
-                sh.sz_cdna4 = ops.pack_sz_cdna4(sh.scales, sh.scaled_zeros, sh.in_features)
-                sh.szh_cdna4, sh._sz_key = None, key
-            if sh.szh_cdna4 is None and not torch.cuda.is_current_stream_capturing():
-                sh._build_szh(ops)
-            szh = sh.szh_cdna4 if (sh.szh_cdna4 is not None and sh.szh_cdna4 is not False) else None
-            y32 = ops.partial_cdna4(x, sh.qweight, sh.sz_cdna4, szh)
-        return y32
+        return self._shard_partial(x)
+
+    def _shard_partial(self, x):
+        """the K shard's product as unrounded fp32 (awq_w4a16_partial_cdna4 on the shard's cdna4 buffers)"""
+        from . import ops
+        sh = self.shard
+        if not x.is_contiguous():
+            x = x.contiguous()
+        key = sh._side_key()
+        if sh.sz_cdna4 is None or getattr(sh, "_sz_key", None) != key:
+            sh.sz_cdna4 = ops.pack_sz_cdna4(sh.scales, sh.scaled_zeros, sh.in_features)
+            sh.szh_cdna4, sh._sz_key = None, key
+        if sh.szh_cdna4 is None and not torch.cuda.is_current_stream_capturing():
+            sh._build_szh(ops)
+        szh = sh.szh_cdna4 if (sh.szh_cdna4 is not None and sh.szh_cdna4 is not False) else None
+        return ops.partial_cdna4(x, sh.qweight, sh.sz_cdna4, szh)
 
     def check(self):
         """after a synchronize: raise if a one-shot round of this module's reducer timed out (its output was poisoned with NaNs; every

@@ -209,6 +209,7 @@ class WQLinear(nn.Module):
         self.sz_cdna4 = eng.pack_sz_cdna4(self.scales, self.scaled_zeros, self.in_features)
         self._sz_key = self._side_key()  # the first forward finds both side buffers current (no rebuild, no host sync)
         self._build_szh(eng)
+        self._decode_served = {}
         self.layout = "cdna4"
         return self
 
@@ -228,6 +229,7 @@ class WQLinear(nn.Module):
             return self
         self.qweight = load_engine().repack_cdna4_to_v2(self.qweight)
         self.sz_cdna4 = self.szh_cdna4 = None
+        self._decode_served = {}
         self.layout = "v2"
         return self
 
@@ -240,6 +242,7 @@ class WQLinear(nn.Module):
         marker = state_dict.pop(prefix + "qweight_layout", None)
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
         self.szh_cdna4 = None
+        self._decode_served = {}  # (the plan verdicts are memoised per row count: re-asked after a load / layout change, e.g. when test knobs moved)
         if self.w_bit == 3:
             self.layout, self.sz_cdna4 = "w3c", None
         elif marker is not None and int(marker) == 1:

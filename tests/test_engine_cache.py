@@ -219,3 +219,71 @@ def test_in_place_entry_follows_aliases_and_refuses_what_it_cannot_serve(eng):
     finally:
         eng.cdna4_cache_enable(True)
         eng.cdna4_cache_inplace(False)
+
+
+def test_in_place_entry_overwritten_then_called_through_an_alias(eng):
+    """convert in place, overwrite the buffer with fresh v2 bytes (`qw.copy_`, what load_state_dict does), then call through an
+    ALIAS (`.detach()`): the alias shares the version counter, the entry is stale -- reconverted, never followed (the cdna4 kernels on v2
+    bytes would be silently wrong).  The same state through cdna4_is_converted / cdna4_restore / cdna4_cache_clear: overwritten bytes are v2
+    data, nothing is "restored" over them."""
+    N, K = 256, 1280
+    a, b = make_case(N, K, torch.bfloat16, seed=41, M=4), make_case(N, K, torch.bfloat16, seed=42, M=4)
+    try:
+        eng.cdna4_cache_inplace(True)
+        qw, s, z = _dev(a)
+        x = a["x"].cuda()
+        check_forward(eng.gemv_forward_cuda_new(x, qw, s, z, 4, N, K, 128).cpu(), a["x"], a["q"], a["scales"], a["scaled_zeros"], torch.bfloat16)
+        assert eng.cdna4_is_converted(qw) is True
+        # fresh v2 bytes over the converted ones; first consumer is an alias
+        qw.copy_(b["qweight"].cuda())
+        s.copy_(b["scales"].cuda())
+        z.copy_(b["scaled_zeros"].cuda())
+        assert eng.cdna4_is_converted(qw.detach()) is False, "overwritten: the buffer holds v2 data again"
+        y = eng.gemv_forward_cuda_new(x, qw.detach(), s, z, 4, N, K, 128).cpu()
+        check_forward(y, a["x"], b["q"], b["scales"], b["scaled_zeros"], torch.bfloat16)
+        assert eng.cdna4_is_converted(qw) is True
+        # overwrite again, then restore / clear: the fresh v2 bytes must come through untouched
+        qw.copy_(a["qweight"].cuda())
+        assert eng.cdna4_restore(qw.detach()) is False
+        assert torch.equal(qw.cpu(), a["qweight"])
+        s.copy_(a["scales"].cuda())
+        z.copy_(a["scaled_zeros"].cuda())
+        eng.gemv_forward_cuda_new(x, qw, s, z, 4, N, K, 128)
+        qw.copy_(b["qweight"].cuda())
+        eng.cdna4_cache_clear()
+        assert torch.equal(qw.cpu(), b["qweight"])
+    finally:
+        eng.cdna4_cache_enable(True)
+        eng.cdna4_cache_inplace(False)
+
+
+def test_in_place_entries_release_their_storage_when_the_model_is_deleted(eng):
+    """an in-place entry holds the caller's tensor; once every other holder is gone the next sweep (a cache miss) must drop it so the
+    weights go back to the allocator -- the mode exists to save memory."""
+    N, K = 2048, 2048
+    a, b = make_case(N, K, torch.bfloat16, seed=43, M=2), make_case(256, 512, torch.bfloat16, seed=44, M=2)
+    try:
+        eng.cdna4_cache_inplace(True)
+        torch.cuda.synchronize()
+        base = torch.cuda.memory_allocated()
+        qw, s, z = _dev(a)
+        x = a["x"].cuda()
+        eng.gemv_forward_cuda_new(x, qw, s, z, 2, N, K, 128)
+        # a live alias keeps the entry (and its bytes) alive across a sweep
+        alias = qw.detach()
+        del qw
+        qb, sb, zb = _dev(b)
+        eng.gemv_forward_cuda_new(b["x"].cuda(), qb, sb, zb, 2, 256, 512, 128)   # miss -> sweep
+        assert eng.cdna4_cache_info()["entries"] == 2
+        y = eng.gemv_forward_cuda_new(x, alias, s, z, 2, N, K, 128).cpu()
+        check_forward(y, a["x"], a["q"], a["scales"], a["scaled_zeros"], torch.bfloat16)
+        held = torch.cuda.memory_allocated()
+        del alias, s, z, x, y
+        qc, sc, zc = _dev(make_case(256, 512, torch.bfloat16, seed=45, M=2))
+        eng.gemv_forward_cuda_new(b["x"].cuda(), qc, sc, zc, 2, 256, 512, 128)   # miss -> sweep drops the orphaned entry
+        torch.cuda.synchronize()
+        assert eng.cdna4_cache_info()["entries"] == 2
+        assert torch.cuda.memory_allocated() <= held - N * K // 2 + (1 << 20), (base, held, torch.cuda.memory_allocated())
+    finally:
+        eng.cdna4_cache_enable(True)
+        eng.cdna4_cache_inplace(False)

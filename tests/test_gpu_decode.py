@@ -6,9 +6,12 @@ import pytest
 import torch
 
 from oracle import awq_oracle as O
-from tests.helpers import check_forward, make_case, assert_bits
+from tests.helpers import check_forward, check_fused_tail, make_case, assert_bits
 
 pytestmark = pytest.mark.gpu
+# norm-wise distance of the fused tail from the oracle's tail: the largest value measured on MI355X over this file's cases + 20 %
+# (profiles/r05_test_stats.txt); the HARD criterion is check_fused_tail's elementwise hull
+REL_TAIL = {torch.bfloat16: 3e-3, torch.float16: 3e-3}
 
 
 @pytest.fixture(scope="module")
@@ -87,8 +90,7 @@ def test_fused_gate_up_both_arrangements(ops, dtype, M, F, K):
     assert exact2
     y2 = ops.decode_cdna4(x.cuda(), ops.repack_v2_to_cdna4(qi), szh2, None, 2).cpu()
     for y in (y1, y2):
-        rel = ((y.float() - ref.float()).norm() / ref.float().norm()).item()
-        assert rel <= 3e-3, rel   # three roundings to T deep; the exact-match fraction is the sharper check
+        check_fused_tail(y, g, u, REL_TAIL[dtype], what=f"decode gate/up F={F} K={K} M={M}")
         assert_bits(y, ref, 0.05)
     assert_bits(y1, y2, 0.01)  # same math; only the split-K order inside a block differs
 
@@ -153,7 +155,6 @@ def test_fused_gate_up_on_the_skinny_kernel(ops, dtype, M, F, K):
         y = ops.decode_cdna4(x.cuda(), c4, szh, None, 2).cpu()
     finally:
         ops._capi.tune(decode_skinny_from=0)
-    rel = ((y.float() - ref.float()).norm() / ref.float().norm()).item()
-    assert rel <= 3e-3, rel
+    check_fused_tail(y, g, u, REL_TAIL[dtype], what=f"skinny gate/up F={F} K={K} M={M}")
     assert_bits(y, ref, 0.05)
     assert_bits(y, y_dma, 0.01)

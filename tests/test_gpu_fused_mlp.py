@@ -6,9 +6,13 @@ import pytest
 import torch
 
 from oracle import awq_oracle as O
-from tests.helpers import check_forward, make_case, assert_bits
+from tests.helpers import check_forward, check_fused_tail, make_case, assert_bits, record_rel, _dequant_f64
 
 pytestmark = pytest.mark.gpu
+
+# norm-wise distance of the fused tail from the oracle's tail: the largest value measured on MI355X over this file's cases + 20 %
+# (profiles/r05_test_stats.txt); the HARD criterion is check_fused_tail's elementwise hull
+REL_TAIL = {torch.bfloat16: 3e-3, torch.float16: 3e-3}
 
 
 def _pair(F, K, dtype, seed, M):
@@ -17,7 +21,7 @@ def _pair(F, K, dtype, seed, M):
     x = cg["x"]
     g = O.wqlinear_forward(x, None, cg["scales"], cg["scaled_zeros"], None, 128, q_int=cg["q"])
     u = O.wqlinear_forward(x, None, cu["scales"], cu["scaled_zeros"], None, 128, q_int=cu["q"])
-    return cg, cu, x, torch.nn.functional.silu(g) * u
+    return cg, cu, x, torch.nn.functional.silu(g) * u, g, u
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -30,7 +34,7 @@ def test_gate_up_entry_every_row_count(dtype, M, F, K):
         pytest.skip("full-size case: bf16, M = 1, 9, 2048 only")
     if M == 2048 and F * K < 2048 * 2048:
         pytest.skip("M = 2048 on the two larger shapes only")
-    cg, cu, x, ref = _pair(F, K, dtype, F + K + M, M)
+    cg, cu, x, ref, gt, up = _pair(F, K, dtype, F + K + M, M)
     qi, si, zi = interleave_gate_up(cg["qweight"].cuda(), cu["qweight"].cuda(), cg["scales"].cuda(), cu["scales"].cuda(),
                                     cg["scaled_zeros"].cuda(), cu["scaled_zeros"].cuda())
     c4 = ops.repack_v2_to_cdna4(qi)
@@ -40,8 +44,7 @@ def test_gate_up_entry_every_row_count(dtype, M, F, K):
     ys = [ops.mlp_gate_up_forward_cdna4(x.cuda(), c4, szp, szh).cpu(), ops.mlp_gate_up_forward_cdna4(x.cuda(), c4, szp, None).cpu()]
     for y in ys:
         assert y.shape == (M, F)
-        rel = ((y.float() - ref.float()).norm() / ref.float().norm()).item()
-        assert rel <= 3e-3, rel          # three roundings to T deep; the exact-match fraction is the sharper check
+        check_fused_tail(y, gt, up, REL_TAIL[dtype], what=f"gate_up entry F={F} K={K} M={M}")
         assert_bits(y, ref, (0.05 if M <= 300 else 0.07))
     assert_bits(ys[0], ys[1], 0.01)
     # the fused tail == the unfused product path on the same interleaved stream: GEMM, de-interleave, F.silu * up, all in T
@@ -61,7 +64,7 @@ def test_module_matches_reference_sequence(dtype):
     from llm_awq_amd.fused_mlp import QuantLlamaMLP, make_fused_mlp
     from llm_awq_amd.qmodule import WQLinear
     H, F = 1024, 2816
-    cg, cu, x, act = _pair(F, H, dtype, 77, 40)
+    cg, cu, x, act, _gt, _up = _pair(F, H, dtype, 77, 40)
     cd = make_case(H, F, dtype, seed=79, M=1)
 
     def lin(c, k, n):
@@ -92,8 +95,14 @@ def test_module_matches_reference_sequence(dtype):
         # down_proj on the module's own activations must satisfy the forward bound; against the oracle's activations the few
         # last-bit differences of `a` pass through a 2816-term dot product
         check_forward(y, a, cd["q"], cd["scales"], cd["scaled_zeros"], dtype)
+        # against the oracle run on the ORACLE's activations: y - ref = (y - W a) + W (a - act); the first term is held to 1e-3 above, the second is
+        # the module's few last-bit differences of `a` through down_proj -- computed, not guessed
         ref = O.wqlinear_forward(act[:M], None, cd["scales"], cd["scaled_zeros"], None, 128, q_int=cd["q"])
-        assert ((y.float() - ref.float()).norm() / ref.float().norm()).item() < 4e-3
+        Wd = _dequant_f64(cd["q"], cd["scales"], cd["scaled_zeros"])
+        through = ((a.double() - act[:M].double()) @ Wd.t()).norm().item() / ref.double().norm().item()
+        rel = ((y.double() - ref.double()).norm() / ref.double().norm()).item()
+        record_rel(f"module down_proj M={M}", rel, 1e-3 + through + 1.2e-3)
+        assert rel <= 1e-3 + through + 1.2e-3, (rel, through)  # (+ the T rounding of y(a) vs y(act) where they differ: one ulp rms ~1.1e-3)
     # 3-D input [batch, seq, hidden] like the model passes
     y3 = blk.mlp(x[:12].view(2, 6, H).cuda())
     assert y3.shape == (2, 6, H)

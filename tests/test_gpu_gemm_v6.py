@@ -9,7 +9,10 @@ import pytest
 import torch
 
 from oracle import awq_oracle as O
-from tests.helpers import check_forward, make_case, cuda_gen, assert_bits
+from tests.helpers import check_forward, check_fused_tail, make_case, cuda_gen, assert_bits
+
+# norm-wise distance of the fused tail from the oracle's tail: measured on MI355X + 20 % (profiles/r05_test_stats.txt); the HARD criterion is the hull
+REL_TAIL = {torch.bfloat16: 3e-3, torch.float16: 3e-3}
 
 pytestmark = pytest.mark.gpu
 
@@ -92,7 +95,7 @@ def test_v6_fused_silu_mul(ops, dtype, M):
     finally:
         _reset(ops)
     assert y.shape == (M, F)
-    assert ((y.float() - ref.float()).norm() / ref.float().norm()).item() <= 3e-3
+    check_fused_tail(y, g, u, REL_TAIL[dtype], what=f"v6 fused tail M={M}")
     assert_bits(y, ref, 0.05)
     assert_bits(y, y4, 0.001)
 
@@ -114,9 +117,9 @@ def test_v6_w3_tiles(ops, dtype):
             y = ops.forward_w3(x, qw, s, z, szp)
         finally:
             _reset(ops)
-        ref = x.float() @ W.t()
-        assert ((y.float() - ref).norm() / ref.norm()).item() < (2.5e-3 if dtype == torch.bfloat16 else 4e-4)
-        assert_bits(ref.to(dtype), y, 0.03)
+        ref = (x.float() @ W.t()).to(dtype)  # fp32 accumulate, ONE rounding to T (the oracle's statement), so the rounding is on both sides
+        assert ((y.float() - ref.float()).norm() / ref.float().norm()).item() <= 1e-3
+        assert_bits(ref, y, 0.03)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -282,7 +285,7 @@ def test_v6_block_pair_k_split_w3_tiles(ops, dtype):
     finally:
         ops._capi.tune(gemm_v6_pair=1, gemm_v6_pair_min_nit=64)
     ref = (x.float() @ W.t()).to(dtype) + bias
-    assert ((y.float() - ref.float()).norm() / ref.float().norm()).item() < (2.5e-3 if dtype == torch.bfloat16 else 4e-4)
+    assert ((y.float() - ref.float()).norm() / ref.float().norm()).item() <= 1.5e-3  # (1e-3 for the product + the bias add's own rounding on top of a shifted value)
     assert_bits(ref, y, 0.03)
     assert_bits(y, y0, 0.01)
     assert ops._capi.lib().awq_w4a16_gemm_cdna4_pair_plan(2048, 4096, 11008) == 1  # (the Llama-2-7B down_proj shape itself)

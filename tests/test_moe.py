@@ -7,17 +7,7 @@ import torch
 from llm_awq_amd import moe as MOE
 from llm_awq_amd.qmodule import WQLinear
 from oracle import awq_oracle as O
-from tests.helpers import check_forward, make_case, Gen, cuda_gen, assert_bits
-
-
-def oracle_grouped(x_sorted, qweight, scales, scaled_zeros, offsets):
-    off = offsets.tolist()
-    outs = []
-    for e in range(qweight.shape[0]):
-        xe = x_sorted[off[e]:off[e + 1]]
-        if xe.shape[0]:
-            outs.append(O.wqlinear_forward(xe, qweight[e], scales[e], scaled_zeros[e], None, 128))
-    return torch.cat(outs) if outs else x_sorted.new_zeros(0, qweight.shape[1] * 4)
+from tests.helpers import check_forward, make_case, Gen, cuda_gen, assert_bits, oracle_grouped_linear, oracle_sparse_moe
 
 
 def _experts(E, N, K, dtype, seed):
@@ -41,11 +31,12 @@ def test_sort_by_expert():
 
 def test_sparse_moe_block_with_oracle_matmul():
     dtype, E, H, F, T = torch.bfloat16, 4, 128, 256, 9
-    w1 = MOE.GroupedWQLinear(_experts(E, F, H, dtype, 10)[0], matmul=oracle_grouped)
-    w3 = MOE.GroupedWQLinear(_experts(E, F, H, dtype, 20)[0], matmul=oracle_grouped)
-    w2 = MOE.GroupedWQLinear(_experts(E, H, F, dtype, 30)[0], matmul=oracle_grouped)
+    # (the product classes run the HIP kernels only; the oracle-backed subclasses of the routing glue live in tests/helpers.py)
+    w1 = oracle_grouped_linear(_experts(E, F, H, dtype, 10)[0])
+    w3 = oracle_grouped_linear(_experts(E, F, H, dtype, 20)[0])
+    w2 = oracle_grouped_linear(_experts(E, H, F, dtype, 30)[0])
     assert w1.qweight.shape == (E, F // 4, H) and w1.scales.shape == (E, 8, F)
-    blk = MOE.SparseMoeMLP(w1, w3, w2, top_k=2)
+    blk = oracle_sparse_moe(w1, w3, w2, top_k=2)
     g = Gen(0)
     x = g.randn(T, H).to(dtype)
     logits = g.randn(T, E)

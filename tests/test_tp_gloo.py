@@ -1,7 +1,7 @@
 """not-gpu: the N > 1 path (llm_awq_amd.parallel) on CPU with the gloo backend, world_size 2.
 The shard matmul is the ORACLE here (there is no GPU in this container, and the product never falls back
-to it: TPWQLinear takes the shard product as an injected test seam -- `partial=` the fp32 partial of a row split,
-`matmul=` the T output of a column split); what is under test is the sharding of the v2 buffers, the fp32 sum over
+to it: the product class's arithmetic hooks run the HIP kernels only; tests/helpers.oracle_tp_linear is a TEST subclass
+that overrides them with the oracle); what is under test is the sharding of the v2 buffers, the fp32 sum over
 ranks, the single rounding to T and bias-after-reduce, against the SINGLE-DEVICE ORACLE within SURVEY.md 8(e)'s 1e-3."""
 import os
 import socket
@@ -29,7 +29,7 @@ def _worker(rank, world, port, dtype_name, result_q):
     try:
         from llm_awq_amd.qmodule import WQLinear
         from oracle import awq_oracle as O
-        from tests.helpers import Gen
+        from tests.helpers import Gen, oracle_tp_linear
 
         dtype = getattr(torch, dtype_name)
         K, N, M = 1280, 96, 5  # 10 groups -> 5 per rank; N/16 = 6 slabs -> 3 per rank
@@ -40,20 +40,14 @@ def _worker(rank, world, port, dtype_name, result_q):
         full.bias = (g.randn(N) * 0.02).to(dtype)
         x = g.randn(M, K).to(dtype)
 
-        def oracle_mm(xs, qw, s, z):
-            return O.wqlinear_forward(xs, qw, s, z, None, 128)
-
-        def oracle_partial(xs, qw, s, z):
-            return O.wqlinear_partial_f32(xs, qw, s, z, 128)
-
         ref = O.wqlinear_forward(x, d["qweight"], d["scales"], d["scaled_zeros"], full.bias, 128).float()
-        row = P.TPWQLinear(full, "row", partial=oracle_partial)
+        row = oracle_tp_linear(full, "row")
         y_row_t = row(x)
         assert y_row_t.dtype == dtype
         y_row = y_row_t.float()
         # the pre-round-4 numerics (every partial rounded to T before the sum) through the legacy seam: what the fp32 partials fix
-        y_old = P.TPWQLinear(full, "row", matmul=oracle_mm)(x).float()
-        col = P.TPWQLinear(full, "column", matmul=oracle_mm)
+        y_old = oracle_tp_linear(full, "row", rounded_partials=True)(x).float()
+        col = oracle_tp_linear(full, "column")
         y_col_local = col(x)
         parts = [torch.empty_like(y_col_local) for _ in range(world)]
         dist.all_gather(parts, y_col_local)
@@ -138,7 +132,7 @@ def test_row_split_fp32_partials_match_the_single_device_oracle(dtype_name, worl
     of the oracle partials rounded once is within 1e-3 of the single-device oracle (bf16 with T-rounded partials: 2.6-2.9e-3)"""
     from llm_awq_amd.qmodule import WQLinear
     from oracle import awq_oracle as O
-    from tests.helpers import Gen
+    from tests.helpers import Gen, oracle_tp_linear
     dtype = getattr(torch, dtype_name)
     K, N, M = 2048, 64, 6
     g = Gen(23 + world)
@@ -151,9 +145,9 @@ def test_row_split_fp32_partials_match_the_single_device_oracle(dtype_name, worl
     acc32 = torch.zeros(M, N)
     acc_t = torch.zeros(M, N)
     for r in range(world):
-        tp = P.TPWQLinear(full, "row", world=world, rank=r, partial=lambda xs, qw, s, z: O.wqlinear_partial_f32(xs, qw, s, z, 128))
+        tp = oracle_tp_linear(full, "row", world=world, rank=r)
         k0, k1 = tp.bounds
-        p32 = tp._partial(x[:, k0:k1].contiguous(), tp.shard.qweight, tp.shard.scales, tp.shard.scaled_zeros)
+        p32 = tp.partial(x)
         acc32 += p32
         acc_t += p32.to(dtype).float()
     y = acc32.to(dtype) + full.bias

@@ -139,10 +139,10 @@ def test_gpu_w3_prefill_full_shape_both_tile_widths(ops, dtype):
     for M in (2048, 300):
         x = torch.randn(M, K, device="cuda", generator=g).to(dtype)
         y = ops.forward_w3(x, qw, s, z, szp)
-        ref = x.float() @ W.t()
-        rel = ((y.float() - ref).norm() / ref.norm()).item()
-        assert rel < (2.5e-3 if dtype == torch.bfloat16 else 4e-4), (M, rel)
-        assert_bits(ref.to(dtype), y, 0.03)
+        ref = (x.float() @ W.t()).to(dtype)  # fp32 accumulate, ONE rounding to T: the rounding is on both sides
+        rel = ((y.float() - ref.float()).norm() / ref.float().norm()).item()
+        assert rel <= 1e-3, (M, rel)         # BASELINE.json's tolerance
+        assert_bits(ref, y, 0.03)
 
 
 @pytest.mark.gpu
@@ -168,7 +168,7 @@ def test_gpu_wqlinear_w3_module(ops):
     for M in (1, 7, 64):
         x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
         y = m(x)
-        ref = (x.float() @ W.float().t())
-        rel = ((y.float() - ref).norm() / ref.norm()).item()
-        assert rel < 2.5e-3, (M, rel)
-        assert_bits(ref.to(torch.bfloat16), y, 0.03)
+        ref = (x.float() @ W.float().t()).to(torch.bfloat16)  # one rounding to T on both sides
+        rel = ((y.float() - ref.float()).norm() / ref.float().norm()).item()
+        assert rel <= 1e-3, (M, rel)
+        assert_bits(ref, y, 0.03)
