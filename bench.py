@@ -15,6 +15,8 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JS
               duration (HIP events over the timed region, on the launch stream) vs 8 TB/s.
   prefill   = the same 160 linears at M = 2048 (the size BASELINE.md / SURVEY.md 8(d) quote), tok/s and fraction of the
               2.5 PFLOP/s dense bf16 MFMA peak; prefill_m4096 / prefill_m512 beside it.
+  prefill_m64 / prefill_m128 = short prompts on the same weights (fraction of the MFMA roofline; HBM-side they are weight-stream bound).
+  w3_llama2_7b / tp70b_world1 / moe_mixtral = BASELINE.json configs 3, 4 (world size 1) and 5 as compact legs (bench_extra.py).
   dropin    = the SAME work through the reference's own entry points on RAW reference-layout (v2) buffers:
               awq_inference_engine.gemv_forward_cuda_new / gemm_forward_cuda_new (pybind.cpp:22-23), 160 calls per token.
   cpu_baseline = the reference's pure-PyTorch pseudo-quant Linear (awq/quantize/quantizer.py:106-122,
@@ -95,6 +97,8 @@ def main():
     ap.add_argument("--prefill-m", type=int, default=2048, help="prefill rows of the headline GEMM figure (SURVEY.md 8(d) / BASELINE.md quote M = 2048)")
     ap.add_argument("--prefill-m2", type=int, default=4096, help="second prefill size reported beside it (0 = skip)")
     ap.add_argument("--prefill-m3", type=int, default=512, help="a short prompt (split-K territory) reported beside them (0 = skip)")
+    ap.add_argument("--prefill-small", default="64,128", help="short prompts (the reference's M <= 192 tile territory, gemm_cuda.cu:1155-1206) reported as prefill_m<M> beside the others ('' = skip)")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the compact legs of BASELINE.json configs 3 / 4 (world size 1) / 5 (bench_extra.py: w3_llama2_7b, tp70b_world1, moe_mixtral)")
     ap.add_argument("--prefill-iters", type=int, default=10, help="timed prefill passes per size (after two untimed ones); median and min are reported")
     ap.add_argument("--no-prefill", action="store_true")
     ap.add_argument("--no-dropin", action="store_true")
@@ -218,7 +222,7 @@ def main():
             elif m <= 8 and epi == 1:
                 outs.append(eng.mlp_gate_up_cdna4(x, qw, szp))
             else:
-                outs.append(eng.forward_cdna4(x, qw, s, z, szp, None))               # prefill GEMM (gate/up: one GEMM over the pair)
+                outs.append(eng.forward_cdna4(x, qw, s, z, szp, None, szh if m >= 256 else None))   # WQLinear.forward, prefill GEMM (with the layer's sz_half side buffer, as the module passes it)
         if probe_streams and decode:
             for st in probe_streams:
                 e2 = torch.cuda.Event()
@@ -412,7 +416,8 @@ def main():
     pk = "gemm_cdna4_v6_kernel (256- / 192- / 128-wide blocks) + gemm_cdna4_v6_pair_kernel (down_proj at <= 2048 rows: pairs of 256-wide blocks, half of K each) + gemm_cdna4_v4n_kernel (split-K launches of short prompts)"
     if not args.no_prefill:
         out["prefill"] = prefill(args.prefill_m, run_main, pk)
-        for extra in (args.prefill_m2, args.prefill_m3):
+        small = [int(v) for v in args.prefill_small.split(",") if v.strip()]
+        for extra in (args.prefill_m2, args.prefill_m3, *small):
             if extra and extra != args.prefill_m:
                 out["prefill_m%d" % extra] = prefill(extra, run_main, pk)
 
@@ -444,6 +449,13 @@ def main():
                                       **dropin_leg(False)}
             eng.cdna4_cache_inplace(False)  # (clears the cache: every qweight gets its v2 interleave back)
         out["dropin"] = drop
+
+    # ---------------- BASELINE.json configs 3, 4 (world size 1) and 5 on the same clock (compact legs: bench_extra.py) ----------------
+    if native_leg and not args.no_extra_configs and args.dtype == "bf16" and not args.tune:
+        import bench_extra
+        del raw[:], nat[:]
+        torch.cuda.empty_cache()
+        out.update(bench_extra.run_all(eng, dev, side, max(5, args.steps // 2), max(2, args.warmup // 2), max(3, args.prefill_iters // 2)))
 
     # ---------------- CPU baseline (reference's pseudo-quant Linear on the host cores) ----------------
     if not args.no_cpu_baseline:

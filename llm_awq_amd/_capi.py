@@ -41,7 +41,10 @@ SIGNATURES = {
     "awq_w4a16_mlp_decode_cdna4_state_bytes": (_sz, [_i, _i]),
     "awq_w4a16_mlp_decode_cdna4_plan": (_i, [_i, _i, _i, _i]),
     "awq_w4a16_mlp_decode_cdna4": (_i, [_vp] * 7 + [_i] * 6 + [_vp, _vp]),
+    "awq_w4a16_mlp_decode_cdna4_set_stamps": (_i, [_vp]),
     "awq_w4a16_mlp_gate_up_forward_cdna4": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "awq_w4a16_mlp_gate_up_forward_cdna4_workspace_bytes": (_sz, [_i, _i, _i]),
+    "awq_w4a16_mlp_gate_up_forward_cdna4_ws": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "awq_w4a16_rmsnorm_forward_cdna4": (_i, [_vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "awq_rmsnorm": (_i, [_vp, _vp, ctypes.c_float, _vp, _i, _i, _i, _vp]),
     "awq_w4a16_forward_cdna4_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -51,6 +54,7 @@ SIGNATURES = {
     "awq_w4a16_decode_cdna4_plan": (_i, [_i, _i, _i, _i, _vp]),
     "awq_w4a16_gemm_cdna4": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "awq_w4a16_forward_cdna4": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "awq_w4a16_forward_cdna4_szh": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "awq_w4a16_moe_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "awq_w4a16_moe_forward_cdna4": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "awq_silu_mul": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),

@@ -246,6 +246,14 @@ int awq_w4a16_mlp_decode_cdna4(const void* x, const void* gate_up_qweight, const
 
 int awq_w4a16_mlp_gate_up_forward_cdna4(const void* x, const void* qweight_interleaved, const void* sz_packed, const void* sz_half,
                                         void* out, int m, int n2, int k, int group_size, int dtype, void* stream) {
+  return awq_w4a16_mlp_gate_up_forward_cdna4_ws(x, qweight_interleaved, sz_packed, sz_half, out, m, n2, k, group_size, dtype, nullptr, 0, stream);
+}
+
+size_t awq_w4a16_mlp_gate_up_forward_cdna4_workspace_bytes(int m, int n2, int k) { return m > 8 ? awq::gemm_cdna4_v3_workspace_bytes(m, n2, k) : 0; }
+
+int awq_w4a16_mlp_gate_up_forward_cdna4_ws(const void* x, const void* qweight_interleaved, const void* sz_packed, const void* sz_half,
+                                           void* out, int m, int n2, int k, int group_size, int dtype, void* workspace, size_t workspace_bytes,
+                                           void* stream) {
   if (!x || !qweight_interleaved || !sz_packed || !out) return AWQ_ERR_NULL;
   if (group_size != 128) return AWQ_ERR_GROUP;
   if (dtype != AWQ_F16 && dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
@@ -261,7 +269,12 @@ int awq_w4a16_mlp_gate_up_forward_cdna4(const void* x, const void* qweight_inter
   }
   // prefill / batched decode: the tile kernels with the SiLU * mul tail fused into their epilogue (out is [m, n2 / 2]: the
   // [m, n2] intermediate of the reference's two GEMMs + F.silu + multiply never exists)
-  if (awq::launch_gemm_cdna4_v3(x, qweight_interleaved, sz_packed, nullptr, out, m, n2, k, 0, dtype, nullptr, 0, (hipStream_t)stream, 4, 2, sz_half) != 0)
+  if (workspace && ((reinterpret_cast<uintptr_t>(workspace) & 63) != 0 || workspace_bytes < awq::gemm_cdna4_v3_workspace_bytes(m, n2, k))) {
+    workspace = nullptr;  // (optional scratch: without it the columns behind the full rounds run as 256 x 128 blocks)
+    workspace_bytes = 0;
+  }
+  if (awq::launch_gemm_cdna4_v3(x, qweight_interleaved, sz_packed, nullptr, out, m, n2, k, 0, dtype, workspace, workspace_bytes, (hipStream_t)stream, 4, 2,
+                                sz_half) != 0)
     return AWQ_ERR_SHAPE;
   return finish_launch();
 }
@@ -311,6 +324,20 @@ int awq_w4a16_gemm_cdna4(const void* x, const void* qweight, const void* scales,
   if (!skinny && !(sz_packed && m <= 8 && awq::launch_gemv_cdna4(x, qweight, sz_packed, nullptr, out, m, n, k, 0, 4, dtype, (hipStream_t)stream) == 0))
     awq::launch_gemm(x, qweight, scales, scaled_zeros, sz_packed, out, m, n, k, dtype, 1, workspace, workspace_bytes, (hipStream_t)stream);
   return finish_launch();
+}
+
+int awq_w4a16_forward_cdna4_szh(const void* x, const void* qweight, const void* scales, const void* scaled_zeros, const void* sz_packed,
+                                const void* sz_half, const void* bias, void* out, int m, int n, int k, int group_size, int dtype, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  if (sz_half && sz_packed && m >= 256 && group_size == 128 && awq::gemm_variant_get() == 0 && aligned16(sz_half)) {
+    // prefill with the layer's sz_half side buffer: the tile kernels dequantise in the f16-mantissa form (every block width, the block pairs included)
+    int st0 = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
+    if (st0 != AWQ_OK) return st0;
+    if ((n % 16) != 0 || (bias && !aligned16(bias))) return (n % 16) ? AWQ_ERR_SHAPE : AWQ_ERR_ALIGN;
+    if (awq::launch_gemm_cdna4_v3(x, qweight, sz_packed, bias, out, m, n, k, 0, dtype, workspace, workspace_bytes, (hipStream_t)stream, 4, 0, sz_half) == 0)
+      return finish_launch();
+  }
+  return awq_w4a16_forward_cdna4(x, qweight, scales, scaled_zeros, sz_packed, bias, out, m, n, k, group_size, dtype, workspace, workspace_bytes, stream);
 }
 
 int awq_w4a16_forward_cdna4(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
@@ -508,7 +535,16 @@ int awq_tune_set(const char* key, int value) {
   if (awq::gemm_tune_set(key, value) == 0) return AWQ_OK;
   if (awq::gemv_cdna4_tune_set(key, value) == 0) return AWQ_OK;
   if (awq::gemm_v3_tune_set(key, value) == 0) return AWQ_OK;
+  if (!strcmp(key, "mlp_engine_probe")) {  // AWQ_PROBES builds: bit 0 no math, bit 1 no weight DMA (timing only, wrong results)
+    awq::mlp_engine_set_probe(value);
+    return AWQ_OK;
+  }
   return AWQ_ERR_SHAPE;
+}
+
+int awq_w4a16_mlp_decode_cdna4_set_stamps(void* device_u64) {
+  awq::mlp_engine_set_stamps(device_u64);
+  return AWQ_OK;
 }
 
 }  // extern "C"

@@ -25,8 +25,8 @@ int g_v6_szh = 1;  // knob gemm_v6_szh: 1 = v6 dequantises in the f16-mantissa f
 int g_v4 = 1;  // knob gemm_v4: 0 = the tile kernels take no m below 256 (the skinny kernel serves 9 .. 255 rows); the loop it once selected is gone
 void launch_wide(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
                  int n_end, int dtype, hipStream_t st, int bits, int epi, const void* szh = nullptr, int tile_n = 256) {
-  if (g_v6 && m >= 256) {  // (szh: the caller's sz_half side buffer, reported exact for this layer -> the f16-mantissa dequant form)
-    if (szh != nullptr && bits == 4 && g_v6_szh) launch_gemm_cdna4_v6(x, qw, szh, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, epi, 1);
+  if (g_v6 && m >= 256) {  // (szh: the caller's sz_half side buffer, reported exact for this layer -> the f16-mantissa dequant form, every block width)
+    if (szh != nullptr && bits == 4 && g_v6_szh) launch_gemm_cdna4_v6(x, qw, szh, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, epi, 1, tile_n);
     else launch_gemm_cdna4_v6(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, epi, 0, tile_n);
     return;
   }
@@ -46,9 +46,14 @@ int narrow_kernel(int m, int n_cols, int k, int bits, bool has_ws, int epi) {
   return g_v6_128 && g_v6 && bits == 4 && m >= TM ? 1 : 0;
 }
 void launch_narrow(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin,
-                   int n_end, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits, int epi) {
+                   int n_end, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits, int epi, const void* szh = nullptr) {
+  const bool use_szh = szh != nullptr && bits == 4 && g_v6_szh;
+  // columns whose 256-wide tiles fill at most half the chip: pairs of 256 x 256 blocks, each half of K and half of the rows (needs the workspace)
+  if (g_v6 && g_v6_pair && g_splitk && !g_tile_n && ws != nullptr && m >= TM &&
+      launch_gemm_cdna4_v6_pair(x, qw, use_szh ? szh : szp, bias, out, m, n, k, n_begin, n_end, dtype, ws, ws_bytes, st, bits, epi, use_szh ? 1 : 0) == 0)
+    return;
   if (narrow_kernel(m, n_end - n_begin, k, bits, ws != nullptr, epi) == 1) {
-    launch_gemm_cdna4_v6(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, epi, 0, 128);
+    launch_gemm_cdna4_v6(x, qw, use_szh ? szh : szp, bias, out, m, n, k, n_begin, n_end, dtype, st, bits, epi, use_szh ? 1 : 0, 128);
     return;
   }
   launch_gemm_cdna4_v4n(x, qw, szp, bias, out, m, n, k, n_begin, n_end, dtype, g_splitk ? ws : nullptr, ws_bytes, st, bits, epi);
@@ -138,7 +143,10 @@ size_t gemm_cdna4_v3_workspace_bytes(int m, int n, int k) {
   if (m < TM) return gemm_v4n_workspace_bytes(m, n, k);
   const Plan p = plan_tiles(m, n, 0);
   if (p.mode == 1) return gemm_v4n_workspace_bytes(m, n, k);
-  if (p.mode == 2) return gemm_v4n_workspace_bytes(m, n - (int)(p.cols_main * 256), k);
+  if (p.mode == 2) {  // the columns behind the full rounds: a block-pair launch where they fill at most half the chip, else the narrow tiles' split-K scratch
+    const int rest = n - (int)(p.cols_main * 256);
+    return gemm_cdna4_v3_pair_plan(m, rest, k) ? gemm_v6_pair_workspace_bytes(m, rest, k) : gemm_v4n_workspace_bytes(m, rest, k);
+  }
   return 0;
 }
 
@@ -151,7 +159,10 @@ size_t gemm_cdna4_v3_workspace_bytes_w3(int m, int n, int k) {
   if (m < TM) return gemm_v4n_workspace_bytes(m, n, k);
   const Plan p = plan_tiles(m, n, 0);
   if (p.mode == 1) return gemm_v4n_workspace_bytes(m, n, k);
-  if (p.mode == 2) return gemm_v4n_workspace_bytes(m, n - (int)(p.cols_main * 256), k);
+  if (p.mode == 2) {
+    const int rest = n - (int)(p.cols_main * 256);
+    return gemm_cdna4_v3_pair_plan(m, rest, k) ? gemm_v6_pair_workspace_bytes(m, rest, k) : gemm_v4n_workspace_bytes(m, rest, k);
+  }
   return 0;
 }
 
@@ -180,19 +191,20 @@ int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, const v
   // (w3c tiles have no skinny kernel: the masked single-row-tile path of the narrow kernel serves every m > 8)
   if (!szp || !(gemm_cdna4_v3_takes(m, k) || ((bits == 3 || epi) && m > 8)) || (n % 16) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return -1;
   // tiles that fill at most half the chip and a long K: pairs of 256 x 256 blocks, each half of K, combined inside the launch (needs the workspace)
-  if (g_v6 && g_v6_pair && g_splitk && (bits == 4 || bits == 3) && epi == 0 && !tile_n && !g_tile_n && ws != nullptr &&
-      launch_gemm_cdna4_v6_pair(x, qw, szp, bias, out, m, n, k, dtype, ws, ws_bytes, st, bits) == 0)
+  const bool use_szh = szh != nullptr && bits == 4 && g_v6_szh;
+  if (g_v6 && g_v6_pair && g_splitk && (bits == 4 || bits == 3) && (epi == 0 || epi == 2) && !tile_n && !g_tile_n && ws != nullptr &&
+      launch_gemm_cdna4_v6_pair(x, qw, use_szh ? szh : szp, bias, out, m, n, k, 0, n, dtype, ws, ws_bytes, st, bits, epi, use_szh ? 1 : 0) == 0)
     return 0;
   const bool allow192 = g_v6 != 0 && g_v6_192 != 0 && bits == 4 && m >= TM;
   Plan p = m < TM ? Plan{1, 0} : plan_tiles(m, n, tile_n ? tile_n : g_tile_n, allow192);  // m < 256: only the narrow-tile kernel masks rows
   if (g_v6 >= 2) p = Plan{0, 0};  // experiments: every tile 256-wide
   if (p.mode == 3) {
-    launch_wide(x, qw, szp, bias, out, m, n, k, 0, n, dtype, st, bits, epi, nullptr, 192);
+    launch_wide(x, qw, szp, bias, out, m, n, k, 0, n, dtype, st, bits, epi, szh, 192);
   } else if (p.mode == 2) {
     launch_wide(x, qw, szp, bias, out, m, n, k, 0, (int)(p.cols_main * 256), dtype, st, bits, epi, szh);
-    launch_narrow(x, qw, szp, bias, out, m, n, k, (int)(p.cols_main * 256), n, dtype, ws, ws_bytes, st, bits, epi);
+    launch_narrow(x, qw, szp, bias, out, m, n, k, (int)(p.cols_main * 256), n, dtype, ws, ws_bytes, st, bits, epi, szh);
   } else if (p.mode == 1) {
-    launch_narrow(x, qw, szp, bias, out, m, n, k, 0, n, dtype, ws, ws_bytes, st, bits, epi);
+    launch_narrow(x, qw, szp, bias, out, m, n, k, 0, n, dtype, ws, ws_bytes, st, bits, epi, szh);
   } else {
     launch_wide(x, qw, szp, bias, out, m, n, k, 0, n, dtype, st, bits, epi, szh);
   }

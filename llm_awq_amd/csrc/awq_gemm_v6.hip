@@ -56,7 +56,7 @@ __device__ __forceinline__ f32x4 v6_mfma4(const u32x2& a, const u32x2& b, const 
     if constexpr (DT::id == 1 && !F16FORM) asm volatile("s_nop 3\n\tv_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
     else asm volatile("s_nop 3\n\tv_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
   } else {  // K loop (the nops stay: hipcc materialises the C splat with v_mov copies right in front of the statement, and a VALU write
-            // followed directly by the MFMA's read of that register returned the stale value -- found in the 32x32x16 experiment, tools/experiments/awq_gemm_v7_32x32_rowswap.hip.txt)
+            // followed directly by the MFMA's read of that register returned the stale value -- found in the 32x32x16 experiment, tools/EXPERIMENTS.md: awq_gemm_v7_32x32_rowswap)
     if constexpr (DT::id == 1 && !F16FORM) asm volatile("s_nop 3\n\tv_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
     else asm volatile("s_nop 3\n\tv_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
   }
@@ -84,9 +84,11 @@ __device__ __forceinline__ void v6_tile(char* smem, const uint16_t* __restrict__
                                         float* __restrict__ part = nullptr, u32x2* flag = nullptr, u32 token = 0) {
   // one 256 x (64 NS) output tile: rows [m0, m0 + 256) of x (all readable), weight rows [n0, ...) below n_end; rows outside
   // [row_lo, row_hi) are computed but NOT stored (grouped GEMM: they belong to another expert's segment).
-  // K split over a PAIR of blocks (gemm_cdna4_v6_pair_kernel; nit_range >= 0: only the quantisation groups [g0, g0 + nit_range) are summed):
-  // ROLE 1 = the upper K range: its fp32 accumulators go to `part` in register order (1 KiB per wave store, write-through), then `flag` takes the
-  // launch's token; ROLE 2 = the lower K range: waits for the token, adds the partner's partials to its own accumulators, runs the epilogue.
+  // K split over a PAIR of blocks (gemm_cdna4_v6_pair_kernel; nit_range >= 0: only the quantisation groups [g0, g0 + nit_range) are summed), SYMMETRIC since
+  // round 5: ROLE 1 sums the lower half of K and finishes rows [0, 128) of the tile, ROLE 2 the upper half and rows [128, 256).  Each block sends the eight
+  // accumulator fragments it does NOT finish to `part` (register order, 1 KiB per wave store: 128 KiB each way, concurrently), raises the partner's flag,
+  // waits for its own, adds the partner's partials to the eight fragments it keeps and runs the epilogue on its 128 rows.  (Round 4's form -- one block
+  // sends all 256 KiB, the other adds and runs the whole epilogue -- left ~17 us of serial tail behind the K loops: profiles/r04_v6_pair.txt.)
   using vec8 = typename DT::vec8;
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
@@ -366,66 +368,90 @@ __device__ __forceinline__ void v6_tile(char* smem, const uint16_t* __restrict__
     cur = nxt;
   }
 
-  if constexpr (ROLE == 1) {
-    // upper K range of a block pair: fp32 partials in register order, write-through (the partner may sit behind another XCD's L2), every store
-    // acknowledged, then the flag.  (The last product MFMAs are opaque asm: let them retire before their accumulators are read.)
+  // rows of the tile this block finishes: fragments [F0, F0 + FN) (16 rows each)
+  constexpr int F0 = ROLE == 2 ? 8 : 0, FN = ROLE ? 8 : 16;
+  if constexpr (ROLE != 0) {
+    static_assert(NS == 4, "pair split: 256-wide blocks");
+    constexpr int H = ROLE - 1, O = 1 - H, OF0 = 8 * O;
+    // flag line of the pair (8 x u32x2): [h] = "the partials for the block that finishes half h are complete" {token, ~token}; [2 + h] = mailbox of that
+    // block {token, its XCC id}, written at its start (gemm_cdna4_v6_pair_kernel); [7].x = sticky error word
+    // Where does the partner run?  Blocks of a pair share blockIdx & 7, which has been the XCD on every launch observed -- but placement is not a
+    // contract, so the partner SAYS where it is: same XCD -> plain stores (the lines stay in the shared L2: the reader's sc1 loads hit there, and the
+    // hand-over never reaches the fabric or the Infinity Cache the neighbouring launches live in); anything else, including "not heard from yet" ->
+    // write-through stores.  The reader's loads are sc1 either way (L2-served; correct for both producer forms).
+    u32 my_xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(my_xcc));
+    u32x2 mb;
+    asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(mb) : "v"(flag + 2 + O) : "memory");
+    const bool same_xcd = (u32)__builtin_amdgcn_readfirstlane(mb.x) == token && (u32)__builtin_amdgcn_readfirstlane(mb.y) == my_xcc;
+    // (the last product MFMAs are opaque asm: let them retire before their accumulators are read)
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : : : "memory");
-    float* pw = part + (size_t)wv * (16 * NS * 256) + lane * 4;
+    {
+      float* pw = part + (size_t)O * (size_t)(V6_TM * V6_TN / 2) + (size_t)wv * (8 * NS * 256) + lane * 4;
+      if (same_xcd) {
 #pragma unroll
-    for (int f = 0; f < 16; ++f)
+        for (int f = 0; f < 8; ++f)
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        const f32x4 v = acc[f][s];
-        const float* dst = pw + (f * NS + s) * 256;
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");  // (sc1 nt measured no different: profiles/r04_v6_pair.txt)
+          for (int s2 = 0; s2 < NS; ++s2) {
+            const f32x4 v = acc[OF0 + f][s2];
+            const float* dst = pw + (f * NS + s2) * 256;
+            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+          }
+      } else {
+#pragma unroll
+        for (int f = 0; f < 8; ++f)
+#pragma unroll
+          for (int s2 = 0; s2 < NS; ++s2) {
+            const f32x4 v = acc[OF0 + f][s2];
+            const float* dst = pw + (f * NS + s2) * 256;
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+          }
       }
-    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");  // every store acknowledged by the L2 (plain) / by memory (write-through)
     __builtin_amdgcn_s_barrier();
     if (tid == 0) {
-      const u32x2 fv = {token, token ^ 0xA5A5A5A5u};
-      asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(flag), "v"(fv) : "memory");
+      const u32x2 fv = {token, token ^ 0xA5A5A5A5u}, z = {0u, 0u};
+      asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(flag + O), "v"(fv) : "memory");
+      asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(flag + 2 + O), "v"(z) : "memory");  // the partner's mailbox is read: free for the next launch / replay
     }
-    return;
-  }
-  if constexpr (ROLE == 2) {
-    // lower K range: the partner's partials, added in fp32 (acc = lower + upper), then the ordinary epilogue.  Bounded wait: a lost partner turns
-    // into NaN outputs and the sticky error word behind the flags, not a hung queue
+    // the partner's partials for MY half.  Bounded wait: a lost partner turns into NaN outputs and the sticky error word, not a hung queue
     bool lost = false;
     for (int spins = 0;; ++spins) {
       u32x2 fv;
-      asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(fv) : "v"(flag) : "memory");
+      asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(fv) : "v"(flag + H) : "memory");
       if ((u32)__builtin_amdgcn_readfirstlane(fv.x) == token && (u32)__builtin_amdgcn_readfirstlane(fv.y) == (token ^ 0xA5A5A5A5u)) break;
       if (spins > (1 << 22)) {
         lost = true;
         break;
       }
-      __builtin_amdgcn_s_sleep(8);
+      __builtin_amdgcn_s_sleep(4);
     }
-    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : : : "memory");
-    const float* pw = part + (size_t)wv * (16 * NS * 256) + lane * 4;
+    const float* pr = part + (size_t)H * (size_t)(V6_TM * V6_TN / 2) + (size_t)wv * (8 * NS * 256) + lane * 4;
 #pragma unroll
-    for (int f0 = 0; f0 < 16; f0 += 4) {
+    for (int f0 = 0; f0 < 8; f0 += 4) {
       f32x4 pv[4 * NS];
 #pragma unroll
       for (int j = 0; j < 4 * NS; ++j) {  // (unconditional loads, one wait naming every destination: the compiler does not see the asynchronous writes)
-        const float* src = pw + ((f0 + j / NS) * NS + (j % NS)) * 256;
+        const float* src = pr + ((f0 + j / NS) * NS + (j % NS)) * 256;
         asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(pv[j]) : "v"(src) : "memory");
       }
-      static_assert(NS == 4, "pair split: 256-wide blocks");
       asm volatile("s_waitcnt vmcnt(0)"
                    : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]), "+v"(pv[6]), "+v"(pv[7]), "+v"(pv[8]), "+v"(pv[9]),
                      "+v"(pv[10]), "+v"(pv[11]), "+v"(pv[12]), "+v"(pv[13]), "+v"(pv[14]), "+v"(pv[15])
                    :
                    : "memory");
+      // lower half of K + upper half of K, in that order on both sides of the pair (fp32 addition commutes: the two blocks produce what ONE block
+      // adding `lower + upper` would)
 #pragma unroll
-      for (int j = 0; j < 4 * NS; ++j) acc[f0 + j / NS][j % NS] = acc[f0 + j / NS][j % NS] + pv[j];
+      for (int j = 0; j < 4 * NS; ++j) acc[F0 + f0 + j / NS][j % NS] = acc[F0 + f0 + j / NS][j % NS] + pv[j];
     }
     if (lost) {
       const float bad = __builtin_nanf("");
 #pragma unroll
-      for (int f = 0; f < 16; ++f)
+      for (int f = 0; f < FN; ++f)
 #pragma unroll
-        for (int s = 0; s < NS; ++s) acc[f][s] = f32x4{bad, bad, bad, bad};
+        for (int s2 = 0; s2 < NS; ++s2) acc[F0 + f][s2] = f32x4{bad, bad, bad, bad};
       if (tid == 0) flag[7].x = 1u;  // (word 14 of the pair's 64-byte flag line: sticky)
     }
   }
@@ -448,14 +474,15 @@ __device__ __forceinline__ void v6_tile(char* smem, const uint16_t* __restrict__
   // ---------------- epilogue through LDS: acc[f][s][r] = C[n = n0 + 16 NS wv + 16 s + 4 g + r][m = m0 + 16 f + i], staged row-major ----
   asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
   __builtin_amdgcn_s_barrier();  // every wave is done with the x stages (the trailing reads of the unused stage have returned)
-  if (ROLE == 2 && tid == 0) {  // (every wave of the block has seen the token: the flag is free for the next launch / the next replay of a graph)
+  if (ROLE != 0 && tid == 0) {  // (every wave of the block has seen the token: the flag is free for the next launch / the next replay of a graph)
     const u32x2 z = {0u, 0u};
-    asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(flag), "v"(z) : "memory");
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(flag + (ROLE - 1)), "v"(z) : "memory");
   }
+  constexpr int RW = 4 * FN, R0 = 16 * F0;  // rows per wave and first row of the block's share of the tile (64 / 0; a pair block: 32 / 0 or 128)
   {
     const u32 wbase = lds0 + i * kV6Pitch + (16 * NS * wv + 4 * g) * 2;
 #pragma unroll
-    for (int f = 0; f < 16; ++f)
+    for (int f = F0; f < F0 + FN; ++f)
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         u32x2 v;
@@ -471,18 +498,18 @@ __device__ __forceinline__ void v6_tile(char* smem, const uint16_t* __restrict__
     const int pr = lane & 15, nn = n0 + 16 * pr;
     const bool ok = nn < n_end && 16 * pr < TN;
 #pragma unroll
-    for (int it0 = 0; it0 < 16; it0 += 4) {
+    for (int it0 = 0; it0 < RW / 4; it0 += 4) {
       u32x4 v[4], u[4];
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const u32 ra = lds0 + (64 * wv + 4 * (it0 + b) + (lane >> 4)) * kV6Pitch + 32 * pr;
+        const u32 ra = lds0 + (R0 + RW * wv + 4 * (it0 + b) + (lane >> 4)) * kV6Pitch + 32 * pr;
         asm volatile("ds_read_b128 %0, %1" : "=v"(v[b]) : "v"(ra) : "memory");
         asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(u[b]) : "v"(ra) : "memory");
       }
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]) : : "memory");
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const int m = m0 + 64 * wv + 4 * (it0 + b) + (lane >> 4);
+        const int m = m0 + R0 + RW * wv + 4 * (it0 + b) + (lane >> 4);
         if (ok && m >= row_lo && m < row_hi) __builtin_nontemporal_store(silu_mul_octet<DT>(v[b], u[b]), reinterpret_cast<u32x4*>(out + (size_t)m * (N >> 1) + (nn >> 1)));
       }
     }
@@ -493,17 +520,17 @@ __device__ __forceinline__ void v6_tile(char* smem, const uint16_t* __restrict__
     u32x4 bv = {0u, 0u, 0u, 0u};
     if (bias != nullptr && ncol_ok) bv = *reinterpret_cast<const u32x4*>(bias + nn);
 #pragma unroll
-    for (int it0 = 0; it0 < 32; it0 += 8) {
+    for (int it0 = 0; it0 < RW / 2; it0 += 8) {
       u32x4 v[8];
 #pragma unroll
       for (int b = 0; b < 8; ++b) {
-        const u32 ra = lds0 + (64 * wv + 2 * (it0 + b) + (lane >> 5)) * kV6Pitch + col * 2;
+        const u32 ra = lds0 + (R0 + RW * wv + 2 * (it0 + b) + (lane >> 5)) * kV6Pitch + col * 2;
         asm volatile("ds_read_b128 %0, %1" : "=v"(v[b]) : "v"(ra) : "memory");
       }
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : : "memory");
 #pragma unroll
       for (int b = 0; b < 8; ++b) {
-        const int m = m0 + 64 * wv + 2 * (it0 + b) + (lane >> 5);
+        const int m = m0 + R0 + RW * wv + 2 * (it0 + b) + (lane >> 5);
         u32x4 o = v[b];
         if (bias != nullptr) {  // `out + self.bias` in T (qmodule.py:221)
           auto add2 = [](u32 a, u32 b2) {
@@ -595,22 +622,22 @@ __global__ __launch_bounds__(256) void moe_gemm_cdna4_v6_kernel(const uint16_t* 
                           N, epi, r_lo, r_hi);
 }
 
-// K split over a PAIR of 256 x 256 blocks (round 4).  A matrix whose 256-wide tiles fill at most half the chip (down_proj of Llama-3-8B at 2048 rows: 8 x 16 =
-// 128 tiles) used to run as 256 x 128 blocks -- two slabs per wave: twice the x-fragment reads and twice the x staging per MFMA, 0.42 of the MFMA peak against
-// 0.51 for the four-slab block (profiles/r04_f_pmc_mfma_m2048.txt).  Here every tile is two four-slab blocks on the SAME XCD (block index mod 8), each summing
-// half of K: the upper half hands its fp32 accumulators to the lower half through the workspace (write-through stores, one flag per pair carrying the launch's
-// token; the reader resets it, so a captured launch replays), which adds them and runs the epilogue -- the role of the reference's split_k_iters + Semaphore
-// (gemm_cuda.cu:546-619) inside one launch, no second kernel.  The producers have the LOWER block indices of an XCD's share (dispatched first: a waiting
-// consumer can never keep its producer off the chip) and `lead` fewer K tiles, so their partials are on the way while the consumers finish.
-template <typename DT, int BITS>
+// K split over a PAIR of 256 x 256 blocks.  A launch whose 256-wide tiles fill at most half the chip (down_proj and o_proj of Llama-3-8B at 2048 rows: 8 x 16 =
+// 128 tiles; the 128 tiles the gate/up launch leaves behind its three full rounds) used to run as 256 x 128 blocks -- two slabs per wave: twice the x-fragment
+// reads and twice the x staging per MFMA, 0.35-0.42 of the MFMA peak against 0.48-0.51 for the four-slab block (profiles/r04_f_pmc_mfma_m2048.txt).  Here every tile
+// is two four-slab blocks on the SAME XCD (block index mod 8), each summing half of K and finishing half of the tile's rows: they swap the fp32 accumulators of the
+// rows they do not finish through the workspace (128 KiB each way; one flag per direction carrying the launch's token, reset by its reader, so a captured launch
+// replays) -- the role of the reference's split_k_iters + Semaphore (gemm_cuda.cu:546-619) inside one launch, no second kernel.  Both blocks of a pair must be
+// resident at once: the launcher only takes grids of at most 256 blocks on a 256-CU device (one block per CU: 160 KiB of LDS, 512 registers per lane).
+template <typename DT, int BITS, int DQ>
 __global__ __launch_bounds__(256) void gemm_cdna4_v6_pair_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw, const u32* __restrict__ szp,
                                                                  const uint16_t* __restrict__ bias, uint16_t* __restrict__ out, int M, int N, int K,
-                                                                 int tiles_m, int tiles_n, int lead, float* __restrict__ ws, u32 token) {
+                                                                 int tiles_m, int tiles_n, int n_begin, int n_end, int epi, float* __restrict__ ws, u32 token) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int T = tiles_m * tiles_n, per = T >> 3;  // T % 8 == 0 (launcher)
   const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
-  const bool producer = idx < per;
-  const int tile = xcd * per + (producer ? idx : idx - per);
+  const bool upper = idx >= per;
+  const int tile = xcd * per + (upper ? idx - per : idx);
   int tm, tn;
   {
     const int full = (tiles_m >> 1) * 2 * tiles_n;
@@ -623,26 +650,30 @@ __global__ __launch_bounds__(256) void gemm_cdna4_v6_pair_kernel(const uint16_t*
       tm = tiles_m - 1;
     }
   }
-  const int nit_all = K >> 7, n_up = (nit_all >> 1) - lead, n_lo = nit_all - n_up;
+  const int nit_all = K >> 7, n_lo = (nit_all + 1) >> 1, n_up = nit_all - n_lo;
   float* part = ws + (size_t)tile * (size_t)(V6_TM * V6_TN);
   u32x2* flag = reinterpret_cast<u32x2*>(ws + (size_t)T * (size_t)(V6_TM * V6_TN)) + (size_t)tile * 8;  // one 64-byte line per pair
-  const int m0 = min(tm * V6_TM, M - V6_TM), n0 = tn * V6_TN;
-  if (producer) v6_tile<DT, BITS, 0, 0, 4, 1>(smem, x, qw, szp, nullptr, out, N, K, m0, n0, N, 0, 0, M, n_lo, n_up, part, flag, token);
-  else v6_tile<DT, BITS, 0, 0, 4, 2>(smem, x, qw, szp, bias, out, N, K, m0, n0, N, 0, 0, M, 0, n_lo, part, flag, token);
+  if (threadIdx.x == 0) {  // this block's mailbox: where it runs (read by the partner when its K loop is done, tens of microseconds from now)
+    u32 my_xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(my_xcc));
+    const u32x2 mv = {token, my_xcc};
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(flag + 2 + (upper ? 1 : 0)), "v"(mv) : "memory");
+  }
+  const int m0 = min(tm * V6_TM, M - V6_TM), n0 = n_begin + tn * V6_TN;
+  if (upper) v6_tile<DT, BITS, 0, DQ, 4, 2>(smem, x, qw, szp, bias, out, N, K, m0, n0, n_end, epi, 0, M, n_lo, n_up, part, flag, token);
+  else v6_tile<DT, BITS, 0, DQ, 4, 1>(smem, x, qw, szp, bias, out, N, K, m0, n0, n_end, epi, 0, M, 0, n_lo, part, flag, token);
 }
 
 namespace {
 int g_v6_probe = 0;
-int g_v6_pair_min_nit = 64;  // knob gemm_v6_pair_min_nit (experiments)
-int g_v6_pair_lead = 1;  // knob gemm_v6_pair_lead: K tiles the producer half of a block pair runs less than half of K
+int g_v6_pair_min_nit = 64;  // knob gemm_v6_pair_min_nit: K tiles from which a half-filled launch takes the pair split (32 = o_proj / the gate/up remainder too, K = 4096: A/B in profiles/r05_v6_pair.txt)
 }
 void gemm_v6_set_probe(int v) { g_v6_probe = v; }
-void gemm_v6_set_pair_lead(int v) { g_v6_pair_lead = v < 0 ? 0 : v; }
+void gemm_v6_set_pair_lead(int) {}  // (round 4's asymmetric hand-over ran the producer half `lead` K tiles short; the symmetric pair splits K evenly)
 void gemm_v6_set_pair_min_nit(int v) { g_v6_pair_min_nit = v < 8 ? 8 : v; }
 
-// Does the block-pair K split serve [m, n] x K?  W4 or W3 tiles, no fused tail; the 256-wide tiles fill between 3/8 and 1/2 of the 256 CUs (so the pairs fill 3/4 .. all
-// of it in ONE round), whole XCD shares, and a K loop long enough to pay for the hand-over (>= 64 groups: down_proj; o_proj's 32 measured no gain on paper:
-// 16 K tiles of ~3.4 us against ~7 us of hand-over and epilogue)
+// Does the block-pair K split serve [m, n_cols] x K?  W4 or W3 tiles; the 256-wide tiles fill between 3/8 and 1/2 of the 256 CUs (so the pairs fill 3/4 .. all
+// of it in ONE round: both blocks of every pair are resident together), whole XCD shares, and a K loop long enough to pay for the hand-over
 bool gemm_v6_pair_takes(int m, int n, int k) {
   if (m < V6_TM || (n % V6_TN) != 0 || (k % 128) != 0 || (k >> 7) < g_v6_pair_min_nit) return false;
   if (device_cu_count() != 256) return false;  // the one-round co-residency of a pair (and its XCD = blockIdx & 7 placement) is the whole MI355X's
@@ -654,26 +685,26 @@ size_t gemm_v6_pair_workspace_bytes(int m, int n, int k) {
   const size_t tiles = (size_t)((m + V6_TM - 1) / V6_TM) * (n / V6_TN);
   return tiles * (size_t)(V6_TM * V6_TN * 4) + tiles * 64;
 }
-// returns -1 if it does not serve the call (shape, workspace): the caller runs the 256 x 128 blocks
-int launch_gemm_cdna4_v6_pair(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int dtype, void* ws,
-                              size_t ws_bytes, hipStream_t st, int bits) {
-  const size_t need = gemm_v6_pair_workspace_bytes(m, n, k);
-  if (need == 0 || ws == nullptr || ws_bytes < need || (reinterpret_cast<uintptr_t>(ws) & 63) != 0) return -1;
+// weight rows [n_begin, n_end) of the [n, k] matrix as block pairs; epi 0 / 2 as launch_gemm_cdna4_v6; szfmt 1: szp = sz_half (W4).  Returns -1 if it does
+// not serve the call (shape, workspace): the caller runs the 256 x 128 blocks
+int launch_gemm_cdna4_v6_pair(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin, int n_end,
+                              int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits, int epi, int szfmt) {
+  const size_t need = gemm_v6_pair_workspace_bytes(m, n_end - n_begin, k);
+  if (need == 0 || ws == nullptr || ws_bytes < need || (reinterpret_cast<uintptr_t>(ws) & 63) != 0 || (epi != 0 && epi != 2) || (szfmt && bits != 4)) return -1;
   constexpr int stage2 = 2 * kV6Stage, stg_epi = V6_TM * kV6Pitch;
   constexpr int smem = stage2 > stg_epi ? stage2 : stg_epi;
-  const int tiles_m = (m + V6_TM - 1) / V6_TM, tiles_n = n / V6_TN;
+  const int tiles_m = (m + V6_TM - 1) / V6_TM, tiles_n = (n_end - n_begin) / V6_TN;
   static std::atomic<u32> counter{0};
   const u32 token = (counter.fetch_add(1, std::memory_order_relaxed) % 0x7FFFFFFEu) + 1u;  // never 0 (= the reset value of a flag)
-  using Kern = void (*)(const uint16_t*, const u32*, const u32*, const uint16_t*, uint16_t*, int, int, int, int, int, int, float*, u32);
-  static const Kern kerns[2][2] = {{gemm_cdna4_v6_pair_kernel<F16, 4>, gemm_cdna4_v6_pair_kernel<F16, 3>},
-                                   {gemm_cdna4_v6_pair_kernel<BF16, 4>, gemm_cdna4_v6_pair_kernel<BF16, 3>}};
-  static LdsOptIn optin[2][2];
-  const int a = dtype == 0 ? 0 : 1, b3 = bits == 3 ? 1 : 0;
-  const Kern kern = kerns[a][b3];
-  optin[a][b3].ensure(reinterpret_cast<const void*>(kern), smem);
-  const int lead = g_v6_pair_lead < (k >> 8) ? g_v6_pair_lead : 0;
+  using Kern = void (*)(const uint16_t*, const u32*, const u32*, const uint16_t*, uint16_t*, int, int, int, int, int, int, int, int, float*, u32);
+  static const Kern kerns[2][3] = {{gemm_cdna4_v6_pair_kernel<F16, 4, 0>, gemm_cdna4_v6_pair_kernel<F16, 3, 0>, gemm_cdna4_v6_pair_kernel<F16, 4, 1>},
+                                   {gemm_cdna4_v6_pair_kernel<BF16, 4, 0>, gemm_cdna4_v6_pair_kernel<BF16, 3, 0>, gemm_cdna4_v6_pair_kernel<BF16, 4, 1>}};
+  static LdsOptIn optin[2][3];
+  const int a = dtype == 0 ? 0 : 1, v = bits == 3 ? 1 : (szfmt ? 2 : 0);
+  const Kern kern = kerns[a][v];
+  optin[a][v].ensure(reinterpret_cast<const void*>(kern), smem);
   hipLaunchKernelGGL(kern, dim3(2 * tiles_m * tiles_n), dim3(256), smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp, (const uint16_t*)bias,
-                     (uint16_t*)out, m, n, k, tiles_m, tiles_n, lead, (float*)ws, token);
+                     (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end, epi, (float*)ws, token);
   return 0;
 }
 
@@ -689,18 +720,20 @@ void launch_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, const 
                                    {gemm_cdna4_v6_kernel<BF16, 4>, gemm_cdna4_v6_kernel<BF16, 3>}};
   const int a = dtype == 0 ? 0 : 1, b = bits == 3 ? 1 : 0;
   if (tn_cols == 192 && bits == 4) {  // 192-column blocks (three slabs per wave)
-    static const Kern kerns_3[2] = {gemm_cdna4_v6_kernel<F16, 4, 0, 0, 3>, gemm_cdna4_v6_kernel<BF16, 4, 0, 0, 3>};
-    static LdsOptIn optin_3[2];
-    const int a3 = dtype == 0 ? 0 : 1;
+    static const Kern kerns_3[4] = {gemm_cdna4_v6_kernel<F16, 4, 0, 0, 3>, gemm_cdna4_v6_kernel<BF16, 4, 0, 0, 3>,
+                                    gemm_cdna4_v6_kernel<F16, 4, 0, 1, 3>, gemm_cdna4_v6_kernel<BF16, 4, 0, 1, 3>};  // [2..3]: szp = sz_half
+    static LdsOptIn optin_3[4];
+    const int a3 = (dtype == 0 ? 0 : 1) + (szfmt == 1 ? 2 : 0);
     optin_3[a3].ensure(reinterpret_cast<const void*>(kerns_3[a3]), smem);
     hipLaunchKernelGGL(kerns_3[a3], dim3(tiles_m * tiles_n), dim3(256), smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp,
                        (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end, epi);
     return;
   }
   if (tn_cols == 128 && bits == 4) {  // 128-column blocks (two slabs per wave): o_proj / down_proj at M = 2048 fill the chip with 256 of them
-    static const Kern kerns_2[2] = {gemm_cdna4_v6_kernel<F16, 4, 0, 0, 2>, gemm_cdna4_v6_kernel<BF16, 4, 0, 0, 2>};
-    static LdsOptIn optin_2[2];
-    const int a2 = dtype == 0 ? 0 : 1;
+    static const Kern kerns_2[4] = {gemm_cdna4_v6_kernel<F16, 4, 0, 0, 2>, gemm_cdna4_v6_kernel<BF16, 4, 0, 0, 2>,
+                                    gemm_cdna4_v6_kernel<F16, 4, 0, 1, 2>, gemm_cdna4_v6_kernel<BF16, 4, 0, 1, 2>};  // [2..3]: szp = sz_half
+    static LdsOptIn optin_2[4];
+    const int a2 = (dtype == 0 ? 0 : 1) + (szfmt == 1 ? 2 : 0);
     optin_2[a2].ensure(reinterpret_cast<const void*>(kerns_2[a2]), smem);
     hipLaunchKernelGGL(kerns_2[a2], dim3(tiles_m * tiles_n), dim3(256), smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp,
                        (const uint16_t*)bias, (uint16_t*)out, m, n, k, tiles_m, tiles_n, n_begin, n_end, epi);

@@ -24,23 +24,11 @@
 
 #include "../../include/awq_cdna4.h"
 #include "awq_device.hpp"
+#include "awq_dma.hpp"
 #include "awq_kernels.hpp"
 
 namespace awq {
 
-#define DMA_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
-
-// `buffer_load_dword(x4) ... lds`: SIZE bytes per lane from rsrc[voff + soff] to LDS at (wave-uniform) dst + lane * SIZE; AUX 2 = nt.
-// (The builtin only exists in the device pass; un-guarded, the host pass silently drops the kernel's launch stub.)
-template <int SIZE, int AUX>
-__device__ __forceinline__ void dma_to_lds(const __amdgpu_buffer_rsrc_t& rsrc, char* dst, u32 voff, u32 soff) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  if constexpr (SIZE == 16 && AUX == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, DMA_LDS_PTR(dst), 16, voff, soff, 0, 2);
-  if constexpr (SIZE == 16 && AUX == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, DMA_LDS_PTR(dst), 16, voff, soff, 0, 0);
-  if constexpr (SIZE == 4 && AUX == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, DMA_LDS_PTR(dst), 4, voff, soff, 0, 0);
-  if constexpr (SIZE == 16 && AUX == 17) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, DMA_LDS_PTR(dst), 16, voff, soff, 0, 17);  // sc0 sc1
-#endif
-}
 // timing probes (builds with AWQ_PROBES=1 only; wrong results): bit 0 = no math (stream only), bit 1 = no weight DMA and no
 // waits for it (math only, on whatever the ring holds)
 #ifdef AWQ_ENABLE_PROBES
@@ -50,32 +38,15 @@ __device__ __forceinline__ void dma_to_lds(const __amdgpu_buffer_rsrc_t& rsrc, c
 #endif
 // bit 8 of the same kernel argument (every build): EPI 0 stores its fp32 sums to `out` as float [M, N] instead of rounding them to T
 constexpr int kDmaF32Out = 0x100;
-template <int N_>
-__device__ __forceinline__ void dma_wait_vm() {
-  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N_) : "memory");
-}
-template <int J, int E, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (J < E) {
-    f(std::integral_constant<int, J>{});
-    static_for<J + 1, E>(f);
-  }
-}
-
 // EPI 0: out[m, n] (+ bias);  EPI 1: qw = [gate; up] stacked along N, out[m, n/2] = silu(gate) * up (two slabs per block);
 // EPI 2: gate / up rows interleaved 8 + 8 inside every 16-row slab (fused_mlp.QuantLlamaMLP stacks them that way), out[m, n/2]
-// `gate` (fused MLP launch, awq_w4a16_mlp_decode_cdna4; gate_target = the launch's epoch): the block streams its weights and scales first, then gathers
-// its activations from the granules the producer blocks of the same launch publish (out_through: the producer side).  nullptr: x is fetched up front (a
-// plain launch: its input was complete before the kernel started).
 template <typename DT, int WAVES, int D, int DQ, int EPI>
 __device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                               const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
-                                              uint16_t* __restrict__ out, int M, int N, int K, int TX, int probe_, int nb,
-                                              int* gate, int gate_target, bool out_through = false, int wv_ = -1) {
+                                              uint16_t* __restrict__ out, int M, int N, int K, int TX, int probe_, int nb) {
   constexpr int NS = EPI == 1 ? 2 : 1;
   const int probe = DMA_PROBE(probe_);
-  // wv_ >= 0: the caller runs several WAVES-wide groups in one block (mlp_decode_kernel), each on its own slab and its own `smem` region
-  const int lane = threadIdx.x & 63, wv = wv_ >= 0 ? wv_ : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, g = lane >> 4;
   const int nit = K >> 7;
   const int TXp = (TX + 3) & ~3;                 // steps covered by the 4-step DMA pieces of x / sz
@@ -110,76 +81,11 @@ __device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __rest
   for (int s = 0; s < NS; ++s)
     for (int q = 0; q < TXp; q += 4)
       dma_to_lds<4, 0>(rs, szs + (s * TXp + q) * 64, lane4, (slab_tile[s] + (u32)(s0 + q)) * 64u);
-  if (gate == nullptr) {
-    for (int r = 0; r < M; ++r)
-      for (int q = 0; q < TXp; q += 4)
-        dma_to_lds<16, 0>(rx, xs + r * xrow + q * 256, lane16, ((u32)r * (u32)K + (u32)(s0 + q) * 128u) * 2u);
-  }
+  for (int r = 0; r < M; ++r)
+    for (int q = 0; q < TXp; q += 4)
+      dma_to_lds<16, 0>(rx, xs + r * xrow + q * 256, lane16, ((u32)r * (u32)K + (u32)(s0 + q) * 128u) * 2u);
 #pragma unroll
   for (int d = 1; d < D; ++d) issue(d, d);
-  bool gave_up = false;  // (fused MLP launch only) this wave's activations never arrived: its partial sums are poisoned, the block's outputs read NaN
-  if (gate != nullptr) {
-    // Fused MLP launch, down_proj side (round 4).  The ring is in flight; h arrives as 8-byte {2 x T, tag} granules the gate/up blocks of the SAME launch
-    // publish with one sc1 store each (no flag, no counter, no fence: tools/ubench/handoff_ubench.hip measured the hop at ~1.3 us).  `x` is the granule
-    // array [M][K / 2] x 8 B, gate_target this launch's epoch.  A wave gathers ITS OWN k range: lane 0 first watches the range's LAST granule (the
-    // producers finish roughly in dispatch order; one 8-byte load per poll keeps the waiting waves off the memory system), then the whole range is
-    // swept (TX dwordx2 sc1 loads per lane and row) and re-swept until every tag carries the epoch; the data halves go to the wave's x slice in LDS.
-    // Bounded: a lost producer turns into a flagged error (gate[2]) and NaN outputs of the waiting block, not a hung queue or a plausible number.
-    const uint64_t* gsrc = reinterpret_cast<const uint64_t*>(x);
-    const u32 epoch = (u32)gate_target;
-    const int gper = K >> 1;                                   // granules per row
-    const int g0 = s0 * 64, g1 = min((s0 + TX) * 64, gper);    // this wave's granule range
-    if (g1 > g0) {
-      int spins = 0;
-      for (;;) {  // stage 1: the sentinel
-        u32x2 sg;
-        const uint64_t* sp = gsrc + (size_t)(M - 1) * gper + (g1 - 1);
-        asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(sg) : "v"(sp) : "memory");
-        if (__builtin_amdgcn_readfirstlane(sg.y) == epoch) break;
-        if (++spins > 400000) {
-          if (lane == 0) __hip_atomic_store(gate + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          gave_up = true;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(16);
-      }
-      const u32 xs_l = (u32)(size_t)(__attribute__((address_space(3))) char*)xs + lane * 4u;
-      for (int r = 0; r < M; ++r) {
-        for (;;) {  // stage 2: the sweep
-          u32x2 gv[16];
-#pragma unroll
-          for (int jj = 0; jj < 16; ++jj) {
-            // UNCONDITIONAL (indices past the range re-read its last granule): a load that is only issued on one side of a branch would have its
-            // result register copied at the join -- before the data has arrived (the compiler does not see the asynchronous write)
-            const uint64_t* gp = gsrc + (size_t)r * gper + min(g0 + jj * 64 + lane, g1 - 1);
-            asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(gv[jj]) : "v"(gp) : "memory");
-          }
-          asm volatile("s_waitcnt vmcnt(0)"
-                       : "+v"(gv[0]), "+v"(gv[1]), "+v"(gv[2]), "+v"(gv[3]), "+v"(gv[4]), "+v"(gv[5]), "+v"(gv[6]), "+v"(gv[7]), "+v"(gv[8]), "+v"(gv[9]),
-                         "+v"(gv[10]), "+v"(gv[11]), "+v"(gv[12]), "+v"(gv[13]), "+v"(gv[14]), "+v"(gv[15])
-                       :
-                       : "memory");
-          bool bad = false;
-#pragma unroll
-          for (int jj = 0; jj < 16; ++jj) bad = bad || gv[jj].y != epoch;
-          if (__builtin_amdgcn_ballot_w64(bad) == 0ull) {
-#pragma unroll
-            for (int jj = 0; jj < 16; ++jj)
-              if (jj < TX) asm volatile("ds_write_b32 %0, %1" : : "v"(xs_l + (u32)(r * xrow + jj * 256)), "v"(gv[jj].x) : "memory");
-            break;
-          }
-          if (++spins > 400000) {
-            if (lane == 0) __hip_atomic_store(gate + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            gave_up = true;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(4);
-        }
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : : : "memory");  // h is staged and (long since) the ring: the counted waits below start from an empty queue
-  }
-
   using vec8 = typename DT::vec8;
   Cdna4DequantT<DT> cd;   // DQ 0: sz_packed in T
   Cdna4DequantH<DT> ch;   // DQ 1: sz_half, f16-mantissa extraction
@@ -194,11 +100,6 @@ __device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __rest
   f32x4 acc[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (gave_up) {
-    const float bad = __builtin_nanf("");
-#pragma unroll
-    for (int s = 0; s < NS; ++s) acc[s] = f32x4{bad, bad, bad, bad};
-  }
 
   int slot = 0;
   auto step = [&](int t, auto vm_, auto reissue_) {
@@ -294,17 +195,7 @@ __device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __rest
       const float sl = to_f(DT::from_float(silu_f32(gt)));
       return DT::from_float(sl * up);
     };
-    if (out_through) {
-      // fused MLP launch, gate/up side: h goes out as 8-byte {h[c], h[c + 1], tag} granules, ONE sc1 (write-through) store each, for the down_proj blocks
-      // of the same launch (see the gather above); `out` is the granule array [M][N / 4] x 8 B, gate_target the epoch.  Waves 0 / 1 take columns
-      // 4 g + {0, 1} / {2, 3} of the slab's eight
-      if (wv < 2 && i < M && g < 2) {
-        const u32 data = (u32)h_of(2 * wv) | ((u32)h_of(2 * wv + 1) << 16);
-        uint64_t* dst = reinterpret_cast<uint64_t*>(out) + (size_t)i * (N >> 2) + nb * 4 + 2 * g + wv;
-        const u32x2 gv = {data, (u32)gate_target};
-        asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(dst), "v"(gv) : "memory");
-      }
-    } else if (wv < 4 && i < M && g < 2) {
+    if (wv < 4 && i < M && g < 2) {
       out[(size_t)i * (N >> 1) + nb * 8 + 4 * g + wv] = h_of(wv);
     }
   }
@@ -315,47 +206,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_dma_kernel(const uint16_t* __
                                                                const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
                                                                uint16_t* __restrict__ out, int M, int N, int K, int TX, int probe_) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemv_dma_body<DT, WAVES, D, DQ, EPI>(smem, x, qw, szp, bias, out, M, N, K, TX, probe_, blockIdx.x, nullptr, 0);
-}
-
-// QuantLlamaMLP.forward at decode in ONE launch (tinychat/modules/fused_mlp.py:33-83: gate/up GEMVs, F.silu, multiply, down_proj), M = 1.
-// Blocks [0, nA) are the gate/up slabs (8 + 8 interleaved pair, SiLU * mul epilogue); blocks [nA, nA + nB) are down_proj's slabs: workgroups start in
-// index order, so they are dispatched behind the last gate/up block (a waiting block can never keep a producer off the chip), stream the head of their
-// weights while the gate/up tail drains, and take h from the granules the producers publish (gemv_dma_body: one sc1 store per granule on one side, a
-// sentinel poll + a sweep of the wave's own k range on the other -- the hop measured ~1.3 us, profiles/r04_handoff_ubench.txt; round 2's form of this
-// kernel counted producers with a two-level fan-in and re-read h through LDS-DMA: ~3 us per MLP more than this one).  Measured: 27.6-28.3 us against
-// 22.4-23.6 us for the two launches (profiles/r04_mlp_one_launch.txt: down_proj's slabs cannot be in LDS before the edge, so their stream starts after it)
-// -- opt-in, not the default route.
-// state: int32 words [0] = epoch of the last finished launch (tags are epoch + 1: the same buffer serves every call, replayed graphs included),
-// [1] = consumers finished, [2] = sticky error flag (a consumer gave up waiting); granules at byte AWQ_MLP_DECODE_COUNTER_BYTES: [M][ffn / 2] x 8 B.
-template <typename DT, int DA, int DB>
-__global__ __launch_bounds__(512) void mlp_decode_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw_gu,
-                                                         const u32* __restrict__ szh_gu, const u32* __restrict__ qw_d,
-                                                         const u32* __restrict__ szh_d, const uint16_t* __restrict__ bias_d,
-                                                         uint16_t* __restrict__ out, int M, int hidden, int ffn, int n_out, int txa, int txb,
-                                                         int group_bytes, int* state) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int nA = ffn >> 4;  // 2 * ffn rows / 16 slabs, two per block
-  const int epoch = (int)((u32)__hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u);  // (stable: only the LAST block to leave advances it)
-  uint16_t* gran = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(state) + AWQ_MLP_DECODE_COUNTER_BYTES);
-  if ((int)blockIdx.x < nA) {
-    // gate/up side: the shape the stand-alone launch runs per CU (four slabs x four waves x a ring of DA tiles, pick_dma) -- here as two blocks of two
-    // four-wave groups, each group on its own slab (8-wave groups on one slab cost the gate/up phase +50 %: profiles/r04_mlp_one_launch.txt)
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int grp = wave >> 2;
-    gemv_dma_body<DT, 4, DA, 1, 2>(smem + grp * group_bytes, x, qw_gu, szh_gu, nullptr, gran, M, 2 * ffn, hidden, txa, 0, 2 * (int)blockIdx.x + grp, nullptr,
-                                   epoch, true, wave & 3);
-  } else {
-    const int nB = n_out >> 4;
-    gemv_dma_body<DT, 8, DB, 1, 0>(smem, gran, qw_d, szh_d, bias_d, out, M, n_out, ffn, txb, 0, (int)blockIdx.x - nA, state, epoch);
-    __syncthreads();
-
-    if (threadIdx.x == 0 && __hip_atomic_fetch_add(state + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nB - 1) {
-      // last consumer: every block has its h; the next launch on this state starts after this one ends and tags with the next epoch
-      __hip_atomic_store(state + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(state, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
+  gemv_dma_body<DT, WAVES, D, DQ, EPI>(smem, x, qw, szp, bias, out, M, N, K, TX, probe_, blockIdx.x);
 }
 
 namespace {
@@ -504,48 +355,6 @@ int launch_gemv_dma(const void* x, const void* qw, const void* szp, const void* 
   }
   AWQ_DDT(BF16, 0)
 #undef AWQ_DDT
-}
-
-// gate/up (8 + 8 interleaved, n2 = 2 * ffn rows, K = hidden) + SiLU * mul + down (K = ffn, n_out rows) in ONE launch, m = 1; sz_half side buffers.
-// state: AWQ_MLP_DECODE_COUNTER_BYTES + m * ffn * 4 bytes of device memory, zero before the first call, owned by one (module, stream).  Returns -1 if the
-// shape is not served (the caller issues the two launches): m != 1, hidden != 4 x 8 x 128 (a gate/up slab = four waves x eight k-steps on a ring of 7),
-// ffn beyond sixteen 128-k steps per down_proj wave, or more LDS than lets two blocks share a CU.
-size_t mlp_decode_state_bytes(int m, int ffn) { return (size_t)AWQ_MLP_DECODE_COUNTER_BYTES + (size_t)m * ffn * 4; }
-// host-side: is (m, hidden, ffn, n_out) served?  On success the two K splits and the LDS per block
-static bool mlp_decode_cfg(int m, int hidden, int ffn, int n_out, int& txa, int& txb, size_t& group, size_t& smem) {
-  if (m != 1 || hidden < 128 || ffn < 128 || n_out < 16 || (hidden % 128) != 0 || (ffn % 128) != 0 || (n_out % 16) != 0) return false;
-  const int nita = hidden / kGroup, nitb = ffn / kGroup;
-  txa = (nita + 3) / 4;
-  txb = (nitb + 7) / 8;
-  if (txa != 8 || txb < 4 || txb > 16) return false;  // compiled for rings of 7 / 4 tiles: hidden = 4096, 4096 <= ffn <= 16384
-  group = dma_smem(4, 7, 1, txa, m);
-  const size_t smem_a = 2 * group, smem_b = dma_smem(8, 4, 1, txb, m);
-  smem = smem_a > smem_b ? smem_a : smem_b;
-  return smem <= 78 * 1024;  // two blocks per CU
-}
-int mlp_decode_plan(int m, int hidden, int ffn, int n_out) {
-  int txa, txb;
-  size_t group, smem;
-  return mlp_decode_cfg(m, hidden, ffn, n_out, txa, txb, group, smem) ? 1 : 0;
-}
-int launch_mlp_decode(const void* x, const void* qw_gu, const void* szh_gu, const void* qw_d, const void* szh_d, const void* bias_d,
-                      void* out, int m, int hidden, int ffn, int n_out, int dtype, int* state, hipStream_t st) {
-  int txa, txb;
-  size_t group, smem;
-  if (!mlp_decode_cfg(m, hidden, ffn, n_out, txa, txb, group, smem)) return -1;
-  const int blocks = ffn / 16 + n_out / 16;
-#define AWQ_MLPD(DT_)                                                                                                              \
-  {                                                                                                                                \
-    auto kern = mlp_decode_kernel<DT_, 7, 4>;                                                                                      \
-    static LdsOptIn optin;                                                                                                         \
-    if (smem > 64 * 1024) optin.ensure(reinterpret_cast<const void*>(kern), (int)smem);                                           \
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), smem, st, (const uint16_t*)x, (const u32*)qw_gu, (const u32*)szh_gu,         \
-                       (const u32*)qw_d, (const u32*)szh_d, (const uint16_t*)bias_d, (uint16_t*)out, m, hidden, ffn, n_out, txa,   \
-                       txb, (int)group, state);                                                                                    \
-  }
-  if (dtype == 0) AWQ_MLPD(F16) else AWQ_MLPD(BF16)
-#undef AWQ_MLPD
-  return 0;
 }
 
 }  // namespace awq

@@ -130,15 +130,17 @@ void gemm_v6_set_probe(int v);
 bool gemm_v6_pair_takes(int m, int n, int k);
 int gemm_cdna4_v3_pair_plan(int m, int n, int k);  // awq_gemm_plan.hip: 1 = the prefill call (with its workspace) takes the block-pair K split
 size_t gemm_v6_pair_workspace_bytes(int m, int n, int k);
-int launch_gemm_cdna4_v6_pair(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int dtype, void* ws,
-                              size_t ws_bytes, hipStream_t st, int bits = 4);
+int launch_gemm_cdna4_v6_pair(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin, int n_end,
+                              int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits = 4, int epi = 0, int szfmt = 0);
 void gemm_v6_set_pair_lead(int v);
 void gemm_v6_set_pair_min_nit(int v);
-// awq_gemv_dma.hip: QuantLlamaMLP.forward at decode (gate/up + SiLU * mul + down) in one launch, m = 1; -1 if the shape is not served
+// awq_mlp_engine.hip: QuantLlamaMLP.forward at decode (gate/up + SiLU * mul + down) in ONE persistent launch, m = 1; -1 if the shape is not served
 int launch_mlp_decode(const void* x, const void* qw_gu, const void* szh_gu, const void* qw_d, const void* szh_d, const void* bias_d, void* out, int m,
                       int hidden, int ffn, int n_out, int dtype, int* state, hipStream_t st);
 size_t mlp_decode_state_bytes(int m, int ffn);
 int mlp_decode_plan(int m, int hidden, int ffn, int n_out);  // 1 = launch_mlp_decode serves the shape (host-side, no launch)
+void mlp_engine_set_stamps(void* device_u64);  // measurement: [256 blocks][16 waves][8] s_memtime stamps per launch (nullptr = off, the default)
+void mlp_engine_set_probe(int v);              // AWQ_PROBES builds: bit 0 no math, bit 1 no weight DMA
 int launch_bias_add(void* out, const void* bias, int m, int n, int dtype, hipStream_t st);
 // out[m, n] = T(in_f32) (+ bias in T); n % 8 == 0 (awq_util.hip)
 int launch_round_bias_f32(const void* in_f32, const void* bias, void* out, int m, int n, int dtype, hipStream_t st);

@@ -422,7 +422,7 @@ torch::Tensor pack_sz_cdna4(torch::Tensor scales, torch::Tensor zeros, int k) {
 
 // WQLinear.forward on cdna4 buffers: any number of rows (<= 16 -> GEMV kernel), bias optional
 torch::Tensor forward_cdna4(torch::Tensor in_feats, torch::Tensor kernel, torch::Tensor scales, torch::Tensor zeros,
-                            torch::Tensor sz_packed, c10::optional<torch::Tensor> bias) {
+                            torch::Tensor sz_packed, c10::optional<torch::Tensor> bias, c10::optional<torch::Tensor> sz_half) {
   check_inputs(in_feats, kernel, scales, zeros);
   TORCH_CHECK(in_feats.scalar_type() == at::kBFloat16 || in_feats.scalar_type() == at::kHalf,
               "the cdna4 interleave is defined for bfloat16 / float16");
@@ -444,9 +444,14 @@ torch::Tensor forward_cdna4(torch::Tensor in_feats, torch::Tensor kernel, torch:
   void* wsp;
   size_t wsb;
   at::Tensor ws = cdna4_workspace(in_feats, m, n, k, wsp, wsb);
-  raise_on(awq_w4a16_forward_cdna4(in_feats.data_ptr(), kernel.data_ptr(), scales.data_ptr(), zeros.data_ptr(),
-                                   sz_packed.data_ptr(), bp, out.data_ptr(), (int)m, (int)n, (int)k, 128, dtype_code(in_feats), wsp,
-                                   wsb, (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()));
+  const void* hp = nullptr;  // the layer's sz_half side buffer (pack_szh_cdna4 reported exact): prompts dequantise in the f16-mantissa form
+  if (sz_half.has_value() && sz_half->defined()) {
+    TORCH_CHECK(sz_half->is_cuda() && sz_half->is_contiguous() && sz_half->scalar_type() == at::kInt && sz_half->numel() == sz_packed.numel());
+    hp = sz_half->data_ptr();
+  }
+  raise_on(awq_w4a16_forward_cdna4_szh(in_feats.data_ptr(), kernel.data_ptr(), scales.data_ptr(), zeros.data_ptr(), sz_packed.data_ptr(), hp, bp,
+                                       out.data_ptr(), (int)m, (int)n, (int)k, 128, dtype_code(in_feats), wsp, wsb,
+                                       (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()));
   return out;
 }
 
@@ -640,8 +645,17 @@ torch::Tensor mlp_gate_up_forward_cdna4(torch::Tensor in_feats, torch::Tensor ke
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(in_feats.device());
   at::Tensor out = torch::empty(shape, in_feats.options());
   if (m == 0) return out;
-  raise_on(awq_w4a16_mlp_gate_up_forward_cdna4(in_feats.data_ptr(), kernel.data_ptr(), sz_packed.data_ptr(), hp, out.data_ptr(), (int)m, (int)n2,
-                                               (int)k, 128, dtype_code(in_feats), (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()));
+  // optional scratch of the prefill plan (block pairs for the columns behind the full rounds): torch's caching allocator, stream-ordered, capture-safe
+  at::Tensor ws;
+  void* wsp = nullptr;
+  const size_t wsb = awq_w4a16_mlp_gate_up_forward_cdna4_workspace_bytes((int)m, (int)n2, (int)k);
+  if (wsb) {
+    ws = torch::empty({(int64_t)wsb}, in_feats.options().dtype(at::kByte));
+    wsp = ws.data_ptr();
+  }
+  raise_on(awq_w4a16_mlp_gate_up_forward_cdna4_ws(in_feats.data_ptr(), kernel.data_ptr(), sz_packed.data_ptr(), hp, out.data_ptr(), (int)m, (int)n2,
+                                                  (int)k, 128, dtype_code(in_feats), wsp, wsb,
+                                                  (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()));
   return out;
 }
 
@@ -739,7 +753,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("repack_cdna4_to_v2", &repack_cdna4_to_v2, "qweight cdna4 -> v2 interleave (same shape)");
   m.def("pack_sz_cdna4", &pack_sz_cdna4, "scales/scaled_zeros [Gpad,N] -> packed int32 [N/16, K/128, 16]");
   m.def("forward_cdna4", &forward_cdna4, "WQLinear forward on cdna4-interleaved buffers", py::arg("in_feats"),
-        py::arg("kernel"), py::arg("scales"), py::arg("zeros"), py::arg("sz_packed"), py::arg("bias") = py::none());
+        py::arg("kernel"), py::arg("scales"), py::arg("zeros"), py::arg("sz_packed"), py::arg("bias") = py::none(), py::arg("sz_half") = py::none());
   m.def("moe_gemm_forward", &moe_gemm_forward, "grouped per-expert W4A16 GEMM (tokens sorted by expert)", py::arg("x_sorted"),
         py::arg("kernel"), py::arg("scales"), py::arg("zeros"), py::arg("expert_offsets"), py::arg("cdna4") = false);
   m.def("moe_forward_cdna4", &moe_forward_cdna4, "grouped per-expert forward on cdna4 buffers (GEMV for <= 8 rows, GEMM otherwise)");

@@ -247,9 +247,9 @@ def gemv_cdna4(x, qweight, scales, scaled_zeros, sz_packed=None, group_size: int
     return out
 
 
-def gemm_cdna4(x, qweight, scales, scaled_zeros, bias=None, sz_packed=None, group_size: int = 128):
-    """C-ABI awq_w4a16_forward_cdna4: any M (M <= 16 -> GEMV), optional bias."""
-    _need_gpu(x, qweight, scales, scaled_zeros, bias, sz_packed)
+def gemm_cdna4(x, qweight, scales, scaled_zeros, bias=None, sz_packed=None, group_size: int = 128, sz_half=None):
+    """C-ABI awq_w4a16_forward_cdna4 (awq_w4a16_forward_cdna4_szh when the layer's sz_half side buffer is given): any M (M <= 16 -> GEMV), optional bias."""
+    _need_gpu(x, qweight, scales, scaled_zeros, bias, sz_packed, sz_half)
     k = x.shape[-1]
     m = x.numel() // k
     n = qweight.shape[0] * 4
@@ -257,6 +257,12 @@ def gemm_cdna4(x, qweight, scales, scaled_zeros, bias=None, sz_packed=None, grou
     ws_bytes = _capi.lib().awq_w4a16_forward_cdna4_workspace_bytes(m, n, k)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device) if ws_bytes else None
     with torch.cuda.device(x.device):
+        if sz_half is not None:
+            _capi.check(_capi.lib().awq_w4a16_forward_cdna4_szh(x.data_ptr(), qweight.data_ptr(), scales.data_ptr(), scaled_zeros.data_ptr(),
+                                                                 sz_packed.data_ptr() if sz_packed is not None else None, sz_half.data_ptr(),
+                                                                 bias.data_ptr() if bias is not None else None, out.data_ptr(), m, n, k, group_size,
+                                                                 _dt(x), ws.data_ptr() if ws is not None else None, ws_bytes, _stream(x)))
+            return out
         _capi.check(_capi.lib().awq_w4a16_forward_cdna4(x.data_ptr(), qweight.data_ptr(), scales.data_ptr(),
                                                          scaled_zeros.data_ptr(),
                                                          sz_packed.data_ptr() if sz_packed is not None else None,
@@ -312,10 +318,13 @@ def mlp_gate_up_forward_cdna4(x, qweight_interleaved, sz_packed, sz_half=None, g
     m = x.numel() // k
     n2 = qweight_interleaved.shape[0] * 4
     out = torch.empty(*x.shape[:-1], n2 // 2, dtype=x.dtype, device=x.device)
+    ws_bytes = _capi.lib().awq_w4a16_mlp_gate_up_forward_cdna4_workspace_bytes(m, n2, k)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device) if ws_bytes else None
     with torch.cuda.device(x.device):
-        _capi.check(_capi.lib().awq_w4a16_mlp_gate_up_forward_cdna4(x.data_ptr(), qweight_interleaved.data_ptr(), sz_packed.data_ptr(),
-                                                                     sz_half.data_ptr() if sz_half is not None else None, out.data_ptr(),
-                                                                     m, n2, k, group_size, _dt(x), _stream(x)))
+        _capi.check(_capi.lib().awq_w4a16_mlp_gate_up_forward_cdna4_ws(x.data_ptr(), qweight_interleaved.data_ptr(), sz_packed.data_ptr(),
+                                                                        sz_half.data_ptr() if sz_half is not None else None, out.data_ptr(),
+                                                                        m, n2, k, group_size, _dt(x), ws.data_ptr() if ws is not None else None,
+                                                                        ws_bytes, _stream(x)))
     return out
 
 

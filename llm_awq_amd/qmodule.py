@@ -280,8 +280,11 @@ class WQLinear(nn.Module):
                         served = self._decode_served[rows] = rows >= 1 and eng.decode_cdna4_plan(rows, self.out_features, self.in_features, 0)[0] > 0
                     if served:
                         return eng.decode_cdna4(x, self.qweight, self.szh_cdna4, self.bias, 0)
-            fwd = eng.forward_cdna4 if self.layout == "cdna4" else eng.forward_w3
-            return fwd(x, self.qweight, self.scales, self.scaled_zeros, self.sz_cdna4, self.bias)
+            if self.layout == "cdna4":
+                # (prompts: the tile kernels take the layer's sz_half side buffer too when it exists -- the f16-mantissa dequant form, same results)
+                szh = self.szh_cdna4 if (self.szh_cdna4 is not None and self.szh_cdna4 is not False) else None
+                return eng.forward_cdna4(x, self.qweight, self.scales, self.scaled_zeros, self.sz_cdna4, self.bias, szh)
+            return eng.forward_w3(x, self.qweight, self.scales, self.scaled_zeros, self.sz_cdna4, self.bias)
         rows = x.numel() // x.shape[-1]
         if rows < 8:
             out = eng.gemv_forward_cuda_new(x, self.qweight, self.scales, self.scaled_zeros, rows,

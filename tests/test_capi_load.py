@@ -128,10 +128,11 @@ def test_one_launch_mlp_plan_and_state_size():
     L = _capi.lib()
     assert L.awq_w4a16_mlp_decode_cdna4_plan(1, 4096, 14336, 4096) == 1   # Llama-3-8B
     assert L.awq_w4a16_mlp_decode_cdna4_plan(1, 4096, 11008, 4096) == 1   # Llama-2-7B
-    assert L.awq_w4a16_mlp_decode_cdna4_plan(1, 4096, 4096, 256) == 1
+    assert L.awq_w4a16_mlp_decode_cdna4_plan(1, 4096, 4096, 4096) == 1 and L.awq_w4a16_mlp_decode_cdna4_plan(1, 4096, 128, 4096) == 1
+    assert L.awq_w4a16_mlp_decode_cdna4_plan(1, 4096, 4096, 256) == 0    # one down_proj slab per CU of the 256: n_out = 4096
     assert L.awq_w4a16_mlp_decode_cdna4_plan(2, 4096, 14336, 4096) == 0   # one row only
-    assert L.awq_w4a16_mlp_decode_cdna4_plan(1, 8192, 28672, 8192) == 0   # Llama-3-70B: the gate/up ring is compiled for 8 k-steps per wave
-    assert L.awq_w4a16_mlp_decode_cdna4_plan(1, 4096, 2048, 4096) == 0 and L.awq_w4a16_mlp_decode_cdna4_plan(1, 4096, 28672, 4096) == 0
+    assert L.awq_w4a16_mlp_decode_cdna4_plan(1, 8192, 28672, 8192) == 0   # Llama-3-70B: a wave keeps its two k-steps of x in registers (hidden = 4096)
+    assert L.awq_w4a16_mlp_decode_cdna4_plan(1, 4096, 14400, 4096) == 0 and L.awq_w4a16_mlp_decode_cdna4_plan(1, 4096, 28672, 4096) == 0  # ffn % 128, <= 7 slabs per CU
     assert L.awq_w4a16_mlp_decode_cdna4_plan(1, 4096, 14336, 4100) == 0 and L.awq_w4a16_mlp_decode_cdna4_plan(0, 4096, 14336, 4096) == 0
     assert L.awq_w4a16_mlp_decode_cdna4_state_bytes(1, 14336) == _capi.AWQ_MLP_DECODE_COUNTER_BYTES + 14336 * 4
     assert L.awq_w4a16_mlp_decode_cdna4_state_bytes(0, 14336) == 0

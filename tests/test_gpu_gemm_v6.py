@@ -187,8 +187,8 @@ def test_v6_128_wide_blocks_equal_the_default_plan(ops, dtype):
 def test_v6_block_pair_k_split_against_the_oracle(ops, dtype, M, lead, bias):
     """Tiles that fill at most half the chip run as block PAIRS, each summing half of K; the upper half hands its fp32 accumulators over inside the
     launch (the reference's split_k_iters + Semaphore, gemm_cuda.cu:546-619, in one kernel).  Oracle check on a K the oracle takes (the knob lowers the
-    K >= 8192 rule), every lead (K tiles the producer half runs less), a shifted last row tile and the bias epilogue; against the unsplit kernels the
-    result differs only by the association of one fp32 add."""
+    K >= 8192 rule), a shifted last row tile and the bias epilogue; against the unsplit kernels the result differs only by the association of one fp32 add.
+    (`lead`: round 4's asymmetric hand-over ran one half short; the symmetric pair of round 5 splits K evenly and the knob is a no-op kept for old scripts.)"""
     N, K = 4096, 1024
     c = make_case(N, K, dtype, seed=N + K + M, M=M, bias=bias)
     c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
@@ -289,3 +289,65 @@ def test_v6_block_pair_k_split_w3_tiles(ops, dtype):
     assert_bits(ref, y, 0.03)
     assert_bits(y, y0, 0.01)
     assert ops._capi.lib().awq_w4a16_gemm_cdna4_pair_plan(2048, 4096, 11008) == 1  # (the Llama-2-7B down_proj shape itself)
+
+
+def test_v6_block_pair_k4096_launches_sz_half_and_the_fused_tail(ops):
+    """Round 5: the pair split is symmetric (each block finishes half of the tile's rows) and, with knob gemm_v6_pair_min_nit = 32, also serves the K = 4096
+    launches whose 256-wide tiles fill half the chip at 2048 rows -- o_proj (whole matrix) and the 128 column tiles the gate/up launch leaves behind its three
+    full rounds (n_begin > 0, SiLU * mul epilogue) -- in both dequant forms (sz_packed / the layer's sz_half side buffer).  Against the CPU oracle and against
+    the 256 x 128 blocks they replace."""
+    from llm_awq_amd.fused_mlp import interleave_gate_up
+    from tests.helpers import Gen
+    dtype, M, K = torch.bfloat16, 2048, 4096
+    L = ops._capi.lib()
+    # ---- o_proj: 4096 -> 4096 ----
+    N = 4096
+    c = make_case(N, K, dtype, seed=2 * (K * 7 + N))
+    x = Gen(41).randn(M, K).to(dtype)
+    c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
+    s, z = c["scales"].cuda(), c["scaled_zeros"].cuda()
+    szp = ops.pack_sz_cdna4(s, z, K)
+    szh, exact = ops.pack_szh_cdna4(s, z, K)
+    assert exact
+    y_or = (x.float() @ O.dequant_weight(c["q"], c["scales"], c["scaled_zeros"], 128).float().t()).to(dtype)  # the oracle forward: fp32 accumulate, one rounding
+    try:
+        ops._capi.tune(gemm_v6_pair_min_nit=32)
+        assert L.awq_w4a16_gemm_cdna4_pair_plan(M, N, K) == 1 and L.awq_w4a16_forward_cdna4_workspace_bytes(M, N, K) == 128 * (256 * 256 * 4 + 64)
+        ys = [ops.gemm_cdna4(x.cuda(), c4, s, z, None, szp), ops.gemm_cdna4(x.cuda(), c4, s, z, None, szp, sz_half=szh)]
+        ops._capi.tune(gemm_v6_pair_min_nit=64)
+        assert L.awq_w4a16_gemm_cdna4_pair_plan(M, N, K) == 0
+        y128 = ops.gemm_cdna4(x.cuda(), c4, s, z, None, szp)
+    finally:
+        ops._capi.tune(gemm_v6_pair_min_nit=64)
+    for y in ys:
+        yc = y.cpu()
+        assert ((yc.double() - y_or.double()).norm() / y_or.double().norm()).item() <= 1e-3
+        assert_bits(yc, y_or, 0.02, ulps=1)
+        assert_bits(y, y128, 0.01)
+    assert torch.equal(ys[0], ys[1]), "the two dequant forms give the same weights, so the same products in the same order"
+    # ---- gate/up: 4096 -> 2 x 14336 interleaved; 8 x 96 tiles in three full rounds + 128 tiles = 128 pairs behind them ----
+    F = 14336
+    cg, cu = make_case(F, K, dtype, seed=F + K + M, M=1), make_case(F, K, dtype, seed=F + K + M + 1, M=1)
+    qi, si, zi = interleave_gate_up(cg["qweight"].cuda(), cu["qweight"].cuda(), cg["scales"].cuda(), cu["scales"].cuda(),
+                                    cg["scaled_zeros"].cuda(), cu["scaled_zeros"].cuda())
+    c4 = ops.repack_v2_to_cdna4(qi)
+    szp = ops.pack_sz_cdna4(si, zi, K)
+    szh, exact = ops.pack_szh_cdna4(si, zi, K)
+    assert exact
+    gq = L.awq_w4a16_mlp_gate_up_forward_cdna4_workspace_bytes
+    try:
+        ops._capi.tune(gemm_v6_pair_min_nit=32)
+        assert gq(M, 2 * F, K) == 128 * (256 * 256 * 4 + 64)
+        ya = ops.mlp_gate_up_forward_cdna4(x.cuda(), c4, szp, szh)
+        yb = ops.mlp_gate_up_forward_cdna4(x.cuda(), c4, szp, None)
+        assert torch.equal(ya, ops.mlp_gate_up_forward_cdna4(x.cuda(), c4, szp, szh))
+        ops._capi.tune(gemm_v6_pair_min_nit=64)
+        y0 = ops.mlp_gate_up_forward_cdna4(x.cuda(), c4, szp, szh)
+    finally:
+        ops._capi.tune(gemm_v6_pair_min_nit=64)
+    gt = (x.float() @ O.dequant_weight(cg["q"], cg["scales"], cg["scaled_zeros"], 128).float().t()).to(dtype)
+    up = (x.float() @ O.dequant_weight(cu["q"], cu["scales"], cu["scaled_zeros"], 128).float().t()).to(dtype)
+    for y in (ya, yb):
+        check_fused_tail(y.cpu(), gt, up, REL_TAIL[dtype], what="gate/up M=2048 with the remainder as block pairs")
+        assert_bits(y, y0, 0.01)
+    assert torch.equal(ya[:, : 96 * 128], y0[:, : 96 * 128]), "the three full rounds are the same launch either way"
