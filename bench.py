@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--tune", action="append", default=[], help="experiments only: awq_tune_set knobs as key=value")
     ap.add_argument("--layout", default="cdna4", choices=["cdna4", "v2"], help="cdna4 = what the rewritten repacker emits (default); v2 = reference checkpoint layout through gemv/gemm_forward_cuda_new only")
     ap.add_argument("--mlp-decode", default="two", choices=["one", "two"],
-                    help="decode, --mlp interleaved: QuantLlamaMLP.forward as the fused gate/up launch followed by down_proj's (default: faster), or as ONE launch (awq_w4a16_mlp_decode_cdna4, granule hand-over of h; measured slower: profiles/r04_mlp_one_launch.txt)")
+                    help="decode, --mlp interleaved: QuantLlamaMLP.forward as the fused gate/up launch followed by down_proj's (default: faster), or as ONE persistent launch (awq_w4a16_mlp_decode_cdna4, csrc/awq_mlp_engine.hip: per-wave LDS-DMA rings running ahead across the op edge, granule all-gather of h; measured slower: profiles/r05_mlp_engine.txt)")
     ap.add_argument("--overlap-probe", type=int, default=0, help="experiments (NOT a valid decode figure): issue the decode launches round-robin on this many streams inside the graph, i.e. drop the dependency between consecutive linears -- the upper bound of what cross-launch overlap could give")
     ap.add_argument("--repeat-layers", type=int, default=1, help="experiments: run the --layers layers this many times per step (with --layers 1/2 the weights stay in the 256 MB Infinity Cache)")
     ap.add_argument("--mlp", default="interleaved", choices=["interleaved", "stacked", "unfused"],
@@ -364,8 +364,8 @@ def main():
     bytes_step = bytes_native(1) * args.repeat_layers if native_leg else sum(algo_bytes(1, K, N) for (_n, K, N, *_r) in raw)
     avg_launch_us = ev_ms * 1e3 / (args.steps * launches)
     gbs = bytes_step * args.steps / (ev_ms * 1e-3) / 1e9
-    kname = ("awq::gemv_dma_kernel (qkv, o) + awq::mlp_decode_kernel (gate/up + SiLU*mul + down)" if one_launch_mlp else "awq::gemv_dma_kernel") if native_leg else "awq::gemv_dma_kernel (via gemv_forward_cuda_new + the engine's repack cache)"
-    traffic, traffic_src = pmc_traffic(["awq::gemv_dma_kernel", "awq::gemv_cdna4_kernel", "awq::mlp_decode_kernel"])
+    kname = ("awq::gemv_dma_kernel (qkv, o) + awq::mlp_engine_kernel (gate/up + SiLU*mul + down, one persistent launch)" if one_launch_mlp else "awq::gemv_dma_kernel") if native_leg else "awq::gemv_dma_kernel (via gemv_forward_cuda_new + the engine's repack cache)"
+    traffic, traffic_src = pmc_traffic(["awq::gemv_dma_kernel", "awq::gemv_cdna4_kernel", "awq::mlp_engine_kernel"])
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_us": round(avg_launch_us, 3), "algorithmic_bytes_per_launch": bytes_step // launches,

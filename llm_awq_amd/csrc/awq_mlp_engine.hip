@@ -65,12 +65,9 @@ __device__ __forceinline__ void eng_stamp(unsigned long long* stamps, int slot) 
 
 }  // namespace
 
-// probe (AWQ_PROBES builds only; wrong results): bit 0 = no math, bit 1 = no weight DMA
-#ifdef AWQ_ENABLE_PROBES
+// timing probes (knob mlp_engine_probe, AWQ_TUNING=1 processes only; wrong results): bit 0 = no math, bit 1 = no weight DMA.  Compiled into every build:
+// two wave-uniform branches per tile next to ~60 vector instructions
 #define ENG_PROBE(p) (p)
-#else
-#define ENG_PROBE(p) 0
-#endif
 
 template <typename DT>
 __global__ __launch_bounds__(64 * kEngWaves) void mlp_engine_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw_gu,

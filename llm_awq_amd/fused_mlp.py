@@ -9,11 +9,11 @@ The reference module keeps gate_proj / up_proj as raw v2 buffers, issues two `ge
     two streams (896: 3.5 per CU, so half the CUs carried 4 blocks and the rest 3);
   * decode (<= 8 rows): `decode_cdna4(..., epilogue=2)` -- gate, up, SiLU and the multiply in one launch, every intermediate
     rounded to T exactly like the reference's separate ops (fused_mlp.py:39-61, :79-82) -- then down_proj's launch.  With
-    AWQ_MLP_ONE_LAUNCH=1 a single row is served by ONE launch for the whole module (`mlp_decode_cdna4`: down_proj's blocks sit
-    behind the gate/up blocks in the same grid, stream their first weight tiles while the gate/up tail drains and gather h from
-    8-byte {data, tag} granules the gate/up blocks publish -- no flag, no counter); it is correct, graph-replayable and measured
-    SLOWER (profiles/r04_mlp_one_launch.txt: 27.6-28.3 us against 22.4-23.6 us; what follows the last gate/up block -- hop, gather,
-    the rest of down_proj's stream on eight waves -- is as long as a second launch), so it is opt-in;
+    AWQ_MLP_ONE_LAUNCH=1 a single row is served by ONE persistent launch for the whole module (`mlp_decode_cdna4`, csrc/awq_mlp_engine.hip:
+    one 16-wave workgroup per CU, every wave streaming its own tile sequence -- gate/up k-steps, then down_proj k-steps -- through an
+    LDS-DMA ring that runs ahead across the op boundary; h handed over as 8-byte {data, tag} granules, no flag, no counter); it is
+    correct, graph-replayable and measured SLOWER (profiles/r05_mlp_engine.txt: 29.2-30.2 us against 22.0-22.8 us for the two
+    launches; the all-gather of h to every CU costs more than the kernel boundary it removes), so it is opt-in;
   * prefill (>= 8 rows): one GEMM over the interleaved weight (x is read once for both projections) whose tile epilogue pairs
     column n with column n + 8 and stores silu(gate) * up directly -- the [rows, 2 * ffn] intermediate of the reference's two
     GEMMs + F.silu + multiply is never written.
@@ -156,19 +156,20 @@ class QuantLlamaMLP(nn.Module):
     @torch.no_grad()
     def forward(self, x):
         rows = x.numel() // x.shape[-1]
-        if rows == 1 and x.is_cuda and os.environ.get("AWQ_MLP_ONE_LAUNCH") == "1":  # opt-in: measured slower than two launches
+        if rows == 1 and x.is_cuda and os.environ.get("AWQ_MLP_ONE_LAUNCH") == "1":  # opt-in: measured slower than two launches (profiles/r05_mlp_engine.txt)
             y = self._decode_one_launch(x)
             if y is not None:
                 return y
         return self.down_proj(self.our_llama_mlp(x))
 
     def _decode_one_launch(self, x):
-        """gate/up + SiLU * mul + down_proj in ONE launch (`awq_w4a16_mlp_decode_cdna4`, one row): down_proj's blocks stream the head of their
-        weights while the gate/up tail drains and gather h from the tagged granules the gate/up blocks publish.  None when this layer cannot
-        take it (more than one row, scales not f16-exact, down_proj not in the cdna4 layout, shape outside the kernel's range)."""
+        """gate/up + SiLU * mul + down_proj in ONE persistent launch (`awq_w4a16_mlp_decode_cdna4`, one row): every workgroup streams its gate/up
+        slabs and then its down_proj slab through per-wave LDS-DMA rings that run ahead across the op boundary, publishes its share of h as
+        tagged granules and gathers the whole of it.  None when this layer cannot take it (more than one row, scales not f16-exact, down_proj
+        not in the cdna4 layout, shape outside the kernel's range)."""
         eng = load_engine()
         if x.numel() != x.shape[-1] or not eng.mlp_decode_plan(1, self.in_features, self.intermediate_size, self.out_features):
-            return None  # (host-side plan query: the kernel serves one row, hidden = 4096, 4096 <= ffn <= 16384)
+            return None  # (host-side plan query: one row, hidden = 4096, out_features = 4096, ffn <= 14336, a whole 256-CU device)
         if self._fused is None or self._fused[0].device != x.device:
             self._build(x.device)
         c4, s, z, szp, szh = self._fused

@@ -274,7 +274,7 @@ def test_in_place_entries_release_their_storage_when_the_model_is_deleted(eng):
         del qw
         qb, sb, zb = _dev(b)
         eng.gemv_forward_cuda_new(b["x"].cuda(), qb, sb, zb, 2, 256, 512, 128)   # miss -> sweep
-        assert eng.cdna4_cache_info()["entries"] == 2
+        assert eng.cdna4_cache_info()["entries"] == 2, ("the entry of a live alias must survive a sweep", eng.cdna4_cache_info())
         y = eng.gemv_forward_cuda_new(x, alias, s, z, 2, N, K, 128).cpu()
         check_forward(y, a["x"], a["q"], a["scales"], a["scaled_zeros"], torch.bfloat16)
         held = torch.cuda.memory_allocated()
@@ -282,8 +282,8 @@ def test_in_place_entries_release_their_storage_when_the_model_is_deleted(eng):
         qc, sc, zc = _dev(make_case(256, 512, torch.bfloat16, seed=45, M=2))
         eng.gemv_forward_cuda_new(b["x"].cuda(), qc, sc, zc, 2, 256, 512, 128)   # miss -> sweep drops the orphaned entry
         torch.cuda.synchronize()
-        assert eng.cdna4_cache_info()["entries"] == 2
-        assert torch.cuda.memory_allocated() <= held - N * K // 2 + (1 << 20), (base, held, torch.cuda.memory_allocated())
+        assert eng.cdna4_cache_info()["entries"] == 2, ("the orphaned entry must be dropped by the sweep", eng.cdna4_cache_info())
+        assert torch.cuda.memory_allocated() <= held - N * K // 2 + (1 << 20), ("storage not released", base, held, torch.cuda.memory_allocated())
     finally:
         eng.cdna4_cache_enable(True)
         eng.cdna4_cache_inplace(False)

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from oracle import awq_oracle as O
-from tests.helpers import check_forward, check_fused_tail, make_case, cuda_gen, assert_bits
+from tests.helpers import acc_slack, check_forward, check_fused_tail, make_case, cuda_gen, assert_bits, weight_row_norms
 
 # norm-wise distance of the fused tail from the oracle's tail: measured on MI355X + 20 % (profiles/r05_test_stats.txt); the HARD criterion is the hull
 REL_TAIL = {torch.bfloat16: 3e-3, torch.float16: 3e-3}
@@ -95,7 +95,7 @@ def test_v6_fused_silu_mul(ops, dtype, M):
     finally:
         _reset(ops)
     assert y.shape == (M, F)
-    check_fused_tail(y, g, u, REL_TAIL[dtype], what=f"v6 fused tail M={M}")
+    check_fused_tail(y, g, u, REL_TAIL[dtype], what=f"v6 fused tail M={M}", slack_g=acc_slack(x, weight_row_norms(cg)), slack_u=acc_slack(x, weight_row_norms(cu)))
     assert_bits(y, ref, 0.05)
     assert_bits(y, y4, 0.001)
 
@@ -348,6 +348,7 @@ def test_v6_block_pair_k4096_launches_sz_half_and_the_fused_tail(ops):
     gt = (x.float() @ O.dequant_weight(cg["q"], cg["scales"], cg["scaled_zeros"], 128).float().t()).to(dtype)
     up = (x.float() @ O.dequant_weight(cu["q"], cu["scales"], cu["scaled_zeros"], 128).float().t()).to(dtype)
     for y in (ya, yb):
-        check_fused_tail(y.cpu(), gt, up, REL_TAIL[dtype], what="gate/up M=2048 with the remainder as block pairs")
+        check_fused_tail(y.cpu(), gt, up, REL_TAIL[dtype], what="gate/up M=2048 with the remainder as block pairs", slack_g=acc_slack(x, weight_row_norms(cg)),
+                         slack_u=acc_slack(x, weight_row_norms(cu)))
         assert_bits(y, y0, 0.01)
     assert torch.equal(ya[:, : 96 * 128], y0[:, : 96 * 128]), "the three full rounds are the same launch either way"

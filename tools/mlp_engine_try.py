@@ -98,14 +98,21 @@ def stamps(copies, x):
     torch.cuda.synchronize()
     _capi.check(L.awq_w4a16_mlp_decode_cdna4_set_stamps(None))
     t = buf.view(256, 16, 8).cpu().double()
-    t0 = t[:, :, 0].min()
-    span = (t[:, :, 6].max() - t0).item()
+    # s_memtime is per XCD (the eight counters are not synchronised): every stamp is taken relative to ITS OWN wave's start; waves of one block share a CU
+    d = t - t[:, :, :1]
+    blk = t - t[:, :1, :1]          # relative to wave 0 of the same block (same CU, same counter)
     names = ["start", "first tile landed", "gate/up phase done", "h published (wave 0) / past the barrier", "h gathered", "down_proj phase done", "end"]
-    print(f"stamps of one launch (s_memtime ticks since the first wave's start; span {span:.0f} ticks; eager launch incl. events {e0.elapsed_time(e1) * 1e3:.1f} us)")
+    print(f"stamps of one launch (s_memtime ticks = shader cycles, relative to the wave's own start; eager launch incl. events {e0.elapsed_time(e1) * 1e3:.1f} us)")
+    q = torch.tensor([0.0, 0.1, 0.5, 0.9, 1.0], dtype=torch.float64)
     for p, nm in enumerate(names):
-        v = (t[:, :, p] - t0).flatten()
-        w0 = (t[:, 0, p] - t0)
-        print(f"  {nm:42s} all waves min {v.min().item():8.0f} median {v.median().item():8.0f} max {v.max().item():8.0f}   wave 0: median {w0.median().item():8.0f} max {w0.max().item():8.0f}")
+        v = d[:, :, p].flatten()
+        qs = torch.quantile(v, q).tolist()
+        print(f"  {nm:42s} min {qs[0]:7.0f}  p10 {qs[1]:7.0f}  median {qs[2]:7.0f}  p90 {qs[3]:7.0f}  max {qs[4]:7.0f}")
+    print("  by wave index (median over the 256 blocks): start after the block's wave 0 | first tile | gate/up done | past barrier | gathered | down done | end")
+    for w in range(16):
+        row = [blk[:, w, 0].median().item()] + [d[:, w, p].median().item() for p in range(1, 7)]
+        print(f"    wave {w:2d}: " + " ".join(f"{x:8.0f}" for x in row))
+    span = d[:, :, 6].max().item()
     return span
 
 
@@ -124,7 +131,7 @@ def main():
     assert all(int(c["state"][2].item()) == 0 for c in copies)
     span = stamps(copies, x)
     print(f"(ticks per us, if the span is the graph-replay time of the launch minus ~1.5 us of boundary: {span / max(ts[-1][1] - 1.5, 1):.0f})")
-    if os.environ.get("AWQ_PROBES") == "1":
+    if True:
         for pv, nm in ((1, "no math (stream only)"), (2, "no weight DMA (math + hand-over only)"), (3, "neither")):
             _capi.tune(mlp_engine_probe=pv)
             print(f"probe {nm}: {time_graph(lambda c: one(c, x), copies):6.2f} us", flush=True)
