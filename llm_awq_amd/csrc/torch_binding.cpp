@@ -83,11 +83,31 @@ struct CacheEntry {
   hipEvent_t built = nullptr;  // recorded on the building stream; other streams wait for it until it has completed
   hipStream_t build_stream = nullptr;
   bool settled = false;
-  bool inplace = false;  // AWQ_CDNA4_INPLACE=1: c4 IS the caller's qweight storage, converted where it lies (no second copy)
-  uint32_t vc4 = 0;      // in-place entries: c4's version counter at conversion.  c4 is the module's own tensor, and `.detach()` / `.data` / view aliases
-                         // share its counter: a later value means the caller wrote fresh v2 bytes over the converted ones (copy_, load_state_dict)
-  // the converted bytes are still what the cache put there (false: overwritten since -- nothing to restore, nothing to follow)
-  bool inplace_intact() const { return inplace && c4.defined() && tensor_version(c4) == vc4; }
+  // AWQ_CDNA4_INPLACE=1: the caller's qweight storage is converted where it lies (no second copy).  The entry does NOT own that storage -- a cache must
+  // never extend the lifetime of the model's weights (`del model` has to give the memory back) -- it keeps a WEAK reference to it, the
+  // view's geometry, and the version counter the module's tensor shares with its `.detach()` / `.data` / view aliases
+  bool inplace = false;
+  c10::weak_intrusive_ptr<c10::StorageImpl> ws{c10::intrusive_ptr<c10::StorageImpl>()};
+  int64_t ws_offset = 0, ws_n4 = 0, ws_k = 0;
+  c10::Device ws_dev{c10::DeviceType::CPU};
+  bool has_vc = false;
+  c10::VariableVersion vc{c10::VariableVersion::DISABLED};
+  uint32_t vc4 = 0;  // the counter's value at conversion: a later value means the caller wrote fresh v2 bytes over the converted ones (copy_, load_state_dict)
+  bool inplace_alive() const { return inplace && !ws.expired(); }
+  // the converted bytes are still what the cache put there (false: storage gone, or overwritten since -- nothing to restore, nothing to follow)
+  bool inplace_intact() const { return inplace_alive() && (!has_vc || (uint32_t)vc.current_version() == vc4); }
+  bool holds(const torch::Tensor& t) const {  // is `t` a tensor over the converted storage?
+    auto l = ws.lock();
+    return l && l.get() == t.storage().unsafeGetStorageImpl();
+  }
+  // a tensor over the converted bytes (keeps the storage alive for the call); undefined if the storage is gone
+  at::Tensor inplace_tensor() const {
+    auto l = ws.lock();
+    if (!l) return at::Tensor();
+    at::Tensor t = at::empty({0}, at::TensorOptions().dtype(at::kShort).device(ws_dev));
+    t.set_(c10::Storage(std::move(l)), ws_offset, {ws_n4, ws_k}, {ws_k, 1});
+    return t;
+  }
   explicit CacheEntry(const torch::Tensor& tw) : w(tw.getIntrusivePtr()), vw(tensor_version(tw)) {}
 };
 std::mutex g_cache_mu;
@@ -118,23 +138,17 @@ bool cache_enabled() {
 // an in-place entry whose qweight is still alive: put the reference (v2) interleave back before the entry is forgotten, or the next
 // call would take the permuted bytes for v2 data and permute them again
 void restore_inplace(CacheEntry& e) {
-  if (!e.inplace || !e.c4.defined()) return;
-  if (!e.inplace_intact()) {  // overwritten with fresh v2 bytes since the conversion: running the cdna4 -> v2 permutation over them would corrupt them
-    e.inplace = false;
-    e.c4 = at::Tensor();
-    return;
-  }
-  // (not tied to the tensor the entry last followed: that may have been a temporary alias -- `.detach()`, a view -- that is gone, while the
-  // module's own tensor over the same storage is alive; e.c4 holds the storage)
-  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(e.c4.device());
+  if (!e.inplace) return;
+  at::Tensor t = e.inplace_intact() ? e.inplace_tensor() : at::Tensor();
+  e.inplace = false;
+  if (!t.defined()) return;  // storage gone, or overwritten with fresh v2 bytes since the conversion: running the cdna4 -> v2 permutation over them would corrupt them
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(t.device());
   hipStream_t st = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
   if (e.built && st != e.build_stream) (void)hipStreamWaitEvent(st, e.built, 0);
-  at::Tensor tmp = torch::empty_like(e.c4);
-  const int n = (int)e.c4.size(0) * 4, k = (int)e.c4.size(1);
-  if (awq_repack_cdna4_to_v2(e.c4.data_ptr(), tmp.data_ptr(), n, k, (void*)st) == AWQ_OK)
-    (void)hipMemcpyAsync(e.c4.data_ptr(), tmp.data_ptr(), e.c4.nbytes(), hipMemcpyDeviceToDevice, st);
-  e.inplace = false;
-  e.c4 = at::Tensor();
+  at::Tensor tmp = torch::empty_like(t);
+  const int n = (int)t.size(0) * 4, k = (int)t.size(1);
+  if (awq_repack_cdna4_to_v2(t.data_ptr(), tmp.data_ptr(), n, k, (void*)st) == AWQ_OK)
+    (void)hipMemcpyAsync(t.data_ptr(), tmp.data_ptr(), t.nbytes(), hipMemcpyDeviceToDevice, st);
 }
 
 void drop_entry(std::unordered_map<const void*, CacheEntry>::iterator it) {
@@ -148,7 +162,7 @@ void drop_entry(std::unordered_map<const void*, CacheEntry>::iterator it) {
 // is this exact buffer (data pointer incl. storage offset) currently held converted in place?  (g_cache_mu held by the caller)
 bool inplace_converted_locked(const torch::Tensor& kernel) {
   auto it = g_cache.find(kernel.data_ptr());
-  return it != g_cache.end() && it->second.inplace_intact() && it->second.c4.storage().is_alias_of(kernel.storage());
+  return it != g_cache.end() && it->second.inplace_intact() && it->second.holds(kernel);
 }
 // the reference-layout kernels must never read a buffer the cache converted where it lies: callers that cannot be served by the cdna4 path
 // (cache switched off, fp32 scales, a failed scale pack) get an error that names the way out instead of silently wrong products
@@ -177,10 +191,11 @@ bool cdna4_view(const torch::Tensor& kernel, const torch::Tensor& scales, const 
   if (it != g_cache.end()) {
     auto lw = it->second.w.lock();
     // an in-place entry whose storage was overwritten since the conversion (the shared version counter moved) is stale whichever alias asks
-    const bool overwritten = it->second.inplace && it->second.c4.defined() && !it->second.inplace_intact();
-    if (overwritten || lw.get() != kernel.unsafeGetTensorImpl() || it->second.vw != tensor_version(kernel)) {  // address re-used or edited in place
+    const bool gone = it->second.inplace && !it->second.inplace_alive();  // its storage was freed and the address handed to another tensor
+    const bool overwritten = it->second.inplace && it->second.inplace_alive() && !it->second.inplace_intact();
+    if (gone || overwritten || lw.get() != kernel.unsafeGetTensorImpl() || it->second.vw != tensor_version(kernel)) {  // address re-used or edited in place
       CacheEntry& old = it->second;
-      const bool same_bytes = old.inplace_intact() && old.c4.storage().is_alias_of(kernel.storage());
+      const bool same_bytes = old.inplace_intact() && old.holds(kernel);
       if (same_bytes && lw.get() != kernel.unsafeGetTensorImpl()) {
         // ANOTHER tensor over the converted bytes (a view, .detach(), .data, load_state_dict(assign=True) of an alias, a compile wrapper):
         // the storage already holds the cdna4 interleave -- converting "again" would permute it twice.  The entry follows the caller
@@ -204,17 +219,11 @@ bool cdna4_view(const torch::Tensor& kernel, const torch::Tensor& scales, const 
       auto cur = i2++;
       auto lw = cur->second.w.lock();
       // (the key is the tensor's data pointer INCLUDING its storage offset: sharded / flattened parameter buffers are views)
-      // an in-place entry lives as long as anybody else holds the converted storage: the tensor it last followed may have been a temporary
-      // alias, and forgetting the entry while the module's own tensor is alive would have the next call permute the bytes a second time
-      if (cur->second.inplace && cur->second.c4.defined()) {
-        // c4 IS the caller's tensor: the entry's own handle counts once, and so does the temporary `lw` when the entry still follows that tensor.
-        // Anybody else (the module, an alias over the storage) keeps the entry alive; with nobody left the converted bytes are unreachable:
-        // drop without restoring, the storage goes back to the allocator
-        const size_t own = 1 + ((lw && lw.get() == cur->second.c4.unsafeGetTensorImpl()) ? 1 : 0);
-        const size_t impls = 1 + ((lw && lw.get() != cur->second.c4.unsafeGetTensorImpl() && lw->storage().is_alias_of(cur->second.c4.storage())) ? 1 : 0);
-        if (cur->second.c4.use_count() > own || cur->second.c4.storage().use_count() > impls) continue;
-        lw.reset();
-        drop_entry(cur);
+      if (cur->second.inplace) {
+        // an in-place entry lives exactly as long as the storage it converted: the tensor it last followed may have been a temporary alias, and
+        // forgetting the entry while the module's own tensor is alive would have the next call permute the bytes a second time
+        if (cur->second.inplace_alive()) continue;
+        drop_entry(cur);  // the weights are gone (the cache never held them): nothing to restore
         continue;
       }
       if (!lw || lw->data() != cur->first) drop_entry(cur);
@@ -226,8 +235,15 @@ bool cdna4_view(const torch::Tensor& kernel, const torch::Tensor& scales, const 
       at::Tensor tmp = torch::empty_like(kernel);  // stream-ordered allocation: returned to the pool when it goes out of scope
       if (awq_repack_v2_to_cdna4(kernel.data_ptr(), tmp.data_ptr(), (int)n, (int)k, (void*)stream) != AWQ_OK) return false;
       if (hipMemcpyAsync(kernel.data_ptr(), tmp.data_ptr(), kernel.nbytes(), hipMemcpyDeviceToDevice, stream) != hipSuccess) return false;
-      e.c4 = kernel;  // (a raw copy: the tensor's version counter does not move, so the entry stays valid)
+      // (a raw copy: the tensor's version counter does not move, so the entry stays valid)
       e.inplace = true;
+      e.ws = c10::weak_intrusive_ptr<c10::StorageImpl>(c10::intrusive_ptr<c10::StorageImpl>::reclaim_copy(kernel.storage().unsafeGetStorageImpl()));
+      e.ws_offset = kernel.storage_offset();
+      e.ws_n4 = n / 4;
+      e.ws_k = k;
+      e.ws_dev = kernel.device();
+      e.has_vc = !kernel.is_inference();
+      if (e.has_vc) e.vc = kernel.unsafeGetTensorImpl()->version_counter();
       e.vc4 = tensor_version(kernel);
     } else {
       e.c4 = torch::empty_like(kernel);
@@ -267,7 +283,7 @@ bool cdna4_view(const torch::Tensor& kernel, const torch::Tensor& scales, const 
     if (capturing) {
       // built while a graph is being captured: the pack kernel is only RECORDED, so the buffer must not be published (an eager call
       // could hit it before the first replay); it lives for this call's launch alone, decode uses the T-typed sz_packed
-      c4 = e.c4;
+      c4 = e.inplace ? kernel : e.c4;
       szp = nszp;
       if (szh) *szh = at::Tensor();
       return true;
@@ -301,7 +317,7 @@ bool cdna4_view(const torch::Tensor& kernel, const torch::Tensor& scales, const 
     }
   }
   hit->stamp = ++g_cache_clock;
-  c4 = e.c4;
+  c4 = e.inplace ? kernel : e.c4;  // (in place: the caller's tensor IS the converted buffer)
   szp = hit->szp;
   if (szh) *szh = hit->szh;
   return true;

@@ -275,7 +275,7 @@ def check_fused_tail(y: torch.Tensor, gate: torch.Tensor, up: torch.Tensor, rel_
     torch's value or a neighbour one ulp of T away; the multiply and its rounding are deterministic.  silu is monotone on either side of its minimum
     (-0.27846 at -1.27846) and the product is monotone in each factor, so y must lie in the hull of the ORACLE tail over
     {gate -, gate, gate +, the minimum if the gate interval holds it} x {silu -, silu, silu +} x {up -, up, up +} -- no slack on top.
-    Norm-wise: against the oracle's tail, recorded (AWQ_TEST_STATS) and held to `rel_max` = the value measured on MI355X + 20 %."""
+    Norm-wise: against the oracle's tail, recorded (AWQ_TEST_STATS) and held to `rel_max` (BASELINE.json's 1e-3; measured <= 3.7e-4, profiles/r05_test_stats.txt)."""
     dtype = y.dtype
     lo = hi = None
     centre = None

@@ -7,7 +7,7 @@ import torch
 from oracle import awq_oracle as O
 from tests.helpers import Gen, assert_bits, check_forward, make_case, record_rel, rmsnorm_uncertainty
 
-REL_NORM_TAIL = 3e-3  # fused norm + gate/up tail, norm-wise: measured on MI355X + 20 % (profiles/r05_test_stats.txt)
+REL_NORM_TAIL = 1e-3  # fused norm + gate/up tail, norm-wise: BASELINE.json's tolerance (measured on MI355X: <= 5.4e-5, profiles/r05_test_stats.txt)
 
 
 def test_oracle_rmsnorm_matches_llama_rmsnorm_formula():
@@ -69,8 +69,8 @@ def test_gpu_rmsnorm_gate_up_vs_oracle(dtype, M):
     up = O.wqlinear_forward(xn, None, cu["scales"], cu["scaled_zeros"], None, 128, q_int=cu["q"])
     ref = torch.nn.functional.silu(gt) * up
     # (the normalised x may differ in the last bit of T where rstd's last fp32 bits decide -- rmsnorm_uncertainty -- so gate / up can move by more
-    # than one ulp and the one-ulp hull of check_fused_tail does not apply; the norm-wise bound is the value measured on MI355X + 20 %,
-    # profiles/r05_test_stats.txt, beside the flip count)
+    # than one ulp and the one-ulp hull of check_fused_tail does not apply; the norm-wise bound is BASELINE.json's 1e-3 -- measured <= 5.4e-5,
+    # profiles/r05_test_stats.txt -- beside the flip count)
     rel = ((y.float() - ref.float()).norm() / ref.float().norm()).item()
     record_rel(f"rmsnorm + gate/up M={M}", rel, REL_NORM_TAIL)
     assert rel <= REL_NORM_TAIL, rel

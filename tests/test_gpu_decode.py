@@ -9,9 +9,9 @@ from oracle import awq_oracle as O
 from tests.helpers import acc_slack, check_forward, check_fused_tail, make_case, assert_bits, weight_row_norms
 
 pytestmark = pytest.mark.gpu
-# norm-wise distance of the fused tail from the oracle's tail: the largest value measured on MI355X over this file's cases + 20 %
-# (profiles/r05_test_stats.txt); the HARD criterion is check_fused_tail's elementwise hull
-REL_TAIL = {torch.bfloat16: 3e-3, torch.float16: 3e-3}
+# norm-wise distance of the fused tail from the oracle's tail: BASELINE.json's 1e-3 (measured on MI355X: <= 3.7e-4 over every case of the suite,
+# profiles/r05_test_stats.txt -- 2.7 x below it); the HARD criterion is check_fused_tail's elementwise hull
+REL_TAIL = {torch.bfloat16: 1e-3, torch.float16: 1e-3}
 
 
 @pytest.fixture(scope="module")

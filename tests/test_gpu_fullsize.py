@@ -110,7 +110,7 @@ def test_fused_mlp_fullsize(env):
         assert_bits(ref, y, 0.02)
         # the fused launch's T(gate'), T(up') against the plain GEMM's: the same values or one-ulp neighbours -> the tail's elementwise hull
         wn = ops.dequant_cdna4(c4, w["scales"], w["scaled_zeros"]).float().norm(dim=1).cpu()
-        check_fused_tail(y.cpu(), full[:, :F].cpu(), full[:, F:].cpu(), 2e-3, what=f"stacked gate/up vs GEMM M={M}", slack_g=acc_slack(x.cpu(), wn[:F]),
+        check_fused_tail(y.cpu(), full[:, :F].cpu(), full[:, F:].cpu(), 1e-3, what=f"stacked gate/up vs GEMM M={M}", slack_g=acc_slack(x.cpu(), wn[:F]),
                          slack_u=acc_slack(x.cpu(), wn[F:]))
 
 
@@ -139,5 +139,5 @@ def test_llama3_70b_tp8_shards_sum_to_the_unsharded_layer(env, dtype):
     # a shard splits K over a different number of waves than the full matrix does: same products, another fp32 summation order
     assert_bits(got, full, 0.03)
     rel = ((got.float() - full.float()).norm() / full.float().norm()).item()
-    record_rel("70B gate/up shards vs full", rel, 2e-3)
-    assert rel < 2e-3, rel
+    record_rel("70B gate/up shards vs full", rel, 1e-3)
+    assert rel <= 1e-3, rel  # (measured 1.8e-5: profiles/r05_test_stats.txt)

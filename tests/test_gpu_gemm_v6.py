@@ -11,8 +11,9 @@ import torch
 from oracle import awq_oracle as O
 from tests.helpers import acc_slack, check_forward, check_fused_tail, make_case, cuda_gen, assert_bits, weight_row_norms
 
-# norm-wise distance of the fused tail from the oracle's tail: measured on MI355X + 20 % (profiles/r05_test_stats.txt); the HARD criterion is the hull
-REL_TAIL = {torch.bfloat16: 3e-3, torch.float16: 3e-3}
+# norm-wise distance of the fused tail from the oracle's tail: BASELINE.json's 1e-3 (measured on MI355X: <= 3.7e-4 over every case of the suite,
+# profiles/r05_test_stats.txt -- 2.7 x below it); the HARD criterion is check_fused_tail's elementwise hull
+REL_TAIL = {torch.bfloat16: 1e-3, torch.float16: 1e-3}
 
 pytestmark = pytest.mark.gpu
 
