@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libawq_cdna4.so")
+# (AWQ_CDNA4_LIB: another build of the same library, e.g. an AWQ_PROBES=1 build kept beside the product one for timing experiments)
+LIB_PATH = os.environ.get("AWQ_CDNA4_LIB") or os.path.join(_HERE, "lib", "libawq_cdna4.so")
 
 AWQ_F16, AWQ_BF16 = 0, 1
 AWQ_ERR_WORKSPACE = -7  # include/awq_cdna4.h

@@ -30,7 +30,7 @@
 namespace awq {
 
 // timing probes (builds with AWQ_PROBES=1 only; wrong results): bit 0 = no math (stream only), bit 1 = no weight DMA and no
-// waits for it (math only, on whatever the ring holds)
+// waits for it (math only, on whatever the ring holds), bit 2 = no x staging DMA, bit 3 = no scale (sz) staging DMA
 #ifdef AWQ_ENABLE_PROBES
 #define DMA_PROBE(p) ((p) & 0xFF)
 #else
@@ -83,13 +83,17 @@ __device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __rest
   // slices (out-of-range pieces read 0 through the buffer descriptor), then the rest of the ring: step 0's counted wait
   // (D - 1 tiles may stay in flight) covers everything older than tile 1 ----
   issue(0, 0);
+  if (!(probe & 8)) {
 #pragma unroll
-  for (int s = 0; s < NS; ++s)
-    for (int q = 0; q < TXp; q += 4)
-      dma_to_lds<4, 0>(rs, szs + (s * TXp + q) * 64, lane4, (slab_tile[s] + (u32)(s0 + q)) * 64u);
-  for (int r = 0; r < M; ++r)
-    for (int q = 0; q < TXp; q += 4)
-      dma_to_lds<16, 0>(rx, xs + r * xrow + q * 256, lane16, ((u32)r * (u32)K + (u32)(s0 + q) * 128u) * 2u);
+    for (int s = 0; s < NS; ++s)
+      for (int q = 0; q < TXp; q += 4)
+        dma_to_lds<4, 0>(rs, szs + (s * TXp + q) * 64, lane4, (slab_tile[s] + (u32)(s0 + q)) * 64u);
+  }
+  if (!(probe & 4)) {
+    for (int r = 0; r < M; ++r)
+      for (int q = 0; q < TXp; q += 4)
+        dma_to_lds<16, 0>(rx, xs + r * xrow + q * 256, lane16, ((u32)r * (u32)K + (u32)(s0 + q) * 128u) * 2u);
+  }
 #pragma unroll
   for (int d = 1; d < D; ++d) issue(d, d);
   using vec8 = typename DT::vec8;
@@ -138,10 +142,9 @@ __device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __rest
     asm volatile("ds_read_b128 %0, %1 offset:128" : "=v"(xo[2]) : "v"(xa) : "memory");
     asm volatile("ds_read_b128 %0, %1 offset:192" : "=v"(xo[3]) : "v"(xa) : "memory");
     if (BITS != 4) {
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(w3a[0]), "+v"(w3a[NS - 1]), "+v"(w3b[0]), "+v"(w3b[NS - 1]), "+v"(sz[0]), "+v"(sz[NS - 1]), "+v"(xo[0]), "+v"(xo[1]), "+v"(xo[2]), "+v"(xo[3])
-                   :
-                   : "memory");
+      static_assert(BITS == 4 || NS == 1, "w3c tiles: the plain linear (one slab per block)");
+      // (every register named ONCE: a variable listed twice gets a second register that is copied in front of the wait -- the stale copy then wins)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w3a[0]), "+v"(w3b[0]), "+v"(sz[0]), "+v"(xo[0]), "+v"(xo[1]), "+v"(xo[2]), "+v"(xo[3]) : : "memory");
 #pragma unroll
       for (int s = 0; s < NS; ++s) w[s] = w3_expand(w3a[s].x, w3a[s].y, w3b[s]);
     } else if (NS == 1)
