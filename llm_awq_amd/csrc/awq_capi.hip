@@ -510,9 +510,8 @@ int awq_w3a16_forward(const void* x, const void* qweight_w3, const void* scales,
   if (st != AWQ_OK) return st;
   if (check_w3_shape(n, k)) return AWQ_ERR_SHAPE;
   if (m <= 8) {
-    // decode: the LDS-DMA streaming kernel on w3c tiles (knob w3_streaming = 0: the register-ring kernel, which also takes what the streaming plan declines)
-    if (!(awq::w3_streaming_enabled() && awq::launch_gemv_dma(x, qweight_w3, sz_packed, bias, out, m, n, k, 0, dtype, 0, (hipStream_t)stream, 0, 3) == 0) &&
-        awq::launch_gemv_cdna4(x, qweight_w3, sz_packed, bias, out, m, n, k, 0, 3, dtype, (hipStream_t)stream) != 0)
+    // decode: the register-ring kernel (the LDS-DMA streaming kernel on w3c tiles measured equal to 4 % slower: profiles/r05_w3_streaming.txt)
+    if (awq::launch_gemv_cdna4(x, qweight_w3, sz_packed, bias, out, m, n, k, 0, 3, dtype, (hipStream_t)stream) != 0)
       return AWQ_ERR_SHAPE;
     return finish_launch();
   }

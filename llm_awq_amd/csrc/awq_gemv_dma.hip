@@ -30,7 +30,7 @@
 namespace awq {
 
 // timing probes (builds with AWQ_PROBES=1 only; wrong results): bit 0 = no math (stream only), bit 1 = no weight DMA and no
-// waits for it (math only, on whatever the ring holds), bit 2 = no x staging DMA, bit 3 = no scale (sz) staging DMA
+// waits for it (math only, on whatever the ring holds), bit 2 = no x staging DMA, bit 3 = no scale (sz) staging DMA (tools/gemvd_xprobe.py)
 #ifdef AWQ_ENABLE_PROBES
 #define DMA_PROBE(p) ((p) & 0xFF)
 #else
@@ -40,9 +40,7 @@ namespace awq {
 constexpr int kDmaF32Out = 0x100;
 // EPI 0: out[m, n] (+ bias);  EPI 1: qw = [gate; up] stacked along N, out[m, n/2] = silu(gate) * up (two slabs per block);
 // EPI 2: gate / up rows interleaved 8 + 8 inside every 16-row slab (fused_mlp.QuantLlamaMLP stacks them that way), out[m, n/2]
-// BITS 3: w3c tiles (768 B = 64 lanes x 3 words; awq_device.hpp): the DMA moves a tile as 48 lanes x 16 B into the 1-KiB ring slot, a lane reads its three
-// words back at lane * 12 (ds_read2_b32 + ds_read_b32: 4-byte aligned, conflict free) and expands them to the four logical words; DQ 0 only (T-typed sz_packed)
-template <typename DT, int WAVES, int D, int DQ, int EPI, int BITS = 4>
+template <typename DT, int WAVES, int D, int DQ, int EPI>
 __device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                               const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
                                               uint16_t* __restrict__ out, int M, int N, int K, int TX, int probe_, int nb) {
@@ -60,9 +58,7 @@ __device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __rest
   char* xs = szs + NS * TXp * 64;                // [M][xrow]
   const int s0 = wv * TX;                        // this wave's first k-step
 
-  constexpr int kTileBytes = BITS == 4 ? 1024 : 768;
-  static_assert(BITS == 4 || DQ == 0, "w3c tiles dequantise with the T-typed sz_packed");
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(qw), 0, (N >> 4) * nit * kTileBytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(qw), 0, (N >> 4) * nit * 1024, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(szp), 0, (N >> 4) * nit * 64, 0x00020000);
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(x), 0, M * K * 2, 0x00020000);
   u32 slab_tile[NS];
@@ -74,10 +70,8 @@ __device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __rest
     const u32 kg = (u32)min(s0 + t, nit - 1);  // steps past the end (ragged K split) re-read the last tile; their math is skipped
     if (probe & 2) return;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      if (BITS == 4) dma_to_lds<16, 2>(rw, ring + (slot * NS + s) * 1024, lane16, (slab_tile[s] + kg) * 1024u);
-      else if (lane < 48) dma_to_lds<16, 2>(rw, ring + (slot * NS + s) * 1024, lane16, (slab_tile[s] + kg) * (u32)kTileBytes);  // (exec-masked: 48 lanes x 16 B = the 768-byte tile)
-    }
+    for (int s = 0; s < NS; ++s)
+      dma_to_lds<16, 2>(rw, ring + (slot * NS + s) * 1024, lane16, (slab_tile[s] + kg) * 1024u);
   };
   // ---- up front.  The first weight tile goes out FIRST (it has the longest way to come), then the packed scales and the x
   // slices (out-of-range pieces read 0 through the buffer descriptor), then the rest of the ring: step 0's counted wait
@@ -99,11 +93,11 @@ __device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __rest
   using vec8 = typename DT::vec8;
   Cdna4DequantT<DT> cd;   // DQ 0: sz_packed in T
   Cdna4DequantH<DT> ch;   // DQ 1: sz_half, f16-mantissa extraction
-  if (DQ == 0) cd.init(lane, BITS == 4 ? 0x000F000Fu : 0x00070007u);
+  if (DQ == 0) cd.init(lane);
   else ch.init(lane);
   const int mrow = min(i, M - 1);
   const u32 lds0 = (u32)(size_t)(__attribute__((address_space(3))) char*)wbase;
-  const u32 ring_lane = lds0 + (BITS == 4 ? lane16 : lane * 12u);
+  const u32 ring_lane = lds0 + lane16;
   const u32 sz_lane = lds0 + D * NS * 1024 + i * 4;
   const u32 x_lane = lds0 + D * NS * 1024 + NS * TXp * 64 + mrow * xrow + g * 16;
 
@@ -119,35 +113,17 @@ __device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __rest
     u32 sz[NS];
     const u32 ra = ring_lane + slot * (NS * 1024), sa = sz_lane + t * 64, xa = x_lane + t * 256;
     if (!(probe & 2)) dma_wait_vm<VM>();
-    u32x2 w3a[NS];
-    u32 w3b[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      if (BITS == 4) {
-        if (s == 0) asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(w[s]) : "v"(ra) : "memory");
-        else asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(w[s]) : "v"(ra) : "memory");
-      } else {
-        if (s == 0) {
-          asm volatile("ds_read2_b32 %0, %1 offset0:0 offset1:1" : "=v"(w3a[s]) : "v"(ra) : "memory");
-          asm volatile("ds_read_b32 %0, %1 offset:8" : "=v"(w3b[s]) : "v"(ra) : "memory");
-        } else {
-          asm volatile("ds_read2_b32 %0, %1 offset0:0 offset1:1" : "=v"(w3a[s]) : "v"(ra + 1024u) : "memory");
-          asm volatile("ds_read_b32 %0, %1 offset:8" : "=v"(w3b[s]) : "v"(ra + 1024u) : "memory");
-        }
-      }
+      if (s == 0) asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(w[s]) : "v"(ra) : "memory");
+      else asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(w[s]) : "v"(ra) : "memory");
       asm volatile("ds_read_b32 %0, %1" : "=v"(sz[s]) : "v"(sa + s * TXp * 64) : "memory");
     }
     asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(xo[0]) : "v"(xa) : "memory");
     asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(xo[1]) : "v"(xa) : "memory");
     asm volatile("ds_read_b128 %0, %1 offset:128" : "=v"(xo[2]) : "v"(xa) : "memory");
     asm volatile("ds_read_b128 %0, %1 offset:192" : "=v"(xo[3]) : "v"(xa) : "memory");
-    if (BITS != 4) {
-      static_assert(BITS == 4 || NS == 1, "w3c tiles: the plain linear (one slab per block)");
-      // (every register named ONCE: a variable listed twice gets a second register that is copied in front of the wait -- the stale copy then wins)
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w3a[0]), "+v"(w3b[0]), "+v"(sz[0]), "+v"(xo[0]), "+v"(xo[1]), "+v"(xo[2]), "+v"(xo[3]) : : "memory");
-#pragma unroll
-      for (int s = 0; s < NS; ++s) w[s] = w3_expand(w3a[s].x, w3a[s].y, w3b[s]);
-    } else if (NS == 1)
+    if (NS == 1)
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(sz[0]), "+v"(xo[0]), "+v"(xo[1]), "+v"(xo[2]), "+v"(xo[3]) : : "memory");
     else
       asm volatile("s_waitcnt lgkmcnt(0)"
@@ -229,12 +205,12 @@ __device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __rest
   }
 }
 
-template <typename DT, int WAVES, int D, int DQ, int EPI, int BITS = 4>
+template <typename DT, int WAVES, int D, int DQ, int EPI>
 __global__ __launch_bounds__(64 * WAVES) void gemv_dma_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                                const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
                                                                uint16_t* __restrict__ out, int M, int N, int K, int TX, int probe_) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemv_dma_body<DT, WAVES, D, DQ, EPI, BITS>(smem, x, qw, szp, bias, out, M, N, K, TX, probe_, blockIdx.x);
+  gemv_dma_body<DT, WAVES, D, DQ, EPI>(smem, x, qw, szp, bias, out, M, N, K, TX, probe_, blockIdx.x);
 }
 
 namespace {
@@ -242,7 +218,6 @@ struct DmaCfg {
   int waves, tx, d;
   size_t smem;
 };
-int g_w3_streaming = 1;  // knob w3_streaming
 int g_dma_skinny_from = 0;  // knob decode_skinny_from: 0 = by shape (skinny_takes below), 1..8 = from that row count, 9 = never
 int g_dma_waves = 0, g_dma_d = 0, g_dma_probe = 0, g_dma_four = 1;  // gemvd_four: four ring-7 blocks per CU where there are > 3 slabs per CU (rounds 4 + 3 instead of 3 + 3 + 1: +0.6 % decode tok/s, profiles/r03_gemvps.txt)
 
@@ -294,37 +269,35 @@ bool pick_dma(int m, int n_rows, int k, int ns, DmaCfg& c) {
 }
 }  // namespace
 
-bool w3_streaming_enabled() { return g_w3_streaming != 0; }
 int gemv_dma_tune_set(const char* key, int value) {
   if (!strcmp(key, "gemvd_waves")) g_dma_waves = value;
   else if (!strcmp(key, "gemvd_d")) g_dma_d = value;
   else if (!strcmp(key, "gemvd_probe")) g_dma_probe = value;
   else if (!strcmp(key, "gemvd_four")) g_dma_four = value;
   else if (!strcmp(key, "decode_skinny_from")) g_dma_skinny_from = value;
-  else if (!strcmp(key, "w3_streaming")) g_w3_streaming = value;
   else return -1;
   return 0;
 }
 
-template <typename DT, int WAVES, int D, int DQ, int EPI, int BITS = 4>
+template <typename DT, int WAVES, int D, int DQ, int EPI>
 static void launch_dma_cfg(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                            const DmaCfg& c, hipStream_t st, int f32out) {
   constexpr int NS = EPI == 1 ? 2 : 1;
-  auto kern = gemv_dma_kernel<DT, WAVES, D, DQ, EPI, BITS>;
+  auto kern = gemv_dma_kernel<DT, WAVES, D, DQ, EPI>;
   static LdsOptIn optin;
   if (c.smem > 64 * 1024) optin.ensure(reinterpret_cast<const void*>(kern));
   hipLaunchKernelGGL(kern, dim3(n / 16 / NS), dim3(64 * WAVES), c.smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp,
                      (const uint16_t*)bias, (uint16_t*)out, m, n, k, c.tx, (g_dma_probe & 0xFF) | (f32out ? kDmaF32Out : 0));
 }
 
-template <typename DT, int EPI, int DQ, int BITS = 4>
+template <typename DT, int EPI, int DQ>
 static int launch_dma_dt(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                          hipStream_t st, int f32out) {
   DmaCfg c;
   if (!pick_dma(m, n, k, EPI == 1 ? 2 : 1, c)) return -1;
 #define AWQ_DCASE(W_, D_)                                                           \
   if (c.waves == W_ && c.d == D_) {                                                 \
-    launch_dma_cfg<DT, W_, D_, DQ, EPI, BITS>(x, qw, szp, bias, out, m, n, k, c, st, f32out); \
+    launch_dma_cfg<DT, W_, D_, DQ, EPI>(x, qw, szp, bias, out, m, n, k, c, st, f32out); \
     return 0;                                                                       \
   }
   AWQ_DCASE(8, 1) AWQ_DCASE(8, 2) AWQ_DCASE(8, 4) AWQ_DCASE(8, 8)
@@ -354,10 +327,9 @@ int gemv_dma_plan(int m, int n, int k, int epi, int* kernel) {
 // served in chunks of as many rows as do fit, each chunk re-streaming the weights -- as the reference's GEMV does per row
 // (gemv_cuda.cu:187-208 loops over the batch inside one weight pass; here the LDS budget decides).
 int launch_gemv_dma(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int epi,
-                    int dtype, int szfmt, hipStream_t st, int f32out, int bits) {
+                    int dtype, int szfmt, hipStream_t st, int f32out) {
   if (m < 1 || m > 8 || (k % 128) != 0 || (n % (epi == 1 ? 32 : 16)) != 0 || (f32out && (epi != 0 || bias != nullptr))) return -1;
-  if (bits == 3 && (epi != 0 || szfmt != 0 || f32out)) return -1;  // w3c tiles: the plain linear on the T-typed sz_packed
-  if (bits == 4 && skinny_takes(m, n, k, epi) && launch_skinny_decode(x, qw, szp, bias, out, m, n, k, epi, dtype, szfmt, st, f32out) == 0) return 0;
+  if (skinny_takes(m, n, k, epi) && launch_skinny_decode(x, qw, szp, bias, out, m, n, k, epi, dtype, szfmt, st, f32out) == 0) return 0;
   DmaCfg probe_cfg;
   int mc = m;
   while (mc > 1 && !pick_dma(mc, n, k, epi == 1 ? 2 : 1, probe_cfg)) --mc;
@@ -367,7 +339,7 @@ int launch_gemv_dma(const void* x, const void* qw, const void* szp, const void* 
     for (int r = 0; r < m; r += mc) {
       const int rows = m - r < mc ? m - r : mc;
       const int rc = launch_gemv_dma((const char*)x + (size_t)r * k * 2, qw, szp, bias, (char*)out + (size_t)r * ncols * (f32out ? 4 : 2), rows, n, k,
-                                     epi, dtype, szfmt, st, f32out, bits);
+                                     epi, dtype, szfmt, st, f32out);
       if (rc != 0) return rc;
     }
     return 0;
@@ -376,10 +348,6 @@ int launch_gemv_dma(const void* x, const void* qw, const void* szp, const void* 
   if (epi == 0) return launch_dma_dt<DT_, 0, DQ_>(x, qw, szp, bias, out, m, n, k, st, f32out); \
   if (epi == 1) return launch_dma_dt<DT_, 1, DQ_>(x, qw, szp, bias, out, m, n, k, st, 0);      \
   return launch_dma_dt<DT_, 2, DQ_>(x, qw, szp, bias, out, m, n, k, st, 0);
-  if (bits == 3) {
-    if (dtype == 0) return launch_dma_dt<F16, 0, 0, 3>(x, qw, szp, bias, out, m, n, k, st, 0);
-    return launch_dma_dt<BF16, 0, 0, 3>(x, qw, szp, bias, out, m, n, k, st, 0);
-  }
   if (szfmt == 1) {
     if (dtype == 0) {
       AWQ_DDT(F16, 1)

@@ -67,11 +67,9 @@ int gemv_cdna4_tune_set(const char* key, int value);
 // [gate; up]; epi 2: gate / up rows interleaved 8 + 8 per slab; both out[m, n/2] = silu(gate) * up.  -1 if the shape is not served.
 // szfmt 0: szp = sz_packed {s | sz << 16} in T;  szfmt 1: szp = sz_half (f16-mantissa dequant, awq_pack_szh_cdna4)
 // f32out (epi 0, no bias): out is float [m, n], the fp32 sums unrounded -- the K-shard partial of a tensor-parallel row split
-// bits 3: w3c tiles (epi 0, szfmt 0 only)
 int launch_gemv_dma(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int epi,
-                    int dtype, int szfmt, hipStream_t st, int f32out = 0, int bits = 4);
+                    int dtype, int szfmt, hipStream_t st, int f32out = 0);
 int gemv_dma_tune_set(const char* key, int value);
-bool w3_streaming_enabled();  // knob w3_streaming (default on): W3 decode on the LDS-DMA streaming kernel
 int launch_moe_gemv_cdna4(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total_rows,
                           int experts, int n, int k, int dtype, hipStream_t st);
 // grouped skinny kernel for 9..255 sorted rows (awq_skinny_cdna4.hip)

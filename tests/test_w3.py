@@ -124,31 +124,6 @@ def test_gpu_forward_vs_oracle(ops, M, N, K, dtype):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("N,K", [(64, 11008), (4096, 4096), (1040, 1280), (256, 4096)])
-def test_gpu_w3_decode_streaming_kernel_vs_register_ring_and_oracle(ops, N, K, dtype):
-    """Round 5: W3 decode runs on the LDS-DMA streaming kernel (awq_gemv_dma.hip, BITS = 3: the 768-byte tile moved as 48 lanes x 16 B,
-    read back at lane * 12) -- every row count 1..8 on the Llama-2-7B shapes incl. the ragged K split of 11008 = 86 groups, bias, against the oracle and against
-    the register-ring kernel it replaces (knob w3_streaming = 0): the same products, another split of K over the waves."""
-    d = make_case_w3(N, K, seed=N + K, M=8, bias=True, dtype=dtype)
-    qw, s, z = d["qweight"].cuda(), d["scales"].cuda(), d["scaled_zeros"].cuda()
-    szp = ops.pack_sz_cdna4(s, z, K)
-    b = d["bias"].cuda()
-    for M in (1, 2, 3, 5, 8):
-        x = d["x"][:M].contiguous()
-        try:
-            ops._capi.tune(w3_streaming=1)
-            y = ops.forward_w3(x.cuda(), qw, s, z, szp, b)
-            assert torch.equal(y, ops.forward_w3(x.cuda(), qw, s, z, szp, b))
-            ops._capi.tune(w3_streaming=0)
-            y0 = ops.forward_w3(x.cuda(), qw, s, z, szp, b)
-        finally:
-            ops._capi.tune(w3_streaming=1)
-        check_forward(y.cpu(), x, d["q"], d["scales"], d["scaled_zeros"], dtype, bias=d["bias"])
-        assert_bits(y, y0, 0.02, what=f"streaming vs register ring M={M}")
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_gpu_w3_prefill_full_shape_both_tile_widths(ops, dtype):
     """Llama-2-7B's stacked gate/up (4096 -> 22016) at M = 2048 and 300: 256-wide tiles for the full rounds + 128-wide for the
     rest, against fp32 torch on the weights of dequant_w3 (bit exact vs the oracle: test_gpu_dequant_bit_exact and
