@@ -71,6 +71,7 @@ bool moe_v6_enabled() { return g_moe_v6 != 0; }
 
 int gemm_v3_tune_set(const char* key, int value) {
   if (!strcmp(key, "moe_v6")) g_moe_v6 = value;
+  else if (!strcmp(key, "moe_tail")) moe_v6_set_tail(value);
   else if (!strcmp(key, "gemm_v4")) g_v4 = value;
   else if (!strcmp(key, "gemm_v6")) {  // units: 0 off, 1 = the 256-wide tiles, 2 = every tile; tens (probe builds): timing-only probe of the kernel
     g_v6 = value % 10;

@@ -585,15 +585,20 @@ template <typename DT>
 __global__ __launch_bounds__(256) void moe_gemm_cdna4_v6_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                                 const u32* __restrict__ szp, const int* __restrict__ offsets,
                                                                 uint16_t* __restrict__ out, int total, int experts, int N, int K,
-                                                                int row_tiles, int tiles_n, int epi) {
+                                                                int row_tiles, int tiles_n, int epi, int tail) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // Tile walk (round 4).  The launch is sized for the host's upper bound (total / 256 + experts row tiles); the REAL count depends on the device-side
   // offsets, so every block first adds it up (experts + 1 scalar loads) and the eight XCDs split the real tiles into eight contiguous chunks -- the
   // phantom blocks end up as the tail of EVERY chunk instead of being one XCD's whole share (with 21 real row tiles of a bound of 24 the old walk
   // left XCD 7 idle).  Inside a chunk the order is expert-major, then column tile, then the expert's row tiles: the two or three row tiles of an
   // expert that share a weight column tile run back to back on one XCD (the dense kernel's two-row band), so only the first of them misses its L2.
+  // `tail` (round 5): an expert's last partial row tile with fewer than `tail` rows is NOT a tile of this launch -- a 256-row tile for a handful of rows is
+  // almost all waste (2048 tokens x top-2 over 8 experts: 21 row tiles for 16 tiles of work) -- those rows go to the grouped skinny kernel's tail pass
+  // (awq_skinny_cdna4.hip, one weight stream of that expert); 0 = every partial tile is a tile
+  const int tmin = tail > 1 ? tail : 1;
+  auto tiles_of = [&](int c) { return (c >> 8) + ((c & 255) >= tmin ? 1 : 0); };
   int R = 0;
-  for (int e2 = 0; e2 < experts; ++e2) R += (offsets[e2 + 1] - offsets[e2] + V6_TM - 1) / V6_TM;
+  for (int e2 = 0; e2 < experts; ++e2) R += tiles_of(offsets[e2 + 1] - offsets[e2]);
   const int T = R * tiles_n;
   int tile;
   {
@@ -606,7 +611,7 @@ __global__ __launch_bounds__(256) void moe_gemm_cdna4_v6_kernel(const uint16_t* 
   for (; e < experts; ++e) {
     lo = offsets[e];
     hi = offsets[e + 1];
-    const int cnt = (hi - lo + V6_TM - 1) / V6_TM;
+    const int cnt = tiles_of(hi - lo);
     if (tile < cnt * tiles_n) {
       tn = tile / cnt;  // (row-tile major inside the expert measured equal on the plain launch and 5 % slower on the fused w1 / w3 one: profiles/r04_moe_sweep.txt)
       rt = tile - tn * cnt;
@@ -763,6 +768,10 @@ void launch_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, const 
 }
 
 // grouped GEMM over sorted tokens with the v6 tile; needs total >= 256.  Returns -1 if unsupported.
+namespace {
+int g_moe_tail = 64;  // knob moe_tail: partial row tiles below this many rows go to the grouped skinny kernel's tail pass (0 = every partial tile is a tile)
+}
+void moe_v6_set_tail(int v) { g_moe_tail = v < 0 ? 0 : (v > 64 ? 64 : v); }
 int launch_moe_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total, int experts,
                              int n, int k, int dtype, hipStream_t st, int epi) {
   if ((epi != 0 && epi != 2) || (epi == 2 && (n % 32) != 0)) return -1;
@@ -775,8 +784,11 @@ int launch_moe_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, con
   auto kern = dtype == 0 ? moe_gemm_cdna4_v6_kernel<F16> : moe_gemm_cdna4_v6_kernel<BF16>;
   optin[dtype == 0 ? 0 : 1].ensure(reinterpret_cast<const void*>(kern), smem);
   const int row_tiles = total / V6_TM + experts, tiles_n = (n + V6_TN - 1) / V6_TN;
+  const int tail = experts <= 64 ? g_moe_tail : 0;  // (the tail pass keeps its list of qualifying experts in 64 LDS words)
   hipLaunchKernelGGL(kern, dim3(row_tiles * tiles_n), dim3(256), smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp,
-                     (const int*)offsets, (uint16_t*)out, total, experts, n, k, row_tiles, tiles_n, epi);
+                     (const int*)offsets, (uint16_t*)out, total, experts, n, k, row_tiles, tiles_n, epi, tail);
+  // the rows of the partial tiles this launch left out (the launches read the same device-side offsets and split every expert's rows the same way)
+  if (tail > 0 && launch_moe_skinny_tail_cdna4(x, qw, szp, offsets, out, experts, n, k, dtype, st, epi, tail) != 0) return -1;
   return 0;
 }
 

@@ -72,6 +72,10 @@ int launch_gemv_dma(const void* x, const void* qw, const void* szp, const void* 
 int gemv_dma_tune_set(const char* key, int value);
 int launch_moe_gemv_cdna4(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total_rows,
                           int experts, int n, int k, int dtype, hipStream_t st);
+// tail pass of the grouped prefill GEMM (awq_skinny_cdna4.hip): the rows of every expert's last partial 256-row tile when there are fewer than `tail` of them
+int launch_moe_skinny_tail_cdna4(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int experts, int n, int k,
+                                 int dtype, hipStream_t st, int epi, int tail);
+void moe_v6_set_tail(int v);  // knob moe_tail (0 .. 64; default 64)
 // grouped skinny kernel for 9..255 sorted rows (awq_skinny_cdna4.hip)
 int launch_moe_skinny_cdna4(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total_rows,
                             int experts, int n, int k, int dtype, hipStream_t st);

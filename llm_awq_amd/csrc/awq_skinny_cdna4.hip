@@ -175,19 +175,49 @@ __global__ __launch_bounds__(64 * WAVES) void skinny_cdna4_kernel(const uint16_t
 // Grouped (per-expert) form for MoE batches between the grouped GEMV (<= 8 sorted rows) and the grouped prefill GEMM
 // (>= 256): block = (expert, slab group); expert e owns rows [offsets[e], offsets[e+1]) of the sorted x / out and the e-th
 // slice of the stacked cdna4 weights / packed scales; more than 16 CB rows run as further passes over the expert's slabs.
-template <typename DT, int WAVES, int NS, int CB>
+// tail > 0 (round 5): the TAIL PASS behind the grouped prefill GEMM (launch_moe_gemm_cdna4_v6 with the same threshold): only the rows of an expert's last
+// partial 256-row tile, and only when their number lies in [tail_lo, tail) -- the tile launch leaves exactly the remainders below `tail` out.  The grid is a fixed
+// number of blocks (what fits the chip at once) that stride over the work items (qualifying expert, slab group) found from the device-side offsets: a grid of
+// experts x groups blocks of which most exit at once costs more in block dispatch than the tails cost to compute (7168 blocks for Mixtral's w1 / w3).
+// EPI 2: the expert's w1 / w3 rows are interleaved 8 + 8 per slab (N = 2 x ffn), out [rows, N / 2] = silu(w1 x) * (w3 x)
+constexpr int kMoeTailMaxExperts = 64;  // (the tail pass scans the offsets per work item: keep that loop short)
+template <typename DT, int WAVES, int NS, int CB, int EPI = 0>
 __global__ __launch_bounds__(64 * WAVES) void moe_skinny_cdna4_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                                        const u32* __restrict__ szp,
                                                                        const int* __restrict__ offsets,
-                                                                       uint16_t* __restrict__ out, int N, int K, int groups) {
+                                                                       uint16_t* __restrict__ out, int N, int K, int groups, int experts, int tail_lo, int tail) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const size_t et = (size_t)(N >> 4) * (K >> 7);             // tiles per expert
+  const int ncol = EPI == 2 ? (N >> 1) : N;
+  if (tail > 0) {
+    auto qualifies = [&](int e2) {
+      const int rem = (offsets[e2 + 1] - offsets[e2]) & 255;
+      return rem >= tail_lo && rem < tail;
+    };
+    int nq = 0;
+    for (int e2 = 0; e2 < experts; ++e2) nq += qualifies(e2) ? 1 : 0;  // (block-uniform scalar loop over the offsets)
+    for (int item = blockIdx.x; item < nq * groups; item += gridDim.x) {
+      const int q = item / groups, nb = item - q * groups;
+      int e = 0;
+      for (int seen = 0; e < experts; ++e) {  // the q-th qualifying expert (no LDS list: the kernel's LDS budget is the staging region's, up to 128 KiB + opt-in)
+        if (qualifies(e)) {
+          if (seen == q) break;
+          ++seen;
+        }
+      }
+      const int lo = offsets[e], cnt = offsets[e + 1] - lo, rem = cnt & 255;
+      skinny_cdna4_body<DT, WAVES, NS, CB, 0, EPI>(smem, x + (size_t)(lo + cnt - rem) * K, qw + (size_t)e * et * 256, szp + (size_t)e * et * 16, nullptr,
+                                                   out + (size_t)(lo + cnt - rem) * ncol, rem, N, K, nb);
+      __syncthreads();  // the item's reduction reads of the LDS region are done before the next item stages x into it
+    }
+    return;
+  }
   const int e = blockIdx.x / groups, nb = blockIdx.x - e * groups;
   const int row0 = offsets[e], m_e = offsets[e + 1] - row0;  // block-uniform
-  const size_t et = (size_t)(N >> 4) * (K >> 7);             // tiles per expert
   for (int r0 = 0; r0 < m_e; r0 += 16 * CB) {
     if (r0 > 0) __syncthreads();  // the previous pass's reduction reads of the LDS region are done
-    skinny_cdna4_body<DT, WAVES, NS, CB>(smem, x + (size_t)(row0 + r0) * K, qw + (size_t)e * et * 256, szp + (size_t)e * et * 16, nullptr,
-                                         out + (size_t)(row0 + r0) * N, min(m_e - r0, 16 * CB), N, K, nb);
+    skinny_cdna4_body<DT, WAVES, NS, CB, 0, EPI>(smem, x + (size_t)(row0 + r0) * K, qw + (size_t)e * et * 256, szp + (size_t)e * et * 16, nullptr,
+                                                 out + (size_t)(row0 + r0) * ncol, min(m_e - r0, 16 * CB), N, K, nb);
   }
 }
 
@@ -276,17 +306,48 @@ int launch_skinny_decode(const void* x, const void* qw, const void* szp, const v
 #undef AWQ_SD
 }
 
-template <typename DT, int WAVES, int NS, int CB>
+template <typename DT, int WAVES, int NS, int CB, int EPI = 0>
 static void launch_moe_skinny(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int experts, int n, int k,
-                              hipStream_t st) {
+                              hipStream_t st, int tail_lo = 0, int tail = 0) {
   const size_t xbytes = (size_t)WAVES * 16 * CB * 256, rbytes = (size_t)WAVES * NS * CB * 1024;
   const size_t smem = xbytes > rbytes ? xbytes : rbytes;
-  auto kern = moe_skinny_cdna4_kernel<DT, WAVES, NS, CB>;
+  auto kern = moe_skinny_cdna4_kernel<DT, WAVES, NS, CB, EPI>;
   static LdsOptIn optin;  // per (kernel instantiation, device)
   if (smem > 64 * 1024) optin.ensure(reinterpret_cast<const void*>(kern));
   const int groups = (n / 16 + NS - 1) / NS;
-  hipLaunchKernelGGL(kern, dim3(experts * groups), dim3(64 * WAVES), smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp,
-                     (const int*)offsets, (uint16_t*)out, n, k, groups);
+  int blocks = experts * groups;
+  if (tail > 0) {  // tail pass: what the chip holds at once (LDS-limited), striding over the qualifying (expert, slab group) items
+    const int per_cu = smem <= 32 * 1024 ? 4 : (smem <= 64 * 1024 ? 2 : 1);
+    const int cap = device_cu_count() * per_cu;
+    if (blocks > cap) blocks = cap;
+  }
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * WAVES), smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp,
+                     (const int*)offsets, (uint16_t*)out, n, k, groups, experts, tail_lo, tail);
+}
+
+// the tail pass of the grouped prefill GEMM: every expert's last partial row tile of fewer than `tail` (<= 64) rows, one weight stream of that expert
+// (blocks of experts without such a tail exit at once); epi 0 / 2 as the tile launch.  Returns -1 if unsupported.
+int launch_moe_skinny_tail_cdna4(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int experts, int n, int k,
+                                 int dtype, hipStream_t st, int epi, int tail) {
+  if (!szp || experts < 1 || experts > kMoeTailMaxExperts || (n % 16) != 0 || (k % 128) != 0 || tail < 1 || tail > 64 || (epi != 0 && epi != 2) ||
+      (epi == 2 && (n % 32) != 0))
+    return -1;
+  if ((size_t)n * (size_t)k / 8 >= (1ull << 31)) return -1;
+  // three launches by remainder size -- 1..16 rows: one 16-row x block (32 KiB of LDS, five blocks per CU); 17..32: two; 33..tail-1: four (128 KiB, one block
+  // per CU) -- each a grid of (expert, slab group) blocks of which only the experts with such a remainder do any work
+#define AWQ_MST(DT_, EPI_)                                                                                              \
+  {                                                                                                                     \
+    launch_moe_skinny<DT_, 8, 2, 1, EPI_>(x, qw, szp, offsets, out, experts, n, k, st, 1, tail < 17 ? tail : 17);       \
+    if (tail > 17) launch_moe_skinny<DT_, 8, 2, 2, EPI_>(x, qw, szp, offsets, out, experts, n, k, st, 17, tail < 33 ? tail : 33); \
+    if (tail > 33) launch_moe_skinny<DT_, 8, 2, 4, EPI_>(x, qw, szp, offsets, out, experts, n, k, st, 33, tail);        \
+  }
+  if (dtype == 0) {
+    if (epi == 2) AWQ_MST(F16, 2) else AWQ_MST(F16, 0)
+  } else {
+    if (epi == 2) AWQ_MST(BF16, 2) else AWQ_MST(BF16, 0)
+  }
+#undef AWQ_MST
+  return 0;
 }
 
 // 9 <= total_rows <= 255 sorted rows over `experts` experts (stacked cdna4 weights + packed sz).  The column-block count is

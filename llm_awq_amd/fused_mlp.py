@@ -187,6 +187,14 @@ class QuantLlamaMLP(nn.Module):
             x = x.contiguous()
         return eng.mlp_decode_cdna4(x, c4, szh, d.qweight, d.szh_cdna4, self._state, d.bias)
 
+    def check(self):
+        """after a synchronize: raise if a workgroup of the one-launch engine gave up waiting for h (bounded spin; its outputs were poisoned with NaNs).  The
+        engine wants the whole device -- 256 co-resident workgroups -- so a serving loop that shares the GPU with other streams calls this at its own sync
+        points (once per generated token is enough); forward() cannot poll the word without a host sync."""
+        if self._state is not None and int(self._state[2].item()) != 0:
+            raise RuntimeError("QuantLlamaMLP: the one-launch decode engine timed out waiting for activations from another workgroup (the 256 workgroups "
+                               "were not co-resident: another kernel held CUs); its outputs for that call are NaN.  Unset AWQ_MLP_ONE_LAUNCH or give it the device")
+
     @torch.no_grad()
     def our_llama_mlp(self, x):
         eng = load_engine()

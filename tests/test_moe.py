@@ -130,7 +130,8 @@ def test_gpu_grouped_decode_and_module(counts):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("counts", [[300, 0, 1, 255], [256, 256], [1, 700, 3, 40], [0, 0, 0, 256], [511, 2, 257, 0, 90]])
+@pytest.mark.parametrize("counts", [[300, 0, 1, 255], [256, 256], [1, 700, 3, 40], [0, 0, 0, 256], [511, 2, 257, 0, 90], [300, 256, 10, 0, 270, 511, 63, 64],
+                                    [40, 40, 40, 40, 40, 40, 40, 40]])
 def test_gpu_grouped_prefill_v6_and_128(counts, dtype):
     """>= 256 sorted rows: the grouped kernel on the v6 tile (default; awq_gemm_v6.hip) -- tiles straddling expert boundaries, the shifted
     last tile, empty experts, segments shorter than a tile -- against the per-expert oracle and against the 128 x 128 grouped kernel (knob
@@ -150,8 +151,16 @@ def test_gpu_grouped_prefill_v6_and_128(counts, dtype):
     finally:
         ops._capi.tune(moe_v6=1)
     assert_bits(y6, y_ref, 0.01, what="v6 tile vs 128 x 128 grouped kernel")
+    # round 5: partial row tiles of fewer than 64 rows are served by the grouped skinny kernel's tail pass behind the tile launch (knob moe_tail = 0:
+    # every partial tile is a tile) -- the same products, another split of K over the waves for those rows
+    try:
+        ops._capi.tune(moe_tail=0)
+        y_all_tiles = grp(x, off)
+    finally:
+        ops._capi.tune(moe_tail=64)
+    assert_bits(y6, y_all_tiles, 0.01, what="tail pass vs every partial tile a tile")
     x = x.cpu()
-    for y in (y6.cpu(), y_ref.cpu()):
+    for y in (y6.cpu(), y_ref.cpu(), y_all_tiles.cpu()):
         for e in range(E):
             lo, hi = int(off[e]), int(off[e + 1])
             if hi > lo:
