@@ -9,7 +9,7 @@ export AWQ_TEST_STATS=$PWD/$O/test_stats.jsonl
 ( OMP_NUM_THREADS=24 timeout 500 python -m pytest tests/test_engine_cache.py tests/test_gpu_fused_mlp.py tests/test_gpu_decode.py tests/test_gpu_gemm_v6.py tests/test_gpu_fullsize.py tests/test_w3.py tests/test_fused_norm.py tests/test_moe.py tests/test_gpu_tp_partial.py "tests/test_gpu_oracle_fullsize.py::test_full_shapes_against_the_oracle" -m gpu -q -n 4 -rf --tb=short 2>&1 | grep -v amdgpu.ids | tail -150 ) > $O/pytest.log
 unset AWQ_TEST_STATS
 grep -E "^FAILED|passed|failed" $O/pytest.log | cut -c1-300 | tail -30
-for k in "gemm_v6_pair=0" "gemm_v6_pair=1" "gemm_v6_pair=0" "gemm_v6_pair=1"; do echo -n "$k: "; AWQ_TUNING=1 timeout 120 python bench.py --steps 5 --warmup 2 --no-dropin --no-cpu-baseline --no-batched-decode --no-extra-configs --prefill-m3 0 --prefill-small "" --tune $k 2>/dev/null | tail -1 | python -c "
+for k in "gemm_v6_pair=0" "gemm_v6_pair=1" "gemm_v6_pair=0" "gemm_v6_pair=1"; do echo -n "$k: "; AWQ_TUNING=1 timeout 120 python bench.py --steps 5 --warmup 2 --no-dropin --no-cpu-baseline --no-batched-decode --no-extra-configs --prefill-m3 0 --prefill-small 0 --tune $k 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); p=d['prefill']; print(p['ms_per_pass'], p['roofline']['frac'], 'm4096', d['prefill_m4096']['roofline']['frac'])"; done 2>&1 | tee $O/pair_ab_bench.log
 ( timeout 300 python bench.py --steps 20 --warmup 5 2> $O/bench.err | tail -1 ) > $O/bench.json
