@@ -65,9 +65,12 @@ __device__ __forceinline__ void eng_stamp(unsigned long long* stamps, int slot) 
 
 }  // namespace
 
-// timing probes (knob mlp_engine_probe, AWQ_TUNING=1 processes only; wrong results): bit 0 = no math, bit 1 = no weight DMA.  Compiled into every build:
-// two wave-uniform branches per tile next to ~60 vector instructions
+// timing probes (knob mlp_engine_probe; AWQ_PROBES=1 builds only, wrong results): bit 0 = no math, bit 1 = no weight DMA (profiles/r05_mlp_engine.txt)
+#ifdef AWQ_ENABLE_PROBES
 #define ENG_PROBE(p) (p)
+#else
+#define ENG_PROBE(p) 0
+#endif
 
 template <typename DT>
 __global__ __launch_bounds__(64 * kEngWaves) void mlp_engine_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw_gu,

@@ -131,7 +131,7 @@ def main():
     assert all(int(c["state"][2].item()) == 0 for c in copies)
     span = stamps(copies, x)
     print(f"(ticks per us, if the span is the graph-replay time of the launch minus ~1.5 us of boundary: {span / max(ts[-1][1] - 1.5, 1):.0f})")
-    if True:
+    if os.environ.get("AWQ_PROBES") == "1":  # (an AWQ_PROBES=1 build of the library: AWQ_CDNA4_LIB=... beside the product one)
         for pv, nm in ((1, "no math (stream only)"), (2, "no weight DMA (math + hand-over only)"), (3, "neither")):
             _capi.tune(mlp_engine_probe=pv)
             print(f"probe {nm}: {time_graph(lambda c: one(c, x), copies):6.2f} us", flush=True)
