@@ -188,15 +188,21 @@ def moe_mixtral(eng, dev, stream, iters, dtype=torch.bfloat16):
     szpi = torch.stack([eng.pack_sz_cdna4(si[e], zi[e], H) for e in range(E)])
     qw2, sD, zD = torch.stack(q2), torch.stack(s2), torch.stack(z2)
     szp2 = torch.stack([eng.pack_sz_cdna4(s2[e], z2[e], F) for e in range(E)])
+
+    def stacked_szh(ss, zz, K):  # the experts' sz_half side buffers (what GroupedGateUp / GroupedWQLinear build), None unless every expert is exact
+        hs = [eng.pack_szh_cdna4(ss[e], zz[e], K) for e in range(E)]
+        return torch.stack([h for (h, _ok) in hs]) if all(ok for (_h, ok) in hs) else None
+
+    szhi, szh2 = stacked_szh(si, zi, H), stacked_szh(s2, z2, F)
     del qi, q2
     rgen = torch.Generator(device=dev).manual_seed(1234)  # the same routing in every run
     ids = torch.stack([torch.randperm(E, device=dev, generator=rgen)[:2] for _ in range(T)])
     _order, off = sort_by_expert(ids, E)
     cnts = (off[1:] - off[:-1]).tolist()
     xs = torch.randn(2 * T, H, device=dev, generator=gen).to(dtype)
-    h = ops.moe_mlp_gate_up_cdna4(xs, qwi, sI, zI, szpi, off)
-    us1, us1m = _median_us(lambda: ops.moe_mlp_gate_up_cdna4(xs, qwi, sI, zI, szpi, off), stream, iters)
-    us2, us2m = _median_us(lambda: ops.moe_forward_cdna4(h, qw2, sD, zD, szp2, off), stream, iters)
+    h = ops.moe_mlp_gate_up_cdna4(xs, qwi, sI, zI, szpi, off, sz_half=szhi)
+    us1, us1m = _median_us(lambda: ops.moe_mlp_gate_up_cdna4(xs, qwi, sI, zI, szpi, off, sz_half=szhi), stream, iters)
+    us2, us2m = _median_us(lambda: ops.moe_forward_cdna4(h, qw2, sD, zD, szp2, off, sz_half=szh2), stream, iters)
     f1, f2 = 2.0 * 2 * T * (2 * F) * H, 2.0 * 2 * T * H * F
     return {"workload": "Mixtral-8x7B W4A16 g128 bf16 expert block: E = 8, top-2, 2048 tokens = 4096 sorted rows, seeded routing",
             "rows_per_expert": cnts, "row_tiles_256": sum((c + 255) // 256 for c in cnts),

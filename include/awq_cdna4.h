@@ -236,6 +236,11 @@ int awq_w4a16_moe_gemm(const void* x_sorted, const void* qweight, const void* sc
 int awq_w4a16_moe_forward_cdna4(const void* x_sorted, const void* qweight, const void* scales, const void* scaled_zeros,
                                 const void* sz_packed, const void* expert_offsets, void* out, int total_tokens,
                                 int num_experts, int n, int k, int gpad, int group_size, int dtype, void* stream);
+/* the same with the experts' stacked sz_half side buffers (int32 [E, N/16, K/128, 16], every expert reported exact by awq_pack_szh_cdna4; NULL = the call
+ * above): the grouped tile launch (>= 256 sorted rows) dequantises in the f16-mantissa form, identical results */
+int awq_w4a16_moe_forward_cdna4_szh(const void* x_sorted, const void* qweight, const void* scales, const void* scaled_zeros, const void* sz_packed,
+                                    const void* sz_half, const void* expert_offsets, void* out, int total_tokens, int num_experts, int n, int k,
+                                    int gpad, int group_size, int dtype, void* stream);
 
 /* out = T(T(silu(gate)) * up) elementwise over `count` values (count % 8 == 0): the activation step between the projections where it is not
  * fused into a kernel epilogue (tinychat/modules/fused_mlp.py:79-82: c = F.silu(gate_output) * up_output, every op rounded to T). */
@@ -250,6 +255,10 @@ int awq_silu_mul(const void* gate, const void* up, void* out, size_t count, int 
 int awq_w4a16_moe_mlp_gate_up_cdna4(const void* x_sorted, const void* qweight_interleaved, const void* scales, const void* scaled_zeros,
                                     const void* sz_packed, const void* expert_offsets, void* out, void* scratch, size_t scratch_bytes,
                                     int total_tokens, int num_experts, int n2, int k, int gpad, int group_size, int dtype, void* stream);
+int awq_w4a16_moe_mlp_gate_up_cdna4_szh(const void* x_sorted, const void* qweight_interleaved, const void* scales, const void* scaled_zeros,
+                                        const void* sz_packed, const void* sz_half, const void* expert_offsets, void* out, void* scratch,
+                                        size_t scratch_bytes, int total_tokens, int num_experts, int n2, int k, int gpad, int group_size, int dtype,
+                                        void* stream);
 
 /* ---- W3A16 ("w3c" tiles): BASELINE.json's INT3 configuration.  The reference has NO packed 3-bit format
  * (awq/quantize/qmodule.py:82-83 raises for w_bit != 4; INT3 exists only as pseudo-quantisation,

@@ -58,8 +58,10 @@ SIGNATURES = {
     "awq_w4a16_forward_cdna4_szh": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "awq_w4a16_moe_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "awq_w4a16_moe_forward_cdna4": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "awq_w4a16_moe_forward_cdna4_szh": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "awq_silu_mul": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
     "awq_w4a16_moe_mlp_gate_up_cdna4": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "awq_w4a16_moe_mlp_gate_up_cdna4_szh": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "awq_pack_w3": (_i, [_vp, _vp, _i, _i, _vp]),
     "awq_unpack_w3": (_i, [_vp, _vp, _i, _i, _vp]),
     "awq_dequant_w3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -418,7 +418,15 @@ int awq_w4a16_moe_gemm(const void* x_sorted, const void* qweight, const void* sc
 int awq_w4a16_moe_forward_cdna4(const void* x_sorted, const void* qweight, const void* scales, const void* scaled_zeros,
                                 const void* sz_packed, const void* expert_offsets, void* out, int total_tokens,
                                 int num_experts, int n, int k, int gpad, int group_size, int dtype, void* stream) {
+  return awq_w4a16_moe_forward_cdna4_szh(x_sorted, qweight, scales, scaled_zeros, sz_packed, nullptr, expert_offsets, out, total_tokens, num_experts, n, k, gpad,
+                                         group_size, dtype, stream);
+}
+
+int awq_w4a16_moe_forward_cdna4_szh(const void* x_sorted, const void* qweight, const void* scales, const void* scaled_zeros, const void* sz_packed,
+                                    const void* sz_half, const void* expert_offsets, void* out, int total_tokens, int num_experts, int n, int k,
+                                    int gpad, int group_size, int dtype, void* stream) {
   if (!expert_offsets || !sz_packed) return AWQ_ERR_NULL;
+  if (sz_half && !aligned16(sz_half)) return AWQ_ERR_ALIGN;
   if (dtype != AWQ_F16 && dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
   if (num_experts < 1 || gpad * 128 < k || total_tokens < 0 || (n % 16) != 0) return AWQ_ERR_SHAPE;
   if (total_tokens == 0) return AWQ_OK;
@@ -433,7 +441,7 @@ int awq_w4a16_moe_forward_cdna4(const void* x_sorted, const void* qweight, const
     return finish_launch();
   if (total_tokens >= 256 && awq::moe_v6_enabled() && awq::moe_v4_enabled() &&
       awq::launch_moe_gemm_cdna4_v6(x_sorted, qweight, sz_packed, expert_offsets, out, total_tokens, num_experts, n, k, dtype,
-                                    (hipStream_t)stream) == 0)
+                                    (hipStream_t)stream, 0, sz_half) == 0)
     return finish_launch();
   awq::launch_moe_gemm(x_sorted, qweight, scales, scaled_zeros, expert_offsets, out, total_tokens, num_experts, n, k, gpad, dtype, 1,
                        (hipStream_t)stream);
@@ -452,7 +460,16 @@ int awq_silu_mul(const void* gate, const void* up, void* out, size_t count, int 
 int awq_w4a16_moe_mlp_gate_up_cdna4(const void* x_sorted, const void* qweight_interleaved, const void* scales, const void* scaled_zeros,
                                     const void* sz_packed, const void* expert_offsets, void* out, void* scratch, size_t scratch_bytes,
                                     int total_tokens, int num_experts, int n2, int k, int gpad, int group_size, int dtype, void* stream) {
+  return awq_w4a16_moe_mlp_gate_up_cdna4_szh(x_sorted, qweight_interleaved, scales, scaled_zeros, sz_packed, nullptr, expert_offsets, out, scratch, scratch_bytes,
+                                             total_tokens, num_experts, n2, k, gpad, group_size, dtype, stream);
+}
+
+int awq_w4a16_moe_mlp_gate_up_cdna4_szh(const void* x_sorted, const void* qweight_interleaved, const void* scales, const void* scaled_zeros,
+                                        const void* sz_packed, const void* sz_half, const void* expert_offsets, void* out, void* scratch,
+                                        size_t scratch_bytes, int total_tokens, int num_experts, int n2, int k, int gpad, int group_size, int dtype,
+                                        void* stream) {
   if (!expert_offsets || !sz_packed || !x_sorted || !qweight_interleaved || !out) return AWQ_ERR_NULL;
+  if (sz_half && !aligned16(sz_half)) return AWQ_ERR_ALIGN;
   if (dtype != AWQ_F16 && dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
   if (group_size != 128) return AWQ_ERR_GROUP;
   if (num_experts < 1 || total_tokens < 0 || n2 < 32 || (n2 % 32) != 0 || k < 128 || (k % 128) != 0) return AWQ_ERR_SHAPE;
@@ -460,7 +477,7 @@ int awq_w4a16_moe_mlp_gate_up_cdna4(const void* x_sorted, const void* qweight_in
   if (!aligned16(x_sorted) || !aligned16(qweight_interleaved) || !aligned16(out) || !aligned16(sz_packed) || !aligned16(scratch)) return AWQ_ERR_ALIGN;
   const hipStream_t st = (hipStream_t)stream;
   if (total_tokens >= 256 && awq::moe_v6_enabled() &&
-      awq::launch_moe_gemm_cdna4_v6(x_sorted, qweight_interleaved, sz_packed, expert_offsets, out, total_tokens, num_experts, n2, k, dtype, st, 2) == 0)
+      awq::launch_moe_gemm_cdna4_v6(x_sorted, qweight_interleaved, sz_packed, expert_offsets, out, total_tokens, num_experts, n2, k, dtype, st, 2, sz_half) == 0)
     return finish_launch();
   // fewer than 256 sorted rows (grouped GEMV / grouped skinny kernel) -- or the v6 tile switched off: the pair's [total, n2] product goes
   // through the caller's scratch, then the SiLU * mul tail as its own launch

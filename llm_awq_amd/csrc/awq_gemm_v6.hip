@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void gemm_cdna4_v6_kernel(const uint16_t* __re
 // tinychat loops over experts).  Row tile rt of expert e covers its rows [lo + 256 rt, min(.. + 256, hi)); the tile itself always reads
 // 256 in-range rows of x (shifted up at the end of the token list) and the epilogue stores only the segment's rows, so a short segment
 // costs one tile and never sees another expert's weights in its outputs.
-template <typename DT>
+template <typename DT, int DQ = 0>
 __global__ __launch_bounds__(256) void moe_gemm_cdna4_v6_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                                 const u32* __restrict__ szp, const int* __restrict__ offsets,
                                                                 uint16_t* __restrict__ out, int total, int experts, int N, int K,
@@ -623,8 +623,9 @@ __global__ __launch_bounds__(256) void moe_gemm_cdna4_v6_kernel(const uint16_t* 
   const int r_lo = lo + rt * V6_TM, r_hi = min(r_lo + V6_TM, hi);
   const size_t ew = (size_t)(N >> 4) * (K >> 7);  // tiles per expert
   // epi 2: every expert's rows are its w1 / w3 pair interleaved 8 + 8 per 16-row slab (N = 2 x ffn): out [total, N / 2] = silu(w1 x) * (w3 x)
-  v6_tile<DT, 4, 0, 0, 4>(smem, x, qw + (size_t)e * ew * 256, szp + (size_t)e * ew * 16, nullptr, out, N, K, min(r_lo, total - V6_TM), tn * V6_TN,
-                          N, epi, r_lo, r_hi);
+  // (DQ 1: szp is the experts' stacked sz_half side buffer -- the f16-mantissa dequant form, as the dense launches use it)
+  v6_tile<DT, 4, 0, DQ, 4>(smem, x, qw + (size_t)e * ew * 256, szp + (size_t)e * ew * 16, nullptr, out, N, K, min(r_lo, total - V6_TM), tn * V6_TN,
+                           N, epi, r_lo, r_hi);
 }
 
 // K split over a PAIR of 256 x 256 blocks.  A launch whose 256-wide tiles fill at most half the chip (down_proj and o_proj of Llama-3-8B at 2048 rows: 8 x 16 =
@@ -773,19 +774,23 @@ int g_moe_tail = 64;  // knob moe_tail: partial row tiles below this many rows g
 }
 void moe_v6_set_tail(int v) { g_moe_tail = v < 0 ? 0 : (v > 64 ? 64 : v); }
 int launch_moe_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total, int experts,
-                             int n, int k, int dtype, hipStream_t st, int epi) {
+                             int n, int k, int dtype, hipStream_t st, int epi, const void* szh) {
   if ((epi != 0 && epi != 2) || (epi == 2 && (n % 32) != 0)) return -1;
   if (total < V6_TM || experts < 1 || (n % 16) != 0 || (k % 128) != 0 || (size_t)total * (size_t)k >= (1ull << 31) ||
       (size_t)n * (size_t)k / 8 >= (1ull << 31))
     return -1;
   constexpr int stage2 = 2 * kV6Stage, stg_epi = V6_TM * kV6Pitch;
   constexpr int smem = stage2 > stg_epi ? stage2 : stg_epi;
-  static LdsOptIn optin[2];
-  auto kern = dtype == 0 ? moe_gemm_cdna4_v6_kernel<F16> : moe_gemm_cdna4_v6_kernel<BF16>;
-  optin[dtype == 0 ? 0 : 1].ensure(reinterpret_cast<const void*>(kern), smem);
+  static LdsOptIn optin[4];
+  using MKern = void (*)(const uint16_t*, const u32*, const u32*, const int*, uint16_t*, int, int, int, int, int, int, int, int);
+  static const MKern kerns[4] = {moe_gemm_cdna4_v6_kernel<F16, 0>, moe_gemm_cdna4_v6_kernel<BF16, 0>, moe_gemm_cdna4_v6_kernel<F16, 1>,
+                                 moe_gemm_cdna4_v6_kernel<BF16, 1>};  // [2..3]: the tile launch reads the stacked sz_half buffer
+  const int ki = (dtype == 0 ? 0 : 1) + (szh != nullptr ? 2 : 0);
+  const MKern kern = kerns[ki];
+  optin[ki].ensure(reinterpret_cast<const void*>(kern), smem);
   const int row_tiles = total / V6_TM + experts, tiles_n = (n + V6_TN - 1) / V6_TN;
   const int tail = experts <= 64 ? g_moe_tail : 0;  // (the tail pass keeps its list of qualifying experts in 64 LDS words)
-  hipLaunchKernelGGL(kern, dim3(row_tiles * tiles_n), dim3(256), smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp,
+  hipLaunchKernelGGL(kern, dim3(row_tiles * tiles_n), dim3(256), smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)(szh != nullptr ? szh : szp),
                      (const int*)offsets, (uint16_t*)out, total, experts, n, k, row_tiles, tiles_n, epi, tail);
   // the rows of the partial tiles this launch left out (the launches read the same device-side offsets and split every expert's rows the same way)
   if (tail > 0 && launch_moe_skinny_tail_cdna4(x, qw, szp, offsets, out, experts, n, k, dtype, st, epi, tail) != 0) return -1;

@@ -120,8 +120,9 @@ size_t gemm_cdna4_v3_workspace_bytes_w3(int m, int n, int k);  // same rule for 
 bool moe_v4_enabled();  // knob moe_v4 (default on): the grouped skinny / tile kernels; 0 = the 128 x 128 grouped kernel for every batch above 8 rows
 // the same grouped GEMM on the v6 tile (awq_gemm_v6.hip: one pipelined wave per SIMD, weights in registers); total >= 256
 // epi 2: per-expert w1 / w3 pair interleaved 8 + 8 per slab (n = 2 x ffn), out [total, n / 2] = silu(w1 x) * (w3 x) fused into the tile epilogue
+// szh: the experts' stacked sz_half side buffers (optional): the tile launch then dequantises in the f16-mantissa form; the tail pass keeps sz_packed
 int launch_moe_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total, int experts,
-                             int n, int k, int dtype, hipStream_t st, int epi = 0);
+                             int n, int k, int dtype, hipStream_t st, int epi = 0, const void* szh = nullptr);
 // out[t, 8 j + c] = T(T(silu(in[t, 16 j + c])) * in[t, 16 j + 8 + c]): the SiLU * mul tail on an [m, n2] result of the 8 + 8 interleaved pair
 int launch_silu_mul_interleaved(const void* in, void* out, int m, int n2, int dtype, hipStream_t st);
 int launch_silu_mul(const void* gate, const void* up, void* out, size_t count, int dtype, hipStream_t st);  // out = T(T(silu(gate)) * up), count % 8 == 0

@@ -46,7 +46,20 @@ class _LayoutMarker:
         # they are in -- untouched; resetting it would have an already converted module permute its bytes a second time
         if had_qweight:
             self.layout = "cdna4" if (marker is not None and int(marker) == 1) else "v2"
-        self.sz_cdna4 = None  # rebuilt from the (possibly new) scales at the next forward
+        self.sz_cdna4 = self.szh_cdna4 = None  # rebuilt from the (possibly new) scales at the next forward
+
+
+def _stack_side_buffers(scales, scaled_zeros, in_features, pack_sz, pack_szh):
+    """stacked sz_packed [E, N/16, K/128, 16] and, when EVERY expert's scales are f16-exact, the stacked sz_half (else None)"""
+    E = scales.shape[0]
+    szp = torch.stack([pack_sz(scales[e].contiguous(), scaled_zeros[e].contiguous(), in_features) for e in range(E)])
+    hs = []
+    for e in range(E):
+        h, exact = pack_szh(scales[e].contiguous(), scaled_zeros[e].contiguous(), in_features)
+        if not exact:
+            return szp, None
+        hs.append(h)
+    return szp, torch.stack(hs)
 
 
 class GroupedWQLinear(_LayoutMarker, nn.Module):
@@ -64,6 +77,7 @@ class GroupedWQLinear(_LayoutMarker, nn.Module):
         self.register_buffer("scales", torch.stack([e.scales for e in experts]).contiguous())
         self.register_buffer("scaled_zeros", torch.stack([e.scaled_zeros for e in experts]).contiguous())
         self.sz_cdna4 = None  # stacked packed scales int32 [E, N/16, K/128, 16], built lazily for the cdna4 layout
+        self.szh_cdna4 = None  # stacked sz_half (f16-mantissa dequant of the grouped tile launch) when every expert's scales are f16-exact
 
     @torch.no_grad()
     def to_cdna4(self):
@@ -79,10 +93,11 @@ class GroupedWQLinear(_LayoutMarker, nn.Module):
         eng = load_engine()
         if self.layout == "cdna4":
             if self.sz_cdna4 is None or self.sz_cdna4.device != self.scales.device:
-                self.sz_cdna4 = torch.stack([eng.pack_sz_cdna4(self.scales[e].contiguous(), self.scaled_zeros[e].contiguous(),
-                                                                self.in_features) for e in range(self.num_experts)])
-            return eng.moe_forward_cdna4(x_sorted.contiguous(), self.qweight, self.scales, self.scaled_zeros, self.sz_cdna4,
-                                         expert_offsets)
+                # (building sz_half reads an exactness flag back per expert: once per module, not inside a graph capture)
+                self.sz_cdna4, self.szh_cdna4 = _stack_side_buffers(self.scales, self.scaled_zeros, self.in_features, eng.pack_sz_cdna4, eng.pack_szh_cdna4)
+            from . import ops
+            return ops.moe_forward_cdna4(x_sorted.contiguous(), self.qweight, self.scales, self.scaled_zeros, self.sz_cdna4, expert_offsets,
+                                         sz_half=getattr(self, "szh_cdna4", None))
         return eng.moe_gemm_forward(x_sorted.contiguous(), self.qweight, self.scales, self.scaled_zeros, expert_offsets, False)
 
 
@@ -112,14 +127,13 @@ class GroupedGateUp(_LayoutMarker, nn.Module):
         self.register_buffer("scales", torch.stack(ss).contiguous())          # T [E, Gpad, 2F]
         self.register_buffer("scaled_zeros", torch.stack(zs).contiguous())
         self.layout = "v2"
-        self.sz_cdna4 = None
+        self.sz_cdna4 = self.szh_cdna4 = None
 
     @torch.no_grad()
     def _to_cdna4(self):
         from . import ops
         self.qweight = torch.stack([ops.repack_v2_to_cdna4(self.qweight[e].contiguous()) for e in range(self.num_experts)])
-        self.sz_cdna4 = torch.stack([ops.pack_sz_cdna4(self.scales[e].contiguous(), self.scaled_zeros[e].contiguous(), self.in_features)
-                                     for e in range(self.num_experts)])
+        self.sz_cdna4, self.szh_cdna4 = _stack_side_buffers(self.scales, self.scaled_zeros, self.in_features, ops.pack_sz_cdna4, ops.pack_szh_cdna4)
         self.layout = "cdna4"
 
     @torch.no_grad()
@@ -127,10 +141,10 @@ class GroupedGateUp(_LayoutMarker, nn.Module):
         from . import ops
         if self.layout != "cdna4":
             self._to_cdna4()
-        elif self.sz_cdna4 is None or self.sz_cdna4.device != self.qweight.device:  # (a loaded cdna4 checkpoint, or the module moved: only the side buffer)
-            self.sz_cdna4 = torch.stack([ops.pack_sz_cdna4(self.scales[e].contiguous(), self.scaled_zeros[e].contiguous(), self.in_features)
-                                         for e in range(self.num_experts)])
-        return ops.moe_mlp_gate_up_cdna4(x_sorted.contiguous(), self.qweight, self.scales, self.scaled_zeros, self.sz_cdna4, expert_offsets)
+        elif self.sz_cdna4 is None or self.sz_cdna4.device != self.qweight.device:  # (a loaded cdna4 checkpoint, or the module moved: only the side buffers)
+            self.sz_cdna4, self.szh_cdna4 = _stack_side_buffers(self.scales, self.scaled_zeros, self.in_features, ops.pack_sz_cdna4, ops.pack_szh_cdna4)
+        return ops.moe_mlp_gate_up_cdna4(x_sorted.contiguous(), self.qweight, self.scales, self.scaled_zeros, self.sz_cdna4, expert_offsets,
+                                         sz_half=getattr(self, "szh_cdna4", None))
 
 
 class SparseMoeMLP(nn.Module):

@@ -423,25 +423,27 @@ def moe_gemm(x_sorted, qweight, scales, scaled_zeros, expert_offsets, layout: st
     return out
 
 
-def moe_forward_cdna4(x_sorted, qweight, scales, scaled_zeros, sz_packed, expert_offsets, group_size: int = 128):
-    """C-ABI awq_w4a16_moe_forward_cdna4: grouped GEMV for <= 8 sorted rows (decode), grouped GEMM otherwise."""
-    _need_gpu(x_sorted, qweight, scales, scaled_zeros, sz_packed, expert_offsets)
+def moe_forward_cdna4(x_sorted, qweight, scales, scaled_zeros, sz_packed, expert_offsets, group_size: int = 128, sz_half=None):
+    """C-ABI awq_w4a16_moe_forward_cdna4(_szh): grouped GEMV for <= 8 sorted rows (decode), grouped GEMM otherwise; sz_half = the experts' stacked
+    sz_half side buffers (every expert exact) for the f16-mantissa dequant form of the grouped tile launch."""
+    _need_gpu(x_sorted, qweight, scales, scaled_zeros, sz_packed, expert_offsets, sz_half)
     assert expert_offsets.dtype == torch.int32 and qweight.dim() == 3 and sz_packed.dtype == torch.int32
     e, n, k = qweight.shape[0], qweight.shape[1] * 4, qweight.shape[2]
     t = x_sorted.shape[0]
     out = torch.empty(t, n, dtype=x_sorted.dtype, device=x_sorted.device)
     with torch.cuda.device(x_sorted.device):
-        _capi.check(_capi.lib().awq_w4a16_moe_forward_cdna4(x_sorted.data_ptr(), qweight.data_ptr(), scales.data_ptr(),
-                                                             scaled_zeros.data_ptr(), sz_packed.data_ptr(),
-                                                             expert_offsets.data_ptr(), out.data_ptr(), t, e, n, k,
-                                                             scales.shape[1], group_size, _dt(x_sorted), _stream(x_sorted)))
+        _capi.check(_capi.lib().awq_w4a16_moe_forward_cdna4_szh(x_sorted.data_ptr(), qweight.data_ptr(), scales.data_ptr(),
+                                                                 scaled_zeros.data_ptr(), sz_packed.data_ptr(),
+                                                                 sz_half.data_ptr() if sz_half is not None else None,
+                                                                 expert_offsets.data_ptr(), out.data_ptr(), t, e, n, k,
+                                                                 scales.shape[1], group_size, _dt(x_sorted), _stream(x_sorted)))
     return out
 
 
-def moe_mlp_gate_up_cdna4(x_sorted, qweight_interleaved, scales, scaled_zeros, sz_packed, expert_offsets, group_size: int = 128):
+def moe_mlp_gate_up_cdna4(x_sorted, qweight_interleaved, scales, scaled_zeros, sz_packed, expert_offsets, group_size: int = 128, sz_half=None):
     """C-ABI awq_w4a16_moe_mlp_gate_up_cdna4: silu(x . W1_e^T) * (x . W3_e^T) for tokens sorted by expert, every expert's w1 / w3 rows
     interleaved 8 + 8 per slab (qweight int16 [E, 2F/4, K]); out [T, F].  One grouped launch from 256 sorted rows on."""
-    _need_gpu(x_sorted, qweight_interleaved, scales, scaled_zeros, sz_packed, expert_offsets)
+    _need_gpu(x_sorted, qweight_interleaved, scales, scaled_zeros, sz_packed, expert_offsets, sz_half)
     e, n2, k = qweight_interleaved.shape[0], qweight_interleaved.shape[1] * 4, qweight_interleaved.shape[2]
     t = x_sorted.shape[0]
     out = torch.empty(t, n2 // 2, dtype=x_sorted.dtype, device=x_sorted.device)
@@ -450,8 +452,9 @@ def moe_mlp_gate_up_cdna4(x_sorted, qweight_interleaved, scales, scaled_zeros, s
     scratch = torch.empty(t, n2, dtype=x_sorted.dtype, device=x_sorted.device) if 0 < t < 256 else None
     with torch.cuda.device(x_sorted.device):
         for attempt in (0, 1):
-            rc = _capi.lib().awq_w4a16_moe_mlp_gate_up_cdna4(
+            rc = _capi.lib().awq_w4a16_moe_mlp_gate_up_cdna4_szh(
                 x_sorted.data_ptr(), qweight_interleaved.data_ptr(), scales.data_ptr(), scaled_zeros.data_ptr(), sz_packed.data_ptr(),
+                sz_half.data_ptr() if sz_half is not None else None,
                 expert_offsets.data_ptr(), out.data_ptr(), scratch.data_ptr() if scratch is not None else None,
                 scratch.numel() * 2 if scratch is not None else 0, t, e, n2, k, scales.shape[1], group_size, _dt(x_sorted), _stream(x_sorted))
             if rc == _capi.AWQ_ERR_WORKSPACE and scratch is None and attempt == 0 and t > 0:
