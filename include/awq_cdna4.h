@@ -288,6 +288,11 @@ int awq_w3a16_forward(const void* x, const void* qweight_w3, const void* scales,
  * the single-device result in bf16 as well (T-rounded partials: 2.6-2.9e-3).  sz_half is optional (NULL = read sz_packed). ---- */
 int awq_w4a16_partial_cdna4(const void* x, const void* qweight_cdna4, const void* sz_packed, const void* sz_half, float* out_f32, int m,
                             int n, int k, int group_size, int dtype, void* stream);
+/* The same for a 3-bit layer (w3c tiles, awq_pack_w3_from_v1; the reference's w_bit = 3 is NotImplemented at
+ * awq/quantize/qmodule.py:95-96, so the sharded form is new as well): m <= 8 the register-ring decode kernel with an fp32
+ * epilogue, above that the prefill tiles' fp32 epilogue. */
+int awq_w3a16_partial(const void* x, const void* qweight_w3, const void* sz_packed, float* out_f32, int m, int n, int k,
+                      int group_size, int dtype, void* stream);
 /* out[m, n] = T(in_f32[m, n]) (+ bias[n] in T; may be NULL): the single rounding after an RCCL sum of the partials.  n % 8 == 0. */
 int awq_round_bias_f32(const float* in_f32, const void* bias, void* out, int m, int n, int dtype, void* stream);
 

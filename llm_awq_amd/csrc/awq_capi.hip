@@ -544,6 +544,24 @@ int awq_w3a16_forward(const void* x, const void* qweight_w3, const void* scales,
   return finish_launch();
 }
 
+// tensor-parallel row split of a 3-bit layer: the K shard's product as fp32 [m, n], unrounded, no bias (the W3 twin of
+// awq_w4a16_partial_cdna4; awq_round_bias_f32 rounds the reduced sum once)
+int awq_w3a16_partial(const void* x, const void* qweight_w3, const void* sz_packed, float* out_f32, int m, int n, int k,
+                      int group_size, int dtype, void* stream) {
+  if (!x || !qweight_w3 || !sz_packed || !out_f32) return AWQ_ERR_NULL;
+  if (dtype != AWQ_F16 && dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
+  if (group_size != 128) return AWQ_ERR_GROUP;
+  if (m < 1 || check_w3_shape(n, k)) return AWQ_ERR_SHAPE;
+  if (!aligned16(x) || !aligned16(qweight_w3) || !aligned16(out_f32) || !aligned16(sz_packed)) return AWQ_ERR_ALIGN;
+  const hipStream_t st = (hipStream_t)stream;
+  if (m <= 8) {
+    if (awq::launch_gemv_cdna4(x, qweight_w3, sz_packed, nullptr, out_f32, m, n, k, 3, 3, dtype, st) != 0) return AWQ_ERR_SHAPE;
+    return finish_launch();
+  }
+  if (awq::launch_gemm_cdna4_v3(x, qweight_w3, sz_packed, nullptr, out_f32, m, n, k, 0, dtype, nullptr, 0, st, 3, 3) != 0) return AWQ_ERR_SHAPE;
+  return finish_launch();
+}
+
 int awq_tune_set(const char* key, int value) {
   if (!key) return AWQ_ERR_NULL;
   // the knobs select between shipped code paths (tests force each of them) or, in AWQ_PROBES builds, timing probes; all of them

@@ -247,6 +247,9 @@ __device__ __forceinline__ void gemv_cdna4_body(char* smem, const uint16_t* __re
       uint16_t o = DT::from_float(v[0]);
       if (bias != nullptr) o = DT::from_float(to_f(o) + to_f(bias[nn]));  // `out + self.bias` in T (qmodule.py:221)
       out[(size_t)i * N + nn] = o;
+    } else if (EPI == 3) {
+      // row-split shard: the fp32 sum leaves unrounded, the caller reduces it across ranks before the one rounding
+      reinterpret_cast<float*>(out)[(size_t)i * N + nn] = v[0];
     } else {
       // fused_mlp.py:79-82: c = F.silu(gate_output) * up_output, every op rounded to T
       const float gt = to_f(DT::from_float(v[0])), up = to_f(DT::from_float(v[NS - 1]));
@@ -386,13 +389,17 @@ static int launch_mb(const void* x, const void* qw, const void* szp, const void*
 }
 
 // epi 0: out[m, n] (+ bias);  epi 1: qw holds [gate; up] stacked along N (n = 2 * ffn rows), out[m, n/2] = silu(gate) * up
-// bits 4: cdna4 W4 tiles; bits 3: w3c tiles (epi 0 only)
+// bits 4: cdna4 W4 tiles; bits 3: w3c tiles (epi 0, or epi 3 = fp32 partial sums out[m, n] with no bias, for row-split shards)
 int launch_gemv_cdna4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                       int epi, int bits, int dtype, hipStream_t st) {
   if (m < 1 || m > 8) return -1;
   if (bits == 4 && g_use_dma && launch_gemv_dma(x, qw, szp, bias, out, m, n, k, epi, dtype, 0, st) == 0) return 0;
   if (epi == 2) return -1;  // interleaved gate / up rows: only the streaming kernel pairs them
   if (bits == 3) {
+    if (epi == 3) {
+      if (dtype == 0) return m <= 4 ? launch_mb<F16, 1, 3, 3>(x, qw, szp, nullptr, out, m, n, k, st) : launch_mb<F16, 2, 3, 3>(x, qw, szp, nullptr, out, m, n, k, st);
+      return m <= 4 ? launch_mb<BF16, 1, 3, 3>(x, qw, szp, nullptr, out, m, n, k, st) : launch_mb<BF16, 2, 3, 3>(x, qw, szp, nullptr, out, m, n, k, st);
+    }
     if (epi != 0) return -1;
     if (dtype == 0) return m <= 4 ? launch_mb<F16, 1, 0, 3>(x, qw, szp, bias, out, m, n, k, st) : launch_mb<F16, 2, 0, 3>(x, qw, szp, bias, out, m, n, k, st);
     return m <= 4 ? launch_mb<BF16, 1, 0, 3>(x, qw, szp, bias, out, m, n, k, st) : launch_mb<BF16, 2, 0, 3>(x, qw, szp, bias, out, m, n, k, st);

@@ -405,6 +405,21 @@ def forward_w3(x, qweight_w3, scales, scaled_zeros, sz_packed, bias=None, group_
     return out
 
 
+def partial_w3(x, qweight_w3, sz_packed, group_size: int = 128):
+    """C-ABI awq_w3a16_partial: the K shard's product of a 3-bit layer as fp32 [..., N], unrounded, no bias (tensor-parallel row split)."""
+    _need_gpu(x, qweight_w3, sz_packed)
+    k = x.shape[-1]
+    m = x.numel() // k
+    n = qweight_w3.shape[0] * 4
+    out = torch.empty(*x.shape[:-1], n, dtype=torch.float32, device=x.device)
+    if m == 0:
+        return out
+    with torch.cuda.device(x.device):
+        _capi.check(_capi.lib().awq_w3a16_partial(x.data_ptr(), qweight_w3.data_ptr(), sz_packed.data_ptr(), out.data_ptr(), m, n, k,
+                                                   group_size, _dt(x), _stream(x)))
+    return out
+
+
 # ---- grouped (per-expert) GEMM for MoE layers ----
 
 def moe_gemm(x_sorted, qweight, scales, scaled_zeros, expert_offsets, layout: str = "v2", group_size: int = 128):

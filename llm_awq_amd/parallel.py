@@ -79,11 +79,32 @@ def shard_stacked_column_parallel(qweight, scales, scaled_zeros, world: int, ran
     return torch.cat(qs, 0).contiguous(), torch.cat(ss, 1).contiguous(), torch.cat(zs, 1).contiguous(), bounds
 
 
+def shard_w3c(qweight, scales, scaled_zeros, mode: str, world: int, rank: int):
+    """K- ("row") or N- ("column") shard of a 3-bit layer.  The w3c buffer is a [N/16, K/128] grid of self-contained 768-byte tiles
+    (include/awq_cdna4.h), so a K cut at a multiple of 128 / an N cut at a multiple of 16 is a plain slice of that grid: no
+    unpacking.  -> (qweight int16 [Nr/4, 3 Kr/4], scales, scaled_zeros, (lo, hi))."""
+    N, K = qweight.shape[0] * 4, qweight.shape[1] * 4 // 3
+    tiles = qweight.contiguous().reshape(N // 16, K // GROUP, 384)  # 384 int16 = one tile
+    if mode == "row":
+        k0, k1 = shard_bounds(K, world, rank, GROUP)
+        assert k1 > k0, "more ranks than 128-k groups"
+        g0, g1 = k0 // GROUP, k1 // GROUP
+        gpad = calculate_zeros_width(k1 - k0, GROUP) * 8
+        s = torch.zeros(gpad, N, dtype=scales.dtype, device=scales.device)
+        z = torch.zeros(gpad, N, dtype=scales.dtype, device=scales.device)
+        s[: g1 - g0] = scales[g0:g1]
+        z[: g1 - g0] = scaled_zeros[g0:g1]
+        return tiles[:, g0:g1].contiguous().reshape(N // 4, (k1 - k0) * 3 // 4), s, z, (k0, k1)
+    n0, n1 = shard_bounds(N, world, rank, 16)
+    return (tiles[n0 // 16: n1 // 16].contiguous().reshape((n1 - n0) // 4, K * 3 // 4), scales[:, n0:n1].contiguous(),
+            scaled_zeros[:, n0:n1].contiguous(), (n0, n1))
+
+
 class TPWQLinear(nn.Module):
     """A WQLinear shard + its collective.
 
     Row mode (K-sharded, the north star's form): the shard computes its product as an UNROUNDED fp32 partial
-    (`awq_w4a16_partial_cdna4`: the same decode / skinny / prefill kernels with an fp32 epilogue), the partials are summed in fp32 --
+    (`awq_w4a16_partial_cdna4`, `awq_w3a16_partial` for a 3-bit layer: the same decode / skinny / prefill kernels with an fp32 epilogue), the partials are summed in fp32 --
     `OneShotAllReduce.reduce_f32` for the latency-class messages, the group's all-reduce on the float tensor above that -- and the sum is
     rounded to T ONCE, then the bias is added in T: what the single-device kernel does with its one accumulator.  (Rounding every rank's
     partial to T first puts a bf16 output 2.6-2.9e-3 norm-wise from the single-device result, outside the 1e-3 budget of SURVEY.md 8(e);
@@ -107,26 +128,28 @@ class TPWQLinear(nn.Module):
         self.world = world if world is not None else dist.get_world_size(group)
         self.rank = rank if rank is not None else dist.get_rank(group)
         self.in_features, self.out_features = full.in_features, full.out_features
-        # the slicing below is defined on the REFERENCE (v2) interleave, where a K cut at a multiple of 64 / an N cut at a multiple
-        # of 4 is a plain column / row slice of the int16 buffer; the cdna4 and w3c tilings permute across those cuts
-        if getattr(full, "w_bit", 4) != 4:
-            raise ValueError("tensor-parallel sharding slices v2 (w_bit = 4) buffers; a w3c module has no v2 form -- shard the "
-                             "integer weights before packing (llm_awq_amd.parallel.shard_bounds gives the cuts)")
+        w3 = getattr(full, "w_bit", 4) == 3
         if hasattr(full, "_refuse_converted"):
             full._refuse_converted("TPWQLinear")
-        relayout = getattr(full, "layout", "v2") == "cdna4"
+        # W4: the slicing is defined on the REFERENCE (v2) interleave, where a K cut at a multiple of 64 / an N cut at a multiple of 4
+        # is a plain column / row slice of the int16 buffer (the cdna4 tiling permutes across those cuts: converted back and forth);
+        # W3: the w3c tiles are cut on their own grid (shard_w3c)
+        relayout = not w3 and getattr(full, "layout", "v2") == "cdna4"
         if relayout:
             full.to_v2()
-        fn = shard_row_parallel if mode == "row" else shard_column_parallel
-        qw, s, z, self.bounds = fn(full.qweight, full.scales, full.scaled_zeros, self.world, self.rank)
-        k_local = qw.shape[1]
-        n_local = qw.shape[0] * 4
+        if w3:
+            qw, s, z, self.bounds = shard_w3c(full.qweight, full.scales, full.scaled_zeros, mode, self.world, self.rank)
+            k_local, n_local = qw.shape[1] * 4 // 3, qw.shape[0] * 4
+        else:
+            fn = shard_row_parallel if mode == "row" else shard_column_parallel
+            qw, s, z, self.bounds = fn(full.qweight, full.scales, full.scaled_zeros, self.world, self.rank)
+            k_local, n_local = qw.shape[1], qw.shape[0] * 4
         self.shard = WQLinear(full.w_bit, full.group_size, k_local, n_local, False, qw.device, dtype=s.dtype)
         self.shard.qweight, self.shard.scales, self.shard.scaled_zeros = qw, s, z
         if relayout:
             full.to_cdna4()
         cdna4_able = n_local % 16 == 0 and k_local % 128 == 0 and self.shard.group_size == 128 and s.dtype in (torch.float16, torch.bfloat16)
-        if qw.is_cuda:
+        if qw.is_cuda and not w3:
             if mode == "row" and not cdna4_able:
                 raise ValueError("a K-sharded WQLinear runs the cdna4 kernels' fp32-partial epilogue: it needs out_features % 16 == 0, "
                                  "group_size 128 and fp16 / bf16 scales")
@@ -181,7 +204,7 @@ class TPWQLinear(nn.Module):
         return self._shard_partial(x)
 
     def _shard_partial(self, x):
-        """the K shard's product as unrounded fp32 (awq_w4a16_partial_cdna4 on the shard's cdna4 buffers)"""
+        """the K shard's product as unrounded fp32 (awq_w4a16_partial_cdna4 on the shard's cdna4 buffers, awq_w3a16_partial on w3c tiles)"""
         from . import ops
         sh = self.shard
         if not x.is_contiguous():
@@ -190,6 +213,8 @@ class TPWQLinear(nn.Module):
         if sh.sz_cdna4 is None or getattr(sh, "_sz_key", None) != key:
             sh.sz_cdna4 = ops.pack_sz_cdna4(sh.scales, sh.scaled_zeros, sh.in_features)
             sh.szh_cdna4, sh._sz_key = None, key
+        if sh.w_bit == 3:
+            return ops.partial_w3(x, sh.qweight, sh.sz_cdna4)
         if sh.szh_cdna4 is None and not torch.cuda.is_current_stream_capturing():
             sh._build_szh(ops)
         szh = sh.szh_cdna4 if (sh.szh_cdna4 is not None and sh.szh_cdna4 is not False) else None

@@ -172,3 +172,94 @@ def test_gpu_wqlinear_w3_module(ops):
         rel = ((y.float() - ref.float()).norm() / ref.float().norm()).item()
         assert rel <= 1e-3, (M, rel)
         assert_bits(ref, y, 0.03)
+
+
+# ---- tensor-parallel sharding of a 3-bit layer (BASELINE config 3 x config 4) ----
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_shard_w3c_is_packing_the_sliced_integers(world):
+    """the w3c buffer is a [N/16, K/128] grid of self-contained tiles: a shard cut on that grid equals packing the sliced integers"""
+    from llm_awq_amd import parallel as P, qmodule as Q
+    d = make_case_w3(80, 640, seed=5)
+    q = torch.from_numpy(d["q"].astype(np.int32))
+    covered = {"row": 0, "column": 0}
+    for mode in ("row", "column"):
+        for r in range(world):
+            qw, s, z, (lo, hi) = P.shard_w3c(d["qweight"], d["scales"], d["scaled_zeros"], mode, world, r)
+            covered[mode] += hi - lo
+            if mode == "row":
+                assert lo % 128 == 0 and torch.equal(qw, Q.pack_w3c(q[:, lo:hi].contiguous()))
+                g0, g1 = lo // 128, hi // 128
+                assert torch.equal(s[: g1 - g0], d["scales"][g0:g1]) and torch.equal(z[: g1 - g0], d["scaled_zeros"][g0:g1])
+                assert s.shape[0] % 8 == 0 and not s[g1 - g0:].any()
+            else:
+                assert lo % 16 == 0 and torch.equal(qw, Q.pack_w3c(q[lo:hi].contiguous()))
+                assert torch.equal(s, d["scales"][:, lo:hi]) and torch.equal(z, d["scaled_zeros"][:, lo:hi])
+    assert covered == {"row": 640, "column": 80}
+
+
+def test_tp_wqlinear_takes_a_w3_module_offline():
+    from llm_awq_amd import parallel as P, qmodule as Q
+    d = make_case_w3(64, 512, seed=6, bias=True)
+    full = Q.WQLinear(3, 128, 512, 64, True, "cpu", dtype=torch.bfloat16)
+    full.qweight, full.scales, full.scaled_zeros, full.bias = d["qweight"], d["scales"], d["scaled_zeros"], d["bias"]
+    row = P.TPWQLinear(full, "row", world=2, rank=1)
+    assert row.shard.w_bit == 3 and row.shard.layout == "w3c" and (row.shard.in_features, row.shard.out_features) == (256, 64)
+    assert row.bounds == (256, 512) and row.bias is full.bias
+    col = P.TPWQLinear(full, "column", world=4, rank=2)
+    assert (col.shard.in_features, col.shard.out_features) == (512, 16) and torch.equal(col.bias, d["bias"][32:48])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,K", [(64, 512), (256, 3584), (1024, 11008)])
+def test_gpu_w3_partial_is_the_unrounded_fp32_product(ops, dtype, N, K):
+    """awq_w3a16_partial: the register-ring decode kernel (m <= 8), the masked narrow tile and the prefill tiles write their fp32 sums"""
+    d = make_case_w3(N, K, seed=N + K, M=600, dtype=dtype)
+    qw, s, z = d["qweight"].cuda(), d["scales"].cuda(), d["scaled_zeros"].cuda()
+    szp = ops.pack_sz_cdna4(s, z, K)
+    W = ops.dequant_w3(qw, s, z).double()
+    for M in (1, 3, 4, 5, 8, 9, 40, 255, 256, 300, 600):
+        x = d["x"][:M].contiguous().cuda()
+        y = ops.partial_w3(x, qw, szp)
+        assert y.dtype == torch.float32 and y.shape == (M, N)
+        y64 = x.double() @ W.t()
+        S = x.double().abs() @ W.abs().t()
+        worst = ((y.double() - y64).abs() / (3e-6 * S + 1e-30)).max().item()
+        assert worst <= 1.0, (M, worst)
+        assert_bits(y.to(dtype), ops.forward_w3(x, qw, s, z, szp), 0.02, "T(partial) vs the T kernel")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_gpu_w3_row_and_column_split_vs_the_single_device_oracle(ops, dtype, world):
+    """every rank's shard run one after the other on the one device: the row split's fp32 partials summed and rounded once, the column
+    split's outputs concatenated -- both against O.wqlinear_forward on the unsharded layer"""
+    from llm_awq_amd import parallel as P, qmodule as Q
+    K, N = 4096, 512
+    d = make_case_w3(N, K, seed=31 + world, M=300, bias=True, dtype=dtype)
+    full = Q.WQLinear(3, 128, K, N, True, "cuda", dtype=dtype)
+    full.qweight, full.scales, full.scaled_zeros, full.bias = d["qweight"].cuda(), d["scales"].cuda(), d["scaled_zeros"].cuda(), d["bias"].cuda()
+    rows = [P.TPWQLinear(full, "row", world=world, rank=r) for r in range(world)]
+    cols = [P.TPWQLinear(full, "column", world=world, rank=r) for r in range(world)]
+    assert all(t.shard.layout == "w3c" and t._reducer is None for t in rows + cols)
+    for M in (1, 7, 64, 300):
+        x = d["x"][:M].contiguous()
+        ref = O.wqlinear_forward(x, None, d["scales"], d["scaled_zeros"], d["bias"], 128, q_int=d["q"]).float()
+        xg = x.cuda()
+        acc = torch.zeros(M, N, device="cuda")
+        for t in rows:
+            p32 = t.partial(xg)
+            assert p32.dtype == torch.float32
+            acc += p32
+        y = ops.round_bias_f32(acc, dtype, full.bias).float().cpu()
+        rel = ((y - ref).norm() / ref.norm()).item()
+        assert rel < 1e-3, (M, rel)
+        assert_bits(y, ref, 0.01, "W3 row split vs single-device oracle")
+        yc = torch.cat([t(xg) for t in cols], dim=-1).cpu()
+        check_forward(yc, x, d["q"], d["scales"], d["scaled_zeros"], dtype, bias=d["bias"])
+        # a world-1 "split" is the module itself
+    one = P.TPWQLinear(full, "row", world=1, rank=0)
+    xg = d["x"][:5].contiguous().cuda()
+    assert_bits(one(xg), full(xg), 0.02, "world-1 row shard vs the module")
