@@ -24,10 +24,18 @@ def _graph_us(run, stream, steps, warmup):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=stream):
             keep = run()  # noqa: F841
-        for _ in range(warmup):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(max(1, warmup)):
+            g.replay()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        # these graphs are 0.1 - 0.5 ms long: a handful of replays ends before the clocks have ramped (the first leg timed after an idle gap read
+        # 5 - 15 % slow).  Keep the GPU busy for ~40 ms before the timed region, as bench.py's own warm-up steps do for the headline legs
+        est_ms = e0.elapsed_time(e1) / max(1, warmup)
+        for _ in range(min(2000, int(40.0 / max(est_ms, 1e-3)))):
             g.replay()
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         for _ in range(steps):
             g.replay()
@@ -78,34 +86,64 @@ def _rand_sz(K, N, levels, dtype, dev, gen):
 
 
 def w3_llama2_7b(eng, dev, stream, steps, warmup, iters, dtype=torch.bfloat16):
-    from llm_awq_amd import synth
+    from llm_awq_amd import ops, synth
     gen = torch.Generator(device=dev).manual_seed(303)
-    names = ("qkv", "o", "gate", "up", "down")
     L_dec, L_pre = 8, 4
-    layers = []
+    layers, fused = [], []
     for _li in range(L_dec):
-        lin = []
-        for nm in names:
+        lin, ints = {}, {}
+        for nm in ("qkv", "o", "gate", "up", "down"):
             K, N = synth.LLAMA2_7B[nm]
             q = torch.randint(0, 8, (N, K), dtype=torch.uint8, device=dev, generator=gen)
             s, z = _rand_sz(K, N, 7, dtype, dev, gen)
-            lin.append((K, N, eng.pack_w3(q), s, z, eng.pack_sz_cdna4(s, z, K)))
-            del q
+            lin[nm] = (K, N, eng.pack_w3(q), s, z, eng.pack_sz_cdna4(s, z, K))
+            if nm in ("gate", "up"):
+                ints[nm] = q
+        # QuantLlamaMLP(w_bit = 3)'s stream: integer rows interleaved 8 + 8 per slab, packed into w3c tiles (fused_mlp.interleave_gate_up_w3)
+        K, F = synth.LLAMA2_7B["gate"]
+        qi = torch.stack([ints["gate"].view(F // 8, 8, K), ints["up"].view(F // 8, 8, K)], 1).reshape(2 * F, K).contiguous()
+
+        def cols(a, b):
+            return torch.stack([a.view(-1, F // 8, 8), b.view(-1, F // 8, 8)], 2).reshape(a.shape[0], 2 * F).contiguous()
+
+        si, zi = cols(lin["gate"][3], lin["up"][3]), cols(lin["gate"][4], lin["up"][4])
+        fused.append((K, 2 * F, eng.pack_w3(qi), eng.pack_sz_cdna4(si, zi, K)))
         layers.append(lin)
+        del ints, qi, si, zi
     xs = {M: {K: torch.randn(M, K, device=dev, generator=gen).to(dtype) for K in (4096, 11008)} for M in (1, 2048)}
 
-    def run(M, n_layers):
-        return [eng.forward_w3(xs[M][K], qw, s, z, szp, None) for lin in layers[:n_layers] for (K, N, qw, s, z, szp) in lin]
+    def lin_fwd(M, ent):
+        K, N, qw, s, z, szp = ent
+        return eng.forward_w3(xs[M][K], qw, s, z, szp, None)
 
+    def run(M, n_layers):  # the block as the module tree runs it: qkv, o, QuantLlamaMLP (fused gate/up + SiLU * mul, then down_proj)
+        outs = []
+        for li in range(n_layers):
+            outs += [lin_fwd(M, layers[li]["qkv"]), lin_fwd(M, layers[li]["o"])]
+            K, N2, qw, szp = fused[li]
+            outs.append(ops.mlp_gate_up_forward_w3(xs[M][K], qw, szp))
+            outs.append(lin_fwd(M, layers[li]["down"]))
+        return outs
+
+    def run_unfused(M, n_layers):  # five WQLinear calls (no fused module): reported beside it
+        return [lin_fwd(M, layers[li][nm]) for li in range(n_layers) for nm in ("qkv", "o", "gate", "up", "down")]
+
+    def wbytes(K, N):
+        return N * K * 3 // 8 + 2 * (K // 128) * N * 2
+
+    K, F = synth.LLAMA2_7B["gate"]
+    by = sum(wbytes(*synth.LLAMA2_7B[nm]) + synth.LLAMA2_7B[nm][0] * 2 + synth.LLAMA2_7B[nm][1] * 2 for nm in ("qkv", "o", "down"))
+    by = (by + wbytes(K, 2 * F) + K * 2 + F * 2) * L_dec
     us = _graph_us(lambda: run(1, L_dec), stream, steps, warmup)
-    by = sum(N * K * 3 // 8 + 2 * (K // 128) * N * 2 + K * 2 + N * 2 for (K, N, *_r) in layers[0]) * L_dec
+    us_u = _graph_us(lambda: run_unfused(1, L_dec), stream, steps, warmup)
     us_p, us_pmin = _median_us(lambda: run(2048, L_pre), stream, iters)
-    fl = sum(2.0 * 2048 * K * N for (K, N, *_r) in layers[0]) * L_pre
-    return {"workload": "Llama-2-7B W3A16 g128 bf16 (w3c tiles): the five WQLinear(w_bit=3) calls of a block, every layer its own weights",
-            "decode_m1": {"layers": L_dec, "launches": 5 * L_dec, "us_per_layer": round(us / L_dec, 2), "tok_s_32_layers": round(1e6 / (us / L_dec * 32), 1),
-                          "algorithmic_bytes_per_layer": by // L_dec, "roofline": _hbm(by, us)},
+    us_pu, _ = _median_us(lambda: run_unfused(2048, L_pre), stream, iters)
+    fl = sum(2.0 * 2048 * K_ * N_ for (K_, N_) in (synth.LLAMA2_7B[nm] for nm in ("qkv", "o", "gate", "up", "down"))) * L_pre
+    return {"workload": "Llama-2-7B W3A16 g128 bf16 (w3c tiles): qkv, o, QuantLlamaMLP(w_bit=3) = fused gate/up + SiLU*mul, down; every layer its own weights",
+            "decode_m1": {"layers": L_dec, "launches": 4 * L_dec, "us_per_layer": round(us / L_dec, 2), "tok_s_32_layers": round(1e6 / (us / L_dec * 32), 1),
+                          "algorithmic_bytes_per_layer": by // L_dec, "roofline": _hbm(by, us), "us_per_layer_five_unfused_calls": round(us_u / L_dec, 2)},
             "prefill_m2048": {"layers": L_pre, "ms_per_layer": round(us_p / L_pre / 1e3, 4), "tok_s_32_layers": round(2048 / (us_p / L_pre * 32 * 1e-6), 1),
-                              "roofline": _mfma(fl, us_p, us_pmin)}}
+                              "roofline": _mfma(fl, us_p, us_pmin), "ms_per_layer_five_unfused_calls": round(us_pu / L_pre / 1e3, 4)}}
 
 
 def tp70b_world1(eng, dev, stream, steps, warmup, iters, dtype=torch.bfloat16):

@@ -288,6 +288,13 @@ int awq_w3a16_forward(const void* x, const void* qweight_w3, const void* scales,
  * the single-device result in bf16 as well (T-rounded partials: 2.6-2.9e-3).  sz_half is optional (NULL = read sz_packed). ---- */
 int awq_w4a16_partial_cdna4(const void* x, const void* qweight_cdna4, const void* sz_packed, const void* sz_half, float* out_f32, int m,
                             int n, int k, int group_size, int dtype, void* stream);
+/* QuantLlamaMLP's gate / up pair + SiLU * mul (tinychat/modules/fused_mlp.py:33-83) for 3-bit projections: qweight_w3_interleaved holds the
+ * two projections' INTEGER rows interleaved 8 + 8 per 16-row slab (gate rows 8 j .. 8 j + 7, then the matching up rows) packed into w3c
+ * tiles, sz_packed the same interleave of their scales / zeros; out[m, n2 / 2] = T(T(silu(T(gate))) * T(up)).  m <= 8: the register-ring
+ * decode kernel pairs the rows in its epilogue; above that the prefill tiles' fused tail.  workspace: optional split-K scratch (NULL / 0 ok). */
+size_t awq_w3a16_mlp_gate_up_forward_workspace_bytes(int m, int n2, int k);
+int awq_w3a16_mlp_gate_up_forward(const void* x, const void* qweight_w3_interleaved, const void* sz_packed, void* out, int m, int n2, int k,
+                                  int group_size, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 /* The same for a 3-bit layer (w3c tiles, awq_pack_w3_from_v1; the reference's w_bit = 3 is NotImplemented at
  * awq/quantize/qmodule.py:95-96, so the sharded form is new as well): m <= 8 the register-ring decode kernel with an fp32
  * epilogue, above that the prefill tiles' fp32 epilogue. */

@@ -80,6 +80,8 @@ SIGNATURES = {
     "awq_oneshot_set_spin_limit": (_i, [ctypes.c_uint]),
     "awq_w4a16_partial_cdna4": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "awq_w3a16_partial": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "awq_w3a16_mlp_gate_up_forward_workspace_bytes": (_sz, [_i, _i, _i]),
+    "awq_w3a16_mlp_gate_up_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "awq_round_bias_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "awq_tune_set": (_i, [ctypes.c_char_p, _i]),
 }

@@ -544,6 +544,32 @@ int awq_w3a16_forward(const void* x, const void* qweight_w3, const void* scales,
   return finish_launch();
 }
 
+// QuantLlamaMLP on 3-bit gate / up projections (tinychat/modules/fused_mlp.py:33-83 with this repository's w_bit = 3): the two projections'
+// rows interleaved 8 + 8 per 16-row slab (integer rows, then packed into w3c tiles), out[m, n2 / 2] = silu(gate) * up in the kernels' epilogue
+size_t awq_w3a16_mlp_gate_up_forward_workspace_bytes(int m, int n2, int k) { return m > 8 ? awq::gemm_cdna4_v3_workspace_bytes_w3(m, n2, k) : 0; }
+
+int awq_w3a16_mlp_gate_up_forward(const void* x, const void* qweight_w3_interleaved, const void* sz_packed, void* out, int m, int n2, int k,
+                                  int group_size, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !qweight_w3_interleaved || !sz_packed || !out) return AWQ_ERR_NULL;
+  if (group_size != 128) return AWQ_ERR_GROUP;
+  if (dtype != AWQ_F16 && dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
+  if (m < 1) return AWQ_ERR_BATCH;
+  if (n2 < 32 || (n2 % 32) != 0 || k < 128 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return AWQ_ERR_SHAPE;
+  if (!aligned16(x) || !aligned16(qweight_w3_interleaved) || !aligned16(out) || !aligned16(sz_packed)) return AWQ_ERR_ALIGN;
+  const hipStream_t st = (hipStream_t)stream;
+  if (m <= 8) {
+    if (awq::launch_gemv_cdna4(x, qweight_w3_interleaved, sz_packed, nullptr, out, m, n2, k, 2, 3, dtype, st) != 0) return AWQ_ERR_SHAPE;
+    return finish_launch();
+  }
+  if (workspace && ((reinterpret_cast<uintptr_t>(workspace) & 63) != 0 || workspace_bytes < awq_w3a16_mlp_gate_up_forward_workspace_bytes(m, n2, k))) {
+    workspace = nullptr;
+    workspace_bytes = 0;
+  }
+  if (awq::launch_gemm_cdna4_v3(x, qweight_w3_interleaved, sz_packed, nullptr, out, m, n2, k, 0, dtype, workspace, workspace_bytes, st, 3, 2) != 0)
+    return AWQ_ERR_SHAPE;
+  return finish_launch();
+}
+
 // tensor-parallel row split of a 3-bit layer: the K shard's product as fp32 [m, n], unrounded, no bias (the W3 twin of
 // awq_w4a16_partial_cdna4; awq_round_bias_f32 rounds the reduced sum once)
 int awq_w3a16_partial(const void* x, const void* qweight_w3, const void* sz_packed, float* out_f32, int m, int n, int k,

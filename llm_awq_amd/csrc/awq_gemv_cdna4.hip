@@ -231,6 +231,23 @@ __device__ __forceinline__ void gemv_cdna4_body(char* smem, const uint16_t* __re
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[s * WAVES + wv][r][lane] = acc[s][r];
   __syncthreads();
+  if (EPI == 2) {
+    // QuantLlamaMLP's interleaved pair (fused_mlp.py:79-82): rows 0..7 of the slab are gate rows 8 nb .. 8 nb + 7, rows 8..15 the matching up
+    // rows, so lane (g < 2) pairs with lane + 32; out[m, N / 2] = T(T(silu(T(gate))) * T(up))
+    if (wv < 4 && i < M && g < 2) {
+      const int r = wv;
+      float gsum = 0.f, usum = 0.f;
+#pragma unroll
+      for (int q = 0; q < WAVES; ++q) {
+        gsum += red[q][r][lane];
+        usum += red[q][r][lane + 32];
+      }
+      const float gt = DT::to_float(DT::from_float(gsum)), up = DT::to_float(DT::from_float(usum));
+      const float sl = DT::to_float(DT::from_float(silu_f32(gt)));
+      out[(size_t)i * (N >> 1) + nb * 8 + 4 * g + r] = DT::from_float(sl * up);
+    }
+    return;
+  }
   if (wv < 4 && i < M) {
     const int r = wv;
     float v[NS];
@@ -300,12 +317,15 @@ struct Cfg {
   int waves, s;
 };
 // choose the K split (waves per slab) and, for the chunk mode, the chunk length
-Cfg pick_cfg(int m, int n_rows, int k, int ns, int force_waves, int force_s) {
+Cfg pick_cfg(int m, int n_rows, int k, int ns, int force_waves, int force_s, int bits = 4) {
   // measured on MI355X (tools/gemvc_sweep.py, profiles/r01_gemvc_sweep.txt): short chunks (2..4 steps, 7 when the
   // step count is a multiple of 7) and ~7 k waves in flight chip-wide; a chunk longer than the wave's step count
   // only adds clamped loads
   const int nit = k / kGroup, slabs = n_rows / 16 / ns;
   int waves = slabs >= 768 ? 4 : (slabs >= 384 ? 8 : (nit >= 64 ? 8 : 16));
+  // w3c tiles: eight waves up to ~1000 slabs (Llama-2-7B qkv, 768 slabs: 6.7 vs 7.1 us), four above (the fused gate / up stack, 1376 slabs:
+  // 11.2-11.7 vs 11.8-12.2 us): profiles/r05_w3_fused_mlp.txt
+  if (bits == 3 && slabs >= 768 && slabs < 1024) waves = 8;
   if (ns == 2 && waves > 4 && slabs >= 256) waves >>= 1;  // two slabs per block: half the waves give the same bytes in flight
   while (waves > 4 && waves * 2 > nit) waves >>= 1;
   if (force_waves) waves = force_waves;
@@ -348,7 +368,7 @@ static void launch_cfg(const void* x, const void* qw, const void* szp, const voi
 template <typename DT, int MB, int EPI, int BITS>
 static int launch_mb(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                      hipStream_t st) {
-  const Cfg c = pick_cfg(m, n, k, EPI == 1 ? 2 : 1, g_force_waves, g_force_s);
+  const Cfg c = pick_cfg(m, n, k, EPI == 1 ? 2 : 1, g_force_waves, g_force_s, BITS);
   const int pipe = g_pipe < 0 ? 2 : g_pipe;
   if (pipe >= 2) {  // software-pipelined variant: ring of `pipe` chunks of `ps` steps
     const int per = (k / kGroup + c.waves - 1) / c.waves;
@@ -389,16 +409,20 @@ static int launch_mb(const void* x, const void* qw, const void* szp, const void*
 }
 
 // epi 0: out[m, n] (+ bias);  epi 1: qw holds [gate; up] stacked along N (n = 2 * ffn rows), out[m, n/2] = silu(gate) * up
-// bits 4: cdna4 W4 tiles; bits 3: w3c tiles (epi 0, or epi 3 = fp32 partial sums out[m, n] with no bias, for row-split shards)
+// bits 4: cdna4 W4 tiles; bits 3: w3c tiles (epi 0; epi 2 = gate / up rows interleaved 8 + 8 per slab, out[m, n/2]; epi 3 = fp32 partial sums out[m, n] with no bias, for row-split shards)
 int launch_gemv_cdna4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                       int epi, int bits, int dtype, hipStream_t st) {
   if (m < 1 || m > 8) return -1;
   if (bits == 4 && g_use_dma && launch_gemv_dma(x, qw, szp, bias, out, m, n, k, epi, dtype, 0, st) == 0) return 0;
-  if (epi == 2) return -1;  // interleaved gate / up rows: only the streaming kernel pairs them
+  if (epi == 2 && bits != 3) return -1;  // interleaved gate / up rows of a W4 layer: only the streaming kernel pairs them
   if (bits == 3) {
     if (epi == 3) {
       if (dtype == 0) return m <= 4 ? launch_mb<F16, 1, 3, 3>(x, qw, szp, nullptr, out, m, n, k, st) : launch_mb<F16, 2, 3, 3>(x, qw, szp, nullptr, out, m, n, k, st);
       return m <= 4 ? launch_mb<BF16, 1, 3, 3>(x, qw, szp, nullptr, out, m, n, k, st) : launch_mb<BF16, 2, 3, 3>(x, qw, szp, nullptr, out, m, n, k, st);
+    }
+    if (epi == 2) {  // the interleaved gate / up stack of a 3-bit QuantLlamaMLP
+      if (dtype == 0) return m <= 4 ? launch_mb<F16, 1, 2, 3>(x, qw, szp, nullptr, out, m, n, k, st) : launch_mb<F16, 2, 2, 3>(x, qw, szp, nullptr, out, m, n, k, st);
+      return m <= 4 ? launch_mb<BF16, 1, 2, 3>(x, qw, szp, nullptr, out, m, n, k, st) : launch_mb<BF16, 2, 2, 3>(x, qw, szp, nullptr, out, m, n, k, st);
     }
     if (epi != 0) return -1;
     if (dtype == 0) return m <= 4 ? launch_mb<F16, 1, 0, 3>(x, qw, szp, bias, out, m, n, k, st) : launch_mb<F16, 2, 0, 3>(x, qw, szp, bias, out, m, n, k, st);

@@ -18,6 +18,11 @@ The reference module keeps gate_proj / up_proj as raw v2 buffers, issues two `ge
     column n with column n + 8 and stores silu(gate) * up directly -- the [rows, 2 * ffn] intermediate of the reference's two
     GEMMs + F.silu + multiply is never written.
 
+3-bit projections (`WQLinear(w_bit=3)`, this repository's extension): the same module.  The w3c tiles hold 16 rows each, so the 8 + 8
+interleave is done on the INTEGER rows (`awq_unpack_w3` -> permute -> `awq_pack_w3`) and the fused stream is served by
+`awq_w3a16_mlp_gate_up_forward` (<= 8 rows: the register-ring decode kernel pairs the rows in its epilogue; more: the same tile epilogue).
+Llama-2-7B: 11.2-11.7 us for the fused decode launch against 2 x 6.5-6.7 us (profiles/r05_w3_fused_mlp.txt).
+
 `scaled_zeros - 8 * scales` (fused_mlp.py:69,76): the reference's GEMM branch shifts the zero point by 8 while its GEMV
 branch, `WQLinear.forward` (qmodule.py:220, shift commented out), `from_linear` and the offline repacker (`zp_shift = 0`,
 offline-weight-repacker.py:142) all treat the stored nibbles as UNSIGNED 0..15 (dequantize.cuh:59-69 yields 0..15).  Both
@@ -64,6 +69,37 @@ def deinterleave_gate_up(q, s, z):
     return q4[:, 0].reshape(F2 // 2, K).contiguous(), q4[:, 1].reshape(F2 // 2, K).contiguous(), gs, us, gz, uz
 
 
+def interleave_gate_up_w3(gq3, uq3, gs, us, gz, uz):
+    """the same 8 + 8 interleave for 3-bit projections: the w3c tiles hold 16 rows each, so the rows are interleaved as INTEGERS
+    (awq_unpack_w3 -> permute -> awq_pack_w3, GPU kernels) -> (qweight int16 [2F/4, 3K/4], scales / scaled_zeros [Gpad, 2F])."""
+    from . import ops
+    g, u = ops.unpack_w3(gq3.contiguous()), ops.unpack_w3(uq3.contiguous())  # uint8 [F, K]
+    Fo, K = g.shape
+    assert u.shape == g.shape and Fo % 8 == 0, "intermediate size must be a multiple of 8"
+    q = torch.stack([g.view(Fo // 8, 8, K), u.view(Fo // 8, 8, K)], 1).reshape(2 * Fo, K).contiguous()
+
+    def cols(a, b):
+        return torch.stack([a.view(-1, Fo // 8, 8), b.view(-1, Fo // 8, 8)], 2).reshape(a.shape[0], 2 * Fo).contiguous()
+
+    return ops.pack_w3(q), cols(gs, us), cols(gz, uz)
+
+
+def deinterleave_gate_up_w3(q3, s, z):
+    """inverse of interleave_gate_up_w3"""
+    from . import ops
+    q = ops.unpack_w3(q3.contiguous())
+    F2, K = q.shape
+    q8 = q.view(F2 // 16, 2, 8, K)
+    Fo = F2 // 2
+
+    def cols(a):
+        a4 = a.view(a.shape[0], Fo // 8, 2, 8)
+        return a4[:, :, 0, :].reshape(a.shape[0], Fo).contiguous(), a4[:, :, 1, :].reshape(a.shape[0], Fo).contiguous()
+
+    (gs, us), (gz, uz) = cols(s), cols(z)
+    return (ops.pack_w3(q8[:, 0].reshape(Fo, K).contiguous()), ops.pack_w3(q8[:, 1].reshape(Fo, K).contiguous()), gs, us, gz, uz)
+
+
 _V2_NAMES = ("gate_proj_qweight", "gate_proj_scales", "gate_proj_scaled_zeros", "up_proj_qweight", "up_proj_scales", "up_proj_scaled_zeros")
 
 
@@ -82,8 +118,13 @@ class QuantLlamaMLP(nn.Module):
         self.register_buffer("up_proj_qweight", up_proj.qweight)
         self.register_buffer("up_proj_scales", up_proj.scales)
         self.register_buffer("up_proj_scaled_zeros", up_proj.scaled_zeros)
-        if getattr(gate_proj, "layout", "v2") != "v2" or getattr(up_proj, "layout", "v2") != "v2":
+        if gate_proj.w_bit != up_proj.w_bit:
+            raise ValueError("QuantLlamaMLP: gate_proj and up_proj must share w_bit")
+        want = "w3c" if gate_proj.w_bit == 3 else "v2"  # (3-bit projections only exist as w3c tiles; their rows are interleaved as integers)
+        if getattr(gate_proj, "layout", "v2") != want or getattr(up_proj, "layout", "v2") != want:
             raise ValueError("QuantLlamaMLP is built from v2 (reference layout) gate / up projections; it makes its own cdna4 stream")
+        if gate_proj.w_bit == 3 and (gate_proj.out_features % 16 != 0 or gate_proj.group_size != 128):
+            raise ValueError("QuantLlamaMLP (w_bit = 3): intermediate size % 16 == 0 and group_size 128")
         self.in_features = gate_proj.in_features
         self.intermediate_size = gate_proj.out_features
         self.out_features = down_proj.out_features
@@ -109,9 +150,11 @@ class QuantLlamaMLP(nn.Module):
     @torch.no_grad()
     def _v2_from_fused(self):
         c4, s, z, _szp, _szh = self._fused
+        names = ("gate_proj_qweight", "up_proj_qweight", "gate_proj_scales", "up_proj_scales", "gate_proj_scaled_zeros", "up_proj_scaled_zeros")
+        if self.w_bit == 3:
+            return dict(zip(names, deinterleave_gate_up_w3(c4, s, z)))
         q = load_engine().repack_cdna4_to_v2(c4)
-        return dict(zip(("gate_proj_qweight", "up_proj_qweight", "gate_proj_scales", "up_proj_scales", "gate_proj_scaled_zeros",
-                         "up_proj_scaled_zeros"), deinterleave_gate_up(q, s, z)))
+        return dict(zip(names, deinterleave_gate_up(q, s, z)))
 
     @staticmethod
     def _fill_state_dict(module, state_dict, prefix, local_metadata):
@@ -139,12 +182,17 @@ class QuantLlamaMLP(nn.Module):
                 eng.cdna4_is_converted(self.gate_proj_qweight) or eng.cdna4_is_converted(self.up_proj_qweight)):
             raise RuntimeError("QuantLlamaMLP: gate_proj / up_proj qweight was converted in place by the engine cache (AWQ_CDNA4_INPLACE); "
                                "call awq_inference_engine.cdna4_restore(qweight) on both before the fused stream is built")
-        q, s, z = interleave_gate_up(self.gate_proj_qweight, self.up_proj_qweight, self.gate_proj_scales, self.up_proj_scales,
-                                     self.gate_proj_scaled_zeros, self.up_proj_scaled_zeros)
-        c4 = eng.repack_v2_to_cdna4(q)
-        szp = eng.pack_sz_cdna4(s, z, self.in_features)
-        szh, exact = eng.pack_szh_cdna4(s, z, self.in_features)
-        self._fused = (c4, s, z, szp, szh if exact else None)
+        if self.w_bit == 3:
+            c4, s, z = interleave_gate_up_w3(self.gate_proj_qweight, self.up_proj_qweight, self.gate_proj_scales, self.up_proj_scales,
+                                             self.gate_proj_scaled_zeros, self.up_proj_scaled_zeros)
+            self._fused = (c4, s, z, eng.pack_sz_cdna4(s, z, self.in_features), None)
+        else:
+            q, s, z = interleave_gate_up(self.gate_proj_qweight, self.up_proj_qweight, self.gate_proj_scales, self.up_proj_scales,
+                                         self.gate_proj_scaled_zeros, self.up_proj_scaled_zeros)
+            c4 = eng.repack_v2_to_cdna4(q)
+            szp = eng.pack_sz_cdna4(s, z, self.in_features)
+            szh, exact = eng.pack_szh_cdna4(s, z, self.in_features)
+            self._fused = (c4, s, z, szp, szh if exact else None)
         if getattr(self.down_proj, "layout", None) == "v2" and self.down_proj.out_features % 16 == 0:
             self.down_proj.to_cdna4()
         if c4.is_cuda and os.environ.get("AWQ_MLP_KEEP_V2") != "1":
@@ -168,7 +216,7 @@ class QuantLlamaMLP(nn.Module):
         tagged granules and gathers the whole of it.  None when this layer cannot take it (more than one row, scales not f16-exact, down_proj
         not in the cdna4 layout, shape outside the kernel's range)."""
         eng = load_engine()
-        if x.numel() != x.shape[-1] or not eng.mlp_decode_plan(1, self.in_features, self.intermediate_size, self.out_features):
+        if self.w_bit != 4 or x.numel() != x.shape[-1] or not eng.mlp_decode_plan(1, self.in_features, self.intermediate_size, self.out_features):
             return None  # (host-side plan query: one row, hidden = 4096, out_features = 4096, ffn <= 14336, a whole 256-CU device)
         if self._fused is None or self._fused[0].device != x.device:
             self._build(x.device)
@@ -204,6 +252,9 @@ class QuantLlamaMLP(nn.Module):
         if not x.is_contiguous():
             x = x.contiguous()
         # one entry point for every row count: <= 8 rows the streaming decode launch, more the tile kernels with the fused tail
+        if self.w_bit == 3:
+            from . import ops
+            return ops.mlp_gate_up_forward_w3(x, c4, szp)
         return eng.mlp_gate_up_forward_cdna4(x, c4, szp, szh)
 
 

@@ -405,6 +405,22 @@ def forward_w3(x, qweight_w3, scales, scaled_zeros, sz_packed, bias=None, group_
     return out
 
 
+def mlp_gate_up_forward_w3(x, qweight_w3_interleaved, sz_packed, group_size: int = 128):
+    """C-ABI awq_w3a16_mlp_gate_up_forward: QuantLlamaMLP.our_llama_mlp on 3-bit projections (rows interleaved 8 + 8, w3c tiles), any row count."""
+    _need_gpu(x, qweight_w3_interleaved, sz_packed)
+    k = x.shape[-1]
+    m = x.numel() // k
+    n2 = qweight_w3_interleaved.shape[0] * 4
+    out = torch.empty(*x.shape[:-1], n2 // 2, dtype=x.dtype, device=x.device)
+    L = _capi.lib()
+    wsb = L.awq_w3a16_mlp_gate_up_forward_workspace_bytes(m, n2, k)
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device) if wsb else None
+    with torch.cuda.device(x.device):
+        _capi.check(L.awq_w3a16_mlp_gate_up_forward(x.data_ptr(), qweight_w3_interleaved.data_ptr(), sz_packed.data_ptr(), out.data_ptr(), m, n2, k,
+                                                     group_size, _dt(x), ws.data_ptr() if ws is not None else None, wsb, _stream(x)))
+    return out
+
+
 def partial_w3(x, qweight_w3, sz_packed, group_size: int = 128):
     """C-ABI awq_w3a16_partial: the K shard's product of a 3-bit layer as fp32 [..., N], unrounded, no bias (tensor-parallel row split)."""
     _need_gpu(x, qweight_w3, sz_packed)

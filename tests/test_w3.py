@@ -263,3 +263,96 @@ def test_gpu_w3_row_and_column_split_vs_the_single_device_oracle(ops, dtype, wor
     one = P.TPWQLinear(full, "row", world=1, rank=0)
     xg = d["x"][:5].contiguous().cuda()
     assert_bits(one(xg), full(xg), 0.02, "world-1 row shard vs the module")
+
+
+# ---- QuantLlamaMLP on 3-bit projections (tinychat/modules/fused_mlp.py:33-83 with w_bit = 3): awq_w3a16_mlp_gate_up_forward ----
+
+def _w3_pair(F, K, dtype, seed, M):
+    cg = make_case_w3(F, K, seed=seed, M=M, dtype=dtype)
+    cu = make_case_w3(F, K, seed=seed + 1, M=M, dtype=dtype)
+    x = cg["x"]
+    g = O.wqlinear_forward(x, None, cg["scales"], cg["scaled_zeros"], None, 128, q_int=cg["q"])
+    u = O.wqlinear_forward(x, None, cu["scales"], cu["scaled_zeros"], None, 128, q_int=cu["q"])
+    return cg, cu, x, torch.nn.functional.silu(g) * u, g, u
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [1, 4, 5, 8, 9, 64, 300, 2048])
+@pytest.mark.parametrize("F,K", [(256, 768), (1376, 512), (11008, 4096)])
+def test_gpu_w3_gate_up_entry_every_row_count(ops, dtype, M, F, K):
+    """<= 8 rows: the register-ring decode kernel pairs gate row r with up row r of a slab in its epilogue; more rows: the prefill tiles'
+    fused tail on the w3c stream.  Checker: the oracle's statement of the reference sequence (two forwards, F.silu, multiply, all rounded to T)."""
+    from llm_awq_amd.fused_mlp import deinterleave_gate_up_w3, interleave_gate_up_w3
+    from tests.helpers import acc_slack, check_fused_tail, weight_row_norms
+    if F >= 4096 and (M not in (1, 9, 2048) or dtype != torch.bfloat16):
+        pytest.skip("full-size case: bf16, M = 1, 9, 2048 only")
+    if M == 2048 and F < 4096:
+        pytest.skip("M = 2048 on the full-size shape only")
+    cg, cu, x, ref, gt, up = _w3_pair(F, K, dtype, F + K + M, M)
+    dev = [t.cuda() for t in (cg["qweight"], cu["qweight"], cg["scales"], cu["scales"], cg["scaled_zeros"], cu["scaled_zeros"])]
+    qi, si, zi = interleave_gate_up_w3(*dev)
+    assert qi.shape == (2 * F // 4, K * 3 // 4) and si.shape[1] == 2 * F
+    # the stream holds slab j = gate rows 8j..8j+7, then up rows 8j..8j+7, and the inverse gives the projections back bit for bit
+    qint = ops.unpack_w3(qi).cpu().view(F // 8, 2, 8, K)
+    assert (qint[:, 0].reshape(F, K).numpy() == cg["q"]).all() and (qint[:, 1].reshape(F, K).numpy() == cu["q"]).all()
+    for a, b in zip(deinterleave_gate_up_w3(qi, si, zi), dev):
+        assert torch.equal(a, b)
+    szp = ops.pack_sz_cdna4(si, zi, K)
+    y = ops.mlp_gate_up_forward_w3(x.cuda(), qi, szp).cpu()
+    assert y.shape == (M, F)
+    check_fused_tail(y, gt, up, 1e-3, what=f"W3 gate_up entry F={F} K={K} M={M}", slack_g=acc_slack(x, weight_row_norms(cg)),
+                     slack_u=acc_slack(x, weight_row_norms(cu)))
+    assert_bits(y, ref, (0.05 if M <= 300 else 0.07))
+    # the fused tail == the unfused product path on the same interleaved stream
+    full = ops.forward_w3(x.cuda(), qi, si, zi, szp).view(M, F // 8, 2, 8)
+    unfused = (torch.nn.functional.silu(full[:, :, 0, :]) * full[:, :, 1, :]).reshape(M, F).cpu()
+    assert_bits(y, unfused, (0.002 if dtype == torch.bfloat16 else 0.01))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gpu_w3_quant_llama_mlp_module(ops, dtype):
+    """QuantLlamaMLP built from three WQLinear(w_bit = 3) modules through make_fused_mlp: reference-named state dict, every row count, down_proj behind it"""
+    import torch.nn as nn
+    from llm_awq_amd import qmodule as Q
+    from llm_awq_amd.fused_mlp import QuantLlamaMLP, make_fused_mlp
+    H, F = 1024, 2816
+    cg, cu, x, act, _gt, _up = _w3_pair(F, H, dtype, 177, 40)
+    cd = make_case_w3(H, F, seed=179, M=1, dtype=dtype)
+
+    def lin(c, k, n):
+        m = Q.WQLinear(3, 128, k, n, False, "cuda", dtype=dtype)
+        m.load_state_dict(dict(qweight=c["qweight"], scales=c["scales"], scaled_zeros=c["scaled_zeros"]))
+        return m
+
+    class LlamaMLP(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.gate_proj, self.up_proj, self.down_proj = lin(cg, H, F), lin(cu, H, F), lin(cd, F, H)
+
+    class Block(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.mlp = LlamaMLP()
+
+    blk = make_fused_mlp(Block())
+    mlp = blk.mlp
+    assert isinstance(mlp, QuantLlamaMLP) and mlp.w_bit == 3
+    for M in (1, 5, 8, 9, 40):
+        xm = x[:M].contiguous()
+        a = mlp.our_llama_mlp(xm.cuda()).cpu()
+        assert_bits(a, act[:M], 0.05)
+        y = mlp(xm.cuda()).cpu()
+        check_forward(y, a, cd["q"], cd["scales"], cd["scaled_zeros"], dtype)
+    # the six reference-named buffers were released once the fused stream existed; state_dict() rebuilds them bit for bit
+    sd = mlp.state_dict()
+    for name, c in (("gate_proj", cg), ("up_proj", cu)):
+        assert torch.equal(sd[name + "_qweight"].cpu(), c["qweight"]) and torch.equal(sd[name + "_scales"].cpu(), c["scales"])
+        assert torch.equal(sd[name + "_scaled_zeros"].cpu(), c["scaled_zeros"])
+    mlp.load_state_dict(sd)
+    assert_bits(mlp.our_llama_mlp(x[:9].contiguous().cuda()).cpu(), act[:9], 0.05)
+    assert mlp(x[:12].view(2, 6, H).cuda()).shape == (2, 6, H)
+    # mixed bit widths are refused
+    with pytest.raises(ValueError):
+        QuantLlamaMLP(Q.WQLinear(4, 128, H, F, False, "cuda", dtype=dtype), lin(cd, F, H), lin(cu, H, F))
