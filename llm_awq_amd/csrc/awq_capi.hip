@@ -305,7 +305,10 @@ int awq_rmsnorm(const void* x, const void* gamma, float eps, void* out, int m, i
   return finish_launch();
 }
 
-size_t awq_w4a16_forward_cdna4_workspace_bytes(int m, int n, int k) { return awq::gemm_cdna4_v3_workspace_bytes(m, n, k); }
+size_t awq_w4a16_forward_cdna4_workspace_bytes(int m, int n, int k) {
+  if (m > 8 && m < 256 && !awq::gemm_cdna4_v3_takes(m, k)) return awq::skinny_splitk_workspace_bytes(m, n, k);  // short prompts: the skinny launch's K split
+  return awq::gemm_cdna4_v3_workspace_bytes(m, n, k);
+}
 int awq_w4a16_gemm_cdna4_pair_plan(int m, int n, int k) { return awq::gemm_cdna4_v3_pair_plan(m, n, k); }
 int awq_w4a16_gemm_cdna4_plan(int m, int n, int bits, int* mode, int* cols_main) { return awq::gemm_cdna4_v3_plan(m, n, bits, mode, cols_main); }
 int awq_w4a16_gemm_cdna4_narrow_kernel(int m, int n_cols, int k, int bits, int has_workspace, int epilogue) {
@@ -320,7 +323,7 @@ int awq_w4a16_gemm_cdna4(const void* x, const void* qweight, const void* scales,
   if (st != AWQ_OK) return st;
   if ((n % 16) != 0) return AWQ_ERR_SHAPE;
   const bool skinny = sz_packed && m > 8 && m < 256 && awq::gemm_variant_get() == 0 && !awq::gemm_cdna4_v3_takes(m, k) &&
-                      awq::launch_skinny_cdna4(x, qweight, sz_packed, nullptr, out, m, n, k, dtype, (hipStream_t)stream) == 0;
+                      awq::launch_skinny_cdna4(x, qweight, sz_packed, nullptr, out, m, n, k, dtype, (hipStream_t)stream, 0, workspace, workspace_bytes) == 0;
   if (!skinny && !(sz_packed && m <= 8 && awq::launch_gemv_cdna4(x, qweight, sz_packed, nullptr, out, m, n, k, 0, 4, dtype, (hipStream_t)stream) == 0))
     awq::launch_gemm(x, qweight, scales, scaled_zeros, sz_packed, out, m, n, k, dtype, 1, workspace, workspace_bytes, (hipStream_t)stream);
   return finish_launch();
@@ -354,7 +357,7 @@ int awq_w4a16_forward_cdna4(const void* x, const void* qweight, const void* scal
     int st0 = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
     if (st0 != AWQ_OK) return st0;
     if ((n % 16) != 0) return AWQ_ERR_SHAPE;
-    if (awq::launch_skinny_cdna4(x, qweight, sz_packed, bias, out, m, n, k, dtype, (hipStream_t)stream) == 0) return finish_launch();
+    if (awq::launch_skinny_cdna4(x, qweight, sz_packed, bias, out, m, n, k, dtype, (hipStream_t)stream, 0, workspace, workspace_bytes) == 0) return finish_launch();
   }
   if (bias && awq::gemm_cdna4_v3_takes(m, k) && sz_packed && group_size == 128 && awq::gemm_variant_get() == 0) {
     // prefill: bias fused into the prefill GEMM epilogue (awq_gemm_v4.hip / awq_gemm_v4n.hip) (no second kernel)
@@ -597,6 +600,7 @@ int awq_tune_set(const char* key, int value) {
   if (awq::gemv_tune_set(key, value) == 0) return AWQ_OK;
   if (awq::gemm_tune_set(key, value) == 0) return AWQ_OK;
   if (awq::gemv_cdna4_tune_set(key, value) == 0) return AWQ_OK;
+  if (awq::skinny_tune_set(key, value) == 0) return AWQ_OK;
   if (awq::gemm_v3_tune_set(key, value) == 0) return AWQ_OK;
   if (!strcmp(key, "mlp_engine_probe")) {  // AWQ_PROBES builds: bit 0 no math, bit 1 no weight DMA (timing only, wrong results)
     awq::mlp_engine_set_probe(value);

@@ -97,7 +97,11 @@ int launch_gemm_cdna4_v3(const void* x, const void* qw, const void* szp, const v
 int gemm_variant_get();
 // skinny GEMM, 9 <= m <= 255 (row chunks of <= 64), cdna4 layout + packed sz (awq_skinny_cdna4.hip); bias may be nullptr; -1 if unsupported
 int launch_skinny_cdna4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                        int dtype, hipStream_t st, int f32out = 0);
+                        int dtype, hipStream_t st, int f32out = 0, void* ws = nullptr, size_t ws_bytes = 0);
+// the skinny launch's K split across blocks (awq_skinny_cdna4.hip): K parts for a pass of m rows (1 = unsplit), its optional fp32 scratch, knob
+int skinny_splitk_parts(int m, int n, int k);
+size_t skinny_splitk_workspace_bytes(int m, int n, int k);
+int skinny_tune_set(const char* key, int value);
 // batched decode on the same kernel (m <= 16; szfmt 1: szp = sz_half; epi 0 / 2 as launch_gemv_dma); -1 if unsupported
 int launch_skinny_decode(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int epi,
                          int dtype, int szfmt, hipStream_t st, int f32out = 0);

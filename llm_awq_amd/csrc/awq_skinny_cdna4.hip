@@ -9,6 +9,10 @@
 //   * dequantises NS 1-KiB tiles on the matrix core (Cdna4Dequant) -- their packed words are prefetched one step ahead;
 //   * issues NS x CB x 4 v_mfma_f32_16x16x32_bf16 (weights = A operand, 16 x rows = B operand), fp32 accumulation.
 // Split-K partials are reduced through LDS in fp32; one rounding; bias fused.  Numerics as everywhere else.
+#include <string.h>
+
+#include <atomic>
+
 #include "awq_device.hpp"
 #include "awq_kernels.hpp"
 
@@ -20,7 +24,7 @@ namespace awq {
 template <typename DT, int WAVES, int NS, int CB, int DQ = 0, int EPI = 0>
 __device__ __forceinline__ void skinny_cdna4_body(char* smem, const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                   const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
-                                                  uint16_t* __restrict__ out, int M, int N, int K, int nb, int f32out = 0) {
+                                                  uint16_t* __restrict__ out, int M, int N, int K, int nb, int f32out = 0, int k0 = 0, int kn = -1) {
   using vec8 = typename DT::vec8;
   constexpr int XB = 4 * CB;            // staging pieces per step: 4 x rows (1 KiB) each
   constexpr int XBYTES = 16 * CB * 256; // wave-private x region: 16 CB rows x 256 B
@@ -48,7 +52,10 @@ __device__ __forceinline__ void skinny_cdna4_body(char* smem, const uint16_t* __
   Cdna4DequantH<DT> ch;
   if (DQ == 0) cd.init(lane);
   else ch.init(lane);
-  const int cnt = (nit - wv + WAVES - 1) / WAVES;  // this wave's steps: kg = wv + WAVES * t
+  // the block's K part: k-steps [k0, k0 + kn) (kn < 0: all of K).  f32out 2 = a split-K partial: fp32 sums stored write-through (sc1) for the
+  // block that arrives last at the slab group's ticket, which may sit on another XCD (skinny_splitk_kernel below)
+  if (kn < 0) kn = nit;
+  const int cnt = (kn - wv + WAVES - 1) / WAVES;  // this wave's steps: kg = k0 + wv + WAVES * t
 
   f32x4 acc[NS][CB];
 #pragma unroll
@@ -59,7 +66,7 @@ __device__ __forceinline__ void skinny_cdna4_body(char* smem, const uint16_t* __
   u32x4 w[NS], xr[XB];
   u32 sz[NS];
   auto load_step = [&](int t) {
-    const int kg = min(wv + WAVES * t, nit - 1);
+    const int kg = k0 + min(wv + WAVES * t, kn - 1);
 #pragma unroll
     for (int b = 0; b < XB; ++b) xr[b] = __builtin_amdgcn_raw_buffer_load_b128(rx, xsrc_b[b], (u32)kg * 256u, 0);
 #pragma unroll
@@ -149,7 +156,12 @@ __device__ __forceinline__ void skinny_cdna4_body(char* smem, const uint16_t* __
       }
     } else if (f32out) {
       // K shard of a tensor-parallel row split (awq_w4a16_partial_cdna4): fp32 sums, unrounded, no bias, out = float [M, N]
-      if (slab < nslab && m < M) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + (size_t)m * N + slab * 16 + 4 * g) = f32x4{v[0], v[1], v[2], v[3]};
+      if (slab < nslab && m < M) {
+        float* dst = reinterpret_cast<float*>(out) + (size_t)m * N + slab * 16 + 4 * g;
+        const f32x4 pv = f32x4{v[0], v[1], v[2], v[3]};
+        if (f32out == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(pv) : "memory");
+        else *reinterpret_cast<f32x4*>(dst) = pv;
+      }
     } else if (slab < nslab && m < M) {
       const int nn = slab * 16 + 4 * g;
       uint16_t o[4];
@@ -234,15 +246,137 @@ static void launch_skinny(const void* x, const void* qw, const void* szp, const 
                      (const u32*)szp, (const uint16_t*)bias, (uint16_t*)out, m, n, k, f32out);
 }
 
+// ---- K split ACROSS blocks for the launches whose slab groups leave half the chip idle (N = 4096 at 17..64 rows: 128 blocks of two slabs) ----
+// grid = (slab groups, KS): block (nb, p) sums the k-steps [p nit / KS, (p + 1) nit / KS) of its group and stores the fp32 sums write-through into
+// part p of the workspace ([KS][M][N] floats); after its stores have been acknowledged it takes a ticket of the group; the block that draws the
+// last one adds the KS parts IN PART ORDER (the result does not depend on which block came last), rounds once, adds the bias and puts the
+// ticket word back to 0 -- the role of the reference's split_k_iters + Semaphore (gemm_cuda.cu:546-619), without a second launch.  Ticket
+// words: a library-owned, zero-initialised per-device array (splitk_tickets below); every launch uses its own lane of it.
+template <typename DT, int WAVES, int NS, int CB, int DQ = 0>
+__global__ __launch_bounds__(64 * WAVES) void skinny_splitk_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
+                                                                   const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
+                                                                   uint16_t* __restrict__ out, float* __restrict__ parts, u32* __restrict__ tickets,
+                                                                   int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nb = blockIdx.x, KS = gridDim.y, p = blockIdx.y, kn = (K >> 7) / KS;
+  skinny_cdna4_body<DT, WAVES, NS, CB, DQ, 0>(smem, x, qw, szp, nullptr, reinterpret_cast<uint16_t*>(parts + (size_t)p * M * N), M, N, K, nb, 2, p * kn, kn);
+  asm volatile("s_waitcnt vmcnt(0)" : : : "memory");  // this thread's write-through stores have been acknowledged
+  __syncthreads();                                     // ... and every other thread's; the reduction's LDS reads are done as well
+  u32* bc = reinterpret_cast<u32*>(smem);
+  if (threadIdx.x == 0) bc[0] = __hip_atomic_fetch_add(tickets + nb, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (bc[0] != (u32)(KS - 1)) return;
+  if (threadIdx.x == 0) __hip_atomic_store(tickets + nb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // all KS tickets are drawn: ready for the next launch
+  // the group's tile: M rows x NS * 16 columns, four columns (16 B) per thread and pass; parts read at agent scope (sc1: the writers may sit on other XCDs)
+  constexpr int QC = NS * 4;  // column quads per row
+  const int nslab = N >> 4;
+  for (int idx = threadIdx.x; idx < M * QC; idx += 64 * WAVES) {
+    const int m = idx / QC, q = idx - m * QC, col = nb * NS * 16 + 4 * q;
+    if (col >= nslab * 16) continue;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p0 = 0; p0 < KS; p0 += 4) {  // up to four parts in flight, summed in part order
+      // (every load unconditional, the part index clamped: a load under a branch would make hipcc merge its destination with the untaken
+      // path's value BEFORE the wait below -- a copy of registers the load has not written yet)
+      f32x4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float* src = parts + ((size_t)min(p0 + j, KS - 1) * M + m) * N + col;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[j]) : "v"(src) : "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : : "memory");
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (p0 + j < KS) acc += v[j];
+    }
+    uint16_t o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      o[r] = DT::from_float(acc[r]);
+      if (bias != nullptr) o[r] = DT::from_float(DT::to_float(o[r]) + DT::to_float(bias[col + r]));  // `out + self.bias` in T
+    }
+    *reinterpret_cast<u32x2*>(out + (size_t)m * N + col) = u32x2{(u32)o[0] | ((u32)o[1] << 16), (u32)o[2] | ((u32)o[3] << 16)};
+  }
+}
+
+namespace {
+constexpr int kTicketLanes = 64, kTicketGroups = 512;  // 64 launches in flight x 512 slab groups, 128 KiB per device
+int g_skinny_ks = -1;  // knob skinny_splitk: -1 = by shape, 0 = off, 2 / 4 = force that many K parts where the shape allows it
+// the ticket words of the current device (zeroed once; every launch leaves the words it used at 0).  nullptr while a stream capture is in progress and
+// the array does not exist yet (no allocation inside a capture: that call runs unsplit), or if the allocation failed
+u32* splitk_tickets(hipStream_t st, int groups) {
+  static std::atomic<u32*> bufs[64] = {};
+  static std::atomic<unsigned> next_lane{0};
+  int dev = 0;
+  if (groups > kTicketGroups || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  u32* b = bufs[dev].load(std::memory_order_acquire);
+  if (b == nullptr) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    u32* fresh = nullptr;
+    const size_t bytes = (size_t)kTicketLanes * kTicketGroups * sizeof(u32);
+    if (hipMalloc(reinterpret_cast<void**>(&fresh), bytes) != hipSuccess) return nullptr;
+    if (hipMemset(fresh, 0, bytes) != hipSuccess) {  // (synchronous: visible to every stream that launches after this point)
+      (void)hipFree(fresh);
+      return nullptr;
+    }
+    u32* expected = nullptr;
+    if (bufs[dev].compare_exchange_strong(expected, fresh, std::memory_order_acq_rel)) b = fresh;
+    else {
+      (void)hipFree(fresh);
+      b = expected;
+    }
+  }
+  return b + (size_t)(next_lane.fetch_add(1, std::memory_order_relaxed) % kTicketLanes) * kTicketGroups;
+}
+}  // namespace
+
+int skinny_tune_set(const char* key, int value) {
+  if (!strcmp(key, "skinny_splitk")) g_skinny_ks = value;
+  else return -1;
+  return 0;
+}
+
+// K parts of the skinny launch for (m rows per pass, n, k): 1 = unsplit.  Only the two-slab configurations of launch_skinny_64 (17..64 rows, fewer
+// than 512 slabs) split: their (n / 32) blocks of eight waves hold one CU each
+int skinny_splitk_parts(int m, int n, int k) {
+  const int nslab = n / 16, nit = k / 128, groups = (nslab + 1) / 2;
+  if (g_skinny_ks == 0 || m <= 16 || m > 64 || nslab >= 512 || groups > kTicketGroups) return 1;
+  // by shape: only where the unsplit launch runs two slabs per block (33..64 rows); the knob also forces the 17..32-row launches (one slab per block unsplit)
+  // and a K part keeps at least 32 k-steps (down_proj, K = 14336: -23 % at 48 / 64 rows; o_proj, K = 4096: the ticket round trip costs what the second half of the chip gains, profiles/r05_skinny_splitk.txt)
+  int ks = g_skinny_ks > 0 ? g_skinny_ks : ((m > 32 && groups * 2 <= device_cu_count() + 16 && nit >= 64) ? 2 : 1);
+  while (ks > 1 && ((nit % ks) != 0 || nit / ks < 8)) ks >>= 1;  // every wave of a part keeps at least one k-step
+  return ks < 1 ? 1 : ks;
+}
+// fp32 scratch of the split launch ([parts][rows of a pass][n]); 0 = the launch does not split
+size_t skinny_splitk_workspace_bytes(int m, int n, int k) {
+  if (m < 9 || m > 255) return 0;
+  const int chunks = (m + 63) / 64, rows = (m + chunks - 1) / chunks;
+  const int ks = skinny_splitk_parts(rows, n, k);
+  return ks > 1 ? (size_t)ks * rows * n * sizeof(float) : 0;
+}
+
+template <typename DT, int WAVES, int NS, int CB>
+static void launch_skinny_splitk(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int ks, float* parts,
+                                 u32* tickets, hipStream_t st) {
+  const size_t xbytes = (size_t)WAVES * 16 * CB * 256, rbytes = (size_t)WAVES * NS * CB * 1024;
+  const size_t smem = xbytes > rbytes ? xbytes : rbytes;
+  auto kern = skinny_splitk_kernel<DT, WAVES, NS, CB>;
+  static LdsOptIn optin;
+  if (smem > 64 * 1024) optin.ensure(reinterpret_cast<const void*>(kern));
+  const int nslab = n / 16;
+  hipLaunchKernelGGL(kern, dim3((nslab + NS - 1) / NS, ks), dim3(64 * WAVES), smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp,
+                     (const uint16_t*)bias, (uint16_t*)out, parts, tickets, m, n, k);
+}
+
 template <typename DT>
 static int launch_skinny_64(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                            hipStream_t st, int f32out);
+                            hipStream_t st, int f32out, void* ws, size_t ws_bytes);
 
 // 9 <= m <= 255, cdna4 layout, packed sz required.  Returns -1 if unsupported.  65 <= m <= 255 (below the 256-row tile of
 // the prefill GEMM) runs as row chunks of <= 64: the weights are re-streamed per chunk, which still beats the 128 x 128
 // kernel's long serial K loop on one wave of tiles (measured: profiles/r01_skinny_sweep.txt) except for very wide N.
 int launch_skinny_cdna4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                        int dtype, hipStream_t st, int f32out) {
+                        int dtype, hipStream_t st, int f32out, void* ws, size_t ws_bytes) {
   if (!szp || m < 1 || m > 255 || (n % 16) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31) || (f32out && bias)) return -1;
   if (m > 128 && n >= 16384) return -1;
   const int chunks = (m + 63) / 64, rows = (m + chunks - 1) / chunks;
@@ -250,16 +384,29 @@ int launch_skinny_cdna4(const void* x, const void* qw, const void* szp, const vo
     const int mr = m - r0 < rows ? m - r0 : rows;
     const uint16_t* xr = static_cast<const uint16_t*>(x) + (size_t)r0 * k;
     void* orow = static_cast<char*>(out) + (size_t)r0 * n * (f32out ? 4 : 2);
-    if (dtype == 0) launch_skinny_64<F16>(xr, qw, szp, bias, orow, mr, n, k, st, f32out);
-    else launch_skinny_64<BF16>(xr, qw, szp, bias, orow, mr, n, k, st, f32out);
+    // (the row chunks run one after the other on the stream: they share the optional split-K scratch)
+    if (dtype == 0) launch_skinny_64<F16>(xr, qw, szp, bias, orow, mr, n, k, st, f32out, ws, ws_bytes);
+    else launch_skinny_64<BF16>(xr, qw, szp, bias, orow, mr, n, k, st, f32out, ws, ws_bytes);
   }
   return 0;
 }
 
 template <typename DT>
 static int launch_skinny_64(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                            hipStream_t st, int f32out) {
+                            hipStream_t st, int f32out, void* ws, size_t ws_bytes) {
   const int nslab = n / 16;
+  // half-empty chip (N = 4096 at 17..64 rows): the K split across blocks, when the caller brought the scratch and the ticket array exists
+  const int ks = skinny_splitk_parts(m, n, k);
+  if (ks > 1 && !f32out && ws != nullptr && (reinterpret_cast<uintptr_t>(ws) & 15) == 0 && ws_bytes >= (size_t)ks * m * n * sizeof(float)) {
+    u32* tk = splitk_tickets(st, (nslab + 1) / 2);
+    if (tk != nullptr) {
+      float* parts = static_cast<float*>(ws);
+      if (m <= 32) launch_skinny_splitk<DT, 8, 2, 2>(x, qw, szp, bias, out, m, n, k, ks, parts, tk, st);
+      else if (m <= 48) launch_skinny_splitk<DT, 8, 2, 3>(x, qw, szp, bias, out, m, n, k, ks, parts, tk, st);
+      else launch_skinny_splitk<DT, 8, 2, 4>(x, qw, szp, bias, out, m, n, k, ks, parts, tk, st);
+      return 0;
+    }
+  }
   if (m <= 16) {
     if (nslab >= 1024) launch_skinny<DT, 8, 2, 1>(x, qw, szp, bias, out, m, n, k, st, f32out);
     else if (k / 128 >= 96) launch_skinny<DT, 16, 1, 1>(x, qw, szp, bias, out, m, n, k, st, f32out);

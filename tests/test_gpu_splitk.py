@@ -24,7 +24,10 @@ def test_workspace_query(env):
     ops, _ = env
     L = ops._capi.lib()
     q = L.awq_w4a16_forward_cdna4_workspace_bytes
-    assert q(1, 4096, 4096) == 0 and q(64, 4096, 4096) == 0        # GEMV / skinny: no workspace
+    assert q(1, 4096, 4096) == 0 and q(16, 4096, 4096) == 0 and q(32, 4096, 4096) == 0   # GEMV / skinny with a full grid: no workspace
+    assert q(64, 4096, 4096) == 0                                    # K = 4096: the skinny launch stays unsplit
+    assert q(64, 4096, 14336) == 2 * 64 * 4096 * 4 and q(40, 4096, 14336) == 2 * 40 * 4096 * 4  # skinny, half-empty grid, long K: two K parts of fp32 sums
+    assert q(71, 4096, 8192) == 2 * 36 * 4096 * 4 and q(64, 6144, 14336) == 0 and q(64, 28672, 8192) == 0  # (row chunks share it; wider N fills the chip)
     assert q(4096, 14336, 4096) == 0 and q(2048, 4096, 4096) == 0  # enough tiles: no split
     tile = 256 * 128 * 4                                            # one fp32 partial tile
     for (m, n, k, tiles) in ((256, 4096, 14336, 32), (512, 4096, 4096, 64)):
@@ -186,5 +189,84 @@ def test_small_m_rule(env):
     """The default rule: the GEMM takes m >= 256, and shorter prompts only where its 256-row tile beats the skinny kernel."""
     ops, _ = env
     q = ops._capi.lib().awq_w4a16_forward_cdna4_workspace_bytes
-    assert q(128, 4096, 14336) > 0 and q(71, 4096, 14336) == 0  # K = 14336: from 72 rows
+    assert q(128, 4096, 14336) > 0 and q(71, 4096, 14336) == 2 * 36 * 4096 * 4 < q(72, 4096, 14336)  # K = 14336: from 72 rows (below: the skinny launch's two K parts)
     assert q(128, 4096, 4096) == 0 and q(192, 4096, 4096) > 0   # K = 4096: from 147 rows
+
+
+# ---- the skinny launch's K split across blocks (awq_skinny_cdna4.hip: skinny_splitk_kernel; N = 4096 at 33..64 rows per pass) ----
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("K,N", [(4096, 4096), (14336, 4096), (2048, 1040), (1024, 4096)])
+def test_skinny_split_k_vs_oracle_and_unsplit(env, dtype, K, N):
+    """two (or, forced, four) blocks per slab group each sum a K part; the block that draws the group's last ticket adds the parts in part order, rounds
+    once and adds the bias.  Against the oracle's forward bound, deterministic from call to call, and close to the unsplit launch (another association)."""
+    from oracle import awq_oracle as O  # noqa: F401
+    from tests.helpers import check_forward, make_case
+    ops, _ = env
+    L = ops._capi.lib()
+    c = make_case(N, K, dtype, seed=K + N, M=128, bias=True)
+    qw = ops.repack_v2_to_cdna4(c["qweight"].cuda())
+    s, z, b = c["scales"].cuda(), c["scaled_zeros"].cuda(), c["bias"].cuda()
+    szp = ops.pack_sz_cdna4(s, z, K)
+    for M in (17, 32, 33, 48, 64, 100, 128):
+        x = c["x"][:M].contiguous()
+        xg = x.cuda()
+        outs = {}
+        for knob in (-1, 0, 2, 4):
+            ops._capi.tune(skinny_splitk=knob)
+            try:
+                rows = -(-M // -(-M // 64))
+                parts = L.awq_w4a16_forward_cdna4_workspace_bytes(M, N, K) // (rows * N * 4)
+                y = ops.gemm_cdna4(xg, qw, s, z, b if M != 48 else None, szp)
+                y2 = ops.gemm_cdna4(xg, qw, s, z, b if M != 48 else None, szp)
+            finally:
+                ops._capi.tune(skinny_splitk=-1)
+            assert torch.equal(y, y2), (M, knob)  # the parts are added in part order whichever block arrives last
+            check_forward(y.cpu(), x, c["q"], c["scales"], c["scaled_zeros"], dtype, bias=c["bias"] if M != 48 else None)
+            outs[knob] = (y, parts)
+        nit = K // 128
+        if N * 2 // 32 <= 272 and nit % 2 == 0 and nit // 2 >= 8 and not (M >= 72 and M * K >= 600000):  # (the masked-tile GEMM takes the others)
+            assert outs[-1][1] == (2 if rows > 32 and nit >= 64 else 0), (M, outs[-1][1])  # by shape: only the two-slab launches (33..64 rows per pass) against a long K
+            assert outs[2][1] == 2 and outs[0][1] == 0
+        assert_bits(outs[2][0], outs[0][0], 0.02, "two K parts vs unsplit")
+        assert_bits(outs[4][0], outs[0][0], 0.02, "four K parts vs unsplit")
+
+
+def test_skinny_split_k_graph_replay_and_no_workspace(env):
+    """a captured split launch replays (the last block puts the ticket words back to 0), two split launches in one graph use their own ticket lanes;
+    a caller without scratch gets the unsplit launch"""
+    ops, synth = env
+    L = ops._capi.lib()
+    K, N, M, dtype = 8192, 4096, 64, torch.bfloat16
+    w = synth.random_wq(K, N, dtype=dtype, seed=9, keep_q=False)
+    c4 = ops.repack_v2_to_cdna4(w["qweight"])
+    szp = ops.pack_sz_cdna4(w["scales"], w["scaled_zeros"], K)
+    g = cuda_gen(11)
+    xs = [torch.randn(M, K, device="cuda", generator=g).to(dtype) for _ in range(3)]
+    ref = [ops.gemm_cdna4(x, c4, w["scales"], w["scaled_zeros"], None, szp) for x in xs]
+    assert L.awq_w4a16_forward_cdna4_workspace_bytes(M, N, K) > 0
+    xin, xin_b = xs[0].clone(), xs[0].clone()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=st):
+            yg = ops.gemm_cdna4(xin, c4, w["scales"], w["scaled_zeros"], None, szp)
+            yg2 = ops.gemm_cdna4(xin_b, c4, w["scales"], w["scaled_zeros"], None, szp)  # a second split launch in the same graph (its own ticket lane)
+        for i, x in enumerate(xs):
+            xin.copy_(x)
+            xin_b.copy_(xs[(i + 1) % 3])
+            graph.replay()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(yg, ref[i]) and torch.equal(yg2, ref[(i + 1) % 3])
+    # direct C-ABI call without scratch: unsplit
+    out = torch.empty(M, N, dtype=dtype, device="cuda")
+    ops._capi.check(L.awq_w4a16_forward_cdna4(xs[1].data_ptr(), c4.data_ptr(), w["scales"].data_ptr(), w["scaled_zeros"].data_ptr(), szp.data_ptr(), None,
+                                              out.data_ptr(), M, N, K, 128, 1, None, 0, None))
+    torch.cuda.synchronize()
+    ops._capi.tune(skinny_splitk=0)
+    try:
+        unsplit = ops.gemm_cdna4(xs[1], c4, w["scales"], w["scaled_zeros"], None, szp)
+    finally:
+        ops._capi.tune(skinny_splitk=-1)
+    assert torch.equal(out, unsplit)

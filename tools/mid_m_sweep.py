@@ -40,12 +40,9 @@ def graph_time(fn, items, reps=3):
 def main():
     L = _capi.lib()
     Ms = [int(a) for a in sys.argv[1:]] or [16, 32, 64, 128, 255, 512, 1024, 2048]
-    if os.environ.get("MID_KP"):
-        _capi.tune(gemm_mid_kp=int(os.environ["MID_KP"]))
-    if os.environ.get("MID_DBG"):
-        _capi.tune(gemm_mid_dbg=int(os.environ["MID_DBG"]))
-    if os.environ.get("MID_OFF"):
-        _capi.tune(gemm_mid=0)
+    if os.environ.get("MID_TUNE"):  # knobs as key=value,key=value (AWQ_TUNING=1)
+        _capi.tune(**{kv.split("=")[0]: int(kv.split("=")[1]) for kv in os.environ["MID_TUNE"].split(",")})
+        print("# knobs:", os.environ["MID_TUNE"])
     dtype = torch.bfloat16
     print(f"{'shape':>8} {'K':>6} {'N':>6} {'M':>5} {'us':>9} {'TFLOP/s':>8} {'GB/s':>8} {'stream floor us':>16} {'mfma floor us':>14} {'x floor':>8}")
     for (K, N, name) in SHAPES:
