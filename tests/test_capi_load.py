@@ -62,8 +62,10 @@ def test_prefill_routing_and_workspace_rule_without_gpu():
     q = L.awq_w4a16_forward_cdna4_workspace_bytes
     tile = 256 * 128 * 4
     # decode / skinny territory, and launches that fill the chip: no workspace
-    for (m, n, k) in ((1, 4096, 4096), (64, 4096, 14336), (71, 4096, 14336), (128, 4096, 4096), (2048, 4096, 4096), (4096, 28672, 4096)):
+    for (m, n, k) in ((1, 4096, 4096), (32, 4096, 14336), (64, 4096, 4096), (64, 6144, 14336), (128, 4096, 4096), (2048, 4096, 4096), (4096, 28672, 4096)):
         assert q(m, n, k) == 0, (m, n, k)
+    # the skinny launch's two K parts (33 .. 64 rows per pass, two-slab blocks that leave half the chip idle, K >= 8192): fp32 [2][rows of a pass][n]
+    assert q(64, 4096, 14336) == 2 * 64 * 4096 * 4 and q(71, 4096, 14336) == 2 * 36 * 4096 * 4 and q(40, 4096, 8192) == 2 * 40 * 4096 * 4
     # under-filled launches: whole partial tiles, 2..16 K ranges, at least 2 quantisation groups per range
     for (m, n, k) in ((72, 4096, 14336), (128, 4096, 14336), (147, 4096, 4096), (256, 4096, 4096), (512, 4096, 14336), (1024, 4096, 4096),
                       (256, 1024, 8192), (300, 6144, 4096)):
@@ -81,7 +83,7 @@ def test_prefill_routing_and_workspace_rule_without_gpu():
     try:
         assert L.awq_tune_set(b"gemm_splitk", 0) == 0 and q(256, 4096, 4096) == 0
         assert L.awq_tune_set(b"gemm_splitk", 5) == 0 and q(256, 4096, 14336) == 32 * 5 * tile
-        assert L.awq_tune_set(b"gemm_splitk", 1) == 0 and L.awq_tune_set(b"gemm_small_m", 0) == 0 and q(128, 4096, 14336) == 0
+        assert L.awq_tune_set(b"gemm_splitk", 1) == 0 and L.awq_tune_set(b"gemm_small_m", 0) == 0 and q(128, 4096, 14336) == 2 * 64 * 4096 * 4  # (the skinny launch then takes it: two 64-row passes, two K parts)
     finally:
         L.awq_tune_set(b"gemm_splitk", 1)
         L.awq_tune_set(b"gemm_small_m", 1)
