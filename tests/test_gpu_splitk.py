@@ -204,11 +204,11 @@ def test_skinny_split_k_vs_oracle_and_unsplit(env, dtype, K, N):
     from tests.helpers import check_forward, make_case
     ops, _ = env
     L = ops._capi.lib()
-    c = make_case(N, K, dtype, seed=K + N, M=128, bias=True)
+    c = make_case(N, K, dtype, seed=K + N, M=100, bias=True)
     qw = ops.repack_v2_to_cdna4(c["qweight"].cuda())
     s, z, b = c["scales"].cuda(), c["scaled_zeros"].cuda(), c["bias"].cuda()
     szp = ops.pack_sz_cdna4(s, z, K)
-    for M in (17, 32, 33, 48, 64, 100, 128):
+    for M in (17, 33, 48, 64, 100):
         x = c["x"][:M].contiguous()
         xg = x.cuda()
         outs = {}
@@ -222,7 +222,8 @@ def test_skinny_split_k_vs_oracle_and_unsplit(env, dtype, K, N):
             finally:
                 ops._capi.tune(skinny_splitk=-1)
             assert torch.equal(y, y2), (M, knob)  # the parts are added in part order whichever block arrives last
-            check_forward(y.cpu(), x, c["q"], c["scales"], c["scaled_zeros"], dtype, bias=c["bias"] if M != 48 else None)
+            if knob != 0:  # (the unsplit launch has its own oracle tests: test_gpu_cdna4.py)
+                check_forward(y.cpu(), x, c["q"], c["scales"], c["scaled_zeros"], dtype, bias=c["bias"] if M != 48 else None)
             outs[knob] = (y, parts)
         nit = K // 128
         if N * 2 // 32 <= 272 and nit % 2 == 0 and nit // 2 >= 8 and not (M >= 72 and M * K >= 600000):  # (the masked-tile GEMM takes the others)
