@@ -186,7 +186,7 @@ int awq_rmsnorm(const void* x, const void* gamma, float eps, void* out, int m, i
  * K loop is split over blocks and a second kernel adds the partial tiles in a fixed order -- the role of the reference's
  * split_k_iters + semaphore (gemm_cuda.cu:546-619); for awq_w4a16_gemm_cdna4_pair_plan's shapes the two halves of K meet inside
  * ONE launch (64-byte aligned workspace, any contents; one launch at a time per workspace).  Short prompts on the skinny kernel
- * (9 .. 71 rows) against n = 4096-class projections with k >= 8192 split K over two blocks per slab group the same way inside one
+ * (17 .. 146 rows) against n = 4096-class projections split K over two blocks per slab group the same way inside one
  * launch: fp32 parts in the workspace, added in part order by the block that draws the group's last ticket (the ticket words live in a
  * small zero-initialised per-device array the library allocates at the first such call outside a stream capture).  Without a workspace
  * the call runs unsplit (slower, same contract). */

@@ -263,7 +263,9 @@ __global__ __launch_bounds__(64 * WAVES) void skinny_splitk_kernel(const uint16_
   asm volatile("s_waitcnt vmcnt(0)" : : : "memory");  // this thread's write-through stores have been acknowledged
   __syncthreads();                                     // ... and every other thread's; the reduction's LDS reads are done as well
   u32* bc = reinterpret_cast<u32*>(smem);
-  if (threadIdx.x == 0) bc[0] = __hip_atomic_fetch_add(tickets + nb, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  // (relaxed: the release is the acknowledged write-through stores above, the acquire the sc1 loads below -- an acq_rel atomic would add an L2
+  // write-back and an L2 invalidate of the whole XCD around it)
+  if (threadIdx.x == 0) bc[0] = __hip_atomic_fetch_add(tickets + nb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   if (bc[0] != (u32)(KS - 1)) return;
   if (threadIdx.x == 0) __hip_atomic_store(tickets + nb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // all KS tickets are drawn: ready for the next launch
@@ -339,11 +341,15 @@ int skinny_tune_set(const char* key, int value) {
 // K parts of the skinny launch for (m rows per pass, n, k): 1 = unsplit.  Only the two-slab configurations of launch_skinny_64 (17..64 rows, fewer
 // than 512 slabs) split: their (n / 32) blocks of eight waves hold one CU each
 int skinny_splitk_parts(int m, int n, int k) {
-  const int nslab = n / 16, nit = k / 128, groups = (nslab + 1) / 2;
+  const int nslab = n / 16, nit = k / 128, cus = device_cu_count(), groups = (nslab + 1) / 2;
+  // (qkv, 384 slabs: three slabs per block x two parts = 256 blocks measured 6 % SLOWER than its 192 unsplit two-slab blocks: not built in)
   if (g_skinny_ks == 0 || m <= 16 || m > 64 || nslab >= 512 || groups > kTicketGroups) return 1;
-  // by shape: only where the unsplit launch runs two slabs per block (33..64 rows); the knob also forces the 17..32-row launches (one slab per block unsplit)
-  // and a K part keeps at least 32 k-steps (down_proj, K = 14336: -23 % at 48 / 64 rows; o_proj, K = 4096: the ticket round trip costs what the second half of the chip gains, profiles/r05_skinny_splitk.txt)
-  int ks = g_skinny_ks > 0 ? g_skinny_ks : ((m > 32 && groups * 2 <= device_cu_count() + 16 && nit >= 64) ? 2 : 1);
+  // by shape (profiles/r05_skinny_splitk.txt): 33..64 rows, where the unsplit launch runs two slabs per block and fills half the chip, from K = 4096
+  // (o_proj -12 / -16 % at 48 / 64 rows, down_proj -30 %); 17..32 rows, where the unsplit launch runs ONE slab per block on every CU, only against a
+  // long K (down_proj -15 ... -18 %; o_proj loses 8 %: half the x traffic does not pay for the ticket round trip there).  The knob forces a part count
+  int ks = 1;
+  if (g_skinny_ks > 0) ks = g_skinny_ks;
+  else if (groups * 2 <= cus + 16 && (m > 32 ? nit >= 32 : nit >= 64)) ks = 2;
   while (ks > 1 && ((nit % ks) != 0 || nit / ks < 8)) ks >>= 1;  // every wave of a part keeps at least one k-step
   return ks < 1 ? 1 : ks;
 }

@@ -62,10 +62,13 @@ def test_prefill_routing_and_workspace_rule_without_gpu():
     q = L.awq_w4a16_forward_cdna4_workspace_bytes
     tile = 256 * 128 * 4
     # decode / skinny territory, and launches that fill the chip: no workspace
-    for (m, n, k) in ((1, 4096, 4096), (32, 4096, 14336), (64, 4096, 4096), (64, 6144, 14336), (128, 4096, 4096), (2048, 4096, 4096), (4096, 28672, 4096)):
+    for (m, n, k) in ((1, 4096, 4096), (16, 4096, 14336), (32, 4096, 4096), (64, 28672, 4096), (64, 8192, 8192), (2048, 4096, 4096), (4096, 28672, 4096)):
         assert q(m, n, k) == 0, (m, n, k)
-    # the skinny launch's two K parts (33 .. 64 rows per pass, two-slab blocks that leave half the chip idle, K >= 8192): fp32 [2][rows of a pass][n]
+    # the skinny launch's two K parts where its grid leaves half the chip idle (33 .. 64 rows per pass from K = 4096; 17 .. 32 rows from K = 8192; narrower than
+    # ~272 slabs): fp32 [2][rows of a pass][n]
     assert q(64, 4096, 14336) == 2 * 64 * 4096 * 4 and q(71, 4096, 14336) == 2 * 36 * 4096 * 4 and q(40, 4096, 8192) == 2 * 40 * 4096 * 4
+    assert q(64, 4096, 4096) == 2 * 64 * 4096 * 4 and q(128, 4096, 4096) == 2 * 64 * 4096 * 4 and q(32, 4096, 14336) == 2 * 32 * 4096 * 4
+    assert q(64, 6144, 4096) == 0 and q(64, 4096, 4096 + 128) == 0  # (384 slabs: two parts would be 1.5 rounds of blocks; an odd number of k-steps does not split)
     # under-filled launches: whole partial tiles, 2..16 K ranges, at least 2 quantisation groups per range
     for (m, n, k) in ((72, 4096, 14336), (128, 4096, 14336), (147, 4096, 4096), (256, 4096, 4096), (512, 4096, 14336), (1024, 4096, 4096),
                       (256, 1024, 8192), (300, 6144, 4096)):

@@ -24,11 +24,11 @@ def test_workspace_query(env):
     ops, _ = env
     L = ops._capi.lib()
     q = L.awq_w4a16_forward_cdna4_workspace_bytes
-    assert q(1, 4096, 4096) == 0 and q(16, 4096, 4096) == 0 and q(32, 4096, 4096) == 0   # GEMV / skinny with a full grid: no workspace
-    assert q(64, 4096, 4096) == 0                                    # K = 4096: the skinny launch stays unsplit
-    assert q(64, 4096, 14336) == 2 * 64 * 4096 * 4 and q(40, 4096, 14336) == 2 * 40 * 4096 * 4  # skinny, half-empty grid, long K: two K parts of fp32 sums
-    assert q(71, 4096, 8192) == 2 * 36 * 4096 * 4 and q(64, 6144, 14336) == 0 and q(64, 28672, 8192) == 0  # (row chunks share it; wider N fills the chip)
-    assert q(4096, 14336, 4096) == 0 and q(2048, 4096, 4096) == 0  # enough tiles: no split
+    assert q(1, 4096, 4096) == 0 and q(16, 4096, 4096) == 0 and q(32, 4096, 4096) == 0   # GEMV / skinny with a full grid against a short K: no workspace
+    # skinny launches that leave half the chip idle: two K parts of fp32 sums, [2][rows of a pass][n] (33..64 rows from K = 4096, 17..32 rows from K = 8192)
+    assert q(64, 4096, 4096) == 2 * 64 * 4096 * 4 and q(40, 4096, 14336) == 2 * 40 * 4096 * 4 and q(24, 4096, 14336) == 2 * 24 * 4096 * 4
+    assert q(71, 4096, 8192) == 2 * 36 * 4096 * 4 and q(64, 6144, 4096) == 0  # (row chunks share it; 384 slabs: two parts would be 1.5 rounds of blocks)
+    assert q(64, 28672, 8192) == 0 and q(64, 8192, 8192) == 0                                   # wide N fills the chip unsplit
     tile = 256 * 128 * 4                                            # one fp32 partial tile
     for (m, n, k, tiles) in ((256, 4096, 14336, 32), (512, 4096, 4096, 64)):
         b = q(m, n, k)
@@ -190,13 +190,13 @@ def test_small_m_rule(env):
     ops, _ = env
     q = ops._capi.lib().awq_w4a16_forward_cdna4_workspace_bytes
     assert q(128, 4096, 14336) > 0 and q(71, 4096, 14336) == 2 * 36 * 4096 * 4 < q(72, 4096, 14336)  # K = 14336: from 72 rows (below: the skinny launch's two K parts)
-    assert q(128, 4096, 4096) == 0 and q(192, 4096, 4096) > 0   # K = 4096: from 147 rows
+    assert q(128, 4096, 4096) == 2 * 64 * 4096 * 4 < q(192, 4096, 4096)   # K = 4096: from 147 rows
 
 
 # ---- the skinny launch's K split across blocks (awq_skinny_cdna4.hip: skinny_splitk_kernel; N = 4096 at 33..64 rows per pass) ----
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("K,N", [(4096, 4096), (14336, 4096), (2048, 1040), (1024, 4096)])
+@pytest.mark.parametrize("K,N", [(4096, 4096), (14336, 4096), (2048, 1040), (1024, 4096), (4096, 6144)])
 def test_skinny_split_k_vs_oracle_and_unsplit(env, dtype, K, N):
     """two (or, forced, four) blocks per slab group each sum a K part; the block that draws the group's last ticket adds the parts in part order, rounds
     once and adds the bias.  Against the oracle's forward bound, deterministic from call to call, and close to the unsplit launch (another association)."""
@@ -227,7 +227,7 @@ def test_skinny_split_k_vs_oracle_and_unsplit(env, dtype, K, N):
             outs[knob] = (y, parts)
         nit = K // 128
         if N * 2 // 32 <= 272 and nit % 2 == 0 and nit // 2 >= 8 and not (M >= 72 and M * K >= 600000):  # (the masked-tile GEMM takes the others)
-            assert outs[-1][1] == (2 if rows > 32 and nit >= 64 else 0), (M, outs[-1][1])  # by shape: only the two-slab launches (33..64 rows per pass) against a long K
+            assert outs[-1][1] == (2 if (rows > 32 and nit >= 32) or nit >= 64 else 0), (M, outs[-1][1])  # by shape: 33..64 rows per pass from K = 4096, 17..32 rows from K = 8192
             assert outs[2][1] == 2 and outs[0][1] == 0
         assert_bits(outs[2][0], outs[0][0], 0.02, "two K parts vs unsplit")
         assert_bits(outs[4][0], outs[0][0], 0.02, "four K parts vs unsplit")
