@@ -244,6 +244,7 @@ int awq_w4a16_mlp_decode_cdna4(const void* x, const void* gate_up_qweight, const
   return finish_launch();
 }
 
+static int g_mlp_skinny_max = 64;  // knob mlp_skinny_max: row counts up to this go to the skinny kernel's fused epilogue (8 = never)
 int awq_w4a16_mlp_gate_up_forward_cdna4(const void* x, const void* qweight_interleaved, const void* sz_packed, const void* sz_half,
                                         void* out, int m, int n2, int k, int group_size, int dtype, void* stream) {
   return awq_w4a16_mlp_gate_up_forward_cdna4_ws(x, qweight_interleaved, sz_packed, sz_half, out, m, n2, k, group_size, dtype, nullptr, 0, stream);
@@ -267,6 +268,10 @@ int awq_w4a16_mlp_gate_up_forward_cdna4_ws(const void* x, const void* qweight_in
       return AWQ_ERR_SHAPE;
     return finish_launch();
   }
+  // 9 .. 64 rows: one weight pass on the skinny kernel, rows r and r + 8 of a slab paired in its epilogue (a 256-row tile masked down to m rows costs
+  // the same for every m: 46 vs 31 us at 64 rows on Llama-3-8B's pair, profiles/r05_skinny_splitk.txt)
+  if (m <= g_mlp_skinny_max && awq::launch_skinny_gate_up(x, qweight_interleaved, sz_packed, out, m, n2, k, dtype, (hipStream_t)stream) == 0)
+    return finish_launch();
   // prefill / batched decode: the tile kernels with the SiLU * mul tail fused into their epilogue (out is [m, n2 / 2]: the
   // [m, n2] intermediate of the reference's two GEMMs + F.silu + multiply never exists)
   if (workspace && ((reinterpret_cast<uintptr_t>(workspace) & 63) != 0 || workspace_bytes < awq::gemm_cdna4_v3_workspace_bytes(m, n2, k))) {
@@ -602,6 +607,10 @@ int awq_tune_set(const char* key, int value) {
   if (awq::gemv_cdna4_tune_set(key, value) == 0) return AWQ_OK;
   if (awq::skinny_tune_set(key, value) == 0) return AWQ_OK;
   if (awq::gemm_v3_tune_set(key, value) == 0) return AWQ_OK;
+  if (!strcmp(key, "mlp_skinny_max")) {
+    g_mlp_skinny_max = value;
+    return AWQ_OK;
+  }
   if (!strcmp(key, "mlp_engine_probe")) {  // AWQ_PROBES builds: bit 0 no math, bit 1 no weight DMA (timing only, wrong results)
     awq::mlp_engine_set_probe(value);
     return AWQ_OK;

@@ -374,7 +374,7 @@ static void launch_skinny_splitk(const void* x, const void* qw, const void* szp,
                      (const uint16_t*)bias, (uint16_t*)out, parts, tickets, m, n, k);
 }
 
-template <typename DT>
+template <typename DT, int EPI = 0>
 static int launch_skinny_64(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                             hipStream_t st, int f32out, void* ws, size_t ws_bytes);
 
@@ -397,37 +397,53 @@ int launch_skinny_cdna4(const void* x, const void* qw, const void* szp, const vo
   return 0;
 }
 
-template <typename DT>
+template <typename DT, int EPI>
 static int launch_skinny_64(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                             hipStream_t st, int f32out, void* ws, size_t ws_bytes) {
   const int nslab = n / 16;
   // half-empty chip (N = 4096 at 17..64 rows): the K split across blocks, when the caller brought the scratch and the ticket array exists
   const int ks = skinny_splitk_parts(m, n, k);
-  if (ks > 1 && !f32out && ws != nullptr && (reinterpret_cast<uintptr_t>(ws) & 15) == 0 && ws_bytes >= (size_t)ks * m * n * sizeof(float)) {
+  if (EPI == 0 && ks > 1 && !f32out && ws != nullptr && (reinterpret_cast<uintptr_t>(ws) & 15) == 0 && ws_bytes >= (size_t)ks * m * n * sizeof(float)) {
     u32* tk = splitk_tickets(st, (nslab + 1) / 2);
     if (tk != nullptr) {
       float* parts = static_cast<float*>(ws);
-      if (m <= 32) launch_skinny_splitk<DT, 8, 2, 2>(x, qw, szp, bias, out, m, n, k, ks, parts, tk, st);
-      else if (m <= 48) launch_skinny_splitk<DT, 8, 2, 3>(x, qw, szp, bias, out, m, n, k, ks, parts, tk, st);
-      else launch_skinny_splitk<DT, 8, 2, 4>(x, qw, szp, bias, out, m, n, k, ks, parts, tk, st);
-      return 0;
+      if constexpr (EPI == 0) {
+        if (m <= 32) launch_skinny_splitk<DT, 8, 2, 2>(x, qw, szp, bias, out, m, n, k, ks, parts, tk, st);
+        else if (m <= 48) launch_skinny_splitk<DT, 8, 2, 3>(x, qw, szp, bias, out, m, n, k, ks, parts, tk, st);
+        else launch_skinny_splitk<DT, 8, 2, 4>(x, qw, szp, bias, out, m, n, k, ks, parts, tk, st);
+        return 0;
+      }
     }
   }
   if (m <= 16) {
-    if (nslab >= 1024) launch_skinny<DT, 8, 2, 1>(x, qw, szp, bias, out, m, n, k, st, f32out);
-    else if (k / 128 >= 96) launch_skinny<DT, 16, 1, 1>(x, qw, szp, bias, out, m, n, k, st, f32out);
-    else launch_skinny<DT, 8, 1, 1>(x, qw, szp, bias, out, m, n, k, st, f32out);
+    if (nslab >= 1024) launch_skinny<DT, 8, 2, 1, 0, EPI>(x, qw, szp, bias, out, m, n, k, st, f32out);
+    else if (k / 128 >= 96) launch_skinny<DT, 16, 1, 1, 0, EPI>(x, qw, szp, bias, out, m, n, k, st, f32out);
+    else launch_skinny<DT, 8, 1, 1, 0, EPI>(x, qw, szp, bias, out, m, n, k, st, f32out);
   } else if (m <= 32) {
-    if (nslab >= 512) launch_skinny<DT, 8, 2, 2>(x, qw, szp, bias, out, m, n, k, st, f32out);
-    else launch_skinny<DT, 8, 1, 2>(x, qw, szp, bias, out, m, n, k, st, f32out);
+    if (nslab >= 512) launch_skinny<DT, 8, 2, 2, 0, EPI>(x, qw, szp, bias, out, m, n, k, st, f32out);
+    else launch_skinny<DT, 8, 1, 2, 0, EPI>(x, qw, szp, bias, out, m, n, k, st, f32out);
+  } else if (nslab >= 512 && (nslab + 6) / 7 <= device_cu_count() + 16 && (nslab + 6) / 7 >= device_cu_count() * 9 / 10) {
+    // seven slabs per block where that is ONE round of one block per CU (Llama-3-8B gate/up: 1792 slabs -> 256 blocks): the x slices are read by
+    // 256 blocks instead of 448 -- -7 % at 40 / 48 rows, -13 % at 64 and 128 (profiles/r05_skinny_splitk.txt); a two-deep prefetch of the packed words
+    // for its single wave per SIMD measured 3 % slower again
+    if (m <= 48) launch_skinny<DT, 4, 7, 3, 0, EPI>(x, qw, szp, bias, out, m, n, k, st, f32out);
+    else launch_skinny<DT, 4, 7, 4, 0, EPI>(x, qw, szp, bias, out, m, n, k, st, f32out);
   } else if (m <= 48) {
-    if (nslab >= 512) launch_skinny<DT, 4, 4, 3>(x, qw, szp, bias, out, m, n, k, st, f32out);
-    else launch_skinny<DT, 8, 2, 3>(x, qw, szp, bias, out, m, n, k, st, f32out);
+    if (nslab >= 512) launch_skinny<DT, 4, 4, 3, 0, EPI>(x, qw, szp, bias, out, m, n, k, st, f32out);
+    else launch_skinny<DT, 8, 2, 3, 0, EPI>(x, qw, szp, bias, out, m, n, k, st, f32out);
   } else {
-    if (nslab >= 512) launch_skinny<DT, 4, 4, 4>(x, qw, szp, bias, out, m, n, k, st, f32out);
-    else launch_skinny<DT, 8, 2, 4>(x, qw, szp, bias, out, m, n, k, st, f32out);
+    if (nslab >= 512) launch_skinny<DT, 4, 4, 4, 0, EPI>(x, qw, szp, bias, out, m, n, k, st, f32out);
+    else launch_skinny<DT, 8, 2, 4, 0, EPI>(x, qw, szp, bias, out, m, n, k, st, f32out);
   }
   return 0;
+}
+
+// QuantLlamaMLP's interleaved gate / up stack (EPI 2: out [m, n2 / 2] = silu(gate) * up) for 9 <= m <= 64 rows: ONE weight pass with the x slices in
+// registers, instead of a 256-row tile of the prefill GEMM masked down to m rows (awq_w4a16_mlp_gate_up_forward_cdna4).  Returns -1 if unsupported.
+int launch_skinny_gate_up(const void* x, const void* qw, const void* szp, void* out, int m, int n2, int k, int dtype, hipStream_t st) {
+  if (!szp || m < 9 || m > 64 || (n2 % 32) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return -1;
+  if (dtype == 0) return launch_skinny_64<F16, 2>(x, qw, szp, nullptr, out, m, n2, k, st, 0, nullptr, 0);
+  return launch_skinny_64<BF16, 2>(x, qw, szp, nullptr, out, m, n2, k, st, 0, nullptr, 0);
 }
 
 // Batched decode (launch_gemv_dma hands over the row counts where one weight pass with x in registers beats its LDS-DMA staging of
