@@ -15,7 +15,7 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JS
               duration (HIP events over the timed region, on the launch stream) vs 8 TB/s.
   prefill   = the same 160 linears at M = 2048 (the size BASELINE.md / SURVEY.md 8(d) quote), tok/s and fraction of the
               2.5 PFLOP/s dense bf16 MFMA peak; prefill_m4096 / prefill_m512 beside it.
-  prefill_m64 / prefill_m128 = short prompts on the same weights (fraction of the MFMA roofline; HBM-side they are weight-stream bound).
+  prefill_m16 / prefill_m64 / prefill_m128 = short prompts on the same weights (fraction of the MFMA roofline; HBM-side they are weight-stream bound).
   w3_llama2_7b / tp70b_world1 / moe_mixtral = BASELINE.json configs 3, 4 (world size 1) and 5 as compact legs (bench_extra.py).
   dropin    = the SAME work through the reference's own entry points on RAW reference-layout (v2) buffers:
               awq_inference_engine.gemv_forward_cuda_new / gemm_forward_cuda_new (pybind.cpp:22-23), 160 calls per token.
@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--prefill-m", type=int, default=2048, help="prefill rows of the headline GEMM figure (SURVEY.md 8(d) / BASELINE.md quote M = 2048)")
     ap.add_argument("--prefill-m2", type=int, default=4096, help="second prefill size reported beside it (0 = skip)")
     ap.add_argument("--prefill-m3", type=int, default=512, help="a short prompt (split-K territory) reported beside them (0 = skip)")
-    ap.add_argument("--prefill-small", default="64,128", help="short prompts (the reference's M <= 192 tile territory, gemm_cuda.cu:1155-1206) reported as prefill_m<M> beside the others ('' = skip)")
+    ap.add_argument("--prefill-small", default="16,64,128", help="short prompts (the reference's M <= 192 tile territory, gemm_cuda.cu:1155-1206) reported as prefill_m<M> beside the others ('' = skip)")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the compact legs of BASELINE.json configs 3 / 4 (world size 1) / 5 (bench_extra.py: w3_llama2_7b, tp70b_world1, moe_mixtral)")
     ap.add_argument("--prefill-iters", type=int, default=10, help="timed prefill passes per size (after two untimed ones); median and min are reported")
     ap.add_argument("--no-prefill", action="store_true")
