@@ -25,17 +25,18 @@ def _graph_us(run, stream, steps, warmup):
         with torch.cuda.graph(g, stream=stream):
             keep = run()  # noqa: F841
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for _ in range(max(1, warmup)):
-            g.replay()
-        e1.record(stream)
-        torch.cuda.synchronize()
-        # these graphs are 0.1 - 0.5 ms long: a handful of replays ends before the clocks have ramped (the first leg timed after an idle gap read
-        # 5 - 15 % slow).  Keep the GPU busy for ~40 ms before the timed region, as bench.py's own warm-up steps do for the headline legs
-        est_ms = e0.elapsed_time(e1) / max(1, warmup)
-        for _ in range(min(2000, int(40.0 / max(est_ms, 1e-3)))):
-            g.replay()
-        torch.cuda.synchronize()
+        # these graphs are 0.1 - 0.5 ms long: a handful of replays ends before the clocks have ramped (a leg timed right after an idle gap read 5 - 15 % slow).
+        # Keep the GPU busy for ~40 ms of measured replay time before the timed region, as bench.py's own warm-up steps do for the headline legs
+        busy_ms, rounds = 0.0, 0
+        while busy_ms < 40.0 and rounds < 300:
+            e0.record(stream)
+            for _ in range(max(10, warmup)):
+                g.replay()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            busy_ms += e0.elapsed_time(e1)
+            rounds += 1
+        steps = max(steps, 30)  # (sub-millisecond graphs: a timed region of at least ~8 ms)
         e0.record(stream)
         for _ in range(steps):
             g.replay()
