@@ -261,3 +261,36 @@ def test_v2_gate_up_buffers_are_released_and_state_dict_round_trips(dtype):
     assert torch.equal(fresh(x.cuda()).cpu(), y0)
     mlp.load_state_dict(before)
     assert torch.equal(mlp(x.cuda()).cpu(), y0)
+
+
+@pytest.mark.parametrize("F,K", [(14336, 4096), (7168, 2048)])
+def test_gate_up_short_prompts_on_the_skinny_kernel_wide_shapes(F, K):
+    """9..64 rows of the fused pair run on the skinny kernel's paired epilogue; at Llama-3-8B's width (2 F / 16 = 1792 slabs) in blocks of SEVEN slabs, below
+    that of four.  The CPU oracle at this size is held by test_gate_up_entry_every_row_count (M = 9); here every row-count class against (a) the unfused
+    product path on the same interleaved stream (same accumulators, same roundings: only the fp32 silu differs in its last bits) and (b) fp32 torch on the
+    device-dequantised weights (bit-pinned to the oracle in test_gpu_oracle_fullsize.py), and the masked-tile route the knob mlp_skinny_max = 8 selects."""
+    from llm_awq_amd import ops, synth
+    from llm_awq_amd.fused_mlp import interleave_gate_up
+    dtype = torch.bfloat16
+    g, u = (synth.random_wq(K, F, dtype=dtype, seed=s, keep_q=False) for s in (21, 22))
+    qi, si, zi = interleave_gate_up(g["qweight"], u["qweight"], g["scales"], u["scales"], g["scaled_zeros"], u["scaled_zeros"])
+    c4 = ops.repack_v2_to_cdna4(qi)
+    szp = ops.pack_sz_cdna4(si, zi, K)
+    Wg, Wu = (ops.dequant_v2(w["qweight"], w["scales"], w["scaled_zeros"]).float() for w in (g, u))
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    for M in (9, 16, 17, 33, 48, 64):
+        x = torch.randn(M, K, device="cuda", generator=gen).to(dtype)
+        y = ops.mlp_gate_up_forward_cdna4(x, c4, szp, None)
+        full = ops.gemm_cdna4(x, c4, si, zi, None, szp).view(M, F // 8, 2, 8)
+        unfused = (torch.nn.functional.silu(full[:, :, 0, :]) * full[:, :, 1, :]).reshape(M, F)
+        assert_bits(y, unfused, 0.001, what=f"fused vs unfused skinny M={M}")
+        gt, up = (x.float() @ Wg.t()).to(dtype), (x.float() @ Wu.t()).to(dtype)
+        ref = (torch.nn.functional.silu(gt) * up).float()
+        rel = ((y.float() - ref).norm() / ref.norm()).item()
+        assert rel < 2e-3, (M, rel)  # (two T roundings of fp32 sums taken in another order than torch's: the hull model lives in the oracle tests)
+        ops._capi.tune(mlp_skinny_max=8)
+        try:
+            y_tile = ops.mlp_gate_up_forward_cdna4(x, c4, szp, None)
+        finally:
+            ops._capi.tune(mlp_skinny_max=64)
+        assert_bits(y, y_tile, 0.02, what=f"skinny vs masked tile M={M}")
