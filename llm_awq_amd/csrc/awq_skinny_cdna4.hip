@@ -302,7 +302,13 @@ __global__ __launch_bounds__(64 * WAVES) void skinny_splitk_kernel(const uint16_
 
 namespace {
 constexpr int kTicketLanes = 64, kTicketGroups = 512;  // 64 launches in flight x 512 slab groups, 128 KiB per device
-int g_skinny_ks = -1;  // knob skinny_splitk: -1 = by shape, 0 = off, 2 / 4 = force that many K parts where the shape allows it
+int g_skinny_ks = -1;
+// seven slabs per block make ONE round of one block per CU (Llama-3-8B gate/up: 1792 slabs -> 256 blocks)?  Then the x slices are read by that many blocks
+// instead of 1.75 - 3.5 times as many (profiles/r05_skinny_splitk.txt)
+bool seven_slab_round(int nslab) {
+  const int groups = (nslab + 6) / 7, cus = device_cu_count();
+  return groups <= cus + 16 && groups >= cus * 9 / 10;
+}  // knob skinny_splitk: -1 = by shape, 0 = off, 2 / 4 = force that many K parts where the shape allows it
 // the ticket words of the current device (zeroed once; every launch leaves the words it used at 0).  nullptr while a stream capture is in progress and
 // the array does not exist yet (no allocation inside a capture: that call runs unsplit), or if the allocation failed
 u32* splitk_tickets(hipStream_t st, int groups) {
@@ -416,13 +422,14 @@ static int launch_skinny_64(const void* x, const void* qw, const void* szp, cons
     }
   }
   if (m <= 16) {
-    if (nslab >= 1024) launch_skinny<DT, 8, 2, 1, 0, EPI>(x, qw, szp, bias, out, m, n, k, st, f32out);
+    if (nslab >= 1024 && seven_slab_round(nslab)) launch_skinny<DT, 8, 7, 1, 0, EPI>(x, qw, szp, bias, out, m, n, k, st, f32out);  // (-2 % on the 7-row decode leg, -4 % at 16 rows)
+    else if (nslab >= 1024) launch_skinny<DT, 8, 2, 1, 0, EPI>(x, qw, szp, bias, out, m, n, k, st, f32out);
     else if (k / 128 >= 96) launch_skinny<DT, 16, 1, 1, 0, EPI>(x, qw, szp, bias, out, m, n, k, st, f32out);
     else launch_skinny<DT, 8, 1, 1, 0, EPI>(x, qw, szp, bias, out, m, n, k, st, f32out);
   } else if (m <= 32) {
     if (nslab >= 512) launch_skinny<DT, 8, 2, 2, 0, EPI>(x, qw, szp, bias, out, m, n, k, st, f32out);
     else launch_skinny<DT, 8, 1, 2, 0, EPI>(x, qw, szp, bias, out, m, n, k, st, f32out);
-  } else if (nslab >= 512 && (nslab + 6) / 7 <= device_cu_count() + 16 && (nslab + 6) / 7 >= device_cu_count() * 9 / 10) {
+  } else if (nslab >= 512 && seven_slab_round(nslab)) {
     // seven slabs per block where that is ONE round of one block per CU (Llama-3-8B gate/up: 1792 slabs -> 256 blocks): the x slices are read by
     // 256 blocks instead of 448 -- -7 % at 40 / 48 rows, -13 % at 64 and 128 (profiles/r05_skinny_splitk.txt); a two-deep prefetch of the packed words
     // for its single wave per SIMD measured 3 % slower again
@@ -455,7 +462,8 @@ int launch_skinny_decode(const void* x, const void* qw, const void* szp, const v
   const bool wide = n / 16 >= 1024, deep = !wide && k / 128 >= 96;  // deep: 16 waves split a long K (down_proj: 112 steps)
 #define AWQ_SD(DT_, DQ_, EPI_)                                                                    \
   {                                                                                               \
-    if (wide) launch_skinny<DT_, 8, 2, 1, DQ_, EPI_>(x, qw, szp, bias, out, m, n, k, st, f32out);       \
+    if (wide && seven_slab_round(n / 16)) launch_skinny<DT_, 8, 7, 1, DQ_, EPI_>(x, qw, szp, bias, out, m, n, k, st, f32out); \
+    else if (wide) launch_skinny<DT_, 8, 2, 1, DQ_, EPI_>(x, qw, szp, bias, out, m, n, k, st, f32out);       \
     else if (deep) launch_skinny<DT_, 16, 1, 1, DQ_, EPI_>(x, qw, szp, bias, out, m, n, k, st, f32out); \
     else launch_skinny<DT_, 8, 1, 1, DQ_, EPI_>(x, qw, szp, bias, out, m, n, k, st, f32out);            \
     return 0;                                                                                     \
