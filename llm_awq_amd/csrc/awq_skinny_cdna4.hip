@@ -323,7 +323,8 @@ u32* splitk_tickets(hipStream_t st, int groups) {
     u32* fresh = nullptr;
     const size_t bytes = (size_t)kTicketLanes * kTicketGroups * sizeof(u32);
     if (hipMalloc(reinterpret_cast<void**>(&fresh), bytes) != hipSuccess) return nullptr;
-    if (hipMemset(fresh, 0, bytes) != hipSuccess) {  // (synchronous: visible to every stream that launches after this point)
+    // (the fill is ordered on the null stream and may return before it has run: wait for it, so that launches on ANY stream after this point see zeros)
+    if (hipMemset(fresh, 0, bytes) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
       (void)hipFree(fresh);
       return nullptr;
     }
