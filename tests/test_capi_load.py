@@ -43,6 +43,22 @@ def test_argument_validation_without_gpu():
     assert L.awq_unpack_v2(p16, p16, 6, 64, None) == -4
     assert b"batch size" in L.awq_status_string(-1) and b"group size" in L.awq_status_string(-2)
     assert L.awq_w4a16_gemm_workspace_bytes(2048, 4096, 4096) >= 0
+    # round 5's entries: the 3-bit fused pair and the 3-bit fp32 partial refuse bad arguments before anything is launched
+    gu = L.awq_w3a16_mlp_gate_up_forward  # (x, qweight, sz_packed, out, m, n2, k, group, dtype, workspace, bytes, stream)
+    assert gu(None, p16, p16, p16, 1, 64, 256, 128, 1, None, 0, None) == -6
+    assert gu(p16, p16, p16, p16, 1, 64, 256, 64, 1, None, 0, None) == -2
+    assert gu(p16, p16, p16, p16, 1, 64, 256, 128, 9, None, 0, None) == -3
+    assert gu(p16, p16, p16, p16, 0, 64, 256, 128, 1, None, 0, None) == -1
+    assert gu(p16, p16, p16, p16, 1, 48, 256, 128, 1, None, 0, None) == -4   # n2 % 32: whole slabs of gate AND up rows
+    assert gu(p16, p16, p16, p16, 1, 64, 200, 128, 1, None, 0, None) == -4
+    assert gu(p16 + 2, p16, p16, p16, 1, 64, 256, 128, 1, None, 0, None) == -5
+    assert L.awq_w3a16_mlp_gate_up_forward_workspace_bytes(8, 22016, 4096) == 0
+    pw = L.awq_w3a16_partial  # (x, qweight, sz_packed, out_f32, m, n, k, group, dtype, stream)
+    assert pw(p16, None, p16, p16, 1, 64, 256, 128, 1, None) == -6
+    assert pw(p16, p16, p16, p16, 1, 64, 256, 32, 1, None) == -2
+    assert pw(p16, p16, p16, p16, 1, 64, 256, 128, 5, None) == -3
+    assert pw(p16, p16, p16, p16, 0, 64, 256, 128, 1, None) == -4 and pw(p16, p16, p16, p16, 1, 24, 256, 128, 1, None) == -4
+    assert pw(p16, p16, p16 + 4, p16, 1, 64, 256, 128, 1, None) == -5
 
 
 def test_engine_module_exports():
