@@ -294,7 +294,7 @@ int awq_w4a16_partial_cdna4(const void* x, const void* qweight_cdna4, const void
 /* QuantLlamaMLP's gate / up pair + SiLU * mul (tinychat/modules/fused_mlp.py:33-83) for 3-bit projections: qweight_w3_interleaved holds the
  * two projections' INTEGER rows interleaved 8 + 8 per 16-row slab (gate rows 8 j .. 8 j + 7, then the matching up rows) packed into w3c
  * tiles, sz_packed the same interleave of their scales / zeros; out[m, n2 / 2] = T(T(silu(T(gate))) * T(up)).  m <= 8: the register-ring
- * decode kernel pairs the rows in its epilogue; above that the prefill tiles' fused tail.  workspace: optional split-K scratch (NULL / 0 ok). */
+ * decode kernel pairs the rows in its epilogue; 9 .. 64 rows: the skinny kernel's paired epilogue; above that the prefill tiles' fused tail.  workspace: optional split-K scratch (NULL / 0 ok). */
 size_t awq_w3a16_mlp_gate_up_forward_workspace_bytes(int m, int n2, int k);
 int awq_w3a16_mlp_gate_up_forward(const void* x, const void* qweight_w3_interleaved, const void* sz_packed, void* out, int m, int n2, int k,
                                   int group_size, int dtype, void* workspace, size_t workspace_bytes, void* stream);

@@ -524,6 +524,7 @@ int awq_dequant_w3(const void* qweight_w3, const void* scales, const void* scale
   return finish_launch();
 }
 
+static int g_w3_skinny_max = 64;  // knob w3_skinny_max: 3-bit row counts up to this go to the skinny kernel (8 = never: the masked tile of the prefill GEMM)
 // w3c tiles are read natively by every kernel: the only workspace is the OPTIONAL split-K scratch of short prompts (as for W4)
 size_t awq_w3a16_forward_workspace_bytes(int m, int n, int k) { return m <= 8 ? 0 : awq::gemm_cdna4_v3_workspace_bytes_w3(m, n, k); }
 
@@ -540,9 +541,11 @@ int awq_w3a16_forward(const void* x, const void* qweight_w3, const void* scales,
       return AWQ_ERR_SHAPE;
     return finish_launch();
   }
+  if (bias && !aligned16(bias)) return AWQ_ERR_ALIGN;
+  // 9 .. 64 rows: one weight pass on the skinny kernel (w3c tiles), instead of a 256-row tile masked down to m rows
+  if (m <= g_w3_skinny_max && awq::launch_skinny_w3(x, qweight_w3, sz_packed, bias, out, m, n, k, 0, dtype, (hipStream_t)stream) == 0) return finish_launch();
   // prefill / batched decode: the v4 / v4n weight producers read the 768-byte tiles directly (three words per lane, the fourth
   // rebuilt with six VALU operations per group); bias fused into the epilogue
-  if (bias && !aligned16(bias)) return AWQ_ERR_ALIGN;
   if (workspace && (!aligned16(workspace) || workspace_bytes < awq_w3a16_forward_workspace_bytes(m, n, k))) {
     workspace = nullptr;
     workspace_bytes = 0;
@@ -569,6 +572,7 @@ int awq_w3a16_mlp_gate_up_forward(const void* x, const void* qweight_w3_interlea
     if (awq::launch_gemv_cdna4(x, qweight_w3_interleaved, sz_packed, nullptr, out, m, n2, k, 2, 3, dtype, st) != 0) return AWQ_ERR_SHAPE;
     return finish_launch();
   }
+  if (m <= g_w3_skinny_max && awq::launch_skinny_w3(x, qweight_w3_interleaved, sz_packed, nullptr, out, m, n2, k, 2, dtype, st) == 0) return finish_launch();
   if (workspace && ((reinterpret_cast<uintptr_t>(workspace) & 63) != 0 || workspace_bytes < awq_w3a16_mlp_gate_up_forward_workspace_bytes(m, n2, k))) {
     workspace = nullptr;
     workspace_bytes = 0;
@@ -607,6 +611,10 @@ int awq_tune_set(const char* key, int value) {
   if (awq::gemv_cdna4_tune_set(key, value) == 0) return AWQ_OK;
   if (awq::skinny_tune_set(key, value) == 0) return AWQ_OK;
   if (awq::gemm_v3_tune_set(key, value) == 0) return AWQ_OK;
+  if (!strcmp(key, "w3_skinny_max")) {
+    g_w3_skinny_max = value;
+    return AWQ_OK;
+  }
   if (!strcmp(key, "mlp_skinny_max")) {
     g_mlp_skinny_max = value;
     return AWQ_OK;

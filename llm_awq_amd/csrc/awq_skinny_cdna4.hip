@@ -21,7 +21,7 @@ namespace awq {
 // the block's work for slab group `nb` on M <= 16 CB rows: shared by the plain kernel and the grouped (per-expert) kernel
 // DQ 1: szp is the decode side buffer "sz_half" (f16-mantissa dequant form, Cdna4DequantH); EPI 2: QuantLlamaMLP's 8 + 8 interleaved
 // gate / up slabs, out[m, N / 2] = silu(gate) * up (batched decode of 5..8 rows arrives here from launch_gemv_dma)
-template <typename DT, int WAVES, int NS, int CB, int DQ = 0, int EPI = 0>
+template <typename DT, int WAVES, int NS, int CB, int DQ = 0, int EPI = 0, int BITS = 4>
 __device__ __forceinline__ void skinny_cdna4_body(char* smem, const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                   const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
                                                   uint16_t* __restrict__ out, int M, int N, int K, int nb, int f32out = 0, int k0 = 0, int kn = -1) {
@@ -33,13 +33,15 @@ __device__ __forceinline__ void skinny_cdna4_body(char* smem, const uint16_t* __
   const int nit = K >> 7, nslab = N >> 4;
   char* xs = smem + wv * XBYTES;
 
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(qw), 0, nslab * nit * 1024, 0x00020000);
+  static_assert(BITS == 4 || DQ == 0, "the w3c tiles have no sz_half form");
+  constexpr u32 kTile = BITS == 4 ? 1024u : 768u;  // bytes per 16 x 128 weight tile (BITS 3: the w3c tile, three words per lane)
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(qw), 0, nslab * nit * (int)kTile, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(szp), 0, nslab * nit * 64, 0x00020000);
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(x), 0, M * K * 2, 0x00020000);
   u32 slab_tile[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) slab_tile[s] = (u32)min(nb * NS + s, nslab - 1) * (u32)nit;
-  const u32 wlane_b = lane * 16u, ilane_b = (u32)i * 4u;
+  const u32 wlane_b = BITS == 4 ? lane * 16u : lane * 12u, ilane_b = (u32)i * 4u;
   // staging piece b: LDS row r = 4b + g, slot i  <-  source row min(r, M-1), granule i ^ (r & 15)
   u32 xsrc_b[XB];
 #pragma unroll
@@ -50,7 +52,7 @@ __device__ __forceinline__ void skinny_cdna4_body(char* smem, const uint16_t* __
 
   Cdna4DequantT<DT> cd;
   Cdna4DequantH<DT> ch;
-  if (DQ == 0) cd.init(lane);
+  if (DQ == 0) cd.init(lane, BITS == 4 ? 0x000F000Fu : 0x00070007u);
   else ch.init(lane);
   // the block's K part: k-steps [k0, k0 + kn) (kn < 0: all of K).  f32out 2 = a split-K partial: fp32 sums stored write-through (sc1) for the
   // block that arrives last at the slab group's ticket, which may sit on another XCD (skinny_splitk_kernel below)
@@ -72,7 +74,13 @@ __device__ __forceinline__ void skinny_cdna4_body(char* smem, const uint16_t* __
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const u32 tidx = slab_tile[s] + (u32)kg;
-      w[s] = __builtin_amdgcn_raw_buffer_load_b128(rw, wlane_b, tidx * 1024u, 2);  // aux 2 = nt
+      if (BITS == 4) {
+        w[s] = __builtin_amdgcn_raw_buffer_load_b128(rw, wlane_b, tidx * 1024u, 2);  // aux 2 = nt
+      } else {
+        typedef u32 u32x3 __attribute__((ext_vector_type(3)));
+        const u32x3 w3 = __builtin_amdgcn_raw_buffer_load_b96(rw, wlane_b, tidx * 768u, 2);
+        w[s] = u32x4{w3.x, w3.y, w3.z, 0u};
+      }
       sz[s] = __builtin_amdgcn_raw_buffer_load_b32(rs, ilane_b, tidx * 64u, 0);
     }
   };
@@ -100,7 +108,7 @@ __device__ __forceinline__ void skinny_cdna4_body(char* smem, const uint16_t* __
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       vec8 op[4];
-      if (DQ == 0) cd.tile_packed(wc[s], szc[s], op);
+      if (DQ == 0) cd.tile_packed(BITS == 4 ? wc[s] : w3_expand(wc[s].x, wc[s].y, wc[s].z), szc[s], op);
       else ch.tile(wc[s], szc[s], op);
 #pragma unroll
       for (int a = 0; a < 4; ++a)  // a outer: consecutive MFMAs hit different accumulators
@@ -175,13 +183,13 @@ __device__ __forceinline__ void skinny_cdna4_body(char* smem, const uint16_t* __
   }
 }
 
-template <typename DT, int WAVES, int NS, int CB, int DQ = 0, int EPI = 0>
+template <typename DT, int WAVES, int NS, int CB, int DQ = 0, int EPI = 0, int BITS = 4>
 __global__ __launch_bounds__(64 * WAVES) void skinny_cdna4_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                                    const u32* __restrict__ szp,
                                                                    const uint16_t* __restrict__ bias,
                                                                    uint16_t* __restrict__ out, int M, int N, int K, int f32out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  skinny_cdna4_body<DT, WAVES, NS, CB, DQ, EPI>(smem, x, qw, szp, bias, out, M, N, K, blockIdx.x, EPI == 0 ? f32out : 0);
+  skinny_cdna4_body<DT, WAVES, NS, CB, DQ, EPI, BITS>(smem, x, qw, szp, bias, out, M, N, K, blockIdx.x, EPI == 0 ? f32out : 0);
 }
 
 // Grouped (per-expert) form for MoE batches between the grouped GEMV (<= 8 sorted rows) and the grouped prefill GEMM
@@ -233,12 +241,12 @@ __global__ __launch_bounds__(64 * WAVES) void moe_skinny_cdna4_kernel(const uint
   }
 }
 
-template <typename DT, int WAVES, int NS, int CB, int DQ = 0, int EPI = 0>
+template <typename DT, int WAVES, int NS, int CB, int DQ = 0, int EPI = 0, int BITS = 4>
 static void launch_skinny(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                           hipStream_t st, int f32out = 0) {
   const size_t xbytes = (size_t)WAVES * 16 * CB * 256, rbytes = (size_t)WAVES * NS * CB * 1024;
   const size_t smem = xbytes > rbytes ? xbytes : rbytes;
-  auto kern = skinny_cdna4_kernel<DT, WAVES, NS, CB, DQ, EPI>;
+  auto kern = skinny_cdna4_kernel<DT, WAVES, NS, CB, DQ, EPI, BITS>;
   static LdsOptIn optin;  // per (kernel instantiation, device)
   if (smem > 64 * 1024) optin.ensure(reinterpret_cast<const void*>(kern));
   const int nslab = n / 16;
@@ -452,6 +460,38 @@ int launch_skinny_gate_up(const void* x, const void* qw, const void* szp, void* 
   if (!szp || m < 9 || m > 64 || (n2 % 32) != 0 || (k % 128) != 0 || (size_t)m * (size_t)k >= (1ull << 31)) return -1;
   if (dtype == 0) return launch_skinny_64<F16, 2>(x, qw, szp, nullptr, out, m, n2, k, st, 0, nullptr, 0);
   return launch_skinny_64<BF16, 2>(x, qw, szp, nullptr, out, m, n2, k, st, 0, nullptr, 0);
+}
+
+// The same kernel on w3c tiles (BITS 3: three packed words per lane, the fourth rebuilt with six VALU operations, awq_device.hpp w3_expand) for 9 <= m <= 64
+// rows of a 3-bit layer -- prompts / batched decode that would otherwise pay a 256-row tile of the prefill GEMM masked down to m rows.  epi 0 (bias fused)
+// or 2 (QuantLlamaMLP's interleaved pair, out [m, n / 2]).  A smaller set of block shapes than W4's (no K split across blocks).  Returns -1 if unsupported.
+template <typename DT, int EPI>
+static void launch_skinny_w3_dt(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, hipStream_t st) {
+  const int nslab = n / 16;
+  const bool wide = nslab >= 512;
+  if (m <= 16) {
+    if (wide) launch_skinny<DT, 8, 2, 1, 0, EPI, 3>(x, qw, szp, bias, out, m, n, k, st);
+    else launch_skinny<DT, 8, 1, 1, 0, EPI, 3>(x, qw, szp, bias, out, m, n, k, st);
+  } else if (m <= 32) {
+    if (wide) launch_skinny<DT, 8, 2, 2, 0, EPI, 3>(x, qw, szp, bias, out, m, n, k, st);
+    else launch_skinny<DT, 8, 1, 2, 0, EPI, 3>(x, qw, szp, bias, out, m, n, k, st);
+  } else {  // 33 .. 64 rows: four column blocks (the rows past m are masked)
+    if (wide) launch_skinny<DT, 4, 4, 4, 0, EPI, 3>(x, qw, szp, bias, out, m, n, k, st);
+    else launch_skinny<DT, 8, 2, 4, 0, EPI, 3>(x, qw, szp, bias, out, m, n, k, st);
+  }
+}
+int launch_skinny_w3(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int epi, int dtype, hipStream_t st) {
+  if (!szp || m < 9 || m > 64 || (n % (epi == 2 ? 32 : 16)) != 0 || (k % 128) != 0 || (epi != 0 && epi != 2) || (epi == 2 && bias) ||
+      (size_t)m * (size_t)k >= (1ull << 31))
+    return -1;
+  if (dtype == 0) {
+    if (epi == 2) launch_skinny_w3_dt<F16, 2>(x, qw, szp, nullptr, out, m, n, k, st);
+    else launch_skinny_w3_dt<F16, 0>(x, qw, szp, bias, out, m, n, k, st);
+  } else {
+    if (epi == 2) launch_skinny_w3_dt<BF16, 2>(x, qw, szp, nullptr, out, m, n, k, st);
+    else launch_skinny_w3_dt<BF16, 0>(x, qw, szp, bias, out, m, n, k, st);
+  }
+  return 0;
 }
 
 // Batched decode (launch_gemv_dma hands over the row counts where one weight pass with x in registers beats its LDS-DMA staging of
