@@ -596,6 +596,7 @@ int awq_w3a16_partial(const void* x, const void* qweight_w3, const void* sz_pack
     if (awq::launch_gemv_cdna4(x, qweight_w3, sz_packed, nullptr, out_f32, m, n, k, 3, 3, dtype, st) != 0) return AWQ_ERR_SHAPE;
     return finish_launch();
   }
+  if (m <= g_w3_skinny_max && awq::launch_skinny_w3(x, qweight_w3, sz_packed, nullptr, out_f32, m, n, k, 0, dtype, st, 1) == 0) return finish_launch();
   if (awq::launch_gemm_cdna4_v3(x, qweight_w3, sz_packed, nullptr, out_f32, m, n, k, 0, dtype, nullptr, 0, st, 3, 3) != 0) return AWQ_ERR_SHAPE;
   return finish_launch();
 }

@@ -99,7 +99,8 @@ int gemm_variant_get();
 int launch_skinny_cdna4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                         int dtype, hipStream_t st, int f32out = 0, void* ws = nullptr, size_t ws_bytes = 0);
 // the skinny launch's K split across blocks (awq_skinny_cdna4.hip): K parts for a pass of m rows (1 = unsplit), its optional fp32 scratch, knob
-int launch_skinny_w3(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int epi, int dtype, hipStream_t st);
+int launch_skinny_w3(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int epi, int dtype, hipStream_t st,
+                     int f32out = 0);
 int launch_skinny_gate_up(const void* x, const void* qw, const void* szp, void* out, int m, int n2, int k, int dtype, hipStream_t st);
 int skinny_splitk_parts(int m, int n, int k);
 size_t skinny_splitk_workspace_bytes(int m, int n, int k);

@@ -466,30 +466,32 @@ int launch_skinny_gate_up(const void* x, const void* qw, const void* szp, void* 
 // rows of a 3-bit layer -- prompts / batched decode that would otherwise pay a 256-row tile of the prefill GEMM masked down to m rows.  epi 0 (bias fused)
 // or 2 (QuantLlamaMLP's interleaved pair, out [m, n / 2]).  A smaller set of block shapes than W4's (no K split across blocks).  Returns -1 if unsupported.
 template <typename DT, int EPI>
-static void launch_skinny_w3_dt(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, hipStream_t st) {
+static void launch_skinny_w3_dt(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, hipStream_t st, int f32out) {
   const int nslab = n / 16;
   const bool wide = nslab >= 512;
   if (m <= 16) {
-    if (wide) launch_skinny<DT, 8, 2, 1, 0, EPI, 3>(x, qw, szp, bias, out, m, n, k, st);
-    else launch_skinny<DT, 8, 1, 1, 0, EPI, 3>(x, qw, szp, bias, out, m, n, k, st);
+    if (wide) launch_skinny<DT, 8, 2, 1, 0, EPI, 3>(x, qw, szp, bias, out, m, n, k, st, f32out);
+    else launch_skinny<DT, 8, 1, 1, 0, EPI, 3>(x, qw, szp, bias, out, m, n, k, st, f32out);
   } else if (m <= 32) {
-    if (wide) launch_skinny<DT, 8, 2, 2, 0, EPI, 3>(x, qw, szp, bias, out, m, n, k, st);
-    else launch_skinny<DT, 8, 1, 2, 0, EPI, 3>(x, qw, szp, bias, out, m, n, k, st);
+    if (wide) launch_skinny<DT, 8, 2, 2, 0, EPI, 3>(x, qw, szp, bias, out, m, n, k, st, f32out);
+    else launch_skinny<DT, 8, 1, 2, 0, EPI, 3>(x, qw, szp, bias, out, m, n, k, st, f32out);
   } else {  // 33 .. 64 rows: four column blocks (the rows past m are masked)
-    if (wide) launch_skinny<DT, 4, 4, 4, 0, EPI, 3>(x, qw, szp, bias, out, m, n, k, st);
-    else launch_skinny<DT, 8, 2, 4, 0, EPI, 3>(x, qw, szp, bias, out, m, n, k, st);
+    if (wide) launch_skinny<DT, 4, 4, 4, 0, EPI, 3>(x, qw, szp, bias, out, m, n, k, st, f32out);
+    else launch_skinny<DT, 8, 2, 4, 0, EPI, 3>(x, qw, szp, bias, out, m, n, k, st, f32out);
   }
 }
-int launch_skinny_w3(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int epi, int dtype, hipStream_t st) {
+// f32out (epi 0 only, no bias): out = float [m, n], the unrounded sums of a tensor-parallel row split's K shard (awq_w3a16_partial)
+int launch_skinny_w3(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int epi, int dtype, hipStream_t st,
+                     int f32out) {
   if (!szp || m < 9 || m > 64 || (n % (epi == 2 ? 32 : 16)) != 0 || (k % 128) != 0 || (epi != 0 && epi != 2) || (epi == 2 && bias) ||
-      (size_t)m * (size_t)k >= (1ull << 31))
+      (f32out && (epi != 0 || bias)) || (size_t)m * (size_t)k >= (1ull << 31))
     return -1;
   if (dtype == 0) {
-    if (epi == 2) launch_skinny_w3_dt<F16, 2>(x, qw, szp, nullptr, out, m, n, k, st);
-    else launch_skinny_w3_dt<F16, 0>(x, qw, szp, bias, out, m, n, k, st);
+    if (epi == 2) launch_skinny_w3_dt<F16, 2>(x, qw, szp, nullptr, out, m, n, k, st, 0);
+    else launch_skinny_w3_dt<F16, 0>(x, qw, szp, bias, out, m, n, k, st, f32out);
   } else {
-    if (epi == 2) launch_skinny_w3_dt<BF16, 2>(x, qw, szp, nullptr, out, m, n, k, st);
-    else launch_skinny_w3_dt<BF16, 0>(x, qw, szp, bias, out, m, n, k, st);
+    if (epi == 2) launch_skinny_w3_dt<BF16, 2>(x, qw, szp, nullptr, out, m, n, k, st, 0);
+    else launch_skinny_w3_dt<BF16, 0>(x, qw, szp, bias, out, m, n, k, st, f32out);
   }
   return 0;
 }
