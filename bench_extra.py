@@ -1,6 +1,6 @@
 """bench_extra.py -- the other BASELINE.json configurations on the driver's clock, as compact legs of bench.py's JSON line (N = 1 only).
 
-  w3_llama2_7b   cfg3: Llama-2-7B W3A16 g128 (w3c tiles, 0.375 B / weight): decode M = 1 as a fraction of the HBM roofline, prefill M = 2048 as a
+  w3_llama2_7b   cfg3: Llama-2-7B W3A16 g128 (w3c tiles, 0.375 B / weight): decode M = 1 and batched decode of 16 rows as a fraction of the HBM roofline, prefill M = 2048 as a
                  fraction of the bf16 MFMA roofline; the five WQLinear(w_bit=3) calls of a block (qkv, o, gate, up, down), 8 distinct layers (607 MB,
                  beyond the 256 MB Infinity Cache) for decode, 4 for prefill.
   tp70b_world1   cfg4 at world size 1: the UNSHARDED Llama-3-70B block shapes (8192 -> 10240, 8192 -> 8192, gate/up 8192 -> 2 x 28672 fused,
@@ -111,7 +111,7 @@ def w3_llama2_7b(eng, dev, stream, steps, warmup, iters, dtype=torch.bfloat16):
         fused.append((K, 2 * F, eng.pack_w3(qi), eng.pack_sz_cdna4(si, zi, K)))
         layers.append(lin)
         del ints, qi, si, zi
-    xs = {M: {K: torch.randn(M, K, device=dev, generator=gen).to(dtype) for K in (4096, 11008)} for M in (1, 2048)}
+    xs = {M: {K: torch.randn(M, K, device=dev, generator=gen).to(dtype) for K in (4096, 11008)} for M in (1, 16, 2048)}
 
     def lin_fwd(M, ent):
         K, N, qw, s, z, szp = ent
@@ -137,12 +137,15 @@ def w3_llama2_7b(eng, dev, stream, steps, warmup, iters, dtype=torch.bfloat16):
     by = (by + wbytes(K, 2 * F) + K * 2 + F * 2) * L_dec
     us = _graph_us(lambda: run(1, L_dec), stream, steps, warmup)
     us_u = _graph_us(lambda: run_unfused(1, L_dec), stream, steps, warmup)
+    us16 = _graph_us(lambda: run(16, L_dec), stream, steps, warmup)  # batched decode of 16 rows: one weight pass on the skinny kernel (w3c tiles)
+    by16 = by + L_dec * sum(15 * (K_ + N_) * 2 for (K_, N_) in (synth.LLAMA2_7B[nm] for nm in ("qkv", "o", "down")))
     us_p, us_pmin = _median_us(lambda: run(2048, L_pre), stream, iters)
     us_pu, _ = _median_us(lambda: run_unfused(2048, L_pre), stream, iters)
     fl = sum(2.0 * 2048 * K_ * N_ for (K_, N_) in (synth.LLAMA2_7B[nm] for nm in ("qkv", "o", "gate", "up", "down"))) * L_pre
     return {"workload": "Llama-2-7B W3A16 g128 bf16 (w3c tiles): qkv, o, QuantLlamaMLP(w_bit=3) = fused gate/up + SiLU*mul, down; every layer its own weights",
             "decode_m1": {"layers": L_dec, "launches": 4 * L_dec, "us_per_layer": round(us / L_dec, 2), "tok_s_32_layers": round(1e6 / (us / L_dec * 32), 1),
                           "algorithmic_bytes_per_layer": by // L_dec, "roofline": _hbm(by, us), "us_per_layer_five_unfused_calls": round(us_u / L_dec, 2)},
+            "decode_m16": {"layers": L_dec, "us_per_layer": round(us16 / L_dec, 2), "tok_s_32_layers": round(16e6 / (us16 / L_dec * 32), 1), "roofline": _hbm(by16, us16)},
             "prefill_m2048": {"layers": L_pre, "ms_per_layer": round(us_p / L_pre / 1e3, 4), "tok_s_32_layers": round(2048 / (us_p / L_pre * 32 * 1e-6), 1),
                               "roofline": _mfma(fl, us_p, us_pmin), "ms_per_layer_five_unfused_calls": round(us_pu / L_pre / 1e3, 4)}}
 
