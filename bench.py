@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """bench.py -- Llama-3-8B W4A16 (g128, bf16 activations) WQLinear hot path on MI355X.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.  With N > 1 and no launcher around it
+(WORLD_SIZE unset) the script re-executes itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`.
 
   step      = one decode pass of the hot path: the 160 WQLinear GEMV calls (32 layers x
               {qkv 4096->6144, o 4096->4096, gate 4096->14336, up 4096->14336, down 14336->4096})
@@ -15,7 +16,8 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JS
               duration (HIP events over the timed region, on the launch stream) vs 8 TB/s.
   prefill   = the same 160 linears at M = 2048 (the size BASELINE.md / SURVEY.md 8(d) quote), tok/s and fraction of the
               2.5 PFLOP/s dense bf16 MFMA peak; prefill_m4096 / prefill_m512 beside it.
-  prefill_m16 / prefill_m64 / prefill_m128 = short prompts on the same weights (fraction of the MFMA roofline; HBM-side they are weight-stream bound).
+  prefill_m16 / m64 / m128 / m256 / m1024 = shorter prompts on the same weights (fraction of the MFMA roofline; below ~128 rows they are weight-stream bound:
+              `hbm_frac` = algorithmic bytes of the pass / time / 8 TB/s beside it).  65 .. 192 rows run the mid-M kernel (csrc/awq_midm_cdna4.hip).
   w3_llama2_7b / tp70b_world1 / moe_mixtral = BASELINE.json configs 3, 4 (world size 1) and 5 as compact legs (bench_extra.py).
   dropin    = the SAME work through the reference's own entry points on RAW reference-layout (v2) buffers:
               awq_inference_engine.gemv_forward_cuda_new / gemm_forward_cuda_new (pybind.cpp:22-23), 160 calls per token.
@@ -84,6 +86,20 @@ def profile_consistency(ms_per_step, layers):
         return None
 
 
+def launcher_command(n_gpus, argv, port=None):
+    """argv of the re-exec: this script under `python -m torch.distributed.run`, one process per GPU of ONE node, rendezvous on 127.0.0.1 (the
+    container hostname may not resolve), a free port unless given.  The driver's own form (README) is the same command line."""
+    import socket
+    if port is None:
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL / peer-mapped buffers across processes need it on this driver
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_gpus)}", "--master-addr", "127.0.0.1",
+            "--master-port", str(int(port)), os.path.abspath(__file__), *argv]
+
+
 def algo_bytes(M, K, N, esz=2, group=128):
     """packed int4 + scales + scaled_zeros + x + out."""
     return N * K // 2 + 2 * (K // group) * N * esz + M * K * esz + M * N * esz
@@ -97,7 +113,7 @@ def main():
     ap.add_argument("--prefill-m", type=int, default=2048, help="prefill rows of the headline GEMM figure (SURVEY.md 8(d) / BASELINE.md quote M = 2048)")
     ap.add_argument("--prefill-m2", type=int, default=4096, help="second prefill size reported beside it (0 = skip)")
     ap.add_argument("--prefill-m3", type=int, default=512, help="a short prompt (split-K territory) reported beside them (0 = skip)")
-    ap.add_argument("--prefill-small", default="16,64,128", help="short prompts (the reference's M <= 192 tile territory, gemm_cuda.cu:1155-1206) reported as prefill_m<M> beside the others ('' = skip)")
+    ap.add_argument("--prefill-small", default="16,64,128,256,1024", help="short prompts (the reference's M <= 192 tile territory, gemm_cuda.cu:1155-1206) reported as prefill_m<M> beside the others ('' = skip)")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the compact legs of BASELINE.json configs 3 / 4 (world size 1) / 5 (bench_extra.py: w3_llama2_7b, tp70b_world1, moe_mixtral)")
     ap.add_argument("--prefill-iters", type=int, default=10, help="timed prefill passes per size (after two untimed ones); median and min are reported")
     ap.add_argument("--no-prefill", action="store_true")
@@ -106,6 +122,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-batched-decode", action="store_true", help="skip the M = 4 / M = 7 decode legs")
     ap.add_argument("--layers", type=int, default=LAYERS)
+    ap.add_argument("--launch-check", action="store_true", help="print what the launcher handed this rank (RANK / WORLD_SIZE / MASTER_*) and exit: no GPU touched")
     ap.add_argument("--tune", action="append", default=[], help="experiments only: awq_tune_set knobs as key=value")
     ap.add_argument("--layout", default="cdna4", choices=["cdna4", "v2"], help="cdna4 = what the rewritten repacker emits (default); v2 = reference checkpoint layout through gemv/gemm_forward_cuda_new only")
     ap.add_argument("--mlp-decode", default="two", choices=["one", "two"],
@@ -118,10 +135,19 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"], help="activation / scale dtype: bf16 is BASELINE.json's configuration (default); f16 is the reference's default WQLinear dtype (single-GPU leg only)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as typed (no launcher around it): re-exec the same command line under torch.distributed.run, one rank per GPU
+        cmd = launcher_command(args.gpus, sys.argv[1:])
+        sys.stdout.flush()
+        os.execv(cmd[0], cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.launch_check:  # (tests: what the launcher hands every rank, no GPU touched)
+        print(json.dumps({"launch_check": {"rank": rank, "local_rank": local_rank, "world": world, "master_addr": os.environ.get("MASTER_ADDR"),
+                                           "master_port": os.environ.get("MASTER_PORT"), "ipc_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}}), flush=True)
+        return
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -222,7 +248,7 @@ def main():
             elif m <= 8 and epi == 1:
                 outs.append(eng.mlp_gate_up_cdna4(x, qw, szp))
             else:
-                outs.append(eng.forward_cdna4(x, qw, s, z, szp, None, szh if m >= 256 else None))   # WQLinear.forward, prefill GEMM (with the layer's sz_half side buffer, as the module passes it)
+                outs.append(eng.forward_cdna4(x, qw, s, z, szp, None, szh))   # WQLinear.forward, prompts of any length (with the layer's sz_half side buffer, as the module passes it)
         if probe_streams and decode:
             for st in probe_streams:
                 e2 = torch.cuda.Event()
@@ -245,7 +271,7 @@ def main():
         tot = 0
         for (name, K, N, *_r, epi) in nat:
             b = algo_bytes(M, K, N)
-            if epi and M <= 8:
+            if epi:
                 b -= M * (N // 2) * 2  # fused epilogue writes [M, N/2]
             tot += b
         return tot
@@ -409,11 +435,12 @@ def main():
         ptraffic, psrc = pmc_traffic(["awq::gemm_cdna4_v6", "awq::gemm_cdna4_v4"]) if M == 2048 else (None, None)
         return {"m": M, "ms_per_pass": round(pms, 3), "ms_per_pass_min": round(pmin, 3), "passes_timed": max(1, args.prefill_iters), "statistic": "median",
                 "tok_s": round(M / (pms * 1e-3) * (LAYERS / L), 1),
+                "hbm_frac": round(bytes_native(M) / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),  # (the weight-stream side of the same pass: what bounds it below ~128 rows)
                 "roofline": {"bound": "mfma", "kernel": kernel, "achieved": round(tfl, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(tfl / MFMA_PEAK_TFLOPS, 4), "frac_best_pass": round(tfl_best / MFMA_PEAK_TFLOPS, 4), "traffic": ptraffic,
                              **({"traffic_source": psrc, "traffic_note": "HBM bytes per launch, averaged over the tile-kernel launches of the M = 2048 pass (the PMC passes run with --prefill-m2 0 --prefill-m3 0)"} if ptraffic else {})}}
 
-    pk = "gemm_cdna4_v6_kernel (256- / 192- / 128-wide blocks) + gemm_cdna4_v6_pair_kernel (down_proj at <= 2048 rows: pairs of 256-wide blocks, half of K each) + gemm_cdna4_v4n_kernel (split-K launches of short prompts)"
+    pk = "gemm_cdna4_v6_kernel (256- / 192- / 128-wide blocks) + gemm_cdna4_v6_pair_kernel (down_proj at <= 2048 rows: pairs of 256-wide blocks, half of K each) + gemm_cdna4_v4n_kernel (split-K launches of short prompts); 9 .. 64 rows skinny_cdna4_kernel, 65 .. 192 rows midm_kernel"
     if not args.no_prefill:
         out["prefill"] = prefill(args.prefill_m, run_main, pk)
         small = [int(v) for v in args.prefill_small.split(",") if v.strip()]

@@ -191,6 +191,13 @@ int awq_rmsnorm(const void* x, const void* gamma, float eps, void* out, int m, i
  * small zero-initialised per-device array the library allocates at the first such call outside a stream capture).  Without a workspace
  * the call runs unsplit (slower, same contract). */
 size_t awq_w4a16_forward_cdna4_workspace_bytes(int m, int n, int k);
+/* 9 .. 255 rows (round 6): the mid-M kernel (csrc/awq_midm_cdna4.hip) -- the row range of the reference's 16 / 32 / 64-row tiles + split_k_iters,
+ * gemm_cuda.cu:1155-1206, :546-619.  Its K split across blocks keeps the fp32 parts in the caller's workspace and the ticket words in a library-owned,
+ * zero-initialised per-device array in which a word belongs to ONE launch at a time: eager launches use the lane of their stream, a launch recorded
+ * during a stream capture gets words of its own that are never handed out again (so graphs may be replayed on any streams); no lane / region left, or
+ * no workspace: the call runs unsplit.  awq_midm_init allocates that array for the current device ahead of the first call (optional; the first
+ * split launch outside a capture does it otherwise).  Returns AWQ_OK or AWQ_ERR_LAUNCH. */
+int awq_midm_init(void);
 /* host-side query (no GPU work): the tiles the prefill GEMM launches for an [m, n] output of a 3- or 4-bit matrix.  *mode: 0 = 256 x 256
  * blocks, 1 = 256 x 128, 2 = 256 x 256 for the first *cols_main column tiles and 256 x 128 for the rest, 3 = 256 x 192; returns the number
  * of thread blocks, 0 if the GEMM does not take this m (decode / skinny kernels do).  The counterpart of the reference's tile table,

@@ -49,6 +49,7 @@ SIGNATURES = {
     "awq_w4a16_rmsnorm_forward_cdna4": (_i, [_vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "awq_rmsnorm": (_i, [_vp, _vp, ctypes.c_float, _vp, _i, _i, _i, _vp]),
     "awq_w4a16_forward_cdna4_workspace_bytes": (_sz, [_i, _i, _i]),
+    "awq_midm_init": (_i, []),
     "awq_w4a16_gemm_cdna4_plan": (_i, [_i, _i, _i, _vp, _vp]),
     "awq_w4a16_gemm_cdna4_pair_plan": (_i, [_i, _i, _i]),
     "awq_w4a16_gemm_cdna4_narrow_kernel": (_i, [_i, _i, _i, _i, _i, _i]),

@@ -250,7 +250,11 @@ int awq_w4a16_mlp_gate_up_forward_cdna4(const void* x, const void* qweight_inter
   return awq_w4a16_mlp_gate_up_forward_cdna4_ws(x, qweight_interleaved, sz_packed, sz_half, out, m, n2, k, group_size, dtype, nullptr, 0, stream);
 }
 
-size_t awq_w4a16_mlp_gate_up_forward_cdna4_workspace_bytes(int m, int n2, int k) { return m > 8 ? awq::gemm_cdna4_v3_workspace_bytes(m, n2, k) : 0; }
+size_t awq_w4a16_mlp_gate_up_forward_cdna4_workspace_bytes(int m, int n2, int k) {
+  if (m <= 8) return 0;
+  const size_t a = awq::gemm_cdna4_v3_workspace_bytes(m, n2, k), b = awq::midm_workspace_bytes(m, n2, k);
+  return a > b ? a : b;
+}
 
 int awq_w4a16_mlp_gate_up_forward_cdna4_ws(const void* x, const void* qweight_interleaved, const void* sz_packed, const void* sz_half,
                                            void* out, int m, int n2, int k, int group_size, int dtype, void* workspace, size_t workspace_bytes,
@@ -268,7 +272,12 @@ int awq_w4a16_mlp_gate_up_forward_cdna4_ws(const void* x, const void* qweight_in
       return AWQ_ERR_SHAPE;
     return finish_launch();
   }
-  // 9 .. 64 rows: one weight pass on the skinny kernel, rows r and r + 8 of a slab paired in its epilogue (a 256-row tile masked down to m rows costs
+  // 9 .. 255 rows: the mid-M kernel (x tile shared by the block, waves split N, K split across blocks), rows r and r + 8 of a slab paired in its epilogue
+  if (awq::midm_takes(m, n2, k) &&
+      awq::launch_midm_cdna4(x, qweight_interleaved, sz_half ? sz_half : sz_packed, nullptr, out, m, n2, k, 2, dtype, sz_half ? 1 : 0, 4, 0, workspace, workspace_bytes,
+                             (hipStream_t)stream) == 0)
+    return finish_launch();
+  // (knob midm = 0) 9 .. 64 rows: one weight pass on the skinny kernel, rows r and r + 8 of a slab paired in its epilogue (a 256-row tile masked down to m rows costs
   // the same for every m: 46 vs 31 us at 64 rows on Llama-3-8B's pair, profiles/r05_skinny_splitk.txt)
   if (m <= g_mlp_skinny_max && awq::launch_skinny_gate_up(x, qweight_interleaved, sz_packed, out, m, n2, k, dtype, (hipStream_t)stream) == 0)
     return finish_launch();
@@ -311,9 +320,11 @@ int awq_rmsnorm(const void* x, const void* gamma, float eps, void* out, int m, i
 }
 
 size_t awq_w4a16_forward_cdna4_workspace_bytes(int m, int n, int k) {
-  if (m > 8 && m < 256 && !awq::gemm_cdna4_v3_takes(m, k)) return awq::skinny_splitk_workspace_bytes(m, n, k);  // short prompts: the skinny launch's K split
+  if (awq::midm_takes(m, n, k)) return awq::midm_workspace_bytes(m, n, k);  // 9 .. 255 rows: the fp32 parts of the mid-M kernel's K split
+  if (m > 8 && m < 256 && !awq::gemm_cdna4_v3_takes(m, k)) return awq::skinny_splitk_workspace_bytes(m, n, k);  // (knob midm = 0) the skinny launch's K split
   return awq::gemm_cdna4_v3_workspace_bytes(m, n, k);
 }
+int awq_midm_init(void) { return awq::midm_init() == 0 ? AWQ_OK : AWQ_ERR_LAUNCH; }
 int awq_w4a16_gemm_cdna4_pair_plan(int m, int n, int k) { return awq::gemm_cdna4_v3_pair_plan(m, n, k); }
 int awq_w4a16_gemm_cdna4_plan(int m, int n, int bits, int* mode, int* cols_main) { return awq::gemm_cdna4_v3_plan(m, n, bits, mode, cols_main); }
 int awq_w4a16_gemm_cdna4_narrow_kernel(int m, int n_cols, int k, int bits, int has_workspace, int epilogue) {
@@ -337,6 +348,13 @@ int awq_w4a16_gemm_cdna4(const void* x, const void* qweight, const void* scales,
 int awq_w4a16_forward_cdna4_szh(const void* x, const void* qweight, const void* scales, const void* scaled_zeros, const void* sz_packed,
                                 const void* sz_half, const void* bias, void* out, int m, int n, int k, int group_size, int dtype, void* workspace,
                                 size_t workspace_bytes, void* stream) {
+  if (sz_half && sz_packed && group_size == 128 && aligned16(sz_half) && awq::midm_takes(m, n, k)) {
+    // 9 .. 255 rows with the layer's sz_half side buffer: the mid-M kernel in the f16-mantissa dequant form
+    int st0 = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
+    if (st0 != AWQ_OK) return st0;
+    if (bias && !aligned16(bias)) return AWQ_ERR_ALIGN;
+    if (awq::launch_midm_cdna4(x, qweight, sz_half, bias, out, m, n, k, 0, dtype, 1, 4, 0, workspace, workspace_bytes, (hipStream_t)stream) == 0) return finish_launch();
+  }
   if (sz_half && sz_packed && m >= 256 && group_size == 128 && awq::gemm_variant_get() == 0 && aligned16(sz_half)) {
     // prefill with the layer's sz_half side buffer: the tile kernels dequantise in the f16-mantissa form (every block width, the block pairs included)
     int st0 = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
@@ -357,8 +375,15 @@ int awq_w4a16_forward_cdna4(const void* x, const void* qweight, const void* scal
     if ((n % 16) != 0) return AWQ_ERR_SHAPE;
     if (awq::launch_gemv_cdna4(x, qweight, sz_packed, bias, out, m, n, k, 0, 4, dtype, (hipStream_t)stream) == 0) return finish_launch();
   }
+  if (sz_packed && group_size == 128 && awq::gemm_variant_get() == 0 && awq::midm_takes(m, n, k)) {
+    // 9 .. 255 rows: the mid-M kernel, bias fused
+    int st0 = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
+    if (st0 != AWQ_OK) return st0;
+    if (bias && !aligned16(bias)) return AWQ_ERR_ALIGN;
+    if (awq::launch_midm_cdna4(x, qweight, sz_packed, bias, out, m, n, k, 0, dtype, 0, 4, 0, workspace, workspace_bytes, (hipStream_t)stream) == 0) return finish_launch();
+  }
   if (m > 8 && m < 256 && sz_packed && group_size == 128 && awq::gemm_variant_get() == 0 && !awq::gemm_cdna4_v3_takes(m, k)) {
-    // short prompts / batched decode: skinny kernel, bias fused
+    // (knob midm = 0) short prompts / batched decode: skinny kernel, bias fused
     int st0 = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
     if (st0 != AWQ_OK) return st0;
     if ((n % 16) != 0) return AWQ_ERR_SHAPE;
@@ -393,6 +418,9 @@ int awq_w4a16_partial_cdna4(const void* x, const void* qweight, const void* sz_p
     if (awq::launch_skinny_decode(x, qweight, sz_packed, nullptr, out_f32, m, n, k, 0, dtype, 0, st, 1) == 0) return finish_launch();
     return AWQ_ERR_SHAPE;
   }
+  if (awq::midm_takes(m, n, k) &&
+      awq::launch_midm_cdna4(x, qweight, sz_half ? sz_half : sz_packed, nullptr, out_f32, m, n, k, 0, dtype, sz_half ? 1 : 0, 4, 1, nullptr, 0, st) == 0)
+    return finish_launch();
   if (m < 256 && !awq::gemm_cdna4_v3_takes(m, k)) {
     if (awq::launch_skinny_cdna4(x, qweight, sz_packed, nullptr, out_f32, m, n, k, dtype, st, 1) == 0) return finish_launch();
   }
@@ -611,6 +639,7 @@ int awq_tune_set(const char* key, int value) {
   if (awq::gemm_tune_set(key, value) == 0) return AWQ_OK;
   if (awq::gemv_cdna4_tune_set(key, value) == 0) return AWQ_OK;
   if (awq::skinny_tune_set(key, value) == 0) return AWQ_OK;
+  if (awq::midm_tune_set(key, value) == 0) return AWQ_OK;
   if (awq::gemm_v3_tune_set(key, value) == 0) return AWQ_OK;
   if (!strcmp(key, "w3_skinny_max")) {
     g_w3_skinny_max = value;

@@ -270,6 +270,16 @@ struct Cdna4DequantT {
   __device__ __forceinline__ void tile(const u32x4& w, uint16_t s_bits, uint16_t z_bits, vec8 (&op)[4]) const {
     tile_packed(w, (u32)s_bits | ((u32)z_bits << 16), op);
   }
+  // word-by-word form (awq_midm_cdna4.hip): prep() once per (tile, lane), word(w, p) per 32-k slice
+  struct Prep {
+    u32 b01, b23;
+    float cv;
+  };
+  __device__ __forceinline__ Prep prep(u32 sz) const {
+    const u32 sdup = __builtin_amdgcn_perm(sz, sz, 0x01000100u);  // {s, s}
+    return Prep{sdup & m01, sdup & m23, DT::dq_offset(sz)};
+  }
+  __device__ __forceinline__ vec8 word(u32 w, const Prep& p) const { return word(w, p.b01, p.b23, p.cv); }
   // same, from the packed {scale | scaled_zero << 16} dword: one v_perm for the splat, one v_dot2 for sz - offset * s
   __device__ __forceinline__ void tile_packed(const u32x4& w, u32 sz, vec8 (&op)[4]) const {
     const u32 sdup = __builtin_amdgcn_perm(sz, sz, 0x01000100u);  // {s, s}
@@ -313,6 +323,28 @@ struct Cdna4DequantH {
     asm volatile("" : "+s"(kMaskLo));
     asm volatile("" : "+s"(kMaskHi));
     asm volatile("" : "+v"(kDotC));
+  }
+  // the same tile word by word, for kernels that spread a tile's dequant over the product MFMAs of the tile before it (awq_midm_cdna4.hip):
+  // prep() once per (tile, lane), word() per 32-k slice
+  struct Prep {
+    u32x2 b;
+    f32x4 c;
+  };
+  __device__ __forceinline__ Prep prep(u32 szh) const {
+    Prep p;
+    p.b = u32x2{__builtin_amdgcn_perm(szh, szh, sel01), __builtin_amdgcn_perm(szh, szh, sel23)};
+    const float cv = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, szh), __builtin_bit_cast(f16x2, kDotC), 0.0f, false);
+    p.c = f32x4{cv, cv, cv, cv};
+    return p;
+  }
+  __device__ __forceinline__ vec8 word(u32 w, const Prep& p) const {
+    typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+    const u32 w8 = w >> 8;
+    const u32x2 a0 = {(w & kMaskLo) | kMagic, (w & kMaskHi) | kMagic};
+    const u32x2 a1 = {(w8 & kMaskLo) | kMagic, (w8 & kMaskHi) | kMagic};
+    const f32x4 d0 = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(h16x4, a0), __builtin_bit_cast(h16x4, p.b), p.c, 0, 0, 0);
+    const f32x4 d1 = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(h16x4, a1), __builtin_bit_cast(h16x4, p.b), p.c, 0, 0, 0);
+    return DT::pack8(d0, d1);
   }
   // whole 1-KiB tile -> 4 operands (op[a] covers k = 32a + 8g + 0..7 of the tile's 128 k), szh = this lane's sz_half dword
   __device__ __forceinline__ void tile(const u32x4& w, u32 szh, vec8 (&op)[4]) const {

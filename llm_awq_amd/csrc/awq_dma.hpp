@@ -20,6 +20,17 @@ __device__ __forceinline__ void dma_to_lds(const __amdgpu_buffer_rsrc_t& rsrc, c
   if constexpr (SIZE == 16 && AUX == 17) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, DMA_LDS_PTR(dst), 16, voff, soff, 0, 17);  // sc0 sc1
 #endif
 }
+// the same with the LDS destination given as its 32-bit address (the M0 value): kernels that keep their LDS bookkeeping in integers avoid a
+// generic -> local pointer cast (and its null check) per DMA
+template <int SIZE, int AUX>
+__device__ __forceinline__ void dma_to_lds_at(const __amdgpu_buffer_rsrc_t& rsrc, u32 lds_addr, u32 voff, u32 soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(size_t)lds_addr;
+  if constexpr (SIZE == 16 && AUX == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff, soff, 0, 2);
+  if constexpr (SIZE == 16 && AUX == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff, soff, 0, 0);
+  if constexpr (SIZE == 4 && AUX == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 4, voff, soff, 0, 0);
+#endif
+}
 template <int N_>
 __device__ __forceinline__ void dma_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N_) : "memory");

@@ -105,6 +105,15 @@ int launch_skinny_gate_up(const void* x, const void* qw, const void* szp, void* 
 int skinny_splitk_parts(int m, int n, int k);
 size_t skinny_splitk_workspace_bytes(int m, int n, int k);
 int skinny_tune_set(const char* key, int value);
+// mid-M GEMM (awq_midm_cdna4.hip): 9 <= m <= 255, x tile shared by the block through LDS-DMA, waves split N, K split across blocks (ticket + fp32 parts);
+// szfmt 0: szp = sz_packed, 1: sz_half; epi 0 / 2; f32out: float [m, n] unrounded; ws: the optional scratch of the K split.  -1 if the shape is not served
+int launch_midm_cdna4(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int epi, int dtype, int szfmt,
+                      int bits, int f32out, void* ws, size_t ws_bytes, hipStream_t st);
+bool midm_takes(int m, int n, int k);
+size_t midm_workspace_bytes(int m, int n, int k);
+int midm_parts(int m, int n, int k);
+int midm_tune_set(const char* key, int value);
+int midm_init();
 // batched decode on the same kernel (m <= 16; szfmt 1: szp = sz_half; epi 0 / 2 as launch_gemv_dma); -1 if unsupported
 int launch_skinny_decode(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int epi,
                          int dtype, int szfmt, hipStream_t st, int f32out = 0);

@@ -167,7 +167,7 @@ __device__ __forceinline__ void skinny_cdna4_body(char* smem, const uint16_t* __
       if (slab < nslab && m < M) {
         float* dst = reinterpret_cast<float*>(out) + (size_t)m * N + slab * 16 + 4 * g;
         const f32x4 pv = f32x4{v[0], v[1], v[2], v[3]};
-        if (f32out == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(pv) : "memory");
+        if (f32out == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(pv) : "memory");  // (s_nop: as in awq_gemm_v6.hip -- a > 64-bit store the compiler cannot see; its data registers must survive two more issue slots)
         else *reinterpret_cast<f32x4*>(dst) = pv;
       }
     } else if (slab < nslab && m < M) {

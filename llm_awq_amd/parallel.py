@@ -168,8 +168,14 @@ class TPWQLinear(nn.Module):
         self._reducer = reducer
 
     def _reduce_round(self, y32, dtype):
-        """fp32 partial -> T(sum over ranks) + bias"""
+        """fp32 partial -> T(sum over ranks) + bias.  Small messages (decode): the one-shot reducer / one all-reduce on the fp32 partial.  From
+        RS_AG_MIN_BYTES (prompts: 64 MiB of fp32 at 2048 rows x 8192) the sum is taken as reduce-scatter(fp32) -> round once to T (+ bias) on the
+        rank's own rows -> all-gather(T): the same single rounding, 25 % fewer bytes on the links than an fp32 all-reduce."""
         import torch.distributed as dist
+        if self.world > 1 and y32.numel() * 4 >= RS_AG_MIN_BYTES and (self._reducer is None or hasattr(self._reducer, "reduce_f32")):
+            y = reduce_scatter_round_gather(y32, dtype, self.bias, self._round_rows, dist, self.group, self.world)
+            if y is not None:
+                return y
         if self._reducer is not None and hasattr(self._reducer, "reduce_f32"):
             return self._reducer.reduce_f32(y32, dtype, self.bias)
         if self.world > 1:
@@ -178,6 +184,11 @@ class TPWQLinear(nn.Module):
             else:
                 dist.all_reduce(y32, op=dist.ReduceOp.SUM, group=self.group)
         return self._round_bias(y32, dtype)
+
+    def _round_rows(self, y32_rows, dtype, bias):
+        """T(fp32 rows) + bias in T on a row block of the sum (the reduce-scatter path's middle step): awq_round_bias_f32"""
+        from . import ops
+        return ops.round_bias_f32(y32_rows, dtype, bias)
 
     def _round_bias(self, y32, dtype):
         """T(fp32 sum) + bias in T: awq_round_bias_f32"""
@@ -226,6 +237,32 @@ class TPWQLinear(nn.Module):
         loops call this at their own sync points (once per generated token is enough)."""
         if self._reducer is not None and hasattr(self._reducer, "check"):
             self._reducer.check()
+
+
+RS_AG_MIN_BYTES = 1 << 20  # fp32 partials from this size on are summed by reduce-scatter -> round -> all-gather (below: latency-bound, one all-reduce)
+
+
+def reduce_scatter_round_gather(y32, dtype, bias, round_rows, dist, group, world):
+    """[..., N] fp32 partial of every rank -> [..., N] T(sum over ranks) (+ bias) on every rank:
+       reduce-scatter the fp32 partials over row blocks (rank r ends up with the fp32 SUM of rows [r R, (r + 1) R)), round that block once to T and
+       add the bias (`round_rows`: awq_round_bias_f32 on the GPU), all-gather the T blocks.  Bytes per rank on the links: (w - 1) / w x (4 + 2) per
+       element against 2 (w - 1) / w x 4 of a ring all-reduce in fp32; the numerics are the all-reduce path's (fp32 sum, ONE rounding, bias in T).
+       Rows are padded to a multiple of the world size.  Returns None when the layout does not allow it (no rows to split)."""
+    n = y32.shape[-1]
+    flat = y32.reshape(-1, n)
+    m = flat.shape[0]
+    if m < world:
+        return None
+    rows = (m + world - 1) // world
+    if rows * world != m:
+        pad = torch.zeros(rows * world - m, n, dtype=flat.dtype, device=flat.device)
+        flat = torch.cat([flat, pad], 0)
+    mine = torch.empty(rows, n, dtype=torch.float32, device=flat.device)
+    dist.reduce_scatter_tensor(mine, flat.contiguous(), op=dist.ReduceOp.SUM, group=group)
+    block = round_rows(mine, dtype, bias)
+    out = torch.empty(rows * world, n, dtype=dtype, device=flat.device)
+    dist.all_gather_into_tensor(out, block.contiguous(), group=group)
+    return out[:m].reshape(*y32.shape[:-1], n)
 
 
 _REDUCERS = {}  # id(group) -> (weakref to the group or None, reducer): an entry whose group object died is rebuilt, never reused
@@ -304,7 +341,12 @@ def _make_pass(eng, shards, xs, reducer, dist, world):
             if mode == "row":
                 # K shard: fp32 partial -> sum over ranks in fp32 -> ONE rounding to T (TPWQLinear.forward's path, no module overhead)
                 y32 = ops.partial_cdna4(x, qw, szp, szh)
-                if reducer is not None:
+                y = None
+                if world > 1 and y32.numel() * 4 >= RS_AG_MIN_BYTES:  # prompts: reduce-scatter(fp32) -> one rounding -> all-gather(T), as TPWQLinear does
+                    y = reduce_scatter_round_gather(y32, x.dtype, None, ops.round_bias_f32, dist, None, world)
+                if y is not None:
+                    pass
+                elif reducer is not None:
                     y = reducer.reduce_f32(y32, x.dtype)
                 else:
                     if world > 1:
@@ -425,44 +467,78 @@ def run_tp_bench(args, eng, dist, rank, world, dev, shapes, algo_bytes):
                 xs[kl] = torch.randn(M, kl, device=dev, generator=g).to(dtype)
         return xs
 
+    def local_ms(run_pass, steps, warmup):
+        """rank-local timing (no collective inside): graph replay where it captures"""
+        side = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(side):
+            run_pass()
+            torch.cuda.synchronize()
+            gr = None
+            if not args.no_graph:
+                try:
+                    gr = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gr, stream=side):
+                        keep = run_pass()  # noqa: F841
+                except Exception:  # noqa: BLE001
+                    gr = None
+                    torch.cuda.synchronize()
+            step = (lambda: gr.replay()) if gr is not None else run_pass
+            for _ in range(max(warmup, _CLOCK_RAMP_STEPS)):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) * 1e3 / steps
+
     def measure(reducer):
-        # ---------------- Llama-3-8B decode: the headline line ----------------
+        # ---------------- Llama-3-70B TP (BASELINE.json configs[3]): the HEADLINE of the N > 1 line -- decode M = 1 (K timed steps), prefill M = 2048 beside it ----------------
+        L70 = max(1, int(os.environ.get("AWQ_BENCH_TP70B_LAYERS", "8")))
+        sh70 = _build_shards(eng, _block(synth.LLAMA3_70B), L70, shard_world, rank, dev, dtype, seed0=1 << 20)
+        b70 = sum(algo_bytes(1, kl, nl) for (_nm, kl, nl, *_r) in sh70)
+        launches70 = len(sh70)
+        d_ms, d_graph = _timed(_make_pass(eng, sh70, make_xs(sh70, 1), reducer, dist, world), args.steps, args.warmup, dist, dev, not args.no_graph, rank)
+        Mp = 2048
+        p_ms, _pg = _timed(_make_pass(eng, sh70, make_xs(sh70, Mp), reducer, dist, world), 2, 1, dist, dev, False, rank)
+        flops_rank = sum(2.0 * Mp * kl * nl for (_nm, kl, nl, *_r) in sh70)
+        tp70 = {"workload": f"Llama-3-70B W4A16 g128 bf16, {L70} of 80 decoder blocks timed, tensor parallel over {world} GPUs"
+                            + (f" (shard shapes of a {shard_world}-way split)" if shard_world != world else ""),
+                "layers_timed": L70, "ms_per_step_timed_layers": d_ms, "graph": d_graph, "launches_per_step": launches70, "bytes_rank": b70,
+                "decode": {"m": 1, "ms_per_step_80_layers": round(d_ms * 80 / L70, 4), "tok_s": round(1e3 / (d_ms * 80 / L70), 2), "graph": d_graph,
+                           "hbm_gbs_per_gpu": round(b70 / (d_ms * 1e-3) / 1e9, 1), "hbm_frac_per_gpu": round(b70 / (d_ms * 1e-3) / 1e9 / 8000.0, 4),
+                           "allreduce_bytes": 8192 * 4, "allreduces_per_token": 2 * 80},
+                "prefill": {"m": Mp, "ms_per_pass_80_layers": round(p_ms * 80 / L70, 3), "tok_s": round(Mp / (p_ms * 80 / L70 * 1e-3), 1),
+                            "mfma_tflops_per_gpu": round(flops_rank / (p_ms * 1e-3) / 1e12, 1),
+                            "mfma_frac_per_gpu": round(flops_rank / (p_ms * 1e-3) / 1e12 / 2500.0, 4),
+                            "reduction": "reduce-scatter (fp32) -> one rounding -> all-gather (T)" if world > 1 and Mp * 8192 * 4 >= RS_AG_MIN_BYTES else "all-reduce (fp32) -> one rounding",
+                            "allreduce_bytes": Mp * 8192 * 4, "allreduces_per_pass": 2 * 80}}
+        del sh70
+        torch.cuda.empty_cache()
+        # the SAME workload on ONE GPU (rank 0 alone, unsharded shapes, no collective): the N = 1 point of this line's own scaling curve
+        if world > 1 and shard_world == world and os.environ.get("AWQ_BENCH_N1_REF", "1") != "0":
+            if rank == 0:
+                sh1 = _build_shards(eng, _block(synth.LLAMA3_70B), L70, 1, 0, dev, dtype, seed0=1 << 20)
+                ms1 = local_ms(_make_pass(eng, sh1, make_xs(sh1, 1), None, dist, 1), max(5, args.steps // 2), max(2, args.warmup // 2))
+                tp70["one_gpu_reference"] = {"note": "the unsharded 70B shapes on rank 0's GPU alone, same layers, same kernels, measured in this run",
+                                             "decode_tok_s": round(1e3 / (ms1 * 80 / L70), 2), "ms_per_step_80_layers": round(ms1 * 80 / L70, 4)}
+                del sh1
+                torch.cuda.empty_cache()
+            dist.barrier()
+
+        # ---------------- Llama-3-8B decode under the same sharding (the N = 1 line's model; 64 all-reduces of 8 KiB per token: latency bound) ----------------
         shards = _build_shards(eng, _block(synth.LLAMA3_8B), L, shard_world, rank, dev, dtype)
-        ms_per_step, graphed = _timed(_make_pass(eng, shards, make_xs(shards, 1), reducer, dist, world), args.steps, args.warmup, dist, dev,
-                                      not args.no_graph, rank)
+        ms_per_step, graphed = _timed(_make_pass(eng, shards, make_xs(shards, 1), reducer, dist, world), max(5, args.steps // 2), max(2, args.warmup // 2),
+                                      dist, dev, not args.no_graph, rank)
         bytes_rank = sum(algo_bytes(1, kl, nl) for (_nm, kl, nl, *_r) in shards)
         gbs_rank = bytes_rank / (ms_per_step * 1e-3) / 1e9
         launches = len(shards)
         del shards
         torch.cuda.empty_cache()
 
-        # ---------------- Llama-3-70B TP (BASELINE.json configs[3]): decode M = 1 and prefill M = 2048 ----------------
-        tp70 = None
-        L70 = int(os.environ.get("AWQ_BENCH_TP70B_LAYERS", "8"))
-        if L70 > 0:
-            sh70 = _build_shards(eng, _block(synth.LLAMA3_70B), L70, shard_world, rank, dev, dtype, seed0=1 << 20)
-            b70 = sum(algo_bytes(1, kl, nl) for (_nm, kl, nl, *_r) in sh70)
-            d_ms, d_graph = _timed(_make_pass(eng, sh70, make_xs(sh70, 1), reducer, dist, world), max(5, args.steps // 2), max(2, args.warmup // 2),
-                                   dist, dev, not args.no_graph, rank)
-            Mp = 2048
-            p_ms, _pg = _timed(_make_pass(eng, sh70, make_xs(sh70, Mp), reducer, dist, world), 2, 1, dist, dev, False, rank)
-            flops_rank = sum(2.0 * Mp * kl * nl for (_nm, kl, nl, *_r) in sh70)
-            tp70 = {"workload": f"Llama-3-70B W4A16 g128 bf16, {L70} of 80 decoder blocks timed, tensor parallel over {world} GPUs"
-                                + (f" (shard shapes of a {shard_world}-way split)" if shard_world != world else ""),
-                    "layers_timed": L70,
-                    "decode": {"m": 1, "ms_per_step_80_layers": round(d_ms * 80 / L70, 4), "tok_s": round(1e3 / (d_ms * 80 / L70), 2), "graph": d_graph,
-                               "hbm_gbs_per_gpu": round(b70 / (d_ms * 1e-3) / 1e9, 1), "hbm_frac_per_gpu": round(b70 / (d_ms * 1e-3) / 1e9 / 8000.0, 4),
-                               "allreduce_bytes": 8192 * 4, "allreduces_per_token": 2 * 80},
-                    "prefill": {"m": Mp, "ms_per_pass_80_layers": round(p_ms * 80 / L70, 3), "tok_s": round(Mp / (p_ms * 80 / L70 * 1e-3), 1),
-                                "mfma_tflops_per_gpu": round(flops_rank / (p_ms * 1e-3) / 1e12, 1),
-                                "mfma_frac_per_gpu": round(flops_rank / (p_ms * 1e-3) / 1e12 / 2500.0, 4),
-                                "allreduce_bytes": Mp * 8192 * 4, "allreduces_per_pass": 2 * 80}}
-            del sh70
-            torch.cuda.empty_cache()
-
         ar = {"kind": "oneshot (peer-mapped exchange buffers, csrc/awq_oneshot.hip) for <= 64 KiB, RCCL above" if reducer is not None
                       else "rccl (torch.distributed.all_reduce)",
-              "rccl_ranks": world, "per_step": 2 * L,
+              "rccl_ranks": world, "per_step": 2 * 80,
               "decode_8b": _allreduce_record(dist, reducer, dev, world, 4096, dtype),
               "decode_70b": _allreduce_record(dist, reducer, dev, world, 8192, dtype),
               "prefill_70b_m2048": _allreduce_record(dist, reducer, dev, world, 2048 * 8192, dtype, iters=10),
@@ -482,20 +558,29 @@ def run_tp_bench(args, eng, dist, rank, world, dev, shapes, algo_bytes):
         reducer.close()
         ms_per_step, graphed, gbs_rank, launches, bytes_rank, tp70, ar, _t = measure(None)
         ar["oneshot"] = "timed out on this box: figures above are RCCL"
-    return {"metric": "W4A16 decode+prefill tok/s, Llama-3-8B; achieved %HBM (GEMV) / %MFMA (GEMM)",
-            "value": round(1e3 / ms_per_step * (L / 32), 2),
-            "unit": "decode tok/s (the 160 quantised linears of one token: 32 x {qkv, o, gate, up, down}; attention/norm/lm_head off-path)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+    L70, d_ms = tp70["layers_timed"], tp70.pop("ms_per_step_timed_layers")
+    b70, launches70 = tp70.pop("bytes_rank"), tp70.pop("launches_per_step")
+    gbs70 = b70 / (d_ms * 1e-3) / 1e9
+    return {"metric": "W4A16 decode+prefill tok/s, Llama-3-70B TP over xGMI (BASELINE.json config 4); achieved %HBM (GEMV) / %MFMA (GEMM) per GPU",
+            "value": round(1e3 / (d_ms * 80 / L70), 2),
+            "unit": "decode tok/s of the whole job (the 400 quantised linears of one Llama-3-70B token: 80 x {qkv, o, gate, up, down}; attention/norm/lm_head off-path; "
+                    f"{L70} of 80 blocks timed, scaled)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(d_ms, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"Llama-3-8B W4A16 g128 bf16, decode M=1, tensor parallel over {world} GPUs "
-                                   "(qkv and gate/up N-sharded, o/down K-sharded + all-reduce)",
-                       "layers": L, "decode_m": 1, "graph": graphed, "layout": "cdna4",
-                       "fused_gate_up_silu_mul": True, "launches_per_token": launches, "parallelism": f"tp{world}",
-                       "allreduces_per_step": 2 * L,
+            "config": {"workload": f"Llama-3-70B W4A16 TP={world} over xGMI (column-sharded WQLinear + RCCL all-reduce): qkv and gate/up N-sharded, "
+                                   "o / down K-sharded, fp32 partials summed over the ranks and rounded once",
+                       "layers_timed": L70, "layers_model": 80, "decode_m": 1, "graph": tp70["graph"], "layout": "cdna4",
+                       "fused_gate_up_silu_mul": True, "launches_per_step": launches70, "parallelism": f"tp{world}",
+                       "allreduces_per_step": 2 * L70,
+                       "n1_line": "the N = 1 line of this script times Llama-3-8B on one GPU (BASELINE.json config 2); `tp70b.one_gpu_reference` is THIS workload on one GPU",
                        **({"shard_world": shard_world, "note": "shard shapes of a larger split timed on fewer ranks: a compute floor, not a scaling point"} if shard_world != world else {})},
             "allreduce": ar,
-            **({"tp70b": tp70} if tp70 is not None else {}),
-            "roofline": {"bound": "hbm", "kernel": "awq::gemv_dma_kernel", "achieved": round(gbs_rank, 1),
-                         "peak": 8000.0, "unit": "GB/s per GPU (incl. all-reduce time)", "frac": round(gbs_rank / 8000.0, 4),
+            "tp70b": tp70,
+            "llama3_8b_tp": {"workload": f"Llama-3-8B W4A16 g128 bf16, decode M=1, tensor parallel over {world} GPUs (same sharding)",
+                             "layers": L, "decode_tok_s": round(1e3 / ms_per_step * (L / 32), 2), "ms_per_step": round(ms_per_step, 4), "graph": graphed,
+                             "launches_per_token": launches, "allreduces_per_step": 2 * L,
+                             "hbm_gbs_per_gpu": round(gbs_rank, 1), "hbm_frac_per_gpu": round(gbs_rank / 8000.0, 4)},
+            "roofline": {"bound": "hbm", "kernel": "awq::gemv_dma_kernel", "achieved": round(gbs70, 1),
+                         "peak": 8000.0, "unit": "GB/s per GPU (incl. all-reduce time)", "frac": round(gbs70 / 8000.0, 4),
                          "traffic": None},
             "device": torch.cuda.get_device_name(dev)}

@@ -136,13 +136,18 @@ def check_forward(y_gpu: torch.Tensor, x, q, scales, scaled_zeros, dtype, bias=N
     `x_unc` [M, K] (fused-norm callers): absolute uncertainty of the activations the kernel really multiplied -- elements of
     the normalised x whose rounding to T depends on the last fp32 bits of rstd.  It widens (1) by x_unc @ |W|^T and (3) by the
     flips that slack can cause; (2) is unchanged."""
+    return check_forward_rows(y_gpu, forward_oracle(x, q, scales, scaled_zeros, dtype, bias=bias, x_unc=x_unc))
+
+
+def forward_oracle(x, q, scales, scaled_zeros, dtype, bias=None, x_unc=None):
+    """the oracle side of check_forward for ALL rows of x, computed once: output rows are independent, so a test that runs several row counts m on the
+    first m rows of one x checks each result against the first m rows of this (check_forward_rows)"""
     Wd = _dequant_f64(q, scales, scaled_zeros)
     K = x.shape[-1]
     x2 = x.reshape(-1, K)
     y64 = x2.double() @ Wd.t()
     S = x2.double().abs() @ Wd.abs().t()
     Q = ((x2.double() ** 2) @ (Wd ** 2).t()).sqrt()
-    yg = y_gpu.reshape(y64.shape).double()
     u = ulp(y64, dtype)
     bound = 0.501 * u + 2e-6 * S + 1e-30
     acc = (2.0 ** -24) * (math.sqrt(K) / 4.0 + 1.0) * Q
@@ -154,12 +159,20 @@ def check_forward(y_gpu: torch.Tensor, x, q, scales, scaled_zeros, dtype, bias=N
         y64 = y64 + bias.double()
         u = torch.minimum(u, ulp(y64, dtype))
         bound = bound + 0.501 * ulp(y64, dtype) + ulp(y64, dtype) * 0.5
-    err = (yg - y64).abs()
-    worst = (err / bound).max().item()
-    assert worst <= 1.0, f"elementwise bound violated: worst err/bound = {worst}"
     # BASELINE.json: "<= 1e-3 rel on the fp16/bf16 matmul result" -- norm-wise against the oracle's T-rounded
     # output (the final rounding to bf16 alone is ~1.1e-3 rms per element, so it must be on both sides)
     y_or = O.wqlinear_forward(x, None, scales, scaled_zeros, bias, 128, q_int=q).reshape(y64.shape).double()
+    return dict(y64=y64, bound=bound, acc=acc, u=u, y_or=y_or)
+
+
+def check_forward_rows(y_gpu: torch.Tensor, pre, rows=None):
+    """y_gpu = the kernel's result for the first `rows` rows of the x `pre` (forward_oracle) was built from (default: all)"""
+    n = pre["y64"].shape[0] if rows is None else rows
+    y64, bound, acc, u, y_or = (pre[k][:n] for k in ("y64", "bound", "acc", "u", "y_or"))
+    yg = y_gpu.reshape(y64.shape).double()
+    err = (yg - y64).abs()
+    worst = (err / bound).max().item()
+    assert worst <= 1.0, f"elementwise bound violated: worst err/bound = {worst}"
     rel = ((yg - y_or).norm() / y_or.norm()).item()
     assert rel <= 1e-3, rel
     count = int((y_or != yg).sum().item())
@@ -203,6 +216,10 @@ def oracle_tp_linear(full, mode, rounded_partials=False, **kw):
         def _round_bias(self, y32, dtype):
             y = y32.to(dtype)
             return y + self.bias if self.bias is not None else y
+
+        def _round_rows(self, y32_rows, dtype, bias):
+            y = y32_rows.to(dtype)
+            return y + bias if bias is not None else y
 
     return OracleTPWQLinear(full, mode, **kw)
 

@@ -72,8 +72,8 @@ def test_engine_module_exports():
 
 
 def test_prefill_routing_and_workspace_rule_without_gpu():
-    """awq_w4a16_forward_cdna4_workspace_bytes is pure host logic: which m the prefill GEMM takes (m >= 256, or a shorter prompt
-    with m >= 72 and m * K >= 0.6 M), and how many K ranges an under-filled launch is split into."""
+    """awq_w4a16_forward_cdna4_workspace_bytes is pure host logic: which kernel family takes m rows (decode <= 8, skinny <= 64, mid-M 65 .. 192, tiles above)
+    and how many K parts / ranges an under-filled launch is split into."""
     L = _capi.lib()
     q = L.awq_w4a16_forward_cdna4_workspace_bytes
     tile = 256 * 128 * 4
@@ -82,11 +82,18 @@ def test_prefill_routing_and_workspace_rule_without_gpu():
         assert q(m, n, k) == 0, (m, n, k)
     # the skinny launch's two K parts where its grid leaves half the chip idle (33 .. 64 rows per pass from K = 4096; 17 .. 32 rows from K = 8192; narrower than
     # ~272 slabs): fp32 [2][rows of a pass][n]
-    assert q(64, 4096, 14336) == 2 * 64 * 4096 * 4 and q(71, 4096, 14336) == 2 * 36 * 4096 * 4 and q(40, 4096, 8192) == 2 * 40 * 4096 * 4
-    assert q(64, 4096, 4096) == 2 * 64 * 4096 * 4 and q(128, 4096, 4096) == 2 * 64 * 4096 * 4 and q(32, 4096, 14336) == 2 * 32 * 4096 * 4
+    assert q(64, 4096, 14336) == 2 * 64 * 4096 * 4 and q(40, 4096, 8192) == 2 * 40 * 4096 * 4
+    assert q(64, 4096, 4096) == 2 * 64 * 4096 * 4 and q(32, 4096, 14336) == 2 * 32 * 4096 * 4
     assert q(64, 6144, 4096) == 0 and q(64, 4096, 4096 + 128) == 0  # (384 slabs: two parts would be 1.5 rounds of blocks; an odd number of k-steps does not split)
-    # under-filled launches: whole partial tiles, 2..16 K ranges, at least 2 quantisation groups per range
-    for (m, n, k) in ((72, 4096, 14336), (128, 4096, 14336), (147, 4096, 4096), (256, 4096, 4096), (512, 4096, 14336), (1024, 4096, 4096),
+    # 65 .. 192 rows (129 .. 192 against n < 16384 only): the mid-M kernel -- K parts that fill the chip with blocks of 8 (4) slabs, fp32 [parts][rows of a pass][n]
+    assert q(71, 4096, 14336) == 8 * 71 * 4096 * 4 and q(128, 4096, 14336) == 8 * 128 * 4096 * 4  # down_proj: 32 groups of eight slabs x 8 parts of 14 k-steps
+    assert q(128, 4096, 4096) == 4 * 128 * 4096 * 4    # o_proj: eight parts of eight-slab groups would be 4 k-steps each -> four waves: 64 groups x 4 parts of 8
+    assert q(96, 6144, 4096) == 4 * 96 * 6144 * 4      # qkv: 48 groups x 4 parts
+    assert q(100, 28672, 4096) == 0                    # the gate/up pair fills the chip unsplit (224 groups)
+    assert q(147, 4096, 4096) == 4 * 74 * 4096 * 4     # two passes of 74 rows share the scratch
+    assert q(160, 28672, 4096) == 0                    # (129 .. 255 rows against a wide n: the tile kernels, full rounds: no scratch)
+    # under-filled launches of the tile kernels: whole partial tiles, 2..16 K ranges, at least 2 quantisation groups per range
+    for (m, n, k) in ((200, 4096, 14336), (255, 4096, 4096), (256, 4096, 4096), (512, 4096, 14336), (1024, 4096, 4096),
                       (256, 1024, 8192), (300, 6144, 4096)):
         b = q(m, n, k)
         tiles = ((m + 255) // 256) * ((n + 127) // 128)
@@ -102,10 +109,15 @@ def test_prefill_routing_and_workspace_rule_without_gpu():
     try:
         assert L.awq_tune_set(b"gemm_splitk", 0) == 0 and q(256, 4096, 4096) == 0
         assert L.awq_tune_set(b"gemm_splitk", 5) == 0 and q(256, 4096, 14336) == 32 * 5 * tile
-        assert L.awq_tune_set(b"gemm_splitk", 1) == 0 and L.awq_tune_set(b"gemm_small_m", 0) == 0 and q(128, 4096, 14336) == 2 * 64 * 4096 * 4  # (the skinny launch then takes it: two 64-row passes, two K parts)
+        # knob midm = 0: the round-5 routing (the masked 256-row tile from 72 rows x K >= 8 k; knob gemm_small_m = 0: the skinny launch in 64-row passes, two K parts)
+        assert L.awq_tune_set(b"gemm_splitk", 1) == 0 and L.awq_tune_set(b"midm", 0) == 0
+        b = q(128, 4096, 14336)
+        assert b > 0 and b % (32 * tile) == 0
+        assert L.awq_tune_set(b"gemm_small_m", 0) == 0 and q(128, 4096, 14336) == 2 * 64 * 4096 * 4 and q(71, 4096, 14336) == 2 * 36 * 4096 * 4
     finally:
         L.awq_tune_set(b"gemm_splitk", 1)
         L.awq_tune_set(b"gemm_small_m", 1)
+        L.awq_tune_set(b"midm", 1)
 
 
 def test_prefill_tile_plan_for_the_llama3_shapes():

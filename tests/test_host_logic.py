@@ -116,3 +116,25 @@ def test_no_undefined_names_in_the_python_sources():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_undefined_names.py")], cwd=root, capture_output=True, text=True)
     lines = [ln for ln in r.stdout.splitlines() if "undefined name" in ln and "__file__" not in ln]
     assert not lines, lines
+
+
+def test_bench_launches_itself_for_n_gpus():
+    """`python bench.py --gpus 2` as the driver types it (no launcher, WORLD_SIZE unset) re-executes under torch.distributed.run with one rank per GPU on
+    127.0.0.1; --launch-check makes every rank print what it was handed and exit before touching a GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    cmd = bench.launcher_command(4, ["--gpus", "4", "--steps", "3"], port=29999)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    assert cmd[-5:] == [os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "3"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    recs = sorted((json.loads(line)["launch_check"] for line in r.stdout.splitlines() if line.startswith('{"launch_check"')), key=lambda d: d["rank"])
+    assert [d["rank"] for d in recs] == [0, 1] and all(d["world"] == 2 and d["master_addr"] == "127.0.0.1" and d["ipc_legacy"] == "0" for d in recs)
+    assert [d["local_rank"] for d in recs] == [0, 1]

@@ -88,6 +88,59 @@ def test_tp2_row_and_column_parallel_gloo(dtype_name):
         assert rel <= rel_old + 1e-7, (rel, rel_old)  # never worse than T-rounded partials
 
 
+def _worker_rs_ag(rank, world, port, dtype_name, result_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from llm_awq_amd.qmodule import WQLinear
+        from oracle import awq_oracle as O
+        from tests.helpers import Gen, oracle_tp_linear
+
+        dtype = getattr(torch, dtype_name)
+        K, N = 1280, 96
+        g = Gen(17)
+        d = O.quantize_linear(g.randn(N, K) * 0.02, dtype=dtype)
+        full = WQLinear(4, 128, K, N, True, "cpu", dtype=dtype)
+        full.qweight, full.scales, full.scaled_zeros = d["qweight"], d["scales"], d["scaled_zeros"]
+        full.bias = (g.randn(N) * 0.02).to(dtype)
+        row = oracle_tp_linear(full, "row")
+        out = []
+        for M in (1, 7, 64):  # 1 row: fewer rows than ranks -> the all-reduce path; 7: rows padded to a multiple of the world; 64: even blocks
+            x = g.randn(M, K).to(dtype)
+            ref = O.wqlinear_forward(x, d["qweight"], d["scales"], d["scaled_zeros"], full.bias, 128).float()
+            P.RS_AG_MIN_BYTES = 1 << 40
+            y_ar = row(x)                      # all-reduce of the fp32 partial, one rounding
+            P.RS_AG_MIN_BYTES = 1
+            y_rs = row(x.reshape(1, M, K))     # reduce-scatter(fp32) -> round (+ bias) -> all-gather(T), leading dims kept
+            assert y_rs.shape == (1, M, N) and y_rs.dtype == dtype
+            out.append((M, ((y_rs.float().reshape(M, N) - ref).norm() / ref.norm()).item(), torch.equal(y_rs.reshape(M, N), y_ar)))
+        result_q.put((rank, out))
+    finally:
+        P.RS_AG_MIN_BYTES = 1 << 20
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
+def test_tp2_reduce_scatter_round_all_gather_gloo(dtype_name):
+    """the prefill-sized reduction of a K-sharded layer: reduce-scatter in fp32, ONE rounding on the rank's row block, all-gather
+    in T -- against the single-device oracle at 1e-3 and bit-identical to the fp32 all-reduce path (two ranks: the same two-term sums)"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_rs_ag, args=(r, world, port, dtype_name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _rank, out in res:
+        for (M, rel, same) in out:
+            assert rel < 1e-3, (M, rel)
+            assert same, M
+
+
 def test_shard_bounds():
     assert [P.shard_bounds(14336, 8, r, 128) for r in (0, 7)] == [(0, 1792), (12544, 14336)]
     assert P.shard_bounds(11008, 8, 0, 128) == (0, 1408) and P.shard_bounds(11008, 8, 7, 128) == (9728, 11008)
