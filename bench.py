@@ -125,8 +125,6 @@ def main():
     ap.add_argument("--launch-check", action="store_true", help="print what the launcher handed this rank (RANK / WORLD_SIZE / MASTER_*) and exit: no GPU touched")
     ap.add_argument("--tune", action="append", default=[], help="experiments only: awq_tune_set knobs as key=value")
     ap.add_argument("--layout", default="cdna4", choices=["cdna4", "v2"], help="cdna4 = what the rewritten repacker emits (default); v2 = reference checkpoint layout through gemv/gemm_forward_cuda_new only")
-    ap.add_argument("--mlp-decode", default="two", choices=["one", "two"],
-                    help="decode, --mlp interleaved: QuantLlamaMLP.forward as the fused gate/up launch followed by down_proj's (default: faster), or as ONE persistent launch (awq_w4a16_mlp_decode_cdna4, csrc/awq_mlp_engine.hip: per-wave LDS-DMA rings running ahead across the op edge, granule all-gather of h; measured slower: profiles/r05_mlp_engine.txt)")
     ap.add_argument("--overlap-probe", type=int, default=0, help="experiments (NOT a valid decode figure): issue the decode launches round-robin on this many streams inside the graph, i.e. drop the dependency between consecutive linears -- the upper bound of what cross-launch overlap could give")
     ap.add_argument("--repeat-layers", type=int, default=1, help="experiments: run the --layers layers this many times per step (with --layers 1/2 the weights stay in the 256 MB Infinity Cache)")
     ap.add_argument("--mlp", default="interleaved", choices=["interleaved", "stacked", "unfused"],
@@ -156,6 +154,9 @@ def main():
     if world > 1 or force_tp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force_tp and "WORLD_SIZE" not in os.environ:  # (no launcher around a world-1 run: the env:// rendezvous still wants its variables)
+            os.environ.update({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
+            os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", device_id=dev)
 
     import llm_awq_amd
@@ -211,10 +212,6 @@ def main():
     torch.cuda.synchronize()
 
     probe_streams = [torch.cuda.Stream(device=dev) for _ in range(args.overlap_probe)] if args.overlap_probe > 1 else []
-    one_launch_mlp = args.layout == "cdna4" and args.mlp == "interleaved" and args.mlp_decode == "one" and args.sz == "half"
-    # state of the one-launch MLP (epoch + the granule array of h): launches on one stream are ordered, so the layers share it
-    mlp_state = torch.zeros((eng.mlp_decode_state_bytes(1, 14336) + 3) // 4, dtype=torch.int32, device=dev) if one_launch_mlp else None
-
     def run_native(xs):
         outs = []
         decode = xs[4096].numel() <= 8 * 4096
@@ -225,16 +222,7 @@ def main():
             for st in probe_streams:
                 st.wait_event(ev)
         seq = nat * (args.repeat_layers if decode else 1)
-        skip = False
         for li, (name, K, N, qw, s, z, szp, szh, epi) in enumerate(seq):
-            if skip:  # down_proj: done inside the one-launch MLP
-                skip = False
-                continue
-            if one_launch_mlp and xs[K].numel() == K and not probe_streams and epi == 2 and szh is not None and seq[li + 1][0] == "down" and seq[li + 1][7] is not None:
-                dn = seq[li + 1]
-                outs.append(eng.mlp_decode_cdna4(xs[K], qw, szh, dn[3], dn[7], mlp_state, None))   # QuantLlamaMLP.forward, one row
-                skip = True
-                continue
             if probe_streams and decode:
                 with torch.cuda.stream(probe_streams[li % len(probe_streams)]):
                     outs.append(eng.mlp_gate_up_forward_cdna4(xs[K], qw, szp, szh) if epi == 2 else eng.decode_cdna4(xs[K], qw, szh, None, epi))
@@ -386,17 +374,17 @@ def main():
     # ---------------- decode leg: K timed steps ----------------
     wall_ms, ev_ms, graphed = timed_decode(run_main, args.steps, args.warmup, not args.no_graph)
     ms_per_step = wall_ms / args.steps
-    launches = (len(nat) - (L if one_launch_mlp else 0)) * args.repeat_layers if native_leg else len(raw)
+    launches = len(nat) * args.repeat_layers if native_leg else len(raw)
     bytes_step = bytes_native(1) * args.repeat_layers if native_leg else sum(algo_bytes(1, K, N) for (_n, K, N, *_r) in raw)
     avg_launch_us = ev_ms * 1e3 / (args.steps * launches)
     gbs = bytes_step * args.steps / (ev_ms * 1e-3) / 1e9
-    kname = ("awq::gemv_dma_kernel (qkv, o) + awq::mlp_engine_kernel (gate/up + SiLU*mul + down, one persistent launch)" if one_launch_mlp else "awq::gemv_dma_kernel") if native_leg else "awq::gemv_dma_kernel (via gemv_forward_cuda_new + the engine's repack cache)"
-    traffic, traffic_src = pmc_traffic(["awq::gemv_dma_kernel", "awq::gemv_cdna4_kernel", "awq::mlp_engine_kernel"])
+    kname = "awq::gemv_dma_kernel" if native_leg else "awq::gemv_dma_kernel (via gemv_forward_cuda_new + the engine's repack cache)"
+    traffic, traffic_src = pmc_traffic(["awq::gemv_dma_kernel", "awq::gemv_cdna4_kernel"])
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_us": round(avg_launch_us, 3), "algorithmic_bytes_per_launch": bytes_step // launches,
                 "launches_per_step": launches, "timing": "hip events on the launch stream over the timed region"}
-    if native_leg and graphed and not one_launch_mlp and not probe_streams and args.repeat_layers == 1:
+    if native_leg and graphed and not probe_streams and args.repeat_layers == 1:
         roofline["per_kernel"] = per_kernel_decode(max(5, args.steps // 2), max(2, args.warmup // 2))
     tok_s = 1e3 / ms_per_step * (L * args.repeat_layers / LAYERS)  # tokens/s of a full 32-layer model
 
@@ -409,7 +397,7 @@ def main():
                       "layers": L, "decode_m": 1, "prefill_m": args.prefill_m, "graph": graphed,
                       "layout": args.layout,
                       "clock_ramp_steps": max(CLOCK_RAMP_STEPS, args.warmup),
-                      "decode_mlp": ("one launch per QuantLlamaMLP (gate/up + SiLU*mul + down_proj)" if one_launch_mlp else "gate/up + SiLU*mul launch, then down_proj") if native_leg else "separate",
+                      "decode_mlp": "gate/up + SiLU*mul launch, then down_proj" if native_leg else "separate",
                       "prefill_mlp": "SiLU*mul fused into the gate/up GEMM epilogue" if (native_leg and args.mlp == "interleaved") else "separate",
                       "mlp": args.mlp if native_leg else "unfused (two gemv_forward_cuda_new calls, as tinychat issues them)",
                       "decode_side_buffer": ("sz_half" if args.sz == "half" else "sz_packed") if native_leg else "engine cache",

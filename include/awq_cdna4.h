@@ -128,29 +128,6 @@ int awq_w4a16_gemv_cdna4(const void* x, const void* qweight_cdna4, const void* s
 int awq_w4a16_mlp_gate_up_cdna4(const void* x, const void* qweight_gate_up, const void* sz_packed, void* out, int m,
                                 int n2, int k, int group_size, int dtype, void* stream);
 
-/* QuantLlamaMLP.forward at decode (tinychat/modules/fused_mlp.py:33-83: two gemv_forward_cuda_new + F.silu + multiply, then
- * down_proj's gemv_forward_cuda_new) in ONE persistent launch, m = 1 (csrc/awq_mlp_engine.hip): one 16-wave workgroup per CU; every wave streams
- * its own sequence of weight tiles -- its k-steps of the block's gate/up slabs (8 + 8 interleaved pair, n2 = 2 * ffn rows, K = hidden), then its
- * k-steps of the block's down_proj slab (K = ffn) -- through a wave-private LDS-DMA ring that runs ahead ACROSS the op boundary; the blocks publish
- * h = T(T(silu(gate)) * up) as 8-byte {2 x T, tag} granules, one write-through store each, and every wave gathers its own k range of h (a sweep
- * re-tried until every tag carries this launch's epoch) -- no flag, no counter, no fence on the path.  Both weights with their sz_half side buffers
- * (awq_pack_szh_cdna4 must have reported them exact).  `state`: awq_w4a16_mlp_decode_cdna4_state_bytes(m, ffn) bytes of device memory, ZERO before the
- * first call, owned by one (module, stream) at a time and never written by the caller afterwards (it carries the epoch between calls: replayed graphs
- * work); int32 [2] of it is a sticky error flag (a wave gave up waiting -- bounded spin -- and its block's outputs are NaN): the 256 workgroups must be
- * co-resident, i.e. the launch wants the whole MI355X (nothing else holding LDS on a CU); poll the word at a sync point when other streams share the device.
- * AWQ_ERR_SHAPE for shapes it does not serve (m != 1, hidden != 4096, n_out != 4096, ffn not a multiple of 128 in 128 .. 14336, a device with
- * fewer than 256 CUs): callers then issue the two launches separately. */
-#define AWQ_MLP_DECODE_COUNTER_BYTES 16384
-size_t awq_w4a16_mlp_decode_cdna4_state_bytes(int m, int ffn);
-/* host-side, no launch: 1 if awq_w4a16_mlp_decode_cdna4 serves the shape, 0 if the caller issues the two launches */
-int awq_w4a16_mlp_decode_cdna4_plan(int m, int hidden, int ffn, int n_out);
-int awq_w4a16_mlp_decode_cdna4(const void* x, const void* gate_up_qweight, const void* gate_up_sz_half, const void* down_qweight,
-                               const void* down_sz_half, const void* down_bias, void* out, int m, int hidden, int ffn, int n_out,
-                               int group_size, int dtype, void* state, void* stream);
-/* measurement only: device buffer of 256 x 16 x 8 uint64 the kernel fills with s_memtime stamps per (workgroup, wave) -- start, first tile landed,
- * gate/up phase done, h published, h gathered, down_proj phase done, end -- on every later launch; NULL (the default) switches it off */
-int awq_w4a16_mlp_decode_cdna4_set_stamps(void* device_u64);
-
 /* QuantLlamaMLP.our_llama_mlp for ANY row count (tinychat/modules/fused_mlp.py:36-83: decode = two gemv_forward_cuda_new + F.silu +
  * multiply, prefill = two gemm_forward_cuda_new + F.silu + multiply) on the pair as llm_awq_amd.fused_mlp stacks it: gate and up
  * rows interleaved 8 + 8 inside every 16-row slab (n2 = 2 * intermediate rows).  out[m, n2/2] = T(T(silu(x.Wg^T)) * (x.Wu^T)).

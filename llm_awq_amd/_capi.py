@@ -14,7 +14,6 @@ LIB_PATH = os.environ.get("AWQ_CDNA4_LIB") or os.path.join(_HERE, "lib", "libawq
 
 AWQ_F16, AWQ_BF16 = 0, 1
 AWQ_ERR_WORKSPACE = -7  # include/awq_cdna4.h
-AWQ_MLP_DECODE_COUNTER_BYTES = 16384  # include/awq_cdna4.h: the granule array of awq_w4a16_mlp_decode_cdna4's state starts here
 _lib = None
 
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
@@ -39,10 +38,6 @@ SIGNATURES = {
     "awq_w4a16_decode_cdna4": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "awq_w4a16_gemv_cdna4": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "awq_w4a16_mlp_gate_up_cdna4": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "awq_w4a16_mlp_decode_cdna4_state_bytes": (_sz, [_i, _i]),
-    "awq_w4a16_mlp_decode_cdna4_plan": (_i, [_i, _i, _i, _i]),
-    "awq_w4a16_mlp_decode_cdna4": (_i, [_vp] * 7 + [_i] * 6 + [_vp, _vp]),
-    "awq_w4a16_mlp_decode_cdna4_set_stamps": (_i, [_vp]),
     "awq_w4a16_mlp_gate_up_forward_cdna4": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "awq_w4a16_mlp_gate_up_forward_cdna4_workspace_bytes": (_sz, [_i, _i, _i]),
     "awq_w4a16_mlp_gate_up_forward_cdna4_ws": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),

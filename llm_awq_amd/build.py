@@ -25,7 +25,7 @@ EXT_PATH = os.path.join(EXT_DIR, "awq_inference_engine" + EXT_SUFFIX)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["awq_gemv.hip", "awq_gemv_cdna4.hip", "awq_gemv_dma.hip", "awq_mlp_engine.hip", "awq_v2_kernels.hip", "awq_gemm.hip", "awq_gemm_plan.hip", "awq_gemm_v4n.hip", "awq_gemm_v6.hip", "awq_skinny_cdna4.hip", "awq_midm_cdna4.hip", "awq_util.hip", "awq_oneshot.hip", "awq_capi.hip"]
+HIP_SOURCES = ["awq_gemv.hip", "awq_gemv_cdna4.hip", "awq_gemv_dma.hip", "awq_v2_kernels.hip", "awq_gemm.hip", "awq_gemm_plan.hip", "awq_gemm_v4n.hip", "awq_gemm_v6.hip", "awq_skinny_cdna4.hip", "awq_midm_cdna4.hip", "awq_util.hip", "awq_oneshot.hip", "awq_capi.hip"]
 # (round 4: the experiment kernels that AWQ_PROBES=1 builds once compiled -- v5, v6w -- are history: tools/EXPERIMENTS.md names the commits)
 PROBE_SOURCES = []
 HIP_DEPS = ["awq_device.hpp", "awq_dma.hpp", "awq_kernels.hpp", os.path.join(ROOT, "include", "awq_cdna4.h")]

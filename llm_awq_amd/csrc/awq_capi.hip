@@ -225,25 +225,6 @@ int awq_w4a16_mlp_gate_up_cdna4(const void* x, const void* qweight_gate_up, cons
   return finish_launch();
 }
 
-int awq_w4a16_mlp_decode_cdna4_plan(int m, int hidden, int ffn, int n_out) { return awq::mlp_decode_plan(m, hidden, ffn, n_out); }
-size_t awq_w4a16_mlp_decode_cdna4_state_bytes(int m, int ffn) { return m >= 1 && ffn >= 1 ? awq::mlp_decode_state_bytes(m, ffn) : 0; }
-
-int awq_w4a16_mlp_decode_cdna4(const void* x, const void* gate_up_qweight, const void* gate_up_sz_half, const void* down_qweight,
-                               const void* down_sz_half, const void* down_bias, void* out, int m, int hidden, int ffn, int n_out, int group_size,
-                               int dtype, void* state, void* stream) {
-  if (!x || !gate_up_qweight || !gate_up_sz_half || !down_qweight || !down_sz_half || !out || !state) return AWQ_ERR_NULL;
-  if (group_size != 128) return AWQ_ERR_GROUP;
-  if (dtype != AWQ_F16 && dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
-  if (m < 1 || m > 8) return AWQ_ERR_BATCH;
-  if (!aligned16(x) || !aligned16(gate_up_qweight) || !aligned16(down_qweight) || !aligned16(gate_up_sz_half) || !aligned16(down_sz_half) ||
-      !aligned16(state) || !aligned16(out) || !aligned16(down_bias))
-    return AWQ_ERR_ALIGN;
-  if (awq::launch_mlp_decode(x, gate_up_qweight, gate_up_sz_half, down_qweight, down_sz_half, down_bias, out, m, hidden, ffn, n_out, dtype, (int*)state,
-                             (hipStream_t)stream) != 0)
-    return AWQ_ERR_SHAPE;
-  return finish_launch();
-}
-
 static int g_mlp_skinny_max = 64;  // knob mlp_skinny_max: row counts up to this go to the skinny kernel's fused epilogue (8 = never)
 int awq_w4a16_mlp_gate_up_forward_cdna4(const void* x, const void* qweight_interleaved, const void* sz_packed, const void* sz_half,
                                         void* out, int m, int n2, int k, int group_size, int dtype, void* stream) {
@@ -649,16 +630,7 @@ int awq_tune_set(const char* key, int value) {
     g_mlp_skinny_max = value;
     return AWQ_OK;
   }
-  if (!strcmp(key, "mlp_engine_probe")) {  // AWQ_PROBES builds: bit 0 no math, bit 1 no weight DMA (timing only, wrong results)
-    awq::mlp_engine_set_probe(value);
-    return AWQ_OK;
-  }
   return AWQ_ERR_SHAPE;
-}
-
-int awq_w4a16_mlp_decode_cdna4_set_stamps(void* device_u64) {
-  awq::mlp_engine_set_stamps(device_u64);
-  return AWQ_OK;
 }
 
 }  // extern "C"

@@ -641,9 +641,12 @@ __global__ __launch_bounds__(256) void gemm_cdna4_v6_pair_kernel(const uint16_t*
                                                                  int tiles_m, int tiles_n, int n_begin, int n_end, int epi, float* __restrict__ ws, u32 token) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int T = tiles_m * tiles_n, per = T >> 3;  // T % 8 == 0 (launcher)
+  // partners are NEIGHBOURS in dispatch order (blocks b and b + 8: same blockIdx & 7, consecutive idx): a resident block's partner is the next block
+  // its XCD is handed, so a launch that does not own the whole chip (another stream's kernel holding CUs, a CU mask) cannot fill its CUs with lower
+  // halves that all wait for undispatched upper halves (round 5 dispatched every lower half first)
   const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
-  const bool upper = idx >= per;
-  const int tile = xcd * per + (upper ? idx - per : idx);
+  const bool upper = (idx & 1) != 0;
+  const int tile = xcd * per + (idx >> 1);
   int tm, tn;
   {
     const int full = (tiles_m >> 1) * 2 * tiles_n;

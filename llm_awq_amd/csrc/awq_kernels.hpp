@@ -114,6 +114,9 @@ size_t midm_workspace_bytes(int m, int n, int k);
 int midm_parts(int m, int n, int k);
 int midm_tune_set(const char* key, int value);
 int midm_init();
+// ticket words of an in-launch K split (zero outside a launch that uses them): `groups` words that belong to ONE launch at a time -- the lane of the stream for
+// eager launches, words of their own for launches recorded during a capture; nullptr = none available (the caller runs unsplit).  awq_midm_cdna4.hip
+unsigned* splitk_ticket_words(hipStream_t st, int groups);
 // batched decode on the same kernel (m <= 16; szfmt 1: szp = sz_half; epi 0 / 2 as launch_gemv_dma); -1 if unsupported
 int launch_skinny_decode(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int epi,
                          int dtype, int szfmt, hipStream_t st, int f32out = 0);
@@ -155,13 +158,6 @@ int launch_gemm_cdna4_v6_pair(const void* x, const void* qw, const void* szp, co
                               int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits = 4, int epi = 0, int szfmt = 0);
 void gemm_v6_set_pair_lead(int v);
 void gemm_v6_set_pair_min_nit(int v);
-// awq_mlp_engine.hip: QuantLlamaMLP.forward at decode (gate/up + SiLU * mul + down) in ONE persistent launch, m = 1; -1 if the shape is not served
-int launch_mlp_decode(const void* x, const void* qw_gu, const void* szh_gu, const void* qw_d, const void* szh_d, const void* bias_d, void* out, int m,
-                      int hidden, int ffn, int n_out, int dtype, int* state, hipStream_t st);
-size_t mlp_decode_state_bytes(int m, int ffn);
-int mlp_decode_plan(int m, int hidden, int ffn, int n_out);  // 1 = launch_mlp_decode serves the shape (host-side, no launch)
-void mlp_engine_set_stamps(void* device_u64);  // measurement: [256 blocks][16 waves][8] s_memtime stamps per launch (nullptr = off, the default)
-void mlp_engine_set_probe(int v);              // AWQ_PROBES builds: bit 0 no math, bit 1 no weight DMA
 int launch_bias_add(void* out, const void* bias, int m, int n, int dtype, hipStream_t st);
 // out[m, n] = T(in_f32) (+ bias in T); n % 8 == 0 (awq_util.hip)
 int launch_round_bias_f32(const void* in_f32, const void* bias, void* out, int m, int n, int dtype, hipStream_t st);

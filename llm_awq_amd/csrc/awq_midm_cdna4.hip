@@ -393,8 +393,11 @@ struct TicketPool {
 };
 std::mutex g_ticket_mu;
 TicketPool g_pools[64];
+}  // namespace
 
-u32* midm_tickets(hipStream_t st, int groups) {
+// (shared with the skinny kernel's K split, awq_skinny_cdna4.hip)
+
+unsigned* splitk_ticket_words(hipStream_t st, int groups) {
   int dev = 0;
   if (groups > kLaneWords || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -430,6 +433,8 @@ u32* midm_tickets(hipStream_t st, int groups) {
   tp.lane_stream[free_lane] = st;
   return tp.base + (size_t)free_lane * kLaneWords;
 }
+
+namespace {
 
 int g_midm = 1;                                     // knob midm: 0 = off (the skinny / masked-tile kernels of rounds 1-5 serve 9 .. 255 rows)
 int g_midm_min = 65, g_midm_max = 192;              // knobs midm_min / midm_max: the row counts the forward entries hand to this kernel (tests: 9 .. 255)
@@ -566,7 +571,7 @@ static int launch_midm_pass(const void* x, const void* qw, const void* szp, cons
   u32* tk = nullptr;
   if (c.ks > 1) {
     const int groups = (n / 16 + c.waves * c.ns - 1) / (c.waves * c.ns);
-    if (ws_bytes < (size_t)c.ks * m * n * sizeof(float) || (tk = midm_tickets(st, groups)) == nullptr) c.ks = 1;
+    if (ws_bytes < (size_t)c.ks * m * n * sizeof(float) || (tk = splitk_ticket_words(st, groups)) == nullptr) c.ks = 1;
   }
   float* parts = c.ks > 1 ? static_cast<float*>(ws) : nullptr;
   if (dtype == 0) return szfmt == 1 ? launch_midm_dt<F16, 1>(x, qw, szp, bias, out, parts, tk, m, n, k, c, epi, f32out, st)
@@ -593,6 +598,6 @@ int launch_midm_cdna4(const void* x, const void* qw, const void* szp, const void
 }
 
 // allocate the ticket words of the current device outside any capture / forward call (optional: the first split launch does it otherwise)
-int midm_init() { return midm_tickets(nullptr, 1) != nullptr ? 0 : -1; }
+int midm_init() { return splitk_ticket_words(nullptr, 1) != nullptr ? 0 : -1; }
 
 }  // namespace awq

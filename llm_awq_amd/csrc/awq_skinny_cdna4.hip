@@ -259,7 +259,8 @@ static void launch_skinny(const void* x, const void* qw, const void* szp, const 
 // part p of the workspace ([KS][M][N] floats); after its stores have been acknowledged it takes a ticket of the group; the block that draws the
 // last one adds the KS parts IN PART ORDER (the result does not depend on which block came last), rounds once, adds the bias and puts the
 // ticket word back to 0 -- the role of the reference's split_k_iters + Semaphore (gemm_cuda.cu:546-619), without a second launch.  Ticket
-// words: a library-owned, zero-initialised per-device array (splitk_tickets below); every launch uses its own lane of it.
+// words: splitk_ticket_words (awq_midm_cdna4.hip) -- zero-initialised, library-owned, and private to ONE launch at a time (the lane of the launch's stream;
+// words of its own for a launch recorded during a capture).
 template <typename DT, int WAVES, int NS, int CB, int DQ = 0>
 __global__ __launch_bounds__(64 * WAVES) void skinny_splitk_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                                    const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(64 * WAVES) void skinny_splitk_kernel(const uint16_
 }
 
 namespace {
-constexpr int kTicketLanes = 64, kTicketGroups = 512;  // 64 launches in flight x 512 slab groups, 128 KiB per device
+constexpr int kTicketGroups = 512;  // slab groups of a split launch (its ticket words: splitk_ticket_words, awq_midm_cdna4.hip -- private to the launch)
 int g_skinny_ks = -1;
 // seven slabs per block make ONE round of one block per CU (Llama-3-8B gate/up: 1792 slabs -> 256 blocks)?  Then the x slices are read by that many blocks
 // instead of 1.75 - 3.5 times as many (profiles/r05_skinny_splitk.txt)
@@ -317,34 +318,6 @@ bool seven_slab_round(int nslab) {
   const int groups = (nslab + 6) / 7, cus = device_cu_count();
   return groups <= cus + 16 && groups >= cus * 9 / 10;
 }  // knob skinny_splitk: -1 = by shape, 0 = off, 2 / 4 = force that many K parts where the shape allows it
-// the ticket words of the current device (zeroed once; every launch leaves the words it used at 0).  nullptr while a stream capture is in progress and
-// the array does not exist yet (no allocation inside a capture: that call runs unsplit), or if the allocation failed
-u32* splitk_tickets(hipStream_t st, int groups) {
-  static std::atomic<u32*> bufs[64] = {};
-  static std::atomic<unsigned> next_lane{0};
-  int dev = 0;
-  if (groups > kTicketGroups || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  u32* b = bufs[dev].load(std::memory_order_acquire);
-  if (b == nullptr) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
-    u32* fresh = nullptr;
-    const size_t bytes = (size_t)kTicketLanes * kTicketGroups * sizeof(u32);
-    if (hipMalloc(reinterpret_cast<void**>(&fresh), bytes) != hipSuccess) return nullptr;
-    // (the fill is ordered on the null stream and may return before it has run: wait for it, so that launches on ANY stream after this point see zeros)
-    if (hipMemset(fresh, 0, bytes) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
-      (void)hipFree(fresh);
-      return nullptr;
-    }
-    u32* expected = nullptr;
-    if (bufs[dev].compare_exchange_strong(expected, fresh, std::memory_order_acq_rel)) b = fresh;
-    else {
-      (void)hipFree(fresh);
-      b = expected;
-    }
-  }
-  return b + (size_t)(next_lane.fetch_add(1, std::memory_order_relaxed) % kTicketLanes) * kTicketGroups;
-}
 }  // namespace
 
 int skinny_tune_set(const char* key, int value) {
@@ -419,7 +392,7 @@ static int launch_skinny_64(const void* x, const void* qw, const void* szp, cons
   // half-empty chip (N = 4096 at 17..64 rows): the K split across blocks, when the caller brought the scratch and the ticket array exists
   const int ks = skinny_splitk_parts(m, n, k);
   if (EPI == 0 && ks > 1 && !f32out && ws != nullptr && (reinterpret_cast<uintptr_t>(ws) & 15) == 0 && ws_bytes >= (size_t)ks * m * n * sizeof(float)) {
-    u32* tk = splitk_tickets(st, (nslab + 1) / 2);
+    u32* tk = splitk_ticket_words(st, (nslab + 1) / 2);
     if (tk != nullptr) {
       float* parts = static_cast<float*>(ws);
       if constexpr (EPI == 0) {

@@ -610,36 +610,6 @@ torch::Tensor rmsnorm_forward_cdna4(torch::Tensor in_feats, torch::Tensor gamma,
   return out;
 }
 
-// QuantLlamaMLP.forward for ONE row in one launch (gate/up + SiLU * mul + down); state: mlp_decode_state_bytes(1, ffn) bytes (int32 tensor) of zeros kept by
-// the caller -- one per (module, stream); it carries the hand-over epoch between calls
-int64_t mlp_decode_state_bytes(int64_t m, int64_t ffn) { return (int64_t)awq_w4a16_mlp_decode_cdna4_state_bytes((int)m, (int)ffn); }
-torch::Tensor mlp_decode_cdna4(torch::Tensor in_feats, torch::Tensor gate_up_kernel, torch::Tensor gate_up_sz_half, torch::Tensor down_kernel,
-                               torch::Tensor down_sz_half, torch::Tensor state, c10::optional<torch::Tensor> down_bias) {
-  TORCH_CHECK(in_feats.is_cuda() && gate_up_kernel.is_cuda() && gate_up_sz_half.is_cuda() && down_kernel.is_cuda() && down_sz_half.is_cuda() && state.is_cuda());
-  TORCH_CHECK(in_feats.is_contiguous() && gate_up_kernel.is_contiguous() && gate_up_sz_half.is_contiguous() && down_kernel.is_contiguous() &&
-              down_sz_half.is_contiguous() && state.is_contiguous());
-  TORCH_CHECK((in_feats.scalar_type() == at::kBFloat16 || in_feats.scalar_type() == at::kHalf) && gate_up_kernel.scalar_type() == at::kShort &&
-              down_kernel.scalar_type() == at::kShort && gate_up_sz_half.scalar_type() == at::kInt && down_sz_half.scalar_type() == at::kInt &&
-              state.scalar_type() == at::kInt);
-  const int64_t hidden = in_feats.size(-1), ffn = gate_up_kernel.size(0) * 2, n_out = down_kernel.size(0) * 4;
-  TORCH_CHECK(hidden > 0 && gate_up_kernel.numel() == ffn / 2 * hidden && down_kernel.numel() == n_out / 4 * ffn);
-  TORCH_CHECK(gate_up_sz_half.numel() == 2 * ffn * (hidden / 128) && down_sz_half.numel() == n_out * (ffn / 128));
-  const int64_t m = in_feats.numel() / hidden;
-  TORCH_CHECK(m >= 1 && state.numel() * 4 >= (int64_t)awq_w4a16_mlp_decode_cdna4_state_bytes((int)m, (int)ffn), "state tensor too small (mlp_decode_state_bytes)");
-  const void* bp = nullptr;
-  if (down_bias.has_value() && down_bias->defined()) {
-    TORCH_CHECK(down_bias->is_cuda() && down_bias->is_contiguous() && down_bias->scalar_type() == in_feats.scalar_type() && down_bias->numel() == n_out);
-    bp = down_bias->data_ptr();
-  }
-  std::vector<int64_t> shape = in_feats.sizes().vec();
-  shape.back() = n_out;
-  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(in_feats.device());
-  at::Tensor out = torch::empty(shape, in_feats.options());
-  raise_on(awq_w4a16_mlp_decode_cdna4(in_feats.data_ptr(), gate_up_kernel.data_ptr(), gate_up_sz_half.data_ptr(), down_kernel.data_ptr(),
-                                      down_sz_half.data_ptr(), bp, out.data_ptr(), (int)m, (int)hidden, (int)ffn, (int)n_out, 128,
-                                      dtype_code(in_feats), state.data_ptr(), (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()));
-  return out;
-}
 
 // QuantLlamaMLP.our_llama_mlp for any row count on the 8 + 8 interleaved gate / up pair: out [.., n2 / 2]
 torch::Tensor mlp_gate_up_forward_cdna4(torch::Tensor in_feats, torch::Tensor kernel, torch::Tensor sz_packed, c10::optional<torch::Tensor> sz_half) {
@@ -783,12 +753,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("rmsnorm_forward_cdna4", &rmsnorm_forward_cdna4, "RMSNorm fused in front of the decode GEMV (<= 4 rows)", py::arg("in_feats"),
         py::arg("gamma"), py::arg("eps"), py::arg("kernel"), py::arg("sz_packed"), py::arg("bias") = py::none(),
         py::arg("fused_gate_up") = false);
-  m.def("mlp_decode_cdna4", &mlp_decode_cdna4, "QuantLlamaMLP.forward for one row in ONE launch (granule hand-over of h inside the launch)",
-        py::arg("in_feats"), py::arg("gate_up_kernel"), py::arg("gate_up_sz_half"), py::arg("down_kernel"), py::arg("down_sz_half"),
-        py::arg("state"), py::arg("down_bias") = py::none());
-  m.def("mlp_decode_plan", [](int m, int hidden, int ffn, int n_out) { return awq_w4a16_mlp_decode_cdna4_plan(m, hidden, ffn, n_out) != 0; },
-        "host-side: does mlp_decode_cdna4 serve (m, hidden, ffn, n_out)?");
-  m.def("mlp_decode_state_bytes", &mlp_decode_state_bytes, "bytes of zero-initialised int32 state mlp_decode_cdna4 needs (per module and stream)");
   m.def("mlp_gate_up_forward_cdna4", &mlp_gate_up_forward_cdna4, "silu(x Wg^T) * (x Wu^T) for any row count on the 8 + 8 interleaved gate/up pair",
         py::arg("in_feats"), py::arg("kernel"), py::arg("sz_packed"), py::arg("sz_half") = py::none());
   m.def("mlp_gate_up_cdna4", &mlp_gate_up_cdna4, "silu(x Wg^T) * (x Wu^T) on stacked cdna4 gate/up buffers, <= 8 rows");

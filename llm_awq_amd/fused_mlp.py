@@ -8,12 +8,9 @@ The reference module keeps gate_proj / up_proj as raw v2 buffers, issues two `ge
     cdna4 interleave.  2 * ffn / 16 blocks of one tile stream each (1792 for Llama-3-8B: 7 per CU) instead of ffn / 16 blocks of
     two streams (896: 3.5 per CU, so half the CUs carried 4 blocks and the rest 3);
   * decode (<= 8 rows): `decode_cdna4(..., epilogue=2)` -- gate, up, SiLU and the multiply in one launch, every intermediate
-    rounded to T exactly like the reference's separate ops (fused_mlp.py:39-61, :79-82) -- then down_proj's launch.  With
-    AWQ_MLP_ONE_LAUNCH=1 a single row is served by ONE persistent launch for the whole module (`mlp_decode_cdna4`, csrc/awq_mlp_engine.hip:
-    one 16-wave workgroup per CU, every wave streaming its own tile sequence -- gate/up k-steps, then down_proj k-steps -- through an
-    LDS-DMA ring that runs ahead across the op boundary; h handed over as 8-byte {data, tag} granules, no flag, no counter); it is
-    correct, graph-replayable and measured SLOWER (profiles/r05_mlp_engine.txt: 29.2-30.2 us against 22.0-22.8 us for the two
-    launches; the all-gather of h to every CU costs more than the kernel boundary it removes), so it is opt-in;
+    rounded to T exactly like the reference's separate ops (fused_mlp.py:39-61, :79-82) -- then down_proj's launch.  (A whole-module one-launch engine was built
+    in rounds 2, 4 and 5 and measured 30-37 % slower each time -- the all-gather of h to every CU costs more than the kernel boundary it removes; it was
+    taken out of the library in round 6: tools/EXPERIMENTS.md, profiles/r05_mlp_engine.txt.);
   * prefill (>= 8 rows): one GEMM over the interleaved weight (x is read once for both projections) whose tile epilogue pairs
     column n with column n + 8 and stores silu(gate) * up directly -- the [rows, 2 * ffn] intermediate of the reference's two
     GEMMs + F.silu + multiply is never written.
@@ -132,7 +129,6 @@ class QuantLlamaMLP(nn.Module):
         self.down_proj = down_proj
         self.split_k_iters = down_proj.split_k_iters
         self._fused = None  # (qweight cdna4, scales, scaled_zeros, sz_packed, sz_half or None): built on the first GPU forward
-        self._state = None  # epoch + granule array of the one-launch decode path (opt-in), per device
         self._v2_released = False
         self._v2_meta = None  # (shape, dtype) of the six released buffers
         self._register_state_dict_hook(QuantLlamaMLP._fill_state_dict)
@@ -203,45 +199,7 @@ class QuantLlamaMLP(nn.Module):
 
     @torch.no_grad()
     def forward(self, x):
-        rows = x.numel() // x.shape[-1]
-        if rows == 1 and x.is_cuda and os.environ.get("AWQ_MLP_ONE_LAUNCH") == "1":  # opt-in: measured slower than two launches (profiles/r05_mlp_engine.txt)
-            y = self._decode_one_launch(x)
-            if y is not None:
-                return y
         return self.down_proj(self.our_llama_mlp(x))
-
-    def _decode_one_launch(self, x):
-        """gate/up + SiLU * mul + down_proj in ONE persistent launch (`awq_w4a16_mlp_decode_cdna4`, one row): every workgroup streams its gate/up
-        slabs and then its down_proj slab through per-wave LDS-DMA rings that run ahead across the op boundary, publishes its share of h as
-        tagged granules and gathers the whole of it.  None when this layer cannot take it (more than one row, scales not f16-exact, down_proj
-        not in the cdna4 layout, shape outside the kernel's range)."""
-        eng = load_engine()
-        if self.w_bit != 4 or x.numel() != x.shape[-1] or not eng.mlp_decode_plan(1, self.in_features, self.intermediate_size, self.out_features):
-            return None  # (host-side plan query: one row, hidden = 4096, out_features = 4096, ffn <= 14336, a whole 256-CU device)
-        if self._fused is None or self._fused[0].device != x.device:
-            self._build(x.device)
-        c4, s, z, szp, szh = self._fused
-        d = self.down_proj
-        if szh is None or getattr(d, "layout", None) != "cdna4" or d.w_bit != 4:
-            return None
-        if d.szh_cdna4 is None:
-            d._build_szh(eng)
-        if d.szh_cdna4 is False:
-            return None
-        if self._state is None or self._state.device != x.device:
-            # (one state per module: calls on one stream are ordered; it carries the hand-over epoch from call to call, graph replays included)
-            self._state = torch.zeros((eng.mlp_decode_state_bytes(1, self.intermediate_size) + 3) // 4, dtype=torch.int32, device=x.device)
-        if not x.is_contiguous():
-            x = x.contiguous()
-        return eng.mlp_decode_cdna4(x, c4, szh, d.qweight, d.szh_cdna4, self._state, d.bias)
-
-    def check(self):
-        """after a synchronize: raise if a workgroup of the one-launch engine gave up waiting for h (bounded spin; its outputs were poisoned with NaNs).  The
-        engine wants the whole device -- 256 co-resident workgroups -- so a serving loop that shares the GPU with other streams calls this at its own sync
-        points (once per generated token is enough); forward() cannot poll the word without a host sync."""
-        if self._state is not None and int(self._state[2].item()) != 0:
-            raise RuntimeError("QuantLlamaMLP: the one-launch decode engine timed out waiting for activations from another workgroup (the 256 workgroups "
-                               "were not co-resident: another kernel held CUs); its outputs for that call are NaN.  Unset AWQ_MLP_ONE_LAUNCH or give it the device")
 
     @torch.no_grad()
     def our_llama_mlp(self, x):

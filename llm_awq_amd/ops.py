@@ -286,31 +286,6 @@ def mlp_gate_up_cdna4(x, qweight_gate_up, sz_packed, group_size: int = 128):
     return out
 
 
-def mlp_decode_state(m: int, ffn: int, device) -> torch.Tensor:
-    """zero-initialised state of `mlp_decode_cdna4` (epoch word, counters, the granule array of h): one per (module, stream), never written by the caller"""
-    nbytes = _capi.lib().awq_w4a16_mlp_decode_cdna4_state_bytes(int(m), int(ffn))
-    return torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device=device)
-
-
-def mlp_decode_cdna4(x, gate_up_qweight, gate_up_sz_half, down_qweight, down_sz_half, state, down_bias=None, group_size: int = 128):
-    """C-ABI awq_w4a16_mlp_decode_cdna4: QuantLlamaMLP.forward for ONE row in one launch (gate/up + SiLU * mul + down_proj, h handed over inside the
-    launch as tagged granules).  state: `mlp_decode_state(1, ffn, device)`.  AwqNativeError (unsupported shape) where the two launches must be issued."""
-    _need_gpu(x, gate_up_qweight, gate_up_sz_half, down_qweight, down_sz_half, state, down_bias)
-    hidden = x.shape[-1]
-    m = x.numel() // hidden
-    ffn = gate_up_qweight.shape[0] * 4 // 2
-    n_out = down_qweight.shape[0] * 4
-    assert state.dtype == torch.int32 and state.numel() * 4 >= _capi.lib().awq_w4a16_mlp_decode_cdna4_state_bytes(m, ffn), "state: ops.mlp_decode_state(m, ffn, device)"
-    out = torch.empty(*x.shape[:-1], n_out, dtype=x.dtype, device=x.device)
-    with torch.cuda.device(x.device):
-        _capi.check(_capi.lib().awq_w4a16_mlp_decode_cdna4(x.data_ptr(), gate_up_qweight.data_ptr(), gate_up_sz_half.data_ptr(),
-                                                            down_qweight.data_ptr(), down_sz_half.data_ptr(),
-                                                            down_bias.data_ptr() if down_bias is not None else None,
-                                                            out.data_ptr(), m, hidden, ffn, n_out, group_size, _dt(x),
-                                                            state.data_ptr(), _stream(x)))
-    return out
-
-
 def mlp_gate_up_forward_cdna4(x, qweight_interleaved, sz_packed, sz_half=None, group_size: int = 128):
     """C-ABI awq_w4a16_mlp_gate_up_forward_cdna4: QuantLlamaMLP.our_llama_mlp for any row count on the 8 + 8 interleaved pair."""
     _need_gpu(x, qweight_interleaved, sz_packed, sz_half)

@@ -13,7 +13,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 # Collection order under `-x`: the hot-path parity files first (SURVEY.md 8a rows a4-a8 against the oracle), then the callers
 # either side of the path, peripheral rows (8f) last -- a failure in a nicety must not hide the hot path.
-ORDER = ["test_gpu_oracle_fullsize", "test_gpu_parity", "test_gpu_decode", "test_gpu_gemm_v6", "test_gpu_cdna4",
+ORDER = ["test_gpu_oracle_fullsize", "test_gpu_parity", "test_gpu_decode", "test_gpu_midm", "test_gpu_gemm_v6", "test_gpu_cdna4",
          "test_gpu_fullsize", "test_gpu_splitk", "test_gpu_fused_mlp", "test_w3", "test_moe",
          "test_repacker", "test_loader", "test_engine_cache", "test_gpu_multidevice", "test_oneshot", "test_fused_norm"]
 

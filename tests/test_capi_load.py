@@ -154,23 +154,6 @@ def test_block_pair_k_split_routing():
     assert L.awq_w4a16_forward_cdna4_workspace_bytes(2048, 4096, 14336) == 128 * (256 * 256 * 4 + 64)
 
 
-def test_one_launch_mlp_plan_and_state_size():
-    """host-side queries of awq_w4a16_mlp_decode_cdna4 (QuantLlamaMLP.forward for one row in ONE launch, opt-in): which shapes it serves and how
-    much state (epoch / counters + one 8-byte {2 x T, tag} granule per pair of activations) the caller keeps"""
-    from llm_awq_amd import _capi
-    L = _capi.lib()
-    assert L.awq_w4a16_mlp_decode_cdna4_plan(1, 4096, 14336, 4096) == 1   # Llama-3-8B
-    assert L.awq_w4a16_mlp_decode_cdna4_plan(1, 4096, 11008, 4096) == 1   # Llama-2-7B
-    assert L.awq_w4a16_mlp_decode_cdna4_plan(1, 4096, 4096, 4096) == 1 and L.awq_w4a16_mlp_decode_cdna4_plan(1, 4096, 128, 4096) == 1
-    assert L.awq_w4a16_mlp_decode_cdna4_plan(1, 4096, 4096, 256) == 0    # one down_proj slab per CU of the 256: n_out = 4096
-    assert L.awq_w4a16_mlp_decode_cdna4_plan(2, 4096, 14336, 4096) == 0   # one row only
-    assert L.awq_w4a16_mlp_decode_cdna4_plan(1, 8192, 28672, 8192) == 0   # Llama-3-70B: a wave keeps its two k-steps of x in registers (hidden = 4096)
-    assert L.awq_w4a16_mlp_decode_cdna4_plan(1, 4096, 14400, 4096) == 0 and L.awq_w4a16_mlp_decode_cdna4_plan(1, 4096, 28672, 4096) == 0  # ffn % 128, <= 7 slabs per CU
-    assert L.awq_w4a16_mlp_decode_cdna4_plan(1, 4096, 14336, 4100) == 0 and L.awq_w4a16_mlp_decode_cdna4_plan(0, 4096, 14336, 4096) == 0
-    assert L.awq_w4a16_mlp_decode_cdna4_state_bytes(1, 14336) == _capi.AWQ_MLP_DECODE_COUNTER_BYTES + 14336 * 4
-    assert L.awq_w4a16_mlp_decode_cdna4_state_bytes(0, 14336) == 0
-
-
 def test_batched_decode_routing_for_the_llama3_shapes():
     """host-side query (no GPU): which kernel serves 1 .. 8 rows behind awq_w4a16_decode_cdna4 -- the streaming kernel up to 4 rows and on
     narrow projections, the skinny kernel where the per-slab activation staging would crowd LDS (profiles/r03_decode_m_sweep.txt)"""

@@ -151,83 +151,6 @@ def _granule_h(state, F, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("F", [4096, 11008])
-def test_one_launch_mlp_against_two_launches_and_the_oracle(monkeypatch, dtype, F):
-    """AWQ_MLP_ONE_LAUNCH=1: QuantLlamaMLP.forward for one row as ONE persistent launch (awq_w4a16_mlp_decode_cdna4, csrc/awq_mlp_engine.hip;
-    fused_mlp.py:33-83).  Every workgroup publishes its share of h as tagged granules and gathers the whole of it for its down_proj slab: h itself (read back from the granule array) against the two-launch path and the oracle,
-    the output against the oracle's down_proj on that h, the epoch / error words of the state, three calls in a row and a row count it does not serve."""
-    H = 4096
-    cg, cu, x, act, _gt, _up = _pair(F, H, dtype, 5, 1)
-    cd = make_case(H, F, dtype, seed=7, M=1)
-    mlp = _fused_block(cg, cu, cd, H, F, dtype)
-    y2 = mlp(x.cuda()).cpu()
-    h2 = mlp.our_llama_mlp(x.cuda()).cpu()
-    monkeypatch.setenv("AWQ_MLP_ONE_LAUNCH", "1")
-    for call in range(3):
-        y1 = mlp(x.cuda()).cpu()
-        st = mlp._state.cpu()
-        assert st[0].item() == call + 1 and st[1].item() == 0 and st[2].item() == 0, st[:3]  # the kernel ran (no silent two-launch route), nobody gave up
-        h1, tags = _granule_h(mlp._state, F, dtype)
-        assert bool((tags == call + 1).all())
-        # (the engine splits a slab's K over sixteen waves, the stand-alone launch over four: the same products in another fp32 order)
-        assert_bits(h1, h2, 0.05, what="h through the granules")
-        assert_bits(h1, act, 0.05)
-        check_forward(y1, h1, cd["q"], cd["scales"], cd["scaled_zeros"], dtype)
-        assert_bits(y1, y2, 0.2, what="one launch vs two")  # (h differs in a few last bits, and through down_proj those reach many outputs)
-    # two rows: the module issues the two launches (the kernel is the single-row specialisation) and the state is not touched
-    x2 = torch.cat([x, x * 0.5]).cuda()
-    y = mlp(x2).cpu()
-    assert mlp._state[0].item() == 3
-    assert torch.equal(y[:1], y2)
-
-
-def test_one_launch_mlp_replays_from_a_graph_and_declines_other_shapes(monkeypatch):
-    from llm_awq_amd import ops, synth
-    from llm_awq_amd.fused_mlp import interleave_gate_up
-    dtype = torch.bfloat16
-
-    def build(hidden, ffn, n_out, seed):
-        g = synth.random_wq(hidden, ffn, dtype=dtype, seed=seed, keep_q=False)
-        u = synth.random_wq(hidden, ffn, dtype=dtype, seed=seed + 1, keep_q=False)
-        d = synth.random_wq(ffn, n_out, dtype=dtype, seed=seed + 2, keep_q=False)
-        qi, si, zi = interleave_gate_up(g["qweight"], u["qweight"], g["scales"], u["scales"], g["scaled_zeros"], u["scaled_zeros"])
-        gu_szh, e1 = ops.pack_szh_cdna4(si, zi, hidden)
-        d_szh, e2 = ops.pack_szh_cdna4(d["scales"], d["scaled_zeros"], ffn)
-        assert e1 and e2
-        return dict(gu=ops.repack_v2_to_cdna4(qi), gu_szp=ops.pack_sz_cdna4(si, zi, hidden), gu_szh=gu_szh, d=ops.repack_v2_to_cdna4(d["qweight"]),
-                    d_szh=d_szh, state=ops.mlp_decode_state(1, ffn, "cuda"))
-
-    def two(c, x):
-        return ops.decode_cdna4(ops.mlp_gate_up_forward_cdna4(x, c["gu"], c["gu_szp"], c["gu_szh"]), c["d"], c["d_szh"], None, 0)
-
-    c = build(4096, 14336, 4096, 3)
-    xs = [torch.zeros(1, 4096, device="cuda", dtype=dtype) for _ in range(3)]
-    side = torch.cuda.Stream()
-    with torch.cuda.stream(side):
-        gph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gph, stream=side):
-            ys = [ops.mlp_decode_cdna4(xx, c["gu"], c["gu_szh"], c["d"], c["d_szh"], c["state"]) for xx in xs]  # three launches sharing one state
-        for rep in range(3):
-            for xx in xs:
-                xx.copy_(torch.randn(1, 4096, device="cuda").to(dtype))
-            gph.replay()
-            torch.cuda.synchronize()
-            for xx, yy in zip(xs, ys):
-                ref = two(c, xx)
-                assert_bits(yy, ref, 0.2, what="replay %d" % rep)
-                assert ((yy.float() - ref.float()).norm() / ref.float().norm()).item() < 2e-3
-    st = c["state"][:3].cpu()
-    assert st[0].item() == 9 and st[1].item() == 0 and st[2].item() == 0, st
-    # shapes outside the specialisation: "unsupported shape", nothing launched
-    small = build(2048, 4096, 256, 9)
-    with pytest.raises(ops._capi.AwqNativeError):
-        ops.mlp_decode_cdna4(torch.zeros(1, 2048, device="cuda", dtype=dtype), small["gu"], small["gu_szh"], small["d"], small["d_szh"], small["state"])
-    with pytest.raises((AssertionError, ops._capi.AwqNativeError)):
-        ops.mlp_decode_cdna4(torch.zeros(2, 4096, device="cuda", dtype=dtype), c["gu"], c["gu_szh"], c["d"], c["d_szh"], c["state"])
-    assert c["state"][0].item() == 9
-
-
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_v2_gate_up_buffers_are_released_and_state_dict_round_trips(dtype):
     """fused_mlp.py:19-27 registers the six v2 gate / up buffers: here they are released once the fused cdna4 stream exists (no second
     copy of two thirds of the block's weights) and state_dict() / load_state_dict() still speak the reference's keys bit-exactly."""

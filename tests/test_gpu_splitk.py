@@ -27,7 +27,8 @@ def test_workspace_query(env):
     assert q(1, 4096, 4096) == 0 and q(16, 4096, 4096) == 0 and q(32, 4096, 4096) == 0   # GEMV / skinny with a full grid against a short K: no workspace
     # skinny launches that leave half the chip idle: two K parts of fp32 sums, [2][rows of a pass][n] (33..64 rows from K = 4096, 17..32 rows from K = 8192)
     assert q(64, 4096, 4096) == 2 * 64 * 4096 * 4 and q(40, 4096, 14336) == 2 * 40 * 4096 * 4 and q(24, 4096, 14336) == 2 * 24 * 4096 * 4
-    assert q(71, 4096, 8192) == 2 * 36 * 4096 * 4 and q(64, 6144, 4096) == 0  # (row chunks share it; 384 slabs: two parts would be 1.5 rounds of blocks)
+    assert q(64, 6144, 4096) == 0                                  # (384 slabs: two parts would be 1.5 rounds of blocks)
+    assert q(71, 4096, 8192) == 8 * 71 * 4096 * 4                  # 65 .. 192 rows: the mid-M kernel's parts (tests/test_gpu_midm.py): 32 slab groups x 8 parts of 8 k-steps
     assert q(64, 28672, 8192) == 0 and q(64, 8192, 8192) == 0                                   # wide N fills the chip unsplit
     tile = 256 * 128 * 4                                            # one fp32 partial tile
     for (m, n, k, tiles) in ((256, 4096, 14336, 32), (512, 4096, 4096, 64)):
@@ -186,11 +187,16 @@ def test_small_m_gemm_writes_only_its_rows(env):
 
 
 def test_small_m_rule(env):
-    """The default rule: the GEMM takes m >= 256, and shorter prompts only where its 256-row tile beats the skinny kernel."""
+    """The round-5 rule (knob midm = 0; the default hands 65 .. 192 rows to the mid-M kernel): the GEMM takes m >= 256, and shorter prompts only where its
+    256-row tile beats the skinny kernel."""
     ops, _ = env
     q = ops._capi.lib().awq_w4a16_forward_cdna4_workspace_bytes
-    assert q(128, 4096, 14336) > 0 and q(71, 4096, 14336) == 2 * 36 * 4096 * 4 < q(72, 4096, 14336)  # K = 14336: from 72 rows (below: the skinny launch's two K parts)
-    assert q(128, 4096, 4096) == 2 * 64 * 4096 * 4 < q(192, 4096, 4096)   # K = 4096: from 147 rows
+    ops._capi.tune(midm=0)
+    try:
+        assert q(128, 4096, 14336) > 0 and q(71, 4096, 14336) == 2 * 36 * 4096 * 4 < q(72, 4096, 14336)  # K = 14336: from 72 rows (below: the skinny launch's two K parts)
+        assert q(128, 4096, 4096) == 2 * 64 * 4096 * 4 < q(192, 4096, 4096)   # K = 4096: from 147 rows
+    finally:
+        ops._capi.tune(midm=1)
 
 
 # ---- the skinny launch's K split across blocks (awq_skinny_cdna4.hip: skinny_splitk_kernel; N = 4096 at 33..64 rows per pass) ----
