@@ -63,25 +63,20 @@ def pmc_traffic(kernel_prefixes):
 
 
 def profile_consistency(ms_per_step, layers):
-    """Sum of the decode kernels' AVERAGE durations (one launch of each kernel row per layer) from the last committed
-    `rocprofv3 --kernel-trace --stats` summary (profiles/*bench_kernel_stats.csv, eager launches) next to this run's ms_per_step
-    (graph replay): the two must agree to within the launch-mode difference (a few per cent)."""
-    import csv
+    """The committed rocprofv3 record of the decode step AS TIMED HERE -- one hipGraph replay per step under `rocprofv3 --kernel-trace --stats`
+    (tools/gpu_decode_graph_profile.sh -> profiles/*decode_graph_consistency.json): the sum of the decode kernels' average durations per step next to the
+    ms_per_step the profiled process itself reported (`ratio_in_profile`: must be ~1), and next to this run's ms_per_step (`ratio_vs_this_run`: profiled
+    passes run a few per cent lower clocks, MI355X_MICROARCH.md DVFS note)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*bench_kernel_stats.csv")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*decode_graph_consistency.json")))
     if not files:
         return None
     try:
-        tot_ns, rows = 0.0, 0
-        for r in csv.DictReader(open(files[-1])):
-            if "awq::gemv_dma_kernel" in r["kernel"] or "awq::gemv_cdna4_kernel" in r["kernel"]:
-                tot_ns += float(r["avg_ns"]) * layers
-                rows += 1
-        if not rows:
-            return None
-        prof_ms = tot_ns * 1e-6
-        return {"source": os.path.relpath(files[-1], ROOT), "decode_kernel_rows": rows, "sum_kernel_avg_ms_per_step": round(prof_ms, 4),
-                "ms_per_step": round(ms_per_step, 4), "ratio": round(prof_ms / ms_per_step, 4)}
+        rec = json.load(open(files[-1]))
+        return {"source": os.path.relpath(files[-1], ROOT), "mode": rec.get("mode"), "decode_kernel_rows": len(rec["rows"]),
+                "sum_kernel_avg_ms_per_step": rec["sum_kernel_avg_ms_per_step"], "ms_per_step_in_profile": rec["ms_per_step_reported"],
+                "ratio_in_profile": rec["ratio"], "ms_per_step": round(ms_per_step, 4),
+                "ratio_vs_this_run": round(rec["sum_kernel_avg_ms_per_step"] / ms_per_step, 4)}
     except Exception:
         return None
 

@@ -1,19 +1,21 @@
-// Mid-M GEMM on cdna4-interleaved weights, 9 <= M <= 128 rows per pass, bf16 and fp16 (gfx950): short prompts, chunked prefill and wide
-// batched decode -- the row range the reference serves with gemm_w4a16_T1's four tile shapes + split-K
+// Mid-M GEMM on cdna4-interleaved weights, up to 128 rows per pass, bf16 and fp16 (gfx950): prompts of 65 .. 192 rows (and 17 .. 32 rows of very wide
+// layers) -- the row range the reference serves with gemm_w4a16_T1's 16 / 32 / 64-row tiles + split-K
 // (awq/kernels/csrc/quantization_new/gemm/gemm_cuda.cu:1155-1206, split-K epilogue :546-619, semaphore.h:44-103).
 //
-// Shape of the work (DESIGN.md "Mid-M"): every packed byte is read once (weight-stream bound up to ~64 rows, matrix-core bound above), and the
-// activations are NOT negligible: a block that owns S slabs moves M x 256 B of x per k-step for S KiB of weights.  So
+// Shape of the work (DESIGN.md "Mid-M"): every packed byte is read once, and the activations are NOT negligible: a block that owns S slabs moves
+// M x 256 B of x per k-step for S KiB of weights.  So
 //   * the x tile of a k-step (16 CB rows x 128 k) lands ONCE per block in LDS -- LDS-DMA (`buffer_load_dwordx4 ... lds`, no VGPRs), a ring of DX
 //     stages, XOR-swizzled on the SOURCE side so that the 16 x rows of an MFMA operand are one conflict-free ds_read_b128;
-//   * the block's WAVES waves split N: wave w streams its own NS 16-row slabs (1-KiB tiles + one scale dword per lane straight into registers, a
-//     register ring of DX - 1 k-steps), dequantises them on the matrix core (Cdna4DequantT / H: exact q s + sz, one v_cvt_pk = the reference's single
-//     rounding) and multiplies them against the SHARED x tile: NS x CB x 4 v_mfma_f32_16x16x32 per k-step, fp32 accumulation;
+//   * the block's WAVES waves split N: wave w streams its own NS 16-row slabs (1-KiB tiles + a 256-byte piece of scale dwords by LDS-DMA into a
+//     wave-private ring of DX + 1 slots), dequantises them on the matrix core (Cdna4DequantT / H: exact q s + sz, one v_cvt_pk = the reference's single
+//     rounding) and multiplies them against the SHARED x tile: NS x CB x 4 v_mfma_f32_16x16x32 per k-step, fp32 accumulation; the NEXT k-step's tile is
+//     dequantised word by word between this k-step's product MFMAs;
 //   * the chip is filled by a K split ACROSS blocks (grid.y parts of whole quantisation groups): every block stores its fp32 sums write-through, draws
 //     a ticket of its slab group, and the block that draws the last one adds the parts IN PART ORDER (deterministic), rounds once, adds the bias
 //     (or applies QuantLlamaMLP's SiLU * mul) -- the reference's split_k_iters + Semaphore without a second launch and without a waiting block.
-// One s_barrier per k-step; a wave's VMEM queue per k-step is a fixed group {XP x pieces, NS tiles, NS scale dwords} (out-of-range steps are issued
-// with an out-of-bounds buffer offset: no traffic, same count), so the wait for a stage is a COUNTED vmcnt and nothing ever drains the queue.
+// One s_barrier per k-step; a wave's VMEM queue per k-step is a fixed group {XP x pieces, NS tiles, NS scale pieces} (steps past the block's K range are
+// issued with an out-of-bounds buffer offset: no traffic, same count), so the wait for a stage is a COUNTED vmcnt and nothing ever drains the queue.
+// vmcnt is ONE in-order counter: the x ring is as deep as the weight ring -- the DX - 1 groups in flight are what the CU has outstanding.
 // All LDS reads of the loop are inline asm (hipcc would put vmcnt(0) in front of every LDS read that may alias an in-flight DMA).
 #include <string.h>
 
@@ -489,7 +491,7 @@ bool midm_pick(int m, int n, int k, bool may_split, MidmCfg& c) {
   if (ks > nit / 2) ks = nit / 2 > 0 ? nit / 2 : 1;
   if (!may_split || ks < 1) ks = 1;
   c.ks = ks;
-  return c.cb >= 1 && c.cb <= 8 && (c.waves == 4 || c.waves == 8) && (c.ns == 1 || c.ns == 2) &&
+  return c.cb >= 1 && c.cb <= 8 && ((c.waves == 8 && c.ns == 1) || (c.waves == 4 && (c.ns == 1 || c.ns == 2))) &&
          midm_lds(c.cb, c.waves, c.ns, midm_dx(c.cb, c.waves, c.ns)) <= 160 * 1024;
 }
 // the rows of a call are served in passes of at most 128 (129 .. 255: two equal passes, each re-streaming the weights)
@@ -501,10 +503,13 @@ void midm_passes(int m, int& chunks, int& rows) {
 
 // Which calls the forward entries hand to this kernel (measured against the round-5 kernels on the Llama-3-8B shapes, profiles/r06_midm_sweep.txt):
 // 65 .. 128 rows always (one pass: 0.70 - 0.94 x the time of the skinny kernel's two chunks / the masked 256-row tile); 129 .. 192 rows against
-// n < 16384 only (two passes still beat the masked tile on the 4096 / 6144-wide projections; the 28672-wide gate/up pair fills the chip with tiles).
-// Below 65 rows the skinny kernel (x through registers, up to seven slabs per block, no barrier) is as fast or faster; above 192 the tile is nearly full.
+// n < 16384 only (two passes still beat the masked tile on the 4096 / 6144-wide projections; the 28672-wide gate/up pair fills the chip with tiles);
+// 17 .. 32 rows against n >= 16384 (0.81 - 0.85 x).  Elsewhere below 65 rows the skinny kernel (x through registers, up to seven slabs per block, no
+// barrier) is as fast or faster; above 192 the tile is nearly full.
 bool midm_takes(int m, int n, int k) {
-  if (!g_midm || m < 9 || m > 255 || m < g_midm_min || m > g_midm_max || (n % 16) != 0 || (k % 128) != 0 || k < 256) return false;
+  if (!g_midm || m < 9 || m > 255 || m > g_midm_max || (n % 16) != 0 || (k % 128) != 0 || k < 256) return false;
+  // (17 .. 32 rows against a wide n -- the gate/up pair: 23.5 us against the skinny kernel's 27.7 - 29.4 with its two-slab blocks there)
+  if (m < g_midm_min && !(g_midm_min == 65 && m >= 17 && m <= 32 && n >= 16384)) return false;
   if ((size_t)n * (size_t)k / 2 >= (1ull << 31) || (size_t)m * (size_t)k * 2 >= (1ull << 31)) return false;
   if (m > 128 && n >= 16384 && g_midm_max <= 192) return false;
   int chunks, rows;
@@ -555,8 +560,7 @@ static int launch_midm_dt(const void* x, const void* qw, const void* szp, const 
 #define AWQ_MM_CB(W_, NS_) AWQ_MM(W_, NS_, 1) AWQ_MM(W_, NS_, 2) AWQ_MM(W_, NS_, 3) AWQ_MM(W_, NS_, 4) AWQ_MM(W_, NS_, 5) AWQ_MM(W_, NS_, 6) AWQ_MM(W_, NS_, 7) AWQ_MM(W_, NS_, 8)
   AWQ_MM_CB(8, 1)
   AWQ_MM_CB(4, 1)
-  AWQ_MM_CB(4, 2)
-  AWQ_MM_CB(8, 2)
+  AWQ_MM_CB(4, 2)  // (two slabs per wave: never the plan's choice on the measured shapes -- kept compiled for the knob and the tests of NS > 1)
 #undef AWQ_MM_CB
 #undef AWQ_MM
   return -1;

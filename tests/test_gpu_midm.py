@@ -14,7 +14,7 @@ from tests.helpers import assert_bits, check_forward_rows, forward_oracle, make_
 
 pytestmark = pytest.mark.gpu
 
-CFGS = [(8, 1), (8, 2), (4, 1), (4, 2)]  # (waves, slabs per wave)
+CFGS = [(8, 1), (4, 1), (4, 2)]  # (waves, slabs per wave)
 
 
 @pytest.fixture(scope="module")
@@ -42,7 +42,7 @@ def _reset(ops):
 @pytest.mark.parametrize("N,K", [(1296, 1536), (528, 1024)])
 def test_every_block_shape_and_part_count(env, dtype, N, K):
     ops = env
-    Ms = (9, 16, 17, 33, 48, 64, 65, 100, 128, 200)
+    Ms = (9, 17, 33, 64, 65, 100, 128, 200)
     d = make_case(N, K, dtype, seed=N + K, bias=True, M=max(Ms))
     c4, s, z, szp, szh = _native(ops, d, K)
     bias = d["bias"].cuda()
@@ -52,7 +52,7 @@ def test_every_block_shape_and_part_count(env, dtype, N, K):
     try:
         ops._capi.tune(midm_min=9, midm_max=255)  # (the product hands 65 .. 192 rows to this kernel; here every row count it can serve)
         for (wv, ns) in CFGS:
-            for ks in (1, 2, 3, 5):
+            for ks in (1, 2, 5):
                 ops._capi.tune(midm_waves=wv, midm_ns=ns, midm_ks=ks)
                 for M in Ms:
                     for with_bias in (False, True):
@@ -75,6 +75,8 @@ LLAMA = [("qkv", 4096, 6144), ("o", 4096, 4096), ("gate", 4096, 14336), ("down",
 @pytest.mark.parametrize("name,K,N", LLAMA, ids=[c[0] for c in LLAMA])
 def test_llama3_8b_shapes_against_the_oracle(env, dtype, name, K, N):
     ops = env
+    if dtype == torch.float16 and name in ("o", "gate"):
+        pytest.skip("fp16 on the two extreme shapes (qkv, down); bf16 on all four")
     Ms = (9, 16, 33, 64, 71, 72, 96, 128, 192, 255, 256)
     d = make_case(N, K, dtype, seed=2 * (K * 7 + N), M=256)
     c4, s, z, szp, szh = _native(ops, d, K)

@@ -1,7 +1,7 @@
 """GPU experiment: the mid-M kernel (csrc/awq_midm_cdna4.hip) per Llama-3-8B layer shape and row count, every block shape (waves x slabs per wave) and
 K part count the library compiles, against the round-5 path (knob midm = 0: skinny / masked-tile kernels) -- us per launch over rotating weight copies
 (> the 256 MB Infinity Cache) in one graph, and the norm-wise distance of every configuration's result from the round-5 path's.
-    python tools/midm_sweep.py [M ...]         MIDM_SHAPES=qkv,o,gate+up,down   MIDM_CFGS=8x1,8x2,4x1,4x2   MIDM_KS=0,1,2,4,8,16   MIDM_SZH=1   MIDM_PROBE=0,3,4 (AWQ_PROBES builds)"""
+    python tools/midm_sweep.py [M ...]         MIDM_SHAPES=qkv,o,gate+up,down   MIDM_CFGS=8x1,4x1,4x2   MIDM_KS=0,1,2,4,8,16   MIDM_SZH=1   MIDM_PROBE=0,3,4 (AWQ_PROBES builds)"""
 import os
 import sys
 
@@ -13,7 +13,7 @@ from llm_awq_amd import _capi, ops, synth  # noqa: E402
 SHAPES = [(4096, 6144, "qkv"), (4096, 4096, "o"), (4096, 28672, "gate+up"), (14336, 4096, "down")]
 if os.environ.get("MIDM_SHAPES"):
     SHAPES = [s for s in SHAPES if s[2] in os.environ["MIDM_SHAPES"].split(",")]
-CFGS = [tuple(int(v) for v in c.split("x")) for c in os.environ.get("MIDM_CFGS", "8x1,8x2,4x1,4x2").split(",")]
+CFGS = [tuple(int(v) for v in c.split("x")) for c in os.environ.get("MIDM_CFGS", "8x1,4x1,4x2").split(",")]
 KSS = [int(v) for v in os.environ.get("MIDM_KS", "0").split(",")]
 SZH = os.environ.get("MIDM_SZH", "0") == "1"
 PROBES = [int(v) for v in os.environ.get("MIDM_PROBE", "0").split(",")]  # timing probes (wrong results): bit 0 no x traffic, 1 no weight traffic, 2 no LDS reads / math
