@@ -427,6 +427,13 @@ __device__ __forceinline__ void v6_tile(char* smem, const uint16_t* __restrict__
       }
       __builtin_amdgcn_s_sleep(4);
     }
+    // My own mailbox back to zero as well: the partner read it BEFORE it stored the partials whose flag I have just seen, so nobody needs it any
+    // more -- and a mailbox written by a block that started after its partner's clearing store can no longer survive into the next replay of a captured
+    // launch (same token), where it would have vouched for a placement of the previous replay.
+    if (tid == 0 && !lost) {
+      const u32x2 z = {0u, 0u};
+      asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(flag + 2 + H), "v"(z) : "memory");
+    }
     const float* pr = part + (size_t)H * (size_t)(V6_TM * V6_TN / 2) + (size_t)wv * (8 * NS * 256) + lane * 4;
 #pragma unroll
     for (int f0 = 0; f0 < 8; f0 += 4) {

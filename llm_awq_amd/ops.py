@@ -254,9 +254,9 @@ def gemm_cdna4(x, qweight, scales, scaled_zeros, bias=None, sz_packed=None, grou
     m = x.numel() // k
     n = qweight.shape[0] * 4
     out = torch.empty(*x.shape[:-1], n, dtype=x.dtype, device=x.device)
-    ws_bytes = _capi.lib().awq_w4a16_forward_cdna4_workspace_bytes(m, n, k)
-    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device) if ws_bytes else None
     with torch.cuda.device(x.device):
+        ws_bytes = _capi.lib().awq_w4a16_forward_cdna4_workspace_bytes(m, n, k)  # (inside the device context: the plan asks the CURRENT device for its CU count)
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device) if ws_bytes else None
         if sz_half is not None:
             _capi.check(_capi.lib().awq_w4a16_forward_cdna4_szh(x.data_ptr(), qweight.data_ptr(), scales.data_ptr(), scaled_zeros.data_ptr(),
                                                                  sz_packed.data_ptr() if sz_packed is not None else None, sz_half.data_ptr(),
@@ -293,9 +293,9 @@ def mlp_gate_up_forward_cdna4(x, qweight_interleaved, sz_packed, sz_half=None, g
     m = x.numel() // k
     n2 = qweight_interleaved.shape[0] * 4
     out = torch.empty(*x.shape[:-1], n2 // 2, dtype=x.dtype, device=x.device)
-    ws_bytes = _capi.lib().awq_w4a16_mlp_gate_up_forward_cdna4_workspace_bytes(m, n2, k)
-    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device) if ws_bytes else None
     with torch.cuda.device(x.device):
+        ws_bytes = _capi.lib().awq_w4a16_mlp_gate_up_forward_cdna4_workspace_bytes(m, n2, k)
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device) if ws_bytes else None
         _capi.check(_capi.lib().awq_w4a16_mlp_gate_up_forward_cdna4_ws(x.data_ptr(), qweight_interleaved.data_ptr(), sz_packed.data_ptr(),
                                                                         sz_half.data_ptr() if sz_half is not None else None, out.data_ptr(),
                                                                         m, n2, k, group_size, _dt(x), ws.data_ptr() if ws is not None else None,
@@ -371,9 +371,9 @@ def forward_w3(x, qweight_w3, scales, scaled_zeros, sz_packed, bias=None, group_
     n = qweight_w3.shape[0] * 4
     out = torch.empty(*x.shape[:-1], n, dtype=x.dtype, device=x.device)
     L = _capi.lib()
-    wsb = L.awq_w3a16_forward_workspace_bytes(m, n, k)
-    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
     with torch.cuda.device(x.device):
+        wsb = L.awq_w3a16_forward_workspace_bytes(m, n, k)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
         _capi.check(L.awq_w3a16_forward(x.data_ptr(), qweight_w3.data_ptr(), scales.data_ptr(), scaled_zeros.data_ptr(),
                                         sz_packed.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(),
                                         m, n, k, group_size, _dt(x), ws.data_ptr() if wsb else None, wsb, _stream(x)))
@@ -388,9 +388,9 @@ def mlp_gate_up_forward_w3(x, qweight_w3_interleaved, sz_packed, group_size: int
     n2 = qweight_w3_interleaved.shape[0] * 4
     out = torch.empty(*x.shape[:-1], n2 // 2, dtype=x.dtype, device=x.device)
     L = _capi.lib()
-    wsb = L.awq_w3a16_mlp_gate_up_forward_workspace_bytes(m, n2, k)
-    ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device) if wsb else None
     with torch.cuda.device(x.device):
+        wsb = L.awq_w3a16_mlp_gate_up_forward_workspace_bytes(m, n2, k)
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device) if wsb else None
         _capi.check(L.awq_w3a16_mlp_gate_up_forward(x.data_ptr(), qweight_w3_interleaved.data_ptr(), sz_packed.data_ptr(), out.data_ptr(), m, n2, k,
                                                      group_size, _dt(x), ws.data_ptr() if ws is not None else None, wsb, _stream(x)))
     return out
