@@ -116,27 +116,6 @@ int awq_pack_szh_cdna4(const void* scales, const void* scaled_zeros, void* sz_ha
  *               rows 16 j + 8 .. = the matching up rows): twice the blocks, every block one tile stream */
 int awq_w4a16_decode_cdna4(const void* x, const void* qweight_cdna4, const void* sz_half, const void* bias, void* out, int m, int n,
                            int k, int group_size, int dtype, int epilogue, void* stream);
-/* The same decode launch as one link of a CHAIN of dependent launches that are ordered by in-kernel flags instead of kernel boundaries (round 6; no
- * reference counterpart -- the reference's decode is one gemv_forward_cuda_new per linear on one stream, gemv_cuda.cu:245-338, and pays the full
- * launch-to-launch gap 160 times per token).  The caller puts consecutive links on DIFFERENT streams (or on parallel branches of a captured graph) so that
- * link i + 1 is dispatched while link i still runs: it requests its weight ring and scales at once, waits (bounded) for *wait_word != 0, and only then
- * reads x -- past the L2, which is not coherent across XCDs -- while link i stores its outputs write-through and raises its word when the last block's
- * stores are acknowledged.
- *   signal_state: uint32 [AWQ_CHAIN_STATE_WORDS] (256 bytes, 256-byte aligned) owned by this link, ZEROED by the caller before every pass over the chain (one memset
- *                 for all links): every block counts itself on word 0 once its outputs are acknowledged; word AWQ_CHAIN_TIMEOUT_WORD is set if this link gave
- *                 up waiting for ITS producer (its output is then computed from whatever x held).  NULL: the link signals nobody (a kernel boundary follows).
- *   wait_word / wait_count: word 0 of the previous link's state and that link's block count (awq_w4a16_decode_cdna4_chain_blocks of ITS m, n, k, epilogue);
- *                 NULL / 0 for a link whose x is ready at launch.
- * At most TWO links may be in flight at a time (link i + 2 must be ordered behind link i by its stream / the graph), and a WAITING grid must leave every CU room
- * for its producer's blocks (nothing orders the dispatch of two queues): do not chain INTO a launch whose grid fills the chip's LDS (the 1792-block gate/up pair
- * of Llama-3-8B: keep the kernel boundary in front of it; tools/decode_chain.py).  m as awq_w4a16_decode_cdna4 where the rows fit ONE launch of the streaming
- * kernel (AWQ_ERR_SHAPE otherwise). */
-#define AWQ_CHAIN_STATE_WORDS 64
-#define AWQ_CHAIN_TIMEOUT_WORD 32
-int awq_w4a16_decode_cdna4_chain(const void* x, const void* qweight_cdna4, const void* sz_half, const void* bias, void* out, int m, int n, int k,
-                                 int group_size, int dtype, int epilogue, const void* wait_word, unsigned wait_count, void* signal_state, void* stream);
-/* host-side: the block count of the one launch that serves (m, n, k, epilogue) -- what a consumer link passes as wait_count; 0 if the call is not one launch */
-int awq_w4a16_decode_cdna4_chain_blocks(int m, int n, int k, int epilogue);
 /* gemv on cdna4-interleaved weights (same contract as awq_w4a16_gemv otherwise) */
 int awq_w4a16_gemv_cdna4(const void* x, const void* qweight_cdna4, const void* scales, const void* scaled_zeros,
                          const void* sz_packed, void* out, int m, int n, int k, int group_size, int dtype, void* stream);

@@ -36,8 +36,6 @@ SIGNATURES = {
     "awq_pack_sz_cdna4": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "awq_pack_szh_cdna4": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "awq_w4a16_decode_cdna4": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "awq_w4a16_decode_cdna4_chain": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, ctypes.c_uint, _vp, _vp]),
-    "awq_w4a16_decode_cdna4_chain_blocks": (_i, [_i, _i, _i, _i]),
     "awq_w4a16_gemv_cdna4": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "awq_w4a16_mlp_gate_up_cdna4": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "awq_w4a16_mlp_gate_up_forward_cdna4": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

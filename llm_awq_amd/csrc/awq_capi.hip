@@ -200,26 +200,6 @@ int awq_w4a16_decode_cdna4(const void* x, const void* qweight, const void* sz_ha
   return finish_launch();
 }
 
-int awq_w4a16_decode_cdna4_chain(const void* x, const void* qweight, const void* sz_half, const void* bias, void* out, int m, int n, int k,
-                                 int group_size, int dtype, int epilogue, const void* wait_word, unsigned wait_count, void* signal_state, void* stream) {
-  if (!x || !qweight || !sz_half || !out) return AWQ_ERR_NULL;
-  if (!wait_word && !signal_state) return AWQ_ERR_NULL;
-  if (group_size != 128) return AWQ_ERR_GROUP;
-  if (dtype != AWQ_F16 && dtype != AWQ_BF16) return AWQ_ERR_DTYPE;
-  if (m < 1 || m > 8) return AWQ_ERR_BATCH;
-  if (epilogue < 0 || epilogue > 2 || (epilogue != 0 && bias)) return AWQ_ERR_SHAPE;
-  const int mult = epilogue == 1 ? 32 : 16;
-  if (n < mult || (n % mult) != 0 || k < 128 || (k % 128) != 0) return AWQ_ERR_SHAPE;
-  if (!aligned16(x) || !aligned16(qweight) || !aligned16(out) || !aligned16(sz_half)) return AWQ_ERR_ALIGN;
-  if ((reinterpret_cast<uintptr_t>(wait_word) & 3) != 0 || (reinterpret_cast<uintptr_t>(signal_state) & 3) != 0) return AWQ_ERR_ALIGN;
-  if (wait_word && wait_count == 0) return AWQ_ERR_SHAPE;
-  if (awq::launch_gemv_dma(x, qweight, sz_half, bias, out, m, n, k, epilogue, dtype, 1, (hipStream_t)stream, 0, wait_word, signal_state, wait_count) != 0)
-    return AWQ_ERR_SHAPE;  // (row counts whose x staging does not fit ONE launch of the streaming kernel are not chained)
-  return finish_launch();
-}
-
-int awq_w4a16_decode_cdna4_chain_blocks(int m, int n, int k, int epilogue) { return awq::gemv_dma_blocks(m, n, k, epilogue); }
-
 int awq_w4a16_gemv_cdna4(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
                          const void* sz_packed, void* out, int m, int n, int k, int group_size, int dtype, void* stream) {
   if (group_size != 128) return AWQ_ERR_GROUP;

@@ -43,9 +43,7 @@ constexpr int kDmaF32Out = 0x100;
 template <typename DT, int WAVES, int D, int DQ, int EPI>
 __device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                               const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
-                                              uint16_t* __restrict__ out, int M, int N, int K, int TX, int probe_, int nb,
-                                              const u32* __restrict__ chain_wait = nullptr, u32* __restrict__ chain_signal = nullptr,
-                                              u32 chain_count = 0) {
+                                              uint16_t* __restrict__ out, int M, int N, int K, int TX, int probe_, int nb) {
   constexpr int NS = EPI == 1 ? 2 : 1;
   const int probe = DMA_PROBE(probe_);
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -78,50 +76,20 @@ __device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __rest
   // ---- up front.  The first weight tile goes out FIRST (it has the longest way to come), then the packed scales and the x
   // slices (out-of-range pieces read 0 through the buffer descriptor), then the rest of the ring: step 0's counted wait
   // (D - 1 tiles may stay in flight) covers everything older than tile 1 ----
-  // (chained launch, see below) the first look at the producer's flag is the OLDEST request of wave 0: it returns without waiting for the ring
-  u32 chain_seen = 0;
-  if (chain_wait != nullptr && threadIdx.x == 0) asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=v"(chain_seen) : "v"(chain_wait) : "memory");
   issue(0, 0);
-  if (chain_wait != nullptr && wv == 0) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(chain_seen) : "n"(NS) : "memory");
-  // (a count above the producer's block count is its give-up mark: proceed, the sticky word tells the host)
   if (!(probe & 8)) {
 #pragma unroll
     for (int s = 0; s < NS; ++s)
       for (int q = 0; q < TXp; q += 4)
         dma_to_lds<4, 0>(rs, szs + (s * TXp + q) * 64, lane4, (slab_tile[s] + (u32)(s0 + q)) * 64u);
   }
-  if (chain_wait == nullptr) {
-    if (!(probe & 4)) {
-      for (int r = 0; r < M; ++r)
-        for (int q = 0; q < TXp; q += 4)
-          dma_to_lds<16, 0>(rx, xs + r * xrow + q * 256, lane16, ((u32)r * (u32)K + (u32)(s0 + q) * 128u) * 2u);
-    }
-#pragma unroll
-    for (int d = 1; d < D; ++d) issue(d, d);
-  } else {
-    // ---- chained launch (DESIGN.md "Chained decode launches"): this grid may have been started BEFORE the launch that produces x has finished (it sits on
-    // another queue; nothing but the flag orders the two).  Everything that does not depend on x is requested first -- the whole weight ring and the scale
-    // dwords -- then wave 0 waits for the producer's flag (bounded; a timeout poisons nothing but sets the flag word's neighbour, see chain_signal below),
-    // and x is fetched with sc0 sc1 loads: the producer stored it write-through, and this XCD's L2 may hold a line of the previous token's x ----
-#pragma unroll
-    for (int d = 1; d < D; ++d) issue(d, d);
-    if (threadIdx.x == 0 && chain_seen < chain_count) {
-      u32 seen = 0;
-      for (int spin = 0; spin < (1 << 20); ++spin) {
-        __builtin_amdgcn_s_sleep(32);
-        asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(seen) : "v"(chain_wait) : "memory");
-        if (seen >= chain_count) break;
-      }
-      if (seen < chain_count && chain_signal != nullptr) __hip_atomic_store(chain_signal + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sticky: a wait timed out
-    }
-    // (a poll drains wave 0's DMA queue: harmless, it is waiting anyway; a flag that was up at the first look costs no drain.)  Everybody learns of
-    // the flag through the barrier
-    __syncthreads();
+  if (!(probe & 4)) {
     for (int r = 0; r < M; ++r)
       for (int q = 0; q < TXp; q += 4)
-        dma_to_lds<16, 17>(rx, xs + r * xrow + q * 256, lane16, ((u32)r * (u32)K + (u32)(s0 + q) * 128u) * 2u);
-    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");  // x is the YOUNGEST request here: the loop's counted waits assume it has landed
+        dma_to_lds<16, 0>(rx, xs + r * xrow + q * 256, lane16, ((u32)r * (u32)K + (u32)(s0 + q) * 128u) * 2u);
   }
+#pragma unroll
+  for (int d = 1; d < D; ++d) issue(d, d);
   using vec8 = typename DT::vec8;
   Cdna4DequantT<DT> cd;   // DQ 0: sz_packed in T
   Cdna4DequantH<DT> ch;   // DQ 1: sz_half, f16-mantissa extraction
@@ -191,11 +159,6 @@ __device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __rest
     for (int r = 0; r < 4; ++r) reinterpret_cast<float*>(wbase + s * 1024)[r * 64 + lane] = acc[s][r];
   __syncthreads();
   auto to_f = [](uint16_t b) { return DT::to_float(b); };
-  // a chained launch stores write-through (sc0 sc1): its consumer may sit on another XCD and is NOT behind a kernel boundary
-  auto put = [&](uint16_t* dst, uint16_t v) {
-    if (chain_signal == nullptr) *dst = v;
-    else asm volatile("global_store_short %0, %1, off sc0 sc1" : : "v"(dst), "v"((u32)v) : "memory");
-  };
   if (EPI != 2) {
     if (wv < 4 && i < M) {
       const int r = wv;
@@ -214,12 +177,12 @@ __device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __rest
       } else if (EPI == 0) {
         uint16_t o = DT::from_float(v[0]);
         if (bias != nullptr) o = DT::from_float(to_f(o) + to_f(bias[nn]));  // `out + self.bias` in T (qmodule.py:221)
-        put(out + (size_t)i * N + nn, o);
+        out[(size_t)i * N + nn] = o;
       } else {
         // fused_mlp.py:79-82: c = F.silu(gate_output) * up_output, every op rounded to T
         const float gt = to_f(DT::from_float(v[0])), up = to_f(DT::from_float(v[NS - 1]));
         const float sl = to_f(DT::from_float(silu_f32(gt)));
-        put(out + (size_t)i * (N >> 1) + nn, DT::from_float(sl * up));
+        out[(size_t)i * (N >> 1) + nn] = DT::from_float(sl * up);
       }
     }
   } else {
@@ -237,25 +200,17 @@ __device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __rest
       return DT::from_float(sl * up);
     };
     if (wv < 4 && i < M && g < 2) {
-      put(out + (size_t)i * (N >> 1) + nb * 8 + 4 * g + wv, h_of(wv));
+      out[(size_t)i * (N >> 1) + nb * 8 + 4 * g + wv] = h_of(wv);
     }
-  }
-  // ---- chained launch: this block's outputs are acknowledged -> count it (fire and forget: nobody waits for the atomic).  The consumer polls the count.
-  // chain_signal: u32 [64] on a 256-byte line of its own = {count, -, ..., word 32: sticky timeout of THIS launch's own wait}; zeroed by the host before every pass ----
-  if (chain_signal != nullptr) {
-    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(chain_signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
 template <typename DT, int WAVES, int D, int DQ, int EPI>
 __global__ __launch_bounds__(64 * WAVES) void gemv_dma_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                                const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
-                                                               uint16_t* __restrict__ out, int M, int N, int K, int TX, int probe_,
-                                                               const u32* __restrict__ chain_wait, u32* __restrict__ chain_signal, u32 chain_count) {
+                                                               uint16_t* __restrict__ out, int M, int N, int K, int TX, int probe_) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemv_dma_body<DT, WAVES, D, DQ, EPI>(smem, x, qw, szp, bias, out, M, N, K, TX, probe_, blockIdx.x, chain_wait, chain_signal, chain_count);
+  gemv_dma_body<DT, WAVES, D, DQ, EPI>(smem, x, qw, szp, bias, out, M, N, K, TX, probe_, blockIdx.x);
 }
 
 namespace {
@@ -326,23 +281,23 @@ int gemv_dma_tune_set(const char* key, int value) {
 
 template <typename DT, int WAVES, int D, int DQ, int EPI>
 static void launch_dma_cfg(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                           const DmaCfg& c, hipStream_t st, int f32out, const u32* chain_wait, u32* chain_signal, u32 chain_count) {
+                           const DmaCfg& c, hipStream_t st, int f32out) {
   constexpr int NS = EPI == 1 ? 2 : 1;
   auto kern = gemv_dma_kernel<DT, WAVES, D, DQ, EPI>;
   static LdsOptIn optin;
   if (c.smem > 64 * 1024) optin.ensure(reinterpret_cast<const void*>(kern));
   hipLaunchKernelGGL(kern, dim3(n / 16 / NS), dim3(64 * WAVES), c.smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp,
-                     (const uint16_t*)bias, (uint16_t*)out, m, n, k, c.tx, (g_dma_probe & 0xFF) | (f32out ? kDmaF32Out : 0), chain_wait, chain_signal, chain_count);
+                     (const uint16_t*)bias, (uint16_t*)out, m, n, k, c.tx, (g_dma_probe & 0xFF) | (f32out ? kDmaF32Out : 0));
 }
 
 template <typename DT, int EPI, int DQ>
 static int launch_dma_dt(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
-                         hipStream_t st, int f32out, const u32* chain_wait, u32* chain_signal, u32 chain_count) {
+                         hipStream_t st, int f32out) {
   DmaCfg c;
   if (!pick_dma(m, n, k, EPI == 1 ? 2 : 1, c)) return -1;
 #define AWQ_DCASE(W_, D_)                                                           \
   if (c.waves == W_ && c.d == D_) {                                                 \
-    launch_dma_cfg<DT, W_, D_, DQ, EPI>(x, qw, szp, bias, out, m, n, k, c, st, f32out, chain_wait, chain_signal, chain_count); \
+    launch_dma_cfg<DT, W_, D_, DQ, EPI>(x, qw, szp, bias, out, m, n, k, c, st, f32out); \
     return 0;                                                                       \
   }
   AWQ_DCASE(8, 1) AWQ_DCASE(8, 2) AWQ_DCASE(8, 4) AWQ_DCASE(8, 8)
@@ -367,29 +322,18 @@ int gemv_dma_plan(int m, int n, int k, int epi, int* kernel) {
   return (m + mc - 1) / mc;
 }
 
-int gemv_dma_blocks(int m, int n, int k, int epi) {
-  DmaCfg c;
-  if (m < 1 || m > 8 || (k % 128) != 0 || epi < 0 || epi > 2 || (n % (epi == 1 ? 32 : 16)) != 0 || !pick_dma(m, n, k, epi == 1 ? 2 : 1, c)) return 0;
-  return n / 16 / (epi == 1 ? 2 : 1);
-}
-
 // epi as in the kernel header; returns -1 if the shape is not served.  The kernel stages every row's x slice in LDS up front
 // (m * k * 2 bytes per block): when m rows do not fit (m * k > ~50 k elements: batched decode against K >= 8 k) the rows are
 // served in chunks of as many rows as do fit, each chunk re-streaming the weights -- as the reference's GEMV does per row
 // (gemv_cuda.cu:187-208 loops over the batch inside one weight pass; here the LDS budget decides).
 int launch_gemv_dma(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int epi,
-                    int dtype, int szfmt, hipStream_t st, int f32out, const void* chain_wait_, void* chain_signal_, unsigned chain_count) {
-  const u32* chain_wait = static_cast<const u32*>(chain_wait_);
-  u32* chain_signal = static_cast<u32*>(chain_signal_);
-  const bool chained = chain_wait != nullptr || chain_signal != nullptr;
+                    int dtype, int szfmt, hipStream_t st, int f32out) {
   if (m < 1 || m > 8 || (k % 128) != 0 || (n % (epi == 1 ? 32 : 16)) != 0 || (f32out && (epi != 0 || bias != nullptr))) return -1;
-  if (chained && f32out) return -1;
-  if (!chained && skinny_takes(m, n, k, epi) && launch_skinny_decode(x, qw, szp, bias, out, m, n, k, epi, dtype, szfmt, st, f32out) == 0) return 0;
+  if (skinny_takes(m, n, k, epi) && launch_skinny_decode(x, qw, szp, bias, out, m, n, k, epi, dtype, szfmt, st, f32out) == 0) return 0;
   DmaCfg probe_cfg;
   int mc = m;
   while (mc > 1 && !pick_dma(mc, n, k, epi == 1 ? 2 : 1, probe_cfg)) --mc;
   if (mc < m) {
-    if (chained) return -1;  // (a chained call is ONE launch: the row count must fit the streaming kernel's LDS staging)
     if (!pick_dma(mc, n, k, epi == 1 ? 2 : 1, probe_cfg)) return -1;
     const size_t ncols = epi ? (size_t)n / 2 : (size_t)n;
     for (int r = 0; r < m; r += mc) {
@@ -401,9 +345,9 @@ int launch_gemv_dma(const void* x, const void* qw, const void* szp, const void* 
     return 0;
   }
 #define AWQ_DDT(DT_, DQ_)                                                                   \
-  if (epi == 0) return launch_dma_dt<DT_, 0, DQ_>(x, qw, szp, bias, out, m, n, k, st, f32out, chain_wait, chain_signal, chain_count); \
-  if (epi == 1) return launch_dma_dt<DT_, 1, DQ_>(x, qw, szp, bias, out, m, n, k, st, 0, chain_wait, chain_signal, chain_count);      \
-  return launch_dma_dt<DT_, 2, DQ_>(x, qw, szp, bias, out, m, n, k, st, 0, chain_wait, chain_signal, chain_count);
+  if (epi == 0) return launch_dma_dt<DT_, 0, DQ_>(x, qw, szp, bias, out, m, n, k, st, f32out); \
+  if (epi == 1) return launch_dma_dt<DT_, 1, DQ_>(x, qw, szp, bias, out, m, n, k, st, 0);      \
+  return launch_dma_dt<DT_, 2, DQ_>(x, qw, szp, bias, out, m, n, k, st, 0);
   if (szfmt == 1) {
     if (dtype == 0) {
       AWQ_DDT(F16, 1)

@@ -68,12 +68,7 @@ int gemv_cdna4_tune_set(const char* key, int value);
 // szfmt 0: szp = sz_packed {s | sz << 16} in T;  szfmt 1: szp = sz_half (f16-mantissa dequant, awq_pack_szh_cdna4)
 // f32out (epi 0, no bias): out is float [m, n], the fp32 sums unrounded -- the K-shard partial of a tensor-parallel row split
 int launch_gemv_dma(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int epi,
-                    int dtype, int szfmt, hipStream_t st, int f32out = 0, const void* chain_wait = nullptr, void* chain_signal = nullptr,
-                    unsigned chain_count = 0);
-// chain_wait / chain_signal (awq_w4a16_decode_cdna4_chain): launches on different queues ordered by in-kernel flags instead of kernel boundaries.
-// chain_signal: u32 [64], zeroed before every use: every block of the launch counts itself on word 0 once its outputs are acknowledged (write-through stores);
-// chain_wait / chain_count: a producer's word 0 and its block count -- the launch requests its weight ring first, waits for the count (bounded), then reads x past the L2.
-int gemv_dma_blocks(int m, int n, int k, int epi);  // grid size of the ONE launch that serves the call (0: not one launch)
+                    int dtype, int szfmt, hipStream_t st, int f32out = 0);
 int gemv_dma_tune_set(const char* key, int value);
 int launch_moe_gemv_cdna4(const void* x, const void* qw, const void* szp, const void* offsets, void* out, int total_rows,
                           int experts, int n, int k, int dtype, hipStream_t st);

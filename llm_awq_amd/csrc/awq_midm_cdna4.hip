@@ -27,6 +27,21 @@
 #include "awq_dma.hpp"
 #include "awq_kernels.hpp"
 
+#ifdef AWQ_ENABLE_PROBES
+// (AWQ_PROBES builds only; tools/midm_stamps.py) per-block time stamps of a launch: {start, loop start, loop end, end} x {s_memrealtime (100 MHz), s_memtime (shader clock)}
+__device__ unsigned long long g_midm_stamps[2048 * 8];
+extern "C" __attribute__((visibility("default"))) int awq_dev_midm_stamps(void* host_dst, int blocks) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_midm_stamps), (size_t)blocks * 64, 0, hipMemcpyDeviceToHost);
+}
+#define MIDM_STAMP(j)                                                                \
+  if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 2048) {                    \
+    g_midm_stamps[blockIdx.x * 8 + 2 * (j)] = __builtin_amdgcn_s_memrealtime();      \
+    g_midm_stamps[blockIdx.x * 8 + 2 * (j) + 1] = __builtin_readcyclecounter();      \
+  }
+#else
+#define MIDM_STAMP(j)
+#endif
+
 namespace awq {
 
 namespace {
@@ -127,6 +142,7 @@ template <typename DT, int WAVES, int NS, int CB, int DX, int DW, int DQ, int PR
 __global__ __launch_bounds__(64 * WAVES) void midm_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw, const u32* __restrict__ szp,
                                                         const uint16_t* __restrict__ bias, uint16_t* __restrict__ out, float* __restrict__ parts,
                                                         u32* __restrict__ tickets, int M, int N, int K, int epi, int f32out, int probe_) {
+  MIDM_STAMP(0)
   using vec8 = typename DT::vec8;
   const int probe = PROBE ? probe_ : 0;  // timing probes (AWQ_PROBES builds only; wrong results): bit 0 no x traffic, 1 no weight traffic, 2 no LDS reads / math, 3 no barrier, 4 no vmcnt wait, 5 no waits for the x fragments
   static_assert(DX >= 2 && DW >= DX + 1, "the packed words of step t + 1 must have landed when step t's x stage has");
@@ -302,8 +318,10 @@ __global__ __launch_bounds__(64 * WAVES) void midm_kernel(const uint16_t* __rest
     ws = wnext;
     ++t;
   };
+  MIDM_STAMP(1)
   while (t + DW - 1 < kn) step(std::false_type{});  // every group in range
   while (t < kn) step(std::true_type{});            // the last DW - 1 steps: groups past the K range are issued out of bounds
+  MIDM_STAMP(2)
   asm volatile("s_waitcnt vmcnt(0)" : : : "memory");  // the out-of-range tail groups (no traffic) have retired: LDS may be re-used
   // the K split stores the accumulators with inline-asm (write-through) stores: the compiler's hazard recogniser does not see a VMEM read of the last
   // MFMAs' destination registers there -- keep the required wait states (ISA: XDL write VGPR -> VMEM read) between them by hand
@@ -354,6 +372,10 @@ __global__ __launch_bounds__(64 * WAVES) void midm_kernel(const uint16_t* __rest
         }
       }
     }
+#ifdef AWQ_ENABLE_PROBES
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    MIDM_STAMP(3)
     return;
   }
 

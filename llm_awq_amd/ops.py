@@ -201,36 +201,6 @@ def decode_cdna4(x, qweight, sz_half, bias=None, epilogue: int = 0, group_size: 
     return out
 
 
-CHAIN_STATE_WORDS, CHAIN_TIMEOUT_WORD = 64, 32
-
-
-def decode_chain_blocks(m: int, n: int, k: int, epilogue: int = 0) -> int:
-    """block count of the one launch that serves the call: what the NEXT link of a chain waits for (0: the call is not one launch)"""
-    return int(_capi.lib().awq_w4a16_decode_cdna4_chain_blocks(int(m), int(n), int(k), int(epilogue)))
-
-
-def decode_cdna4_chain(x, qweight, sz_half, bias=None, epilogue: int = 0, wait_state=None, wait_count: int = 0, signal_state=None, out=None,
-                       group_size: int = 128):
-    """C-ABI awq_w4a16_decode_cdna4_chain: the decode launch as one link of a chain ordered by in-kernel counters (include/awq_cdna4.h).
-    wait_state / wait_count: the PREVIOUS link's state row and block count (decode_chain_blocks of its call); signal_state: this link's state row.
-    States: int32 [CHAIN_STATE_WORDS] rows of a 256-byte aligned tensor, zeroed by the caller before every pass.  Consecutive links go on different streams."""
-    _need_gpu(x, qweight, sz_half, bias)
-    k = x.shape[-1]
-    m = x.numel() // k
-    n = qweight.shape[0] * 4
-    if out is None:
-        out = torch.empty(*x.shape[:-1], n // 2 if epilogue else n, dtype=x.dtype, device=x.device)
-    for st in (wait_state, signal_state):
-        assert st is None or (st.dtype == torch.int32 and st.numel() >= CHAIN_STATE_WORDS and st.is_contiguous() and st.device == x.device)
-    with torch.cuda.device(x.device):
-        _capi.check(_capi.lib().awq_w4a16_decode_cdna4_chain(x.data_ptr(), qweight.data_ptr(), sz_half.data_ptr(),
-                                                              bias.data_ptr() if bias is not None else None, out.data_ptr(), m, n, k,
-                                                              group_size, _dt(x), int(epilogue),
-                                                              wait_state.data_ptr() if wait_state is not None else None, int(wait_count),
-                                                              signal_state.data_ptr() if signal_state is not None else None, _stream(x)))
-    return out
-
-
 def partial_cdna4(x, qweight, sz_packed, sz_half=None, group_size: int = 128):
     """C-ABI awq_w4a16_partial_cdna4: the K shard's product x . W^T as fp32 [..., N], unrounded, no bias (tensor-parallel row split)."""
     _need_gpu(x, qweight, sz_packed, sz_half)

@@ -5,4 +5,4 @@ cd "${GRAFT_REPO_ROOT:-.}"
 O=gpurun_out/md; mkdir -p $O
 export TMPDIR=/tmp
 ( timeout 400 python -m pytest tests/test_gpu_midm.py -q -x -k "every_block or deterministic" 2>&1 | tail -5 ) > $O/pytest.log; cat $O/pytest.log
-( MIDM_SZH=1 MIDM_CFGS=${MIDM_CFGS:-8x1} MIDM_LAG=${MIDM_LAG:-1,0} timeout 500 python tools/midm_sweep.py ${MIDM_MS:-16 32 64} 2>&1 | tail -80 ) > $O/sweep.txt; cat $O/sweep.txt
+( MIDM_SZH=1 timeout 500 python tools/midm_sweep.py ${MIDM_MS:-16 32 64} 2>&1 | tail -80 ) > $O/sweep.txt; cat $O/sweep.txt
