@@ -214,7 +214,7 @@ def test_skinny_split_k_vs_oracle_and_unsplit(env, dtype, K, N):
     qw = ops.repack_v2_to_cdna4(c["qweight"].cuda())
     s, z, b = c["scales"].cuda(), c["scaled_zeros"].cuda(), c["bias"].cuda()
     szp = ops.pack_sz_cdna4(s, z, K)
-    for M in (17, 33, 100, 48, 64):  # (100 rows: the mid-M kernel by default -- its parts are tests/test_gpu_midm.py's; the by-shape assertion below reads the last row count)
+    for M in (17, 33, 100, 48, 64):  # (100 rows: the mid-M kernel by default -- its parts are tests/test_gpu_midm.py's; the by-shape assertions below are for the skinny row counts)
         x = c["x"][:M].contiguous()
         xg = x.cuda()
         outs = {}
@@ -232,7 +232,7 @@ def test_skinny_split_k_vs_oracle_and_unsplit(env, dtype, K, N):
                 check_forward(y.cpu(), x, c["q"], c["scales"], c["scaled_zeros"], dtype, bias=c["bias"] if M != 48 else None)
             outs[knob] = (y, parts)
         nit = K // 128
-        if N * 2 // 32 <= 272 and nit % 2 == 0 and nit // 2 >= 8 and not (M >= 72 and M * K >= 600000):  # (the masked-tile GEMM takes the others)
+        if M <= 64 and N * 2 // 32 <= 272 and nit % 2 == 0 and nit // 2 >= 8:  # (65 rows and up: the mid-M kernel / the masked-tile GEMM)
             assert outs[-1][1] == (2 if (rows > 32 and nit >= 32) or nit >= 64 else 0), (M, outs[-1][1])  # by shape: 33..64 rows per pass from K = 4096, 17..32 rows from K = 8192
             assert outs[2][1] == 2 and outs[0][1] == 0
         assert_bits(outs[2][0], outs[0][0], 0.02, "two K parts vs unsplit")
