@@ -24,6 +24,8 @@ def ops():
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,K", [(16, 128), (48, 1280), (64, 11008), (256, 4096), (4096, 512), (6144, 4096), (4096, 14336)])
 def test_pack_szh_matches_oracle_and_decode_vs_oracle(ops, dtype, N, K):
+    if dtype == torch.float16 and N * K >= 6144 * 4096:
+        pytest.skip("the two largest shapes in bf16 only (fp16: the five others)")
     c = make_case(N, K, dtype, seed=N + K, M=8, bias=True)
     s, z = c["scales"].cuda(), c["scaled_zeros"].cuda()
     szh, exact = ops.pack_szh_cdna4(s, z, K)
@@ -67,8 +69,8 @@ def test_decode_ring_configurations(ops, knobs):
 def test_fused_gate_up_both_arrangements(ops, dtype, M, F, K):
     """epilogue 1 (stacked [gate; up]) and epilogue 2 (gate / up rows interleaved 8 + 8 per slab) == the reference's
     QuantLlamaMLP sequence (fused_mlp.py:36-83): two GEMVs, F.silu, multiply, every op rounded to T."""
-    if F >= 4096 and M not in (1, 8):
-        pytest.skip("full-size case: M = 1 and 8 only")
+    if F >= 4096 and (M not in (1, 8) or (M == 1 and dtype == torch.float16)):
+        pytest.skip("full-size case: M = 1 (bf16) and 8 only")
     cg = make_case(F, K, dtype, seed=F + K + M, M=M)
     cu = make_case(F, K, dtype, seed=F + K + M + 1, M=M)
     x = cg["x"]
@@ -116,6 +118,8 @@ def test_inexact_scales_are_flagged(ops):
 def test_batched_decode_on_the_skinny_kernel(ops, dtype, N, K):
     """the decode entry with its rows handed to the skinny kernel (x through registers, shared by a block's slabs; knob
     decode_skinny_from): every row count, bias, both side-buffer forms, narrow and wide (two slabs per block, ragged last block)"""
+    if dtype == torch.float16 and N * K >= 6144 * 4096:
+        pytest.skip("the largest shape in bf16 only")
     c = make_case(N, K, dtype, seed=N + K + 2, M=8, bias=True)  # (the parity of N + K: shares the full-size oracle case of the test above)
     c4 = ops.repack_v2_to_cdna4(c["qweight"].cuda())
     szh, exact = ops.pack_szh_cdna4(c["scales"].cuda(), c["scaled_zeros"].cuda(), K)

@@ -30,10 +30,10 @@ def _pair(F, K, dtype, seed, M):
 def test_gate_up_entry_every_row_count(dtype, M, F, K):
     from llm_awq_amd import ops
     from llm_awq_amd.fused_mlp import interleave_gate_up
-    if F >= 4096 and (M not in (1, 9, 2048) or dtype != torch.bfloat16):
-        pytest.skip("full-size case: bf16, M = 1, 9, 2048 only")
-    if M == 2048 and F * K < 2048 * 2048:
-        pytest.skip("M = 2048 on the two larger shapes only")
+    if F >= 4096 and (M not in (1, 9, 300) or dtype != torch.bfloat16):
+        pytest.skip("full-size case: bf16, M = 1, 9, 300 only (2048 rows of this shape against the CPU oracle: tests/test_gpu_oracle_fullsize.py, the plain linear)")
+    if M == 2048 and F != 2048:
+        pytest.skip("M = 2048 on the (2048, 2048) pair only")
     cg, cu, x, ref, gt, up = _pair(F, K, dtype, F + K + M, M)
     qi, si, zi = interleave_gate_up(cg["qweight"].cuda(), cu["qweight"].cuda(), cg["scales"].cuda(), cu["scales"].cuda(),
                                     cg["scaled_zeros"].cuda(), cu["scaled_zeros"].cuda())

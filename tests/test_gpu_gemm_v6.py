@@ -5,6 +5,8 @@ epilogue all run through it; the checker is the oracle (tests/helpers.check_forw
 awq_gemm_v4n.hip's 256 x 128 tiles (knob gemm_v6 = 0: same products, fp32 accumulation in the same K order; the two differ only in the
 association inside one 32-k MFMA: 16x16x32 against two 32x32x16).  (Round 2's 256 x 256 tile of that loop, awq_gemm_v4.hip, was the second
 implementation here until round 4 removed it from the library.)"""
+import os
+
 import pytest
 import torch
 
@@ -327,6 +329,9 @@ def test_v6_block_pair_k4096_launches_sz_half_and_the_fused_tail(ops):
         assert_bits(y, y128, 0.01)
     assert torch.equal(ys[0], ys[1]), "the two dequant forms give the same weights, so the same products in the same order"
     # ---- gate/up: 4096 -> 2 x 14336 interleaved; 8 x 96 tiles in three full rounds + 128 tiles = 128 pairs behind them ----
+    # (a configuration only the knob reaches -- the default keeps K = 4096 launches off the pairs: run on request, it costs ~20 s of CPU oracle)
+    if os.environ.get("AWQ_TEST_FULL") != "1":
+        return
     F = 14336
     cg, cu = make_case(F, K, dtype, seed=F + K + M, M=1), make_case(F, K, dtype, seed=F + K + M + 1, M=1)
     qi, si, zi = interleave_gate_up(cg["qweight"].cuda(), cu["qweight"].cuda(), cg["scales"].cuda(), cu["scales"].cuda(),

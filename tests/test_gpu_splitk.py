@@ -208,6 +208,8 @@ def test_skinny_split_k_vs_oracle_and_unsplit(env, dtype, K, N):
     once and adds the bias.  Against the oracle's forward bound, deterministic from call to call, and close to the unsplit launch (another association)."""
     from oracle import awq_oracle as O  # noqa: F401
     from tests.helpers import check_forward, make_case
+    if dtype == torch.float16 and (K, N) in ((14336, 4096), (4096, 6144)):
+        pytest.skip("fp16 on the other three shapes (the CPU oracle of these two takes 10 - 20 s per dtype)")
     ops, _ = env
     L = ops._capi.lib()
     c = make_case(N, K, dtype, seed=K + N, M=100, bias=True)
