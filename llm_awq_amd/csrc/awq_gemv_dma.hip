@@ -219,7 +219,7 @@ struct DmaCfg {
   size_t smem;
 };
 int g_dma_skinny_from = 0;  // knob decode_skinny_from: 0 = by shape (skinny_takes below), 1..8 = from that row count, 9 = never
-int g_dma_waves = 0, g_dma_d = 0, g_dma_probe = 0, g_dma_four = 1;  // gemvd_four: four ring-7 blocks per CU where there are > 3 slabs per CU (rounds 4 + 3 instead of 3 + 3 + 1: +0.6 % decode tok/s, profiles/r03_gemvps.txt)
+int g_dma_waves = 0, g_dma_d = 0, g_dma_probe = 0, g_dma_four = 1, g_dma_want = 0;  // gemvd_four: four ring-7 blocks per CU where there are > 3 slabs per CU (rounds 4 + 3 instead of 3 + 3 + 1: +0.6 % decode tok/s, profiles/r03_gemvps.txt)
 
 size_t dma_smem(int waves, int d, int ns, int tx, int m) {
   const int txp = (tx + 3) & ~3;
@@ -250,6 +250,7 @@ bool pick_dma(int m, int n_rows, int k, int ns, DmaCfg& c) {
   if (g_dma_waves) waves = g_dma_waves;
   while (waves > 4 && waves > nit) waves >>= 1;  // (waves beyond the step count idle: their steps are clamped and skipped)
   int want = blocks_per_cu <= 1.0 ? 1 : (blocks_per_cu <= 2.0 ? 2 : (blocks_per_cu <= 3.0 ? 3 : 4));
+  if (g_dma_want) want = g_dma_want;  // knob gemvd_want (experiments): blocks per CU the LDS budget is sized for
   if (waves == 4 && want > 3 && !g_dma_four) want = 3;  // (three ring-8 blocks beat four ring-4 ones: 14.8 vs 15.1 us; four ring-7 blocks beat both)
   // x staging is m * k * 2 bytes per block whatever the wave count: when it crowds out the ring, fewer, longer waves
   while (waves > 4 && dma_smem(waves, 1, ns, (nit + waves - 1) / waves, m) > 150 * 1024) waves >>= 1;
@@ -274,6 +275,7 @@ int gemv_dma_tune_set(const char* key, int value) {
   else if (!strcmp(key, "gemvd_d")) g_dma_d = value;
   else if (!strcmp(key, "gemvd_probe")) g_dma_probe = value;
   else if (!strcmp(key, "gemvd_four")) g_dma_four = value;
+  else if (!strcmp(key, "gemvd_want")) g_dma_want = value;
   else if (!strcmp(key, "decode_skinny_from")) g_dma_skinny_from = value;
   else return -1;
   return 0;
