@@ -219,7 +219,7 @@ struct DmaCfg {
   size_t smem;
 };
 int g_dma_skinny_from = 0;  // knob decode_skinny_from: 0 = by shape (skinny_takes below), 1..8 = from that row count, 9 = never
-int g_dma_waves = 0, g_dma_d = 0, g_dma_probe = 0, g_dma_four = 1, g_dma_want = 0;  // gemvd_four: four ring-7 blocks per CU where there are > 3 slabs per CU (rounds 4 + 3 instead of 3 + 3 + 1: +0.6 % decode tok/s, profiles/r03_gemvps.txt)
+int g_dma_waves = 0, g_dma_d = 0, g_dma_probe = 0, g_dma_four = 1, g_dma_want = 0, g_dma_wide8 = 2;  // gemvd_four: four ring-7 blocks per CU where there are > 3 slabs per CU (rounds 4 + 3 instead of 3 + 3 + 1: +0.6 % decode tok/s, profiles/r03_gemvps.txt)
 
 size_t dma_smem(int waves, int d, int ns, int tx, int m) {
   const int txp = (tx + 3) & ~3;
@@ -235,6 +235,9 @@ bool skinny_takes(int m, int n_rows, int k, int epi) {
   if (epi == 1) return false;  // (the stacked [gate; up] form has no skinny epilogue)
   if (g_dma_skinny_from) return m >= g_dma_skinny_from;
   const double blocks_per_cu = (double)(n_rows / 16) / 256.0;
+  // more than three slabs per CU (the fused gate/up pair; eight-wave blocks from two rows, pick_dma): three co-resident blocks stage 3 m K 2 bytes --
+  // K = 4096: the skinny kernel from five rows (15.97 vs 16.99 us), K = 8192 (70B): from three (47.5 vs 51.0 us; at two rows 46.4 vs 47.1 the other way)
+  if (blocks_per_cu > 3.0 && k < 96 * 128 && g_dma_wide8 != 0) return (size_t)m * (size_t)k * 2 * 3 >= 112 * 1024;
   const int want = blocks_per_cu <= 1.0 ? 1 : (blocks_per_cu <= 2.0 ? 2 : (blocks_per_cu <= 3.0 ? 3 : 4));
   return m >= 5 && (size_t)m * (size_t)k * 2 * want >= 128 * 1024;
 }
@@ -246,7 +249,12 @@ bool pick_dma(int m, int n_rows, int k, int ns, DmaCfg& c) {
   // slabs share a CU (gate/up: 4 waves x 8 tiles), 8 waves x 2..4 tiles for 1..2 slabs per CU, 16 waves x 1..2 for a long K
   const int nit = k / kGroup, slabs = n_rows / 16 / ns;
   const double blocks_per_cu = (double)slabs / 256.0;
-  int waves = nit >= 96 ? 16 : (blocks_per_cu > 3.0 ? 4 : 8);
+  // > 3 slabs per CU (the fused gate/up pair): eight-wave blocks whose ring holds a wave's whole K range (K = 4096: four tiles, nothing re-issued inside the
+  // loop), three co-resident per CU.  The x staging is m x K x 2 bytes per BLOCK, so half as many blocks stage half as much and leave the ring its depth:
+  // gate/up -7 ... -13 % at 2 .. 4 rows, -2.5 % at one row against rounds 2 - 5's four-wave blocks with a ring of seven (profiles/r06_decode_cfg.txt;
+  // knob gemvd_wide8: 0 = the four-wave blocks at every m, 1 = eight waves from two rows only, 2 (default) = at every m)
+  bool wide8 = blocks_per_cu > 3.0 && nit < 96 && m >= (g_dma_wide8 == 2 ? 1 : 2) && g_dma_wide8 != 0;
+  int waves = nit >= 96 ? 16 : (blocks_per_cu > 3.0 && !wide8 ? 4 : 8);
   if (g_dma_waves) waves = g_dma_waves;
   while (waves > 4 && waves > nit) waves >>= 1;  // (waves beyond the step count idle: their steps are clamped and skipped)
   int want = blocks_per_cu <= 1.0 ? 1 : (blocks_per_cu <= 2.0 ? 2 : (blocks_per_cu <= 3.0 ? 3 : 4));
@@ -254,10 +262,12 @@ bool pick_dma(int m, int n_rows, int k, int ns, DmaCfg& c) {
   if (waves == 4 && want > 3 && !g_dma_four) want = 3;  // (three ring-8 blocks beat four ring-4 ones: 14.8 vs 15.1 us; four ring-7 blocks beat both)
   // x staging is m * k * 2 bytes per block whatever the wave count: when it crowds out the ring, fewer, longer waves
   while (waves > 4 && dma_smem(waves, 1, ns, (nit + waves - 1) / waves, m) > 150 * 1024) waves >>= 1;
+  if (waves != 8) wide8 = false;
   const int tx = (nit + waves - 1) / waves;
   int d = tx < 8 ? tx : 8;
   if (waves == 16 && !g_dma_d) d = 1;            // 16 waves per block already keep 16+ KiB per CU in flight (8.2 vs 8.7 us at d = 2)
-  if (waves == 8 && !g_dma_d && d > 2) d = 2;
+  if (waves == 8 && !g_dma_d && d > 2 && !wide8 && (m < 3 || blocks_per_cu <= 1.0)) d = 2;  // (two blocks per CU from three rows: a ring of four, qkv -2 %; o_proj keeps two)
+  if (wide8 && !g_dma_want) want = tx > 4 ? 2 : 3;  // three eight-wave blocks per CU (two when a wave's K range is eight tiles: K = 8192); the LDS budget below picks the depth (4 / 4 / 2 / 2 at 1 .. 4 rows against K = 4096)
   if (g_dma_d) d = g_dma_d < tx ? g_dma_d : tx;
   // LDS: blocks that want to be co-resident on a CU must fit in 160 KiB
   while (d > 1 && dma_smem(waves, d, ns, tx, m) * want > 156 * 1024) --d;
@@ -276,6 +286,7 @@ int gemv_dma_tune_set(const char* key, int value) {
   else if (!strcmp(key, "gemvd_probe")) g_dma_probe = value;
   else if (!strcmp(key, "gemvd_four")) g_dma_four = value;
   else if (!strcmp(key, "gemvd_want")) g_dma_want = value;
+  else if (!strcmp(key, "gemvd_wide8")) g_dma_wide8 = value;
   else if (!strcmp(key, "decode_skinny_from")) g_dma_skinny_from = value;
   else return -1;
   return 0;

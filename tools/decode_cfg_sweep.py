@@ -16,8 +16,13 @@ def main():
     L = _capi.lib()
     dtype = torch.bfloat16
     ms = [int(a) for a in sys.argv[1:]] or [1, 2, 4]
-    shapes = [("qkv", 4096, 6144, 0), ("o", 4096, 4096, 0), ("gate/up", 4096, 28672, 2), ("down", 14336, 4096, 0)]
+    shapes = [("qkv", 4096, 6144, 0), ("o", 4096, 4096, 0), ("gate/up", 4096, 28672, 2), ("down", 14336, 4096, 0),
+              ("gu70b", 8192, 57344, 2), ("gu7b", 4096, 22016, 2), ("qkv70b", 8192, 10240, 0), ("down70b", 28672, 8192, 0)]
+    if os.environ.get("SHAPES"):
+        shapes = [s for s in shapes if s[0] in os.environ["SHAPES"].split(",")]
     cfgs = [(0, 0, 0)] + [(w, 1, d) for w in (4, 8, 16) for d in (1, 2, 4, 8)] + [(0, 0, 0)]  # (want = 1: the ring depth is the forced one unless ONE block exceeds the LDS)
+    if os.environ.get("CFGS"):  # "waves:want:d,..." ; waves = -1: the skinny kernel
+        cfgs = [tuple(int(v) for v in c.split(":")) for c in os.environ["CFGS"].split(",")]
     for (name, K, N, epi) in shapes:
         R = max(10, min(40, (700 << 20) // (N * K // 2)))
         copies = []
@@ -49,7 +54,8 @@ def main():
             ref = None
             line = []
             for (w, want, d) in cfgs:
-                _capi.tune(gemvd_waves=w, gemvd_want=want, gemvd_d=d)
+                _capi.tune(decode_skinny_from=1 if w < 0 else 9)
+                _capi.tune(gemvd_waves=max(w, 0), gemvd_want=want, gemvd_d=d)
                 out.zero_()
                 try:
                     fn(copies[0])
@@ -60,6 +66,9 @@ def main():
                 if ref is None:
                     ref = out.clone()
                 ok = bool((out == ref).all())
+                if (out.float() - ref.float()).abs().max().item() > 0.05 * ref.float().abs().max().item():
+                    line.append(f"{w}w/d{d}:WRONG")
+                    continue
                 us = time_graph(fn, copies)
                 line.append(f"{w}w/d{d}:{us:.2f}{'' if ok else '!'}")
             print(f"{name:8s} M={M}  " + "  ".join(line), flush=True)
