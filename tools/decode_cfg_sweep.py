@@ -21,7 +21,7 @@ def main():
     if os.environ.get("SHAPES"):
         shapes = [s for s in shapes if s[0] in os.environ["SHAPES"].split(",")]
     cfgs = [(0, 0, 0)] + [(w, 1, d) for w in (4, 8, 16) for d in (1, 2, 4, 8)] + [(0, 0, 0)]  # (want = 1: the ring depth is the forced one unless ONE block exceeds the LDS)
-    if os.environ.get("CFGS"):  # "waves:want:d,..." ; waves = -1: the skinny kernel
+    if os.environ.get("CFGS"):  # "waves:want:d[:ns2],..." ; waves = -1: the skinny kernel; ns2 = 1: two slabs per block on the wide launches (knob gemvd_ns2)
         cfgs = [tuple(int(v) for v in c.split(":")) for c in os.environ["CFGS"].split(",")]
     for (name, K, N, epi) in shapes:
         R = max(10, min(40, (700 << 20) // (N * K // 2)))
@@ -53,8 +53,9 @@ def main():
             _capi.tune(decode_skinny_from=9)
             ref = None
             line = []
-            for (w, want, d) in cfgs:
-                _capi.tune(decode_skinny_from=1 if w < 0 else 9)
+            for cfg in cfgs:
+                (w, want, d), ns2 = cfg[:3], (cfg[3] if len(cfg) > 3 else 0)
+                _capi.tune(decode_skinny_from=1 if w < 0 else 9, gemvd_ns2=ns2)
                 _capi.tune(gemvd_waves=max(w, 0), gemvd_want=want, gemvd_d=d)
                 out.zero_()
                 try:
@@ -70,11 +71,11 @@ def main():
                     line.append(f"{w}w/d{d}:WRONG")
                     continue
                 us = time_graph(fn, copies)
-                line.append(f"{w}w/d{d}:{us:.2f}{'' if ok else '!'}")
+                line.append(f"{w}w/d{d}{'/ns2' if ns2 else ''}:{us:.2f}{'' if ok else '!'}")
             print(f"{name:8s} M={M}  " + "  ".join(line), flush=True)
         del copies
         torch.cuda.empty_cache()
-    _capi.tune(gemvd_waves=0, gemvd_want=0, gemvd_d=0, decode_skinny_from=0)
+    _capi.tune(gemvd_waves=0, gemvd_want=0, gemvd_d=0, decode_skinny_from=0, gemvd_ns2=0)
 
 
 if __name__ == "__main__":
