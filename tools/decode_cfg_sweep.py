@@ -55,7 +55,9 @@ def main():
             line = []
             for cfg in cfgs:
                 (w, want, d), ns2 = cfg[:3], (cfg[3] if len(cfg) > 3 else 0)
-                _capi.tune(decode_skinny_from=1 if w < 0 else 9, gemvd_ns2=ns2)
+                _capi.tune(decode_skinny_from=1 if w < 0 else 9)
+                if ns2:  # (the knob exists in builds of the two-slab experiment only: tools/EXPERIMENTS.md)
+                    _capi.tune(gemvd_ns2=ns2)
                 _capi.tune(gemvd_waves=max(w, 0), gemvd_want=want, gemvd_d=d)
                 out.zero_()
                 try:
@@ -75,7 +77,7 @@ def main():
             print(f"{name:8s} M={M}  " + "  ".join(line), flush=True)
         del copies
         torch.cuda.empty_cache()
-    _capi.tune(gemvd_waves=0, gemvd_want=0, gemvd_d=0, decode_skinny_from=0, gemvd_ns2=0)
+    _capi.tune(gemvd_waves=0, gemvd_want=0, gemvd_d=0, decode_skinny_from=0)
 
 
 if __name__ == "__main__":
