@@ -185,6 +185,12 @@ int awq_w4a16_gemm_cdna4_plan(int m, int n, int bits, int* mode, int* cols_main)
  * of the reference's split_k_iters + Semaphore, gemm_cuda.cu:546-619, without a second kernel; 0 = the tiles awq_w4a16_gemm_cdna4_plan names.
  * The two halves' fp32 sums are added once (lower K range + upper K range): another association than the unsplit kernels', same products. */
 int awq_w4a16_gemm_cdna4_pair_plan(int m, int n, int k);
+/* The two blocks of a pair wait for each other's partial sums with a BOUNDED spin; a block whose partner never arrives (a launch that cannot own
+ * the chip: CU masks, another tenant holding every CU) writes NaN to its outputs instead of hanging the queue and counts itself in a library-owned
+ * per-device word.  This query copies that word to the host (it synchronises with the device): *count = pair blocks of the CURRENT device that
+ * gave up since the library was loaded; 0 on a healthy run.  The reference's Semaphore (semaphore.h:44-103) spins without a bound.  Returns
+ * AWQ_OK or AWQ_ERR_LAUNCH. */
+int awq_w4a16_gemm_cdna4_pair_lost(unsigned int* count);
 /* host-side query: which kernel runs the 256 x 128 blocks of such a launch over n_cols weight rows.  Returns 1 = awq_gemm_v6.hip (one wave
  * per SIMD, two slabs per wave: every unsplit launch of W4 tiles at m >= 256), 0 = awq_gemm_v4n.hip unsplit (m < 256: masked single row
  * tile; W3 tiles), ks >= 2 = awq_gemm_v4n.hip with the K loop split into ks ranges (needs the workspace and no fused SiLU*mul tail). */

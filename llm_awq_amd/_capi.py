@@ -47,6 +47,7 @@ SIGNATURES = {
     "awq_midm_init": (_i, []),
     "awq_w4a16_gemm_cdna4_plan": (_i, [_i, _i, _i, _vp, _vp]),
     "awq_w4a16_gemm_cdna4_pair_plan": (_i, [_i, _i, _i]),
+    "awq_w4a16_gemm_cdna4_pair_lost": (_i, [_vp]),
     "awq_w4a16_gemm_cdna4_narrow_kernel": (_i, [_i, _i, _i, _i, _i, _i]),
     "awq_w4a16_decode_cdna4_plan": (_i, [_i, _i, _i, _i, _vp]),
     "awq_w4a16_gemm_cdna4": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),

@@ -307,6 +307,7 @@ size_t awq_w4a16_forward_cdna4_workspace_bytes(int m, int n, int k) {
 }
 int awq_midm_init(void) { return awq::midm_init() == 0 ? AWQ_OK : AWQ_ERR_LAUNCH; }
 int awq_w4a16_gemm_cdna4_pair_plan(int m, int n, int k) { return awq::gemm_cdna4_v3_pair_plan(m, n, k); }
+int awq_w4a16_gemm_cdna4_pair_lost(unsigned int* count) { return awq::gemm_v6_pair_lost(count) == 0 ? AWQ_OK : AWQ_ERR_LAUNCH; }
 int awq_w4a16_gemm_cdna4_plan(int m, int n, int bits, int* mode, int* cols_main) { return awq::gemm_cdna4_v3_plan(m, n, bits, mode, cols_main); }
 int awq_w4a16_gemm_cdna4_narrow_kernel(int m, int n_cols, int k, int bits, int has_workspace, int epilogue) {
   return awq::gemm_cdna4_v3_narrow_kernel(m, n_cols, k, bits, has_workspace, epilogue);

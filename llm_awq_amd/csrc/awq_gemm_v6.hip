@@ -32,6 +32,10 @@
 
 namespace awq {
 
+// blocks of gemm_cdna4_v6_pair_kernel that gave up waiting for their partner since the library was loaded, on this device (their outputs are NaN): a library-owned
+// counter beside the per-pair sticky word in the caller's workspace, which nobody can poll once the workspace is gone.  Host: gemm_v6_pair_lost().
+__device__ unsigned int g_v6_pair_lost;
+
 namespace {
 constexpr int V6_TM = 256, V6_TN = 256, V6_TK = 128;
 constexpr int kV6Stage = V6_TM * V6_TK * 2;  // 64 KiB
@@ -459,7 +463,10 @@ __device__ __forceinline__ void v6_tile(char* smem, const uint16_t* __restrict__
       for (int f = 0; f < FN; ++f)
 #pragma unroll
         for (int s2 = 0; s2 < NS; ++s2) acc[F0 + f][s2] = f32x4{bad, bad, bad, bad};
-      if (tid == 0) flag[7].x = 1u;  // (word 14 of the pair's 64-byte flag line: sticky)
+      if (tid == 0) {
+        flag[7].x = 1u;  // (word 14 of the pair's 64-byte flag line: sticky)
+        atomicAdd(&g_v6_pair_lost, 1u);
+      }
     }
   }
   if (epi == 3) {
@@ -701,6 +708,14 @@ size_t gemm_v6_pair_workspace_bytes(int m, int n, int k) {
   const size_t tiles = (size_t)((m + V6_TM - 1) / V6_TM) * (n / V6_TN);
   return tiles * (size_t)(V6_TM * V6_TN * 4) + tiles * 64;
 }
+// host: how many pair blocks of the CURRENT device ever gave up waiting (a synchronising device-to-host copy of the counter); -1 on a runtime error
+int gemm_v6_pair_lost(unsigned* count) {
+  unsigned v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_v6_pair_lost), sizeof(v), 0, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (count) *count = v;
+  return 0;
+}
+
 // weight rows [n_begin, n_end) of the [n, k] matrix as block pairs; epi 0 / 2 as launch_gemm_cdna4_v6; szfmt 1: szp = sz_half (W4).  Returns -1 if it does
 // not serve the call (shape, workspace): the caller runs the 256 x 128 blocks
 int launch_gemm_cdna4_v6_pair(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin, int n_end,

@@ -152,6 +152,7 @@ void launch_gemm_cdna4_v6(const void* x, const void* qw, const void* szp, const 
 void gemm_v6_set_probe(int v);
 // K split over pairs of 256 x 256 blocks inside one launch (tiles that fill at most half the chip, long K: down_proj at 2048 rows); -1 = not served
 bool gemm_v6_pair_takes(int m, int n, int k);
+int gemm_v6_pair_lost(unsigned* count);  // awq_gemm_v6.hip: pair blocks of the current device that gave up waiting for their partner (outputs NaN) since load
 int gemm_cdna4_v3_pair_plan(int m, int n, int k);  // awq_gemm_plan.hip: 1 = the prefill call (with its workspace) takes the block-pair K split
 size_t gemm_v6_pair_workspace_bytes(int m, int n, int k);
 int launch_gemm_cdna4_v6_pair(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int n_begin, int n_end,

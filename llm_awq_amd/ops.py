@@ -480,3 +480,17 @@ def silu_mul(gate, up):
     with torch.cuda.device(gate.device):
         _capi.check(_capi.lib().awq_silu_mul(gate.data_ptr(), up.data_ptr(), out.data_ptr(), gate.numel(), _dt(gate), _stream(gate)))
     return out
+
+
+def pair_lost_count(device=None) -> int:
+    """C-ABI awq_w4a16_gemm_cdna4_pair_lost: blocks of the block-pair K split (down_proj-shaped prefill launches) of `device` that gave up waiting
+    for their partner since the library was loaded -- their outputs are NaN.  0 on a healthy run; synchronises with the device.  A serving loop
+    that shares the GPU (CU masks, other tenants) polls this between batches and sets the knob `gemm_v6_pair` = 0 when it ever moves."""
+    import ctypes
+    if not torch.cuda.is_available():
+        raise RuntimeError("pair_lost_count needs the GPU the library runs on")
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    c = ctypes.c_uint(0)
+    with torch.cuda.device(dev):
+        _capi.check(_capi.lib().awq_w4a16_gemm_cdna4_pair_lost(ctypes.byref(c)))
+    return int(c.value)

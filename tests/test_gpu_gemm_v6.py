@@ -262,6 +262,8 @@ def test_v6_block_pair_down_proj_full_size_graph_replay_and_routing(ops):
             torch.cuda.synchronize()
             for xx, yy in zip(xs, ys):
                 assert torch.equal(yy, call(xx, ws)), rep
+    # the library-owned count of pair blocks that gave up waiting for their partner (their outputs would be NaN): none on a GPU this process owns
+    assert ops.pair_lost_count() == 0
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
