@@ -237,7 +237,7 @@ bool skinny_takes(int m, int n_rows, int k, int epi) {
   const double blocks_per_cu = (double)(n_rows / 16) / 256.0;
   // more than three slabs per CU (the fused gate/up pair; eight-wave blocks from two rows, pick_dma): three co-resident blocks stage 3 m K 2 bytes --
   // K = 4096: the skinny kernel from five rows (15.97 vs 16.99 us), K = 8192 (70B): from three (47.5 vs 51.0 us; at two rows 46.4 vs 47.1 the other way)
-  if (blocks_per_cu > 3.0 && k < 96 * 128 && g_dma_wide8 != 0) return (size_t)m * (size_t)k * 2 * 3 >= 112 * 1024;
+  if (blocks_per_cu > 3.0 && k >= 32 * 128 && k < 96 * 128 && g_dma_wide8 != 0) return (size_t)m * (size_t)k * 2 * 3 >= 112 * 1024;
   const int want = blocks_per_cu <= 1.0 ? 1 : (blocks_per_cu <= 2.0 ? 2 : (blocks_per_cu <= 3.0 ? 3 : 4));
   return m >= 5 && (size_t)m * (size_t)k * 2 * want >= 128 * 1024;
 }
@@ -253,7 +253,7 @@ bool pick_dma(int m, int n_rows, int k, int ns, DmaCfg& c) {
   // loop), three co-resident per CU.  The x staging is m x K x 2 bytes per BLOCK, so half as many blocks stage half as much and leave the ring its depth:
   // gate/up -7 ... -13 % at 2 .. 4 rows, -2.5 % at one row against rounds 2 - 5's four-wave blocks with a ring of seven (profiles/r06_decode_cfg.txt;
   // knob gemvd_wide8: 0 = the four-wave blocks at every m, 1 = eight waves from two rows only, 2 (default) = at every m)
-  bool wide8 = blocks_per_cu > 3.0 && nit < 96 && m >= (g_dma_wide8 == 2 ? 1 : 2) && g_dma_wide8 != 0;
+  bool wide8 = blocks_per_cu > 3.0 && nit >= 32 && nit < 96 && m >= (g_dma_wide8 == 2 ? 1 : 2) && g_dma_wide8 != 0;  // (measured at K = 4096 and 8192; the short K ranges of tensor-parallel shards keep the four-wave blocks)
   int waves = nit >= 96 ? 16 : (blocks_per_cu > 3.0 && !wide8 ? 4 : 8);
   if (g_dma_waves) waves = g_dma_waves;
   while (waves > 4 && waves > nit) waves >>= 1;  // (waves beyond the step count idle: their steps are clamped and skipped)
