@@ -40,7 +40,7 @@ def test_pack_szh_matches_oracle_and_decode_vs_oracle(ops, dtype, N, K):
             check_forward(y.cpu(), x, c["q"], c["scales"], c["scaled_zeros"], dtype, bias=b)
 
 
-@pytest.mark.parametrize("knobs", [dict(gemvd_waves=4, gemvd_d=4), dict(gemvd_waves=8, gemvd_d=1), dict(gemvd_waves=8, gemvd_d=2),
+@pytest.mark.parametrize("knobs", [dict(gemvd_waves=4, gemvd_d=4), dict(gemvd_waves=8, gemvd_d=1), dict(gemvd_waves=8, gemvd_d=2), dict(gemvd_waves=8, gemvd_d=4), dict(gemvd_waves=8, gemvd_d=8),
                                    dict(gemvd_waves=16, gemvd_d=1), dict(gemvd_waves=16, gemvd_d=2), dict(gemvd_waves=16, gemvd_d=4)])
 def test_decode_ring_configurations(ops, knobs):
     """every compiled (waves, ring depth) incl. ragged step counts, waves with no steps, and the counted tail waits"""
