@@ -86,6 +86,7 @@ int gemm_v3_tune_set(const char* key, int value) {
   else if (!strcmp(key, "gemm_v6_128")) g_v6_128 = value;
   else if (!strcmp(key, "moe_v4")) g_moe_v4 = value;
   else if (!strcmp(key, "gemm_small_m")) g_small_m = value;
+  else if (!strcmp(key, "gemm_splitk_cap")) g_v4n_ksplit_cap = value;
   else if (!strcmp(key, "gemm_splitk")) {  // 0 = off, 1 = auto, n > 1 = force n K ranges
     g_splitk = value;
     g_v4n_ksplit_force = value > 1 ? value : 0;

@@ -471,6 +471,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // block (~1.6 us), fitted to profiles/r01_splitk_sweep.txt: an unsplit block pays its groups + ~2 (pipeline fill, epilogue);
 // a split block its groups + ~0.6; blocks run in rounds of 256 (one per CU); every (tile, range) costs 128 KiB of fp32
 // partials written and read back (~0.041 per block) and the second launch ~1.3.
+int g_v4n_ksplit_cap = 1;   // knob gemm_splitk_cap: 0 = the round-1 rule without the skip below
 int g_v4n_ksplit_force = 0;  // > 1: use exactly this many ranges (knob gemm_splitk = n; experiments)
 int gemm_v4n_ksplit(int m, int n_cols, int k) {
   const long tiles = (long)((m + TM - 1) / TM) * ((n_cols + TN - 1) / TN);
@@ -481,6 +482,9 @@ int gemm_v4n_ksplit(int m, int n_cols, int k) {
   double best_cost = 0.9 * unsplit;  // a split has to be clearly better
   int best = 1;
   for (int d = 2; d <= 16 && nit / d >= 2; ++d) {
+    // (round 6 re-sweep, profiles/r06_splitk_sweep.txt: a full round of blocks with eight or fewer K groups each loses to three quarters of a round with
+    // longer loops -- o_proj at 512 rows: 4 ranges x 64 tiles 37.2 us, 3 ranges 31.9 us; at 256 rows 8 ranges 32.9, 6 ranges 26.4)
+    if (g_v4n_ksplit_cap && tiles * d > 192 && tiles * d <= 256 && nit / d <= 8) continue;
     const double cost = rounds(tiles * d) * ((nit + d - 1) / d + 0.6) + 0.041 * (double)(tiles * d) + 1.3;
     if (cost < best_cost) {
       best_cost = cost;

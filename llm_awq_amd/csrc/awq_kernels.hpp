@@ -130,6 +130,7 @@ void launch_gemm_cdna4_v4n(const void* x, const void* qw, const void* szp, const
                            int n_begin, int n_end, int dtype, void* ws, size_t ws_bytes, hipStream_t st, int bits = 4, int epi = 0);
 size_t gemm_v4n_workspace_bytes(int m, int n_cols, int k);
 extern int g_v4n_ksplit_force;  // knob gemm_splitk > 1
+extern int g_v4n_ksplit_cap;    // knob gemm_splitk_cap
 bool gemm_cdna4_v3_takes(int m, int k);  // m >= 256, or a shorter prompt the 256-row tile still beats the skinny kernel on
 size_t gemm_cdna4_v3_workspace_bytes(int m, int n, int k);
 int gemm_cdna4_v3_plan(int m, int n, int bits, int* mode, int* cols_main);
