@@ -103,7 +103,7 @@ struct Plan {
   int mode;        // 0 = all 256-wide, 1 = all 128-wide, 2 = 256-wide for [0, cols_main * 256) + 128-wide for the rest, 3 = all 192-wide
   long cols_main;
 };
-constexpr double k192Rate = 0.97;  // 256 x 192 blocks of awq_gemm_v6.hip (three slabs per wave) vs its 256 x 256 blocks at equal chip fill
+constexpr double k192Rate = 0.97;  // 256 x 192 blocks of awq_gemm_v6.hip (three slabs per wave) vs its 256 x 256 blocks at equal chip fill (round-6 kernel stats: a round of them is 91 us against 0.75 x 108 = 81, i.e. 0.89 -- with that value only qkv at 4096 rows changes plan, to one 256-wide round + 256 two-slab blocks, and the M = 4096 pass moves by 0.1-0.3 %: tools/EXPERIMENTS.md)
 Plan plan_tiles(int m, int n, int tile_n, bool allow192 = false) {
   if (tile_n == 128) return {1, 0};
   if (tile_n == 256) return {0, 0};
