@@ -38,6 +38,9 @@ namespace awq {
 #endif
 // bit 8 of the same kernel argument (every build): EPI 0 stores its fp32 sums to `out` as float [M, N] instead of rounding them to T
 constexpr int kDmaF32Out = 0x100;
+// bit 9: the waves split K in INTERLEAVED 128-k steps (wave w: steps w, w + WAVES, ...) instead of contiguous ranges: the tiles a block has in flight at any
+// moment are one contiguous run of its slab's stream (launches whose ring is shallower than a wave's K range: down_proj, qkv, o_proj)
+constexpr int kDmaInterleave = 0x200;
 // EPI 0: out[m, n] (+ bias);  EPI 1: qw = [gate; up] stacked along N, out[m, n/2] = silu(gate) * up (two slabs per block);
 // EPI 2: gate / up rows interleaved 8 + 8 inside every 16-row slab (fused_mlp.QuantLlamaMLP stacks them that way), out[m, n/2]
 template <typename DT, int WAVES, int D, int DQ, int EPI>
@@ -56,7 +59,9 @@ __device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __rest
   char* ring = wbase;                            // [D][NS] tiles of 1 KiB
   char* szs = wbase + D * NS * 1024;             // [NS][TXp] x 64 B
   char* xs = szs + NS * TXp * 64;                // [M][xrow]
-  const int s0 = wv * TX;                        // this wave's first k-step
+  const bool il = (probe_ & kDmaInterleave) != 0;
+  const int s0 = il ? wv : wv * TX;              // this wave's first k-step
+  const int sk = il ? WAVES : 1;                 // ... and the distance to its next one
 
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(qw), 0, (N >> 4) * nit * 1024, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(szp), 0, (N >> 4) * nit * 64, 0x00020000);
@@ -65,9 +70,9 @@ __device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __rest
 #pragma unroll
   for (int s = 0; s < NS; ++s) slab_tile[s] = ((u32)nb + (u32)s * (u32)(N >> 5)) * (u32)nit;
 
-  const u32 lane16 = lane * 16u, lane4 = lane * 4u;
+  const u32 lane16 = lane * 16u;
   auto issue = [&](int t, int slot) {  // weight tile(s) of local step t into ring slot `slot`
-    const u32 kg = (u32)min(s0 + t, nit - 1);  // steps past the end (ragged K split) re-read the last tile; their math is skipped
+    const u32 kg = (u32)min(s0 + sk * t, nit - 1);  // steps past the end (ragged K split) re-read the last tile; their math is skipped
     if (probe & 2) return;
 #pragma unroll
     for (int s = 0; s < NS; ++s)
@@ -77,16 +82,18 @@ __device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __rest
   // slices (out-of-range pieces read 0 through the buffer descriptor), then the rest of the ring: step 0's counted wait
   // (D - 1 tiles may stay in flight) covers everything older than tile 1 ----
   issue(0, 0);
+  // a staging piece covers four of the wave's steps: lane / 16 picks the step (sk steps apart in the source), lane % 16 its 4 / 16 bytes
+  const u32 sz_voff = (u32)(lane >> 4) * (u32)(sk * 64) + (u32)(lane & 15) * 4u, x_voff = (u32)(lane >> 4) * (u32)(sk * 256) + (u32)(lane & 15) * 16u;
   if (!(probe & 8)) {
 #pragma unroll
     for (int s = 0; s < NS; ++s)
       for (int q = 0; q < TXp; q += 4)
-        dma_to_lds<4, 0>(rs, szs + (s * TXp + q) * 64, lane4, (slab_tile[s] + (u32)(s0 + q)) * 64u);
+        dma_to_lds<4, 0>(rs, szs + (s * TXp + q) * 64, sz_voff, (slab_tile[s] + (u32)(s0 + sk * q)) * 64u);
   }
   if (!(probe & 4)) {
     for (int r = 0; r < M; ++r)
       for (int q = 0; q < TXp; q += 4)
-        dma_to_lds<16, 0>(rx, xs + r * xrow + q * 256, lane16, ((u32)r * (u32)K + (u32)(s0 + q) * 128u) * 2u);
+        dma_to_lds<16, 0>(rx, xs + r * xrow + q * 256, x_voff, ((u32)r * (u32)K + (u32)(s0 + sk * q) * 128u) * 2u);
   }
 #pragma unroll
   for (int d = 1; d < D; ++d) issue(d, d);
@@ -131,7 +138,7 @@ __device__ __forceinline__ void gemv_dma_body(char* smem, const uint16_t* __rest
                    :
                    : "memory");
     if (REISSUE) issue(t + D, slot);  // the slot's bytes are in registers: refill it for step t + D
-    if (s0 + t < nit && !(probe & 1)) {
+    if (s0 + sk * t < nit && !(probe & 1)) {
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         vec8 op[4];
@@ -219,7 +226,7 @@ struct DmaCfg {
   size_t smem;
 };
 int g_dma_skinny_from = 0;  // knob decode_skinny_from: 0 = by shape (skinny_takes below), 1..8 = from that row count, 9 = never
-int g_dma_waves = 0, g_dma_d = 0, g_dma_probe = 0, g_dma_four = 1, g_dma_want = 0, g_dma_wide8 = 2;  // gemvd_four: four ring-7 blocks per CU where there are > 3 slabs per CU (rounds 4 + 3 instead of 3 + 3 + 1: +0.6 % decode tok/s, profiles/r03_gemvps.txt)
+int g_dma_waves = 0, g_dma_d = 0, g_dma_probe = 0, g_dma_four = 1, g_dma_want = 0, g_dma_wide8 = 2, g_dma_il = 2;  // gemvd_il: 0 = contiguous K ranges per wave everywhere, 1 = interleaved everywhere, 2 (default) = interleaved for eight-wave blocks whose ring is shallower than a wave's K range (qkv -1.2 %, o_proj -3.2 % at one row; 16-wave down_proj no different: profiles/r06_decode_cfg.txt (7))  // gemvd_four: four ring-7 blocks per CU where there are > 3 slabs per CU (rounds 4 + 3 instead of 3 + 3 + 1: +0.6 % decode tok/s, profiles/r03_gemvps.txt)
 
 size_t dma_smem(int waves, int d, int ns, int tx, int m) {
   const int txp = (tx + 3) & ~3;
@@ -239,7 +246,10 @@ bool skinny_takes(int m, int n_rows, int k, int epi) {
   // K = 4096: the skinny kernel from five rows (15.97 vs 16.99 us), K = 8192 (70B): from three (47.5 vs 51.0 us; at two rows 46.4 vs 47.1 the other way)
   if (blocks_per_cu > 3.0 && k >= 32 * 128 && k < 96 * 128 && g_dma_wide8 != 0) return (size_t)m * (size_t)k * 2 * 3 >= 112 * 1024;
   const int want = blocks_per_cu <= 1.0 ? 1 : (blocks_per_cu <= 2.0 ? 2 : (blocks_per_cu <= 3.0 ? 3 : 4));
-  return m >= 5 && (size_t)m * (size_t)k * 2 * want >= 128 * 1024;
+  // (from five rows -- or from the row count at which ONE block's staging reaches 100 KiB: Llama-3-70B's down_proj, K = 28672, two slabs per CU, 56 KiB of x per
+  // row: 39 / 64 / 75 us on the streaming kernel at 2 / 3 / 4 rows (one eight-wave block per CU, then row chunks that re-stream the weights) against 31.5 - 35 on
+  // the skinny kernel; Llama-3-8B's down_proj at four rows -- 112 KiB, ONE slab per CU -- stays: 9.4 vs 9.9 us.  profiles/r06_decode_cfg.txt (6))
+  return (m >= 5 || (size_t)m * (size_t)k * 2 >= 100 * 1024) && (size_t)m * (size_t)k * 2 * want >= 128 * 1024;
 }
 
 // K split and ring depth: as many tiles in flight per CU as LDS allows (<= ~150 KiB per CU over the blocks that share it),
@@ -287,6 +297,7 @@ int gemv_dma_tune_set(const char* key, int value) {
   else if (!strcmp(key, "gemvd_four")) g_dma_four = value;
   else if (!strcmp(key, "gemvd_want")) g_dma_want = value;
   else if (!strcmp(key, "gemvd_wide8")) g_dma_wide8 = value;
+  else if (!strcmp(key, "gemvd_il")) g_dma_il = value;
   else if (!strcmp(key, "decode_skinny_from")) g_dma_skinny_from = value;
   else return -1;
   return 0;
@@ -300,7 +311,7 @@ static void launch_dma_cfg(const void* x, const void* qw, const void* szp, const
   static LdsOptIn optin;
   if (c.smem > 64 * 1024) optin.ensure(reinterpret_cast<const void*>(kern));
   hipLaunchKernelGGL(kern, dim3(n / 16 / NS), dim3(64 * WAVES), c.smem, st, (const uint16_t*)x, (const u32*)qw, (const u32*)szp,
-                     (const uint16_t*)bias, (uint16_t*)out, m, n, k, c.tx, (g_dma_probe & 0xFF) | (f32out ? kDmaF32Out : 0));
+                     (const uint16_t*)bias, (uint16_t*)out, m, n, k, c.tx, (g_dma_probe & 0xFF) | (f32out ? kDmaF32Out : 0) | ((g_dma_il == 1 || (g_dma_il == 2 && c.d < c.tx && c.waves == 8)) ? kDmaInterleave : 0));
 }
 
 template <typename DT, int EPI, int DQ>

@@ -175,6 +175,8 @@ def test_batched_decode_routing_for_the_llama3_shapes():
         assert plan(m, 6144, 4096, 0) == (1, 1 if m == 8 else 0)
     assert plan(8, 28672, 4096, 1)[1] == 0                # the stacked [gate; up] form has no skinny epilogue
     # Llama-3-70B gate/up pair (K = 8192: 16 KiB of x per row and block): the streaming kernel's eight-wave blocks up to two rows, the skinny kernel from three
+    assert plan(1, 8192, 28672) == (1, 0) and plan(2, 8192, 28672) == (1, 1) and plan(4, 8192, 28672) == (1, 1)   # 70B down_proj: 56 KiB of x per row and block, two slabs per CU
+    assert plan(4, 10240, 8192) == (1, 0) and plan(5, 10240, 8192) == (1, 1)                                     # 70B qkv: the streaming kernel up to four rows
     assert plan(1, 57344, 8192, 2) == (1, 0) and plan(2, 57344, 8192, 2) == (1, 0) and plan(3, 57344, 8192, 2) == (1, 1) and plan(8, 57344, 8192, 2) == (1, 1)
     assert plan(9, 4096, 4096)[0] == 0 and plan(4, 4100, 4096)[0] == 0 and plan(4, 4096, 4000)[0] == 0
     try:  # forced / disabled (tests and sweeps)

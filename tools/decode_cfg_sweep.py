@@ -54,11 +54,11 @@ def main():
             ref = None
             line = []
             for cfg in cfgs:
-                (w, want, d), ns2 = cfg[:3], (cfg[3] if len(cfg) > 3 else 0)
+                (w, want, d), ns2, il = cfg[:3], (cfg[3] if len(cfg) > 3 else 0), (cfg[4] if len(cfg) > 4 else 0)  # il: knob gemvd_il (interleaved K split)
                 _capi.tune(decode_skinny_from=1 if w < 0 else 9)
                 if ns2:  # (the knob exists in builds of the two-slab experiment only: tools/EXPERIMENTS.md)
                     _capi.tune(gemvd_ns2=ns2)
-                _capi.tune(gemvd_waves=max(w, 0), gemvd_want=want, gemvd_d=d)
+                _capi.tune(gemvd_waves=max(w, 0), gemvd_want=want, gemvd_d=d, gemvd_il=il)
                 out.zero_()
                 try:
                     fn(copies[0])
@@ -73,11 +73,11 @@ def main():
                     line.append(f"{w}w/d{d}:WRONG")
                     continue
                 us = time_graph(fn, copies)
-                line.append(f"{w}w/d{d}{'/ns2' if ns2 else ''}:{us:.2f}{'' if ok else '!'}")
+                line.append(f"{w}w/d{d}{'/ns2' if ns2 else ''}{'/il%d' % il if il else ''}:{us:.2f}{'' if ok else '!'}")
             print(f"{name:8s} M={M}  " + "  ".join(line), flush=True)
         del copies
         torch.cuda.empty_cache()
-    _capi.tune(gemvd_waves=0, gemvd_want=0, gemvd_d=0, decode_skinny_from=0)
+    _capi.tune(gemvd_waves=0, gemvd_want=0, gemvd_d=0, decode_skinny_from=0, gemvd_il=0)
 
 
 if __name__ == "__main__":
