@@ -461,7 +461,7 @@ unsigned* splitk_ticket_words(hipStream_t st, int groups) {
 namespace {
 
 int g_midm = 1;                                     // knob midm: 0 = off (the skinny / masked-tile kernels of rounds 1-5 serve 9 .. 255 rows)
-int g_midm_min = 65, g_midm_max = 192;              // knobs midm_min / midm_max: the row counts the forward entries hand to this kernel (tests: 9 .. 255)
+int g_midm_min = 65, g_midm_max = 128;              // knobs midm_min / midm_max: the row counts the forward entries hand to this kernel (tests: 9 .. 255); the defaults = the by-shape rules of midm_takes
 int g_midm_waves = 0, g_midm_ns = 0, g_midm_ks = 0;  // knobs midm_waves / midm_ns / midm_ks: force a block shape / part count (experiments, tests)
 int g_midm_probe = 0;                               // knob midm_probe: timing probes of AWQ_PROBES builds (see the kernel)
 }  // namespace
@@ -523,17 +523,37 @@ void midm_passes(int m, int& chunks, int& rows) {
 }
 }  // namespace
 
-// Which calls the forward entries hand to this kernel (measured against the round-5 kernels on the Llama-3-8B shapes, profiles/r06_midm_sweep.txt):
-// 65 .. 128 rows always (one pass: 0.70 - 0.94 x the time of the skinny kernel's two chunks / the masked 256-row tile); 129 .. 192 rows against
-// n < 16384 only (two passes still beat the masked tile on the 4096 / 6144-wide projections; the 28672-wide gate/up pair fills the chip with tiles);
-// 17 .. 32 rows against n >= 16384 (0.81 - 0.85 x).  Elsewhere below 65 rows the skinny kernel (x through registers, up to seven slabs per block, no
-// barrier) is as fast or faster; above 192 the tile is nearly full.
+// Which calls the forward entries hand to this kernel.  Measured against the round-5 kernels on the Llama-3-8B shapes (profiles/r06_midm_sweep.txt) and, third session,
+// on the Llama-3-70B / Llama-2-7B shapes and with the true round-5 baseline above 128 rows (profiles/r06_midm_routing.txt):
+//   * 65 .. 128 rows always (one pass: 0.60 - 0.94 x the time of the skinny kernel's two chunks / the masked 256-row tile on every shape measured);
+//   * 129 .. 192 rows NOT any more: two passes, each re-streaming the weights, lose to the masked tile + split-K wherever K is long (down_proj 14336 -> 4096: 1.22 - 1.32 x,
+//     Llama-3-70B qkv / o: 1.2 - 1.36 x) and tie on the K = 4096 projections (0.96 - 1.13 x) -- the second session's figure for down_proj came from a baseline run with a
+//     scratch sized for another plan;
+//   * below 65 rows the skinny kernel (x through registers, up to seven slabs per block, no barrier) is as fast or faster on the Llama-3-8B shapes, but its block shapes leave
+//     other shapes under-filled -- this kernel's K split across blocks takes: 17 .. 32 rows against n >= 16384 (0.81 - 0.88 x); every row count against a very long K and a
+//     narrow n (Llama-3-70B down_proj, 28672 -> 8192: 0.57 - 0.87 x at 16 .. 64 rows); 33 .. 64 rows against n = 8192-class matrices (the skinny kernel's four-slab blocks fill
+//     half the chip: Llama-3-70B o_proj 0.76 x); 49 .. 64 rows against wide pairs whose slab count is not one round of seven-slab blocks (gate/up of Llama-3-70B / Llama-2-7B: 0.84 - 0.89 x).
+namespace {
+bool midm_small_takes(int m, int n, int k) {
+  const int nslab = n / 16, nit = k / 128, cus = device_cu_count();
+  const int g7 = (nslab + 6) / 7;
+  const bool seven_round = g7 <= cus + 16 && g7 >= cus * 9 / 10;  // (awq_skinny_cdna4.hip: seven slabs per block = one round of one block per CU)
+  if (m >= 17 && m <= 32 && n >= 16384) return true;
+  if (nit >= 192 && nslab <= 512) return true;
+  if (m >= 33 && nslab >= 512 && nslab < 640) return true;
+  if (m >= 49 && n >= 16384 && !seven_round) return true;
+  return false;
+}
+}  // namespace
 bool midm_takes(int m, int n, int k) {
-  if (!g_midm || m < 9 || m > 255 || m > g_midm_max || (n % 16) != 0 || (k % 128) != 0 || k < 256) return false;
-  // (17 .. 32 rows against a wide n -- the gate/up pair: 23.5 us against the skinny kernel's 27.7 - 29.4 with its two-slab blocks there)
-  if (m < g_midm_min && !(g_midm_min == 65 && m >= 17 && m <= 32 && n >= 16384)) return false;
+  if (!g_midm || m < 9 || m > 255 || (n % 16) != 0 || (k % 128) != 0 || k < 256) return false;
+  if (g_midm_min == 65 && g_midm_max == 128) {  // the product's rules
+    if (m > 128 || (m < 65 && !midm_small_takes(m, n, k))) return false;
+  } else {  // knobs (tests, sweeps): a plain row range; 129 .. 192 rows against a wide n stay on the tiles as in the first two sessions
+    if (m < g_midm_min || m > g_midm_max) return false;
+    if (m > 128 && n >= 16384 && g_midm_max <= 192) return false;
+  }
   if ((size_t)n * (size_t)k / 2 >= (1ull << 31) || (size_t)m * (size_t)k * 2 >= (1ull << 31)) return false;
-  if (m > 128 && n >= 16384 && g_midm_max <= 192) return false;
   int chunks, rows;
   midm_passes(m, chunks, rows);
   MidmCfg c;

@@ -72,28 +72,33 @@ def test_engine_module_exports():
 
 
 def test_prefill_routing_and_workspace_rule_without_gpu():
-    """awq_w4a16_forward_cdna4_workspace_bytes is pure host logic: which kernel family takes m rows (decode <= 8, skinny <= 64, mid-M 65 .. 192, tiles above)
+    """awq_w4a16_forward_cdna4_workspace_bytes is pure host logic: which kernel family takes m rows (decode <= 8, skinny <= 64 except where its block shapes under-fill the chip, mid-M 65 .. 128, tiles above)
     and how many K parts / ranges an under-filled launch is split into."""
     L = _capi.lib()
     q = L.awq_w4a16_forward_cdna4_workspace_bytes
     tile = 256 * 128 * 4
     # decode / skinny territory, and launches that fill the chip: no workspace
-    for (m, n, k) in ((1, 4096, 4096), (16, 4096, 14336), (32, 4096, 4096), (64, 28672, 4096), (64, 8192, 8192), (2048, 4096, 4096), (4096, 28672, 4096)):
+    for (m, n, k) in ((1, 4096, 4096), (16, 4096, 14336), (32, 4096, 4096), (64, 28672, 4096), (32, 8192, 8192), (64, 10240, 8192), (2048, 4096, 4096), (4096, 28672, 4096)):
         assert q(m, n, k) == 0, (m, n, k)
     # the skinny launch's two K parts where its grid leaves half the chip idle (33 .. 64 rows per pass from K = 4096; 17 .. 32 rows from K = 8192; narrower than
     # ~272 slabs): fp32 [2][rows of a pass][n]
     assert q(64, 4096, 14336) == 2 * 64 * 4096 * 4 and q(40, 4096, 8192) == 2 * 40 * 4096 * 4
     assert q(64, 4096, 4096) == 2 * 64 * 4096 * 4 and q(32, 4096, 14336) == 2 * 32 * 4096 * 4
     assert q(64, 6144, 4096) == 0 and q(64, 4096, 4096 + 128) == 0  # (384 slabs: two parts would be 1.5 rounds of blocks; an odd number of k-steps does not split)
-    # 65 .. 192 rows (129 .. 192 against n < 16384 only): the mid-M kernel -- K parts that fill the chip with blocks of 8 (4) slabs, fp32 [parts][rows of a pass][n]
+    # 65 .. 128 rows: the mid-M kernel -- K parts that fill the chip with blocks of 8 (4) slabs, fp32 [parts][rows of a pass][n]
     assert q(71, 4096, 14336) == 8 * 71 * 4096 * 4 and q(128, 4096, 14336) == 8 * 128 * 4096 * 4  # down_proj: 32 groups of eight slabs x 8 parts of 14 k-steps
     assert q(128, 4096, 4096) == 4 * 128 * 4096 * 4    # o_proj: eight parts of eight-slab groups would be 4 k-steps each -> four waves: 64 groups x 4 parts of 8
     assert q(96, 6144, 4096) == 4 * 96 * 6144 * 4      # qkv: 48 groups x 4 parts
     assert q(100, 28672, 4096) == 0                    # the gate/up pair fills the chip unsplit (224 groups)
-    assert q(147, 4096, 4096) == 4 * 74 * 4096 * 4     # two passes of 74 rows share the scratch
     assert q(160, 28672, 4096) == 0                    # (129 .. 255 rows against a wide n: the tile kernels, full rounds: no scratch)
+    # ... and the shorter prompts of shapes the skinny kernel's blocks under-fill (round 6, third session): a very long K against a narrow n (Llama-3-70B down_proj),
+    # 33 .. 64 rows against n = 8192 (four-slab skinny blocks = half the chip), 49 .. 64 rows of wide pairs that are not one round of seven-slab blocks
+    for (m, n, k) in ((16, 8192, 28672), (64, 8192, 28672), (48, 8192, 8192), (64, 8192, 8192)):
+        b = q(m, n, k)
+        assert b > 0 and b % (m * n * 4) == 0 and 2 <= b // (m * n * 4) <= 32, (m, n, k, b)
+    assert q(64, 57344, 8192) == 0 and q(64, 22016, 4096) == 0   # (wide pairs fill the chip unsplit)
     # under-filled launches of the tile kernels: whole partial tiles, 2..16 K ranges, at least 2 quantisation groups per range
-    for (m, n, k) in ((200, 4096, 14336), (255, 4096, 4096), (256, 4096, 4096), (512, 4096, 14336), (1024, 4096, 4096),
+    for (m, n, k) in ((147, 4096, 4096), (190, 4096, 14336), (200, 4096, 14336), (255, 4096, 4096), (256, 4096, 4096), (512, 4096, 14336), (1024, 4096, 4096),
                       (256, 1024, 8192), (300, 6144, 4096)):
         b = q(m, n, k)
         tiles = ((m + 255) // 256) * ((n + 127) // 128)

@@ -35,7 +35,7 @@ def _native(ops, d, K):
 
 
 def _reset(ops):
-    ops._capi.tune(midm=1, midm_waves=0, midm_ns=0, midm_ks=0, midm_min=65, midm_max=192)
+    ops._capi.tune(midm=1, midm_waves=0, midm_ns=0, midm_ks=0, midm_min=65, midm_max=128)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -50,7 +50,7 @@ def test_every_block_shape_and_part_count(env, dtype, N, K):
            True: forward_oracle(d["x"], d["q"], d["scales"], d["scaled_zeros"], dtype, bias=d["bias"])}
     xd = d["x"].cuda()
     try:
-        ops._capi.tune(midm_min=9, midm_max=255)  # (the product hands 65 .. 192 rows to this kernel; here every row count it can serve)
+        ops._capi.tune(midm_min=9, midm_max=255)  # (the product hands 65 .. 128 rows -- and some shapes' shorter prompts -- to this kernel; here every row count it can serve)
         for (wv, ns) in CFGS:
             for ks in (1, 2, 5):
                 ops._capi.tune(midm_waves=wv, midm_ns=ns, midm_ks=ks)
@@ -83,7 +83,7 @@ def test_llama3_8b_shapes_against_the_oracle(env, dtype, name, K, N):
     pre = forward_oracle(d["x"], d["q"], d["scales"], d["scaled_zeros"], dtype)
     xd = d["x"].cuda()
     try:
-        for wide in (False, True):  # the product's row range (65 .. 192), then every row count on this kernel
+        for wide in (False, True):  # the product's routing, then every row count on this kernel
             if wide:
                 ops._capi.tune(midm_min=9, midm_max=255)
             for M in Ms:
@@ -163,10 +163,13 @@ def test_workspace_query_and_plan(env):
     L = ops._capi.lib()
     q = L.awq_w4a16_forward_cdna4_workspace_bytes
     assert q(8, 4096, 4096) == 0                      # decode
-    for (m, n, k) in ((72, 4096, 4096), (96, 4096, 14336), (128, 6144, 4096), (190, 4096, 4096)):
+    for (m, n, k) in ((72, 4096, 4096), (96, 4096, 14336), (128, 6144, 4096), (48, 8192, 28672), (64, 8192, 8192)):
         b = q(m, n, k)
-        rows = m if m <= 128 else (m + 1) // 2        # 129 .. 192 rows: two passes share the scratch
-        assert b % (rows * n * 4) == 0 and 2 <= b // (rows * n * 4) <= 32, (m, n, k, b)
+        assert b % (m * n * 4) == 0 and 2 <= b // (m * n * 4) <= 32, (m, n, k, b)
+    ops._capi.tune(midm_max=192)                      # (knob: 129 .. 192 rows as two passes that share the scratch -- the product stops at 128 rows)
+    b = q(190, 4096, 4096)
+    assert b % (95 * 4096 * 4) == 0 and 2 <= b // (95 * 4096 * 4) <= 32, b
+    ops._capi.tune(midm_max=128)
     ops._capi.tune(midm_ks=1)
     try:
         assert q(96, 4096, 4096) == 0

@@ -28,8 +28,9 @@ def test_workspace_query(env):
     # skinny launches that leave half the chip idle: two K parts of fp32 sums, [2][rows of a pass][n] (33..64 rows from K = 4096, 17..32 rows from K = 8192)
     assert q(64, 4096, 4096) == 2 * 64 * 4096 * 4 and q(40, 4096, 14336) == 2 * 40 * 4096 * 4 and q(24, 4096, 14336) == 2 * 24 * 4096 * 4
     assert q(64, 6144, 4096) == 0                                  # (384 slabs: two parts would be 1.5 rounds of blocks)
-    assert q(71, 4096, 8192) == 8 * 71 * 4096 * 4                  # 65 .. 192 rows: the mid-M kernel's parts (tests/test_gpu_midm.py): 32 slab groups x 8 parts of 8 k-steps
-    assert q(64, 28672, 8192) == 0 and q(64, 8192, 8192) == 0                                   # wide N fills the chip unsplit
+    assert q(71, 4096, 8192) == 8 * 71 * 4096 * 4                  # 65 .. 128 rows: the mid-M kernel's parts (tests/test_gpu_midm.py): 32 slab groups x 8 parts of 8 k-steps
+    assert q(64, 28672, 8192) == 0 and q(32, 8192, 8192) == 0                                   # wide N fills the chip unsplit
+    assert q(64, 8192, 8192) % (64 * 8192 * 4) == 0 and q(64, 8192, 8192) >= 2 * 64 * 8192 * 4   # (33 .. 64 rows against n = 8192: the mid-M kernel's K split, round 6)
     tile = 256 * 128 * 4                                            # one fp32 partial tile
     for (m, n, k, tiles) in ((256, 4096, 14336, 32), (512, 4096, 4096, 64)):
         b = q(m, n, k)

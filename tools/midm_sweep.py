@@ -11,8 +11,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from llm_awq_amd import _capi, ops, synth  # noqa: E402
 
 SHAPES = [(4096, 6144, "qkv"), (4096, 4096, "o"), (4096, 28672, "gate+up"), (14336, 4096, "down")]
+OTHER = [(8192, 10240, "qkv70b"), (8192, 8192, "o70b"), (8192, 57344, "gate+up70b"), (28672, 8192, "down70b"), (4096, 12288, "qkv7b"), (4096, 22016, "gate+up7b"), (11008, 4096, "down7b")]  # by name only
 if os.environ.get("MIDM_SHAPES"):
-    SHAPES = [s for s in SHAPES if s[2] in os.environ["MIDM_SHAPES"].split(",")]
+    SHAPES = [s for s in SHAPES + OTHER if s[2] in os.environ["MIDM_SHAPES"].split(",")]
 CFGS = [tuple(int(v) for v in c.split("x")) for c in os.environ.get("MIDM_CFGS", "8x1,4x1,4x2").split(",")]
 KSS = [int(v) for v in os.environ.get("MIDM_KS", "0").split(",")]
 SZH = os.environ.get("MIDM_SZH", "0") == "1"
@@ -85,7 +86,10 @@ def main():
             fn(copies[0])
             ref = out.float().clone()
             print(f"{name:>8} {K:6d} {N:6d} {M:5d} {'round 5':>14} {base:8.1f} {1.0:7.2f} {by / base / 1e3:8.1f} {fl / base / 1e6:8.1f} {0.0:9.1e}", flush=True)
-            _capi.tune(midm=1, midm_min=9, midm_max=255)
+            if os.environ.get("MIDM_PRODUCT") == "1":  # the library's own routing (midm_takes) instead of every row count on this kernel
+                _capi.tune(midm=1, midm_min=65, midm_max=128)
+            else:
+                _capi.tune(midm=1, midm_min=9, midm_max=255)
             for (wv, ns) in CFGS:
                 for ks in KSS:
                     for pr in PROBES:
