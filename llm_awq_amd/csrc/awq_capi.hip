@@ -225,6 +225,7 @@ int awq_w4a16_mlp_gate_up_cdna4(const void* x, const void* qweight_gate_up, cons
   return finish_launch();
 }
 
+static int g_skinny16_szh = 1;     // knob skinny16_szh: 0 = 9 .. 16 rows on the T-typed sz_packed form as in rounds 1 - 5
 static int g_mlp_skinny_max = 64;  // knob mlp_skinny_max: row counts up to this go to the skinny kernel's fused epilogue (8 = never)
 int awq_w4a16_mlp_gate_up_forward_cdna4(const void* x, const void* qweight_interleaved, const void* sz_packed, const void* sz_half,
                                         void* out, int m, int n2, int k, int group_size, int dtype, void* stream) {
@@ -257,6 +258,11 @@ int awq_w4a16_mlp_gate_up_forward_cdna4_ws(const void* x, const void* qweight_in
   if (awq::midm_takes(m, n2, k) &&
       awq::launch_midm_cdna4(x, qweight_interleaved, sz_half ? sz_half : sz_packed, nullptr, out, m, n2, k, 2, dtype, sz_half ? 1 : 0, 4, 0, workspace, workspace_bytes,
                              (hipStream_t)stream) == 0)
+    return finish_launch();
+  // 9 .. 16 rows with the layer's sz_half side buffer: the skinny kernel's one-column-block shapes in the f16-mantissa dequant form (the batched-decode instantiations:
+  // the same block shapes as launch_skinny_gate_up picks at <= 16 rows, ~10 VALU fewer per tile -- round 6, third session)
+  if (m <= 16 && sz_half && g_skinny16_szh &&
+      awq::launch_skinny_decode(x, qweight_interleaved, sz_half, nullptr, out, m, n2, k, 2, dtype, 1, (hipStream_t)stream, 0) == 0)
     return finish_launch();
   // (knob midm = 0) 9 .. 64 rows: one weight pass on the skinny kernel, rows r and r + 8 of a slab paired in its epilogue (a 256-row tile masked down to m rows costs
   // the same for every m: 46 vs 31 us at 64 rows on Llama-3-8B's pair, profiles/r05_skinny_splitk.txt)
@@ -336,6 +342,13 @@ int awq_w4a16_forward_cdna4_szh(const void* x, const void* qweight, const void* 
     if (st0 != AWQ_OK) return st0;
     if (bias && !aligned16(bias)) return AWQ_ERR_ALIGN;
     if (awq::launch_midm_cdna4(x, qweight, sz_half, bias, out, m, n, k, 0, dtype, 1, 4, 0, workspace, workspace_bytes, (hipStream_t)stream) == 0) return finish_launch();
+  }
+  if (sz_half && sz_packed && m >= 9 && m <= 16 && group_size == 128 && g_skinny16_szh && awq::gemm_variant_get() == 0 && aligned16(sz_half) && (n % 16) == 0) {
+    // 9 .. 16 rows with the layer's sz_half side buffer: the skinny kernel's one-column-block shapes in the f16-mantissa dequant form
+    int st0 = check_common(x, qweight, scales, scaled_zeros, out, m, n, k, group_size, dtype);
+    if (st0 != AWQ_OK) return st0;
+    if (bias && !aligned16(bias)) return AWQ_ERR_ALIGN;
+    if (awq::launch_skinny_decode(x, qweight, sz_half, bias, out, m, n, k, 0, dtype, 1, (hipStream_t)stream, 0) == 0) return finish_launch();
   }
   if (sz_half && sz_packed && m >= 256 && group_size == 128 && awq::gemm_variant_get() == 0 && aligned16(sz_half)) {
     // prefill with the layer's sz_half side buffer: the tile kernels dequantise in the f16-mantissa form (every block width, the block pairs included)
@@ -629,6 +642,10 @@ int awq_tune_set(const char* key, int value) {
   }
   if (!strcmp(key, "mlp_skinny_max")) {
     g_mlp_skinny_max = value;
+    return AWQ_OK;
+  }
+  if (!strcmp(key, "skinny16_szh")) {
+    g_skinny16_szh = value;
     return AWQ_OK;
   }
   return AWQ_ERR_SHAPE;
