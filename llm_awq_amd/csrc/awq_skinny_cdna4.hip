@@ -21,7 +21,7 @@ namespace awq {
 // the block's work for slab group `nb` on M <= 16 CB rows: shared by the plain kernel and the grouped (per-expert) kernel
 // DQ 1: szp is the decode side buffer "sz_half" (f16-mantissa dequant form, Cdna4DequantH); EPI 2: QuantLlamaMLP's 8 + 8 interleaved
 // gate / up slabs, out[m, N / 2] = silu(gate) * up (batched decode of 5..8 rows arrives here from launch_gemv_dma)
-template <typename DT, int WAVES, int NS, int CB, int DQ = 0, int EPI = 0, int BITS = 4>
+template <typename DT, int WAVES, int NS, int CB, int DQ = 0, int EPI = 0, int BITS = 4, int XU = 4 * CB>
 __device__ __forceinline__ void skinny_cdna4_body(char* smem, const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                   const u32* __restrict__ szp, const uint16_t* __restrict__ bias,
                                                   uint16_t* __restrict__ out, int M, int N, int K, int nb, int f32out = 0, int k0 = 0, int kn = -1) {
@@ -70,7 +70,7 @@ __device__ __forceinline__ void skinny_cdna4_body(char* smem, const uint16_t* __
   auto load_step = [&](int t) {
     const int kg = k0 + min(wv + WAVES * t, kn - 1);
 #pragma unroll
-    for (int b = 0; b < XB; ++b) xr[b] = __builtin_amdgcn_raw_buffer_load_b128(rx, xsrc_b[b], (u32)kg * 256u, 0);
+    for (int b = 0; b < XU; ++b) xr[b] = __builtin_amdgcn_raw_buffer_load_b128(rx, xsrc_b[b], (u32)kg * 256u, 0);  // (XU < XB: batched decode of <= 4 XU rows -- the pieces past them are never staged, their MFMA columns never stored)
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const u32 tidx = slab_tile[s] + (u32)kg;
@@ -88,7 +88,7 @@ __device__ __forceinline__ void skinny_cdna4_body(char* smem, const uint16_t* __
   for (int t = 0; t < cnt; ++t) {
     // this step's operands: x slice -> LDS (the previous step's reads of the region are retired: same wave, in order)
 #pragma unroll
-    for (int b = 0; b < XB; ++b) *reinterpret_cast<u32x4*>(xs + b * 1024 + lane * 16) = xr[b];
+    for (int b = 0; b < XU; ++b) *reinterpret_cast<u32x4*>(xs + b * 1024 + lane * 16) = xr[b];
     u32x4 wc[NS];
     u32 szc[NS];
 #pragma unroll
@@ -183,13 +183,13 @@ __device__ __forceinline__ void skinny_cdna4_body(char* smem, const uint16_t* __
   }
 }
 
-template <typename DT, int WAVES, int NS, int CB, int DQ = 0, int EPI = 0, int BITS = 4>
+template <typename DT, int WAVES, int NS, int CB, int DQ = 0, int EPI = 0, int BITS = 4, int XU = 4 * CB>
 __global__ __launch_bounds__(64 * WAVES) void skinny_cdna4_kernel(const uint16_t* __restrict__ x, const u32* __restrict__ qw,
                                                                    const u32* __restrict__ szp,
                                                                    const uint16_t* __restrict__ bias,
                                                                    uint16_t* __restrict__ out, int M, int N, int K, int f32out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  skinny_cdna4_body<DT, WAVES, NS, CB, DQ, EPI, BITS>(smem, x, qw, szp, bias, out, M, N, K, blockIdx.x, EPI == 0 ? f32out : 0);
+  skinny_cdna4_body<DT, WAVES, NS, CB, DQ, EPI, BITS, XU>(smem, x, qw, szp, bias, out, M, N, K, blockIdx.x, EPI == 0 ? f32out : 0);
 }
 
 // Grouped (per-expert) form for MoE batches between the grouped GEMV (<= 8 sorted rows) and the grouped prefill GEMM
@@ -241,12 +241,12 @@ __global__ __launch_bounds__(64 * WAVES) void moe_skinny_cdna4_kernel(const uint
   }
 }
 
-template <typename DT, int WAVES, int NS, int CB, int DQ = 0, int EPI = 0, int BITS = 4>
+template <typename DT, int WAVES, int NS, int CB, int DQ = 0, int EPI = 0, int BITS = 4, int XU = 4 * CB>
 static void launch_skinny(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k,
                           hipStream_t st, int f32out = 0) {
   const size_t xbytes = (size_t)WAVES * 16 * CB * 256, rbytes = (size_t)WAVES * NS * CB * 1024;
   const size_t smem = xbytes > rbytes ? xbytes : rbytes;
-  auto kern = skinny_cdna4_kernel<DT, WAVES, NS, CB, DQ, EPI, BITS>;
+  auto kern = skinny_cdna4_kernel<DT, WAVES, NS, CB, DQ, EPI, BITS, XU>;
   static LdsOptIn optin;  // per (kernel instantiation, device)
   if (smem > 64 * 1024) optin.ensure(reinterpret_cast<const void*>(kern));
   const int nslab = n / 16;
@@ -312,6 +312,7 @@ __global__ __launch_bounds__(64 * WAVES) void skinny_splitk_kernel(const uint16_
 namespace {
 constexpr int kTicketGroups = 512;  // slab groups of a split launch (its ticket words: splitk_ticket_words, awq_midm_cdna4.hip -- private to the launch)
 int g_skinny_ks = -1;
+int g_skinny_xu = 1;  // knob skinny_xu: 0 = batched decode stages all sixteen x rows per step as rounds 3 - 5 did
 // seven slabs per block make ONE round of one block per CU (Llama-3-8B gate/up: 1792 slabs -> 256 blocks)?  Then the x slices are read by that many blocks
 // instead of 1.75 - 3.5 times as many (profiles/r05_skinny_splitk.txt)
 bool seven_slab_round(int nslab) {
@@ -322,6 +323,7 @@ bool seven_slab_round(int nslab) {
 
 int skinny_tune_set(const char* key, int value) {
   if (!strcmp(key, "skinny_splitk")) g_skinny_ks = value;
+  else if (!strcmp(key, "skinny_xu")) g_skinny_xu = value;
   else return -1;
   return 0;
 }
@@ -478,6 +480,20 @@ int launch_skinny_decode(const void* x, const void* qw, const void* szp, const v
   const bool wide = n / 16 >= 1024, deep = !wide && k / 128 >= 96;  // deep: 16 waves split a long K (down_proj: 112 steps)
 #define AWQ_SD(DT_, DQ_, EPI_)                                                                    \
   {                                                                                               \
+    if (m <= 4 && g_skinny_xu) {  /* (Llama-3-70B's long-K launches hand over from two / three rows: one piece per step) */ \
+      if (wide && seven_slab_round(n / 16)) launch_skinny<DT_, 8, 7, 1, DQ_, EPI_, 4, 1>(x, qw, szp, bias, out, m, n, k, st, f32out); \
+      else if (wide) launch_skinny<DT_, 8, 2, 1, DQ_, EPI_, 4, 1>(x, qw, szp, bias, out, m, n, k, st, f32out);       \
+      else if (deep) launch_skinny<DT_, 16, 1, 1, DQ_, EPI_, 4, 1>(x, qw, szp, bias, out, m, n, k, st, f32out); \
+      else launch_skinny<DT_, 8, 1, 1, DQ_, EPI_, 4, 1>(x, qw, szp, bias, out, m, n, k, st, f32out);            \
+      return 0;                                                                                   \
+    }                                                                                             \
+    if (m <= 8 && g_skinny_xu) {  /* batched decode: rows 8 .. 15 of the x block are never staged (two of the four pieces per step) */ \
+      if (wide && seven_slab_round(n / 16)) launch_skinny<DT_, 8, 7, 1, DQ_, EPI_, 4, 2>(x, qw, szp, bias, out, m, n, k, st, f32out); \
+      else if (wide) launch_skinny<DT_, 8, 2, 1, DQ_, EPI_, 4, 2>(x, qw, szp, bias, out, m, n, k, st, f32out);       \
+      else if (deep) launch_skinny<DT_, 16, 1, 1, DQ_, EPI_, 4, 2>(x, qw, szp, bias, out, m, n, k, st, f32out); \
+      else launch_skinny<DT_, 8, 1, 1, DQ_, EPI_, 4, 2>(x, qw, szp, bias, out, m, n, k, st, f32out);            \
+      return 0;                                                                                   \
+    }                                                                                             \
     if (wide && seven_slab_round(n / 16)) launch_skinny<DT_, 8, 7, 1, DQ_, EPI_>(x, qw, szp, bias, out, m, n, k, st, f32out); \
     else if (wide) launch_skinny<DT_, 8, 2, 1, DQ_, EPI_>(x, qw, szp, bias, out, m, n, k, st, f32out);       \
     else if (deep) launch_skinny<DT_, 16, 1, 1, DQ_, EPI_>(x, qw, szp, bias, out, m, n, k, st, f32out); \
