@@ -226,7 +226,7 @@ struct DmaCfg {
   size_t smem;
 };
 int g_dma_skinny_from = 0;  // knob decode_skinny_from: 0 = by shape (skinny_takes below), 1..8 = from that row count, 9 = never
-int g_dma_waves = 0, g_dma_d = 0, g_dma_probe = 0, g_dma_four = 1, g_dma_want = 0, g_dma_wide8 = 2, g_dma_il = 2;  // gemvd_il: 0 = contiguous K ranges per wave everywhere, 1 = interleaved everywhere, 2 (default) = interleaved for eight-wave blocks whose ring is shallower than a wave's K range (qkv -1.2 %, o_proj -3.2 % at one row; 16-wave down_proj no different: profiles/r06_decode_cfg.txt (7))  // gemvd_four: four ring-7 blocks per CU where there are > 3 slabs per CU (rounds 4 + 3 instead of 3 + 3 + 1: +0.6 % decode tok/s, profiles/r03_gemvps.txt)
+int g_dma_waves = 0, g_dma_d = 0, g_dma_probe = 0, g_dma_four = 1, g_dma_want = 0, g_dma_wide8 = 2, g_dma_skinny_small = 1, g_dma_il = 2;  // gemvd_il: 0 = contiguous K ranges per wave everywhere, 1 = interleaved everywhere, 2 (default) = interleaved for eight-wave blocks whose ring is shallower than a wave's K range (qkv -1.2 %, o_proj -3.2 % at one row; 16-wave down_proj no different: profiles/r06_decode_cfg.txt (7))  // gemvd_four: four ring-7 blocks per CU where there are > 3 slabs per CU (rounds 4 + 3 instead of 3 + 3 + 1: +0.6 % decode tok/s, profiles/r03_gemvps.txt)
 
 size_t dma_smem(int waves, int d, int ns, int tx, int m) {
   const int txp = (tx + 3) & ~3;
@@ -244,7 +244,15 @@ bool skinny_takes(int m, int n_rows, int k, int epi) {
   const double blocks_per_cu = (double)(n_rows / 16) / 256.0;
   // more than three slabs per CU (the fused gate/up pair; eight-wave blocks from two rows, pick_dma): three co-resident blocks stage 3 m K 2 bytes --
   // K = 4096: the skinny kernel from five rows (15.97 vs 16.99 us), K = 8192 (70B): from three (47.5 vs 51.0 us; at two rows 46.4 vs 47.1 the other way)
-  if (blocks_per_cu > 3.0 && k >= 32 * 128 && k < 96 * 128 && g_dma_wide8 != 0) return (size_t)m * (size_t)k * 2 * 3 >= 112 * 1024;
+  if (blocks_per_cu > 3.0 && k >= 32 * 128 && k < 96 * 128 && g_dma_wide8 != 0) return (size_t)m * (size_t)k * 2 * 3 >= (size_t)(k >= 64 * 128 ? 96 : 112) * 1024;
+  // Since the skinny kernel stages only the x pieces that hold rows (round 6, third session: one 4-row piece per k-step up to four rows instead of four) it is AHEAD of this
+  // kernel from ONE row wherever a CU holds at least 1.5 slabs or the K loop is long enough for its 16-wave shape -- qkv 5.0 vs 5.35 us, down_proj 8.2 vs 8.7 at one row, 7.85 vs
+  // 9.2 at four; Llama-3-70B qkv / o / down -8 ... -9 % at one row -- while ONE slab per CU against a short K keeps this kernel's deeper ring (o_proj 4.2 vs 4.5, Llama-2-7B
+  // down_proj 7.8 vs 9.1): profiles/r06_decode_cfg.txt (9).  Knob decode_skinny_small: 0 = the rule of the first two sessions below, 1 (default) = from two rows, 2 = from one row.
+  // (ONE row stays here: in the token's chain of dependent launches the skinny kernel's isolated -6 % does not show -- bench.py A/B: 0.9766-0.9801 vs 0.9704-0.9772 ms per step,
+  // drop-in leg -2 % -- while four rows gain 5 %: 1.012-1.019 vs 1.066-1.070 ms)
+  // ... except where a CU holds two or more slabs (Llama-3-70B qkv / o / down: its four-launch decode layer 93.9 -> 91.2-92.7 us at one row)
+  if (g_dma_skinny_small && (m >= 2 || g_dma_skinny_small == 2 || blocks_per_cu >= 2.0) && n_rows / 16 < 1024 && (blocks_per_cu >= 1.5 || k >= 96 * 128)) return true;
   const int want = blocks_per_cu <= 1.0 ? 1 : (blocks_per_cu <= 2.0 ? 2 : (blocks_per_cu <= 3.0 ? 3 : 4));
   // (from five rows -- or from the row count at which ONE block's staging reaches 100 KiB: Llama-3-70B's down_proj, K = 28672, two slabs per CU, 56 KiB of x per
   // row: 39 / 64 / 75 us on the streaming kernel at 2 / 3 / 4 rows (one eight-wave block per CU, then row chunks that re-stream the weights) against 31.5 - 35 on
@@ -298,6 +306,7 @@ int gemv_dma_tune_set(const char* key, int value) {
   else if (!strcmp(key, "gemvd_want")) g_dma_want = value;
   else if (!strcmp(key, "gemvd_wide8")) g_dma_wide8 = value;
   else if (!strcmp(key, "gemvd_il")) g_dma_il = value;
+  else if (!strcmp(key, "decode_skinny_small")) g_dma_skinny_small = value;
   else if (!strcmp(key, "decode_skinny_from")) g_dma_skinny_from = value;
   else return -1;
   return 0;

@@ -41,14 +41,14 @@ def test_pack_szh_matches_oracle_and_decode_vs_oracle(ops, dtype, N, K):
 
 
 def test_wide_launch_long_k_every_row_count(ops):
-    """a wide launch (> 3 slabs per CU) against K = 8192 -- the class of Llama-3-70B's gate / up pair: the streaming kernel's eight-wave blocks up to two rows, the
-    skinny kernel from three (round 6: the hand-over follows the bytes three co-resident blocks would stage), every row count against the oracle computed once"""
+    """a wide launch (> 3 slabs per CU) against K = 8192 -- the class of Llama-3-70B's gate / up pair: the streaming kernel's eight-wave blocks at one row, the
+    skinny kernel from two (round 6: the hand-over follows the bytes three co-resident blocks would stage), every row count against the oracle computed once"""
     from tests.helpers import check_forward_rows, forward_oracle
     N, K, dtype = 12320, 8192, torch.bfloat16   # 770 slabs = 3.008 per CU
     L = ops._capi.lib()
     import ctypes
     kern = ctypes.c_int(-1)
-    assert [(L.awq_w4a16_decode_cdna4_plan(m, N, K, 0, ctypes.byref(kern)), kern.value) for m in (1, 2, 3, 8)] == [(1, 0), (1, 0), (1, 1), (1, 1)]
+    assert [(L.awq_w4a16_decode_cdna4_plan(m, N, K, 0, ctypes.byref(kern)), kern.value) for m in (1, 2, 3, 8)] == [(1, 0), (1, 1), (1, 1), (1, 1)]
     c = make_case(N, K, dtype, seed=11, M=8, bias=True)
     szh, exact = ops.pack_szh_cdna4(c["scales"].cuda(), c["scaled_zeros"].cuda(), K)
     assert exact
