@@ -252,7 +252,9 @@ bool skinny_takes(int m, int n_rows, int k, int epi) {
   // (ONE row stays here: in the token's chain of dependent launches the skinny kernel's isolated -6 % does not show -- bench.py A/B: 0.9766-0.9801 vs 0.9704-0.9772 ms per step,
   // drop-in leg -2 % -- while four rows gain 5 %: 1.012-1.019 vs 1.066-1.070 ms)
   // ... except where a CU holds two or more slabs (Llama-3-70B qkv / o / down: its four-launch decode layer 93.9 -> 91.2-92.7 us at one row)
-  if (g_dma_skinny_small && (m >= 2 || g_dma_skinny_small == 2 || blocks_per_cu >= 2.0) && n_rows / 16 < 1024 && (blocks_per_cu >= 1.5 || k >= 96 * 128)) return true;
+  if (g_dma_skinny_small && (m >= 2 || g_dma_skinny_small == 2 || blocks_per_cu >= 2.0) && n_rows / 16 < 1024 &&
+      (blocks_per_cu >= 1.5 || k >= 96 * 128 || (blocks_per_cu <= 1.0 && k >= 32 * 128)))  // (one slab per CU: the skinny kernel's 16-wave shape, o_proj 4.15-4.44 vs 4.26-4.6 us at 2 .. 7 rows)
+    return true;
   const int want = blocks_per_cu <= 1.0 ? 1 : (blocks_per_cu <= 2.0 ? 2 : (blocks_per_cu <= 3.0 ? 3 : 4));
   // (from five rows -- or from the row count at which ONE block's staging reaches 100 KiB: Llama-3-70B's down_proj, K = 28672, two slabs per CU, 56 KiB of x per
   // row: 39 / 64 / 75 us on the streaming kernel at 2 / 3 / 4 rows (one eight-wave block per CU, then row chunks that re-stream the weights) against 31.5 - 35 on

@@ -312,6 +312,7 @@ __global__ __launch_bounds__(64 * WAVES) void skinny_splitk_kernel(const uint16_
 namespace {
 constexpr int kTicketGroups = 512;  // slab groups of a split launch (its ticket words: splitk_ticket_words, awq_midm_cdna4.hip -- private to the launch)
 int g_skinny_ks = -1;
+int g_skinny_deep64 = 32;  // knob skinny_deep64: the k-step count from which a launch of at most ONE slab per CU takes the 16-wave shape (0 = only from 96 steps, as rounds 3 - 5) for batched decode (<= 8 rows; at 12 / 16 rows it measured 0.6-0.9 % slower): o_proj -2 ... -3.5 %, Llama-2-7B down_proj (86 steps) 8.5 -> 6.6 us
 int g_skinny_xu = 1;  // knob skinny_xu: 0 = batched decode stages all sixteen x rows per step as rounds 3 - 5 did
 // seven slabs per block make ONE round of one block per CU (Llama-3-8B gate/up: 1792 slabs -> 256 blocks)?  Then the x slices are read by that many blocks
 // instead of 1.75 - 3.5 times as many (profiles/r05_skinny_splitk.txt)
@@ -324,6 +325,7 @@ bool seven_slab_round(int nslab) {
 int skinny_tune_set(const char* key, int value) {
   if (!strcmp(key, "skinny_splitk")) g_skinny_ks = value;
   else if (!strcmp(key, "skinny_xu")) g_skinny_xu = value;
+  else if (!strcmp(key, "skinny_deep64")) g_skinny_deep64 = value;
   else return -1;
   return 0;
 }
@@ -477,7 +479,7 @@ int launch_skinny_w3(const void* x, const void* qw, const void* szp, const void*
 int launch_skinny_decode(const void* x, const void* qw, const void* szp, const void* bias, void* out, int m, int n, int k, int epi,
                          int dtype, int szfmt, hipStream_t st, int f32out) {
   if (!szp || m < 1 || m > 16 || (n % 16) != 0 || (k % 128) != 0 || (epi != 0 && epi != 2) || (epi == 2 && bias) || (f32out && (epi || bias))) return -1;
-  const bool wide = n / 16 >= 1024, deep = !wide && k / 128 >= 96;  // deep: 16 waves split a long K (down_proj: 112 steps)
+  const bool wide = n / 16 >= 1024, deep = !wide && (k / 128 >= 96 || (g_skinny_deep64 && m <= 8 && k / 128 >= g_skinny_deep64 && n / 16 <= device_cu_count()));  // deep: 16 waves split a long K (down_proj: 112 steps; knob skinny_deep64 = the step count from which that also holds where a CU holds one slab)
 #define AWQ_SD(DT_, DQ_, EPI_)                                                                    \
   {                                                                                               \
     if (m <= 4 && g_skinny_xu) {  /* (Llama-3-70B's long-K launches hand over from two / three rows: one piece per step) */ \
@@ -492,6 +494,13 @@ int launch_skinny_decode(const void* x, const void* qw, const void* szp, const v
       else if (wide) launch_skinny<DT_, 8, 2, 1, DQ_, EPI_, 4, 2>(x, qw, szp, bias, out, m, n, k, st, f32out);       \
       else if (deep) launch_skinny<DT_, 16, 1, 1, DQ_, EPI_, 4, 2>(x, qw, szp, bias, out, m, n, k, st, f32out); \
       else launch_skinny<DT_, 8, 1, 1, DQ_, EPI_, 4, 2>(x, qw, szp, bias, out, m, n, k, st, f32out);            \
+      return 0;                                                                                   \
+    }                                                                                             \
+    if (m <= 12 && g_skinny_xu) {  /* 9 .. 12 rows: three of the four pieces */ \
+      if (wide && seven_slab_round(n / 16)) launch_skinny<DT_, 8, 7, 1, DQ_, EPI_, 4, 3>(x, qw, szp, bias, out, m, n, k, st, f32out); \
+      else if (wide) launch_skinny<DT_, 8, 2, 1, DQ_, EPI_, 4, 3>(x, qw, szp, bias, out, m, n, k, st, f32out);       \
+      else if (deep) launch_skinny<DT_, 16, 1, 1, DQ_, EPI_, 4, 3>(x, qw, szp, bias, out, m, n, k, st, f32out); \
+      else launch_skinny<DT_, 8, 1, 1, DQ_, EPI_, 4, 3>(x, qw, szp, bias, out, m, n, k, st, f32out);            \
       return 0;                                                                                   \
     }                                                                                             \
     if (wide && seven_slab_round(n / 16)) launch_skinny<DT_, 8, 7, 1, DQ_, EPI_>(x, qw, szp, bias, out, m, n, k, st, f32out); \

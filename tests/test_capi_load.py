@@ -172,14 +172,15 @@ def test_batched_decode_routing_for_the_llama3_shapes():
 
     # round 6, third session: the skinny kernel stages only the x pieces that hold rows and is ahead from ONE row wherever a CU holds >= 1.5 slabs or K is long (16-wave shape)
     for m in (1, 2, 3, 4):
-        assert plan(m, 4096, 4096, 0) == (1, 0) and plan(m, 28672, 4096, 2) == (1, 0), m      # o_proj (one slab per CU, short K) and the wide gate/up pair: streaming kernel
+        assert plan(m, 4096, 4096, 0) == (1, int(m >= 2)) and plan(m, 28672, 4096, 2) == (1, 0), m   # o_proj (one slab per CU: the skinny kernel's 16-wave shape from two rows); the wide gate/up pair: streaming kernel
         assert plan(m, 6144, 4096, 0) == (1, int(m >= 2)) and plan(m, 4096, 14336, 0) == (1, int(m >= 2)), m   # qkv (1.5 slabs per CU), down_proj (K = 14336): skinny kernel from two rows
     for m in (5, 6, 7, 8):
         assert plan(m, 28672, 4096, 2) == (1, 1)          # gate/up pair: 7 slabs per CU
         assert plan(m, 4096, 14336, 0) == (1, 1)          # down_proj
-        assert plan(m, 4096, 4096, 0) == (1, 0)           # o_proj: one slab per CU, never
+        assert plan(m, 4096, 4096, 0) == (1, 1)           # o_proj
         assert plan(m, 6144, 4096, 0) == (1, 1)
-    assert plan(1, 4096, 11008) == (1, 0) and plan(6, 4096, 11008) == (1, 1)   # Llama-2-7B down_proj: one slab per CU, K = 86 groups: streaming kernel up to five rows
+    assert plan(1, 4096, 11008) == (1, 0) and plan(2, 4096, 11008) == (1, 1)   # Llama-2-7B down_proj: one slab per CU, K = 86 groups: 16-wave skinny shape from two rows
+    assert plan(4, 5120, 4096) == (1, 0)                                        # (between one and 1.5 slabs per CU: not measured, the streaming kernel as before)
     assert plan(8, 28672, 4096, 1)[1] == 0                # the stacked [gate; up] form has no skinny epilogue
     # Llama-3-70B gate/up pair (K = 8192: 16 KiB of x per row and block): the streaming kernel's eight-wave blocks up to two rows, the skinny kernel from three
     assert plan(1, 8192, 28672) == (1, 1) and plan(1, 10240, 8192) == (1, 1) and plan(1, 8192, 8192) == (1, 1) and plan(1, 12288, 4096) == (1, 1)   # two or more slabs per CU (70B down / qkv / o, 7B qkv): skinny kernel from one row

@@ -14,6 +14,8 @@ from tools.gemvc_sweep import time_graph  # noqa: E402
 
 def main():
     L = _capi.lib()
+    if os.environ.get("EXTRA_TUNE"):  # further knobs for the whole run: "key=value,..."
+        _capi.tune(**{kv.split("=")[0]: int(kv.split("=")[1]) for kv in os.environ["EXTRA_TUNE"].split(",")})
     dtype = torch.bfloat16
     ms = [int(a) for a in sys.argv[1:]] or [1, 2, 4]
     shapes = [("qkv", 4096, 6144, 0), ("o", 4096, 4096, 0), ("gate/up", 4096, 28672, 2), ("down", 14336, 4096, 0),
