@@ -197,7 +197,8 @@ int awq_w4a16_gemm_cdna4_pair_lost(unsigned int* count);
 int awq_w4a16_gemm_cdna4_narrow_kernel(int m, int n_cols, int k, int bits, int has_workspace, int epilogue);
 /* host-side query: how awq_w4a16_decode_cdna4 / awq_w4a16_mlp_gate_up_forward_cdna4 serve m <= 8 rows of an [n, k] matrix.  *kernel: 0 =
  * the LDS-DMA streaming kernel (awq_gemv_dma.hip; x staged per slab), 1 = the skinny kernel (awq_skinny_cdna4.hip; x through registers,
- * one weight pass -- where the streaming kernel's staging of m x k x 2 bytes per slab would crowd its ring out of LDS).  Returns the number
+ * one weight pass -- where the streaming kernel's staging of m x k x 2 bytes per slab would crowd its ring out of LDS, and, since round 6, from two rows on
+ * every launch that is not a wide fused pair or between one and 1.5 slabs per CU: csrc/awq_gemv_dma.hip skinny_takes).  Returns the number
  * of weight passes (1; more when the streaming kernel serves the rows in chunks), 0 if the shape is not served.  The reference's GEMV
  * handles its batch inside one pass, gemv_cuda.cu:187-208, 291-329. */
 int awq_w4a16_decode_cdna4_plan(int m, int n, int k, int epilogue, int* kernel);
