@@ -226,7 +226,7 @@ struct DmaCfg {
   size_t smem;
 };
 int g_dma_skinny_from = 0;  // knob decode_skinny_from: 0 = by shape (skinny_takes below), 1..8 = from that row count, 9 = never
-int g_dma_waves = 0, g_dma_d = 0, g_dma_probe = 0, g_dma_four = 1, g_dma_want = 0, g_dma_wide8 = 2, g_dma_skinny_small = 1, g_dma_il = 2;  // gemvd_il: 0 = contiguous K ranges per wave everywhere, 1 = interleaved everywhere, 2 (default) = interleaved for eight-wave blocks whose ring is shallower than a wave's K range (qkv -1.2 %, o_proj -3.2 % at one row; 16-wave down_proj no different: profiles/r06_decode_cfg.txt (7))  // gemvd_four: four ring-7 blocks per CU where there are > 3 slabs per CU (rounds 4 + 3 instead of 3 + 3 + 1: +0.6 % decode tok/s, profiles/r03_gemvps.txt)
+int g_dma_waves = 0, g_dma_d = 0, g_dma_probe = 0, g_dma_four = 1, g_dma_want = 0, g_dma_wide8 = 2, g_dma_skinny_small = 1, g_dma_skinny_m1 = 1, g_dma_il = 2;  // decode_skinny_m1 (one row): bit 0 = launches with >= 1.5 slabs per CU (qkv: -4 % per launch, 0 ... -1.2 % per token over three boxes), bit 1 = the long-K 16-wave launches (down_proj: neutral, off)  // gemvd_il: 0 = contiguous K ranges per wave everywhere, 1 = interleaved everywhere, 2 (default) = interleaved for eight-wave blocks whose ring is shallower than a wave's K range (qkv -1.2 %, o_proj -3.2 % at one row; 16-wave down_proj no different: profiles/r06_decode_cfg.txt (7))  // gemvd_four: four ring-7 blocks per CU where there are > 3 slabs per CU (rounds 4 + 3 instead of 3 + 3 + 1: +0.6 % decode tok/s, profiles/r03_gemvps.txt)
 
 size_t dma_smem(int waves, int d, int ns, int tx, int m) {
   const int txp = (tx + 3) & ~3;
@@ -252,7 +252,7 @@ bool skinny_takes(int m, int n_rows, int k, int epi) {
   // (ONE row stays here: in the token's chain of dependent launches the skinny kernel's isolated -6 % does not show -- bench.py A/B: 0.9766-0.9801 vs 0.9704-0.9772 ms per step,
   // drop-in leg -2 % -- while four rows gain 5 %: 1.012-1.019 vs 1.066-1.070 ms)
   // ... except where a CU holds two or more slabs (Llama-3-70B qkv / o / down: its four-launch decode layer 93.9 -> 91.2-92.7 us at one row)
-  if (g_dma_skinny_small && (m >= 2 || g_dma_skinny_small == 2 || blocks_per_cu >= 2.0) && n_rows / 16 < 1024 &&
+  if (g_dma_skinny_small && (m >= 2 || g_dma_skinny_small == 2 || blocks_per_cu >= 2.0 || ((g_dma_skinny_m1 & 1) && blocks_per_cu >= 1.5) || ((g_dma_skinny_m1 & 2) && k >= 96 * 128)) && n_rows / 16 < 1024 &&
       (blocks_per_cu >= 1.5 || k >= 96 * 128 || (blocks_per_cu <= 1.0 && k >= 32 * 128)))  // (one slab per CU: the skinny kernel's 16-wave shape, o_proj 4.15-4.44 vs 4.26-4.6 us at 2 .. 7 rows)
     return true;
   const int want = blocks_per_cu <= 1.0 ? 1 : (blocks_per_cu <= 2.0 ? 2 : (blocks_per_cu <= 3.0 ? 3 : 4));
@@ -309,6 +309,7 @@ int gemv_dma_tune_set(const char* key, int value) {
   else if (!strcmp(key, "gemvd_wide8")) g_dma_wide8 = value;
   else if (!strcmp(key, "gemvd_il")) g_dma_il = value;
   else if (!strcmp(key, "decode_skinny_small")) g_dma_skinny_small = value;
+  else if (!strcmp(key, "decode_skinny_m1")) g_dma_skinny_m1 = value;
   else if (!strcmp(key, "decode_skinny_from")) g_dma_skinny_from = value;
   else return -1;
   return 0;

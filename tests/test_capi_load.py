@@ -173,7 +173,7 @@ def test_batched_decode_routing_for_the_llama3_shapes():
     # round 6, third session: the skinny kernel stages only the x pieces that hold rows and is ahead from ONE row wherever a CU holds >= 1.5 slabs or K is long (16-wave shape)
     for m in (1, 2, 3, 4):
         assert plan(m, 4096, 4096, 0) == (1, int(m >= 2)) and plan(m, 28672, 4096, 2) == (1, 0), m   # o_proj (one slab per CU: the skinny kernel's 16-wave shape from two rows); the wide gate/up pair: streaming kernel
-        assert plan(m, 6144, 4096, 0) == (1, int(m >= 2)) and plan(m, 4096, 14336, 0) == (1, int(m >= 2)), m   # qkv (1.5 slabs per CU), down_proj (K = 14336): skinny kernel from two rows
+        assert plan(m, 6144, 4096, 0) == (1, 1) and plan(m, 4096, 14336, 0) == (1, int(m >= 2)), m   # qkv (1.5 slabs per CU): skinny kernel from one row; down_proj (K = 14336, one slab per CU): from two
     for m in (5, 6, 7, 8):
         assert plan(m, 28672, 4096, 2) == (1, 1)          # gate/up pair: 7 slabs per CU
         assert plan(m, 4096, 14336, 0) == (1, 1)          # down_proj
