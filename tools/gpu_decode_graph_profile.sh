@@ -12,7 +12,7 @@ python - "$O" <<'PY'
 import csv, json, sys
 o = sys.argv[1]
 line = json.load(open(o + "/bench_graph.json"))
-rows = [r for r in csv.DictReader(open(o + "/decode_graph_kernel_stats.csv")) if "gemv_dma_kernel" in r["kernel"] or "gemv_cdna4_kernel" in r["kernel"]]
+rows = [r for r in csv.DictReader(open(o + "/decode_graph_kernel_stats.csv")) if "gemv_dma_kernel" in r["kernel"] or "gemv_cdna4_kernel" in r["kernel"] or "skinny_cdna4_kernel" in r["kernel"]]  # (round 6: qkv decodes on the skinny kernel)
 layers = line["config"]["layers"]
 # per_kernel_decode() replays each launch kind on its own as well (its graphs hold the same kernels): the averages below are over ALL launches of a kernel row
 tot = sum(float(r["avg_ns"]) for r in rows) * layers * 1e-6
