@@ -373,7 +373,8 @@ def main():
     bytes_step = bytes_native(1) * args.repeat_layers if native_leg else sum(algo_bytes(1, K, N) for (_n, K, N, *_r) in raw)
     avg_launch_us = ev_ms * 1e3 / (args.steps * launches)
     gbs = bytes_step * args.steps / (ev_ms * 1e-3) / 1e9
-    kname = "awq::gemv_dma_kernel" if native_leg else "awq::gemv_dma_kernel (via gemv_forward_cuda_new + the engine's repack cache)"
+    kname = ("awq::gemv_dma_kernel (o, gate/up, down) + awq::skinny_cdna4_kernel (qkv)" if native_leg
+             else "awq::gemv_dma_kernel / awq::skinny_cdna4_kernel (via gemv_forward_cuda_new + the engine's repack cache)")
     traffic, traffic_src = pmc_traffic(["awq::gemv_dma_kernel", "awq::gemv_cdna4_kernel", "awq::skinny_cdna4_kernel"])
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
