@@ -383,13 +383,16 @@ torch::Tensor gemm_forward_cuda_new(torch::Tensor in_feats, torch::Tensor kernel
   if (m == 0) return out;
   auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
   {
-    at::Tensor c4, szp;
-    if (cdna4_view(kernel, scales, zeros, n, k, stream, c4, szp)) {
+    at::Tensor c4, szp, szh;
+    if (cdna4_view(kernel, scales, zeros, n, k, stream, c4, szp, &szh)) {
       void* wsp;
       size_t wsb;
       at::Tensor ws = cdna4_workspace(in_feats, m, n, k, wsp, wsb);
-      raise_on(awq_w4a16_forward_cdna4(in_feats.data_ptr(), c4.data_ptr(), scales.data_ptr(), zeros.data_ptr(), szp.data_ptr(), nullptr,
-                                       out.data_ptr(), (int)m, (int)n, (int)k, 128, dtype_code(in_feats), wsp, wsb, (void*)stream));
+      // (round 6: the cached sz_half side buffer -- built for the decode entry when the layer's scales are f16-exact -- serves the prompts too: the tile kernels, the
+      // mid-M kernel and the 9 .. 16-row skinny launches dequantise in the f16-mantissa form, as the native modules' calls do; same bits)
+      raise_on(awq_w4a16_forward_cdna4_szh(in_feats.data_ptr(), c4.data_ptr(), scales.data_ptr(), zeros.data_ptr(), szp.data_ptr(),
+                                           szh.defined() ? szh.data_ptr() : nullptr, nullptr, out.data_ptr(), (int)m, (int)n, (int)k, 128, dtype_code(in_feats), wsp,
+                                           wsb, (void*)stream));
       return out;
     }
   }
