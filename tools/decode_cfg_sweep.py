@@ -19,7 +19,7 @@ def main():
     dtype = torch.bfloat16
     ms = [int(a) for a in sys.argv[1:]] or [1, 2, 4]
     shapes = [("qkv", 4096, 6144, 0), ("o", 4096, 4096, 0), ("gate/up", 4096, 28672, 2), ("down", 14336, 4096, 0),
-              ("gu70b", 8192, 57344, 2), ("gu7b", 4096, 22016, 2), ("qkv70b", 8192, 10240, 0), ("down70b", 28672, 8192, 0), ("o70b", 8192, 8192, 0), ("qkv7b", 4096, 12288, 0), ("down7b", 11008, 4096, 0)]
+              ("gu70b", 8192, 57344, 2), ("gu7b", 4096, 22016, 2), ("qkv70b", 8192, 10240, 0), ("down70b", 28672, 8192, 0), ("o70b", 8192, 8192, 0), ("qkv7b", 4096, 12288, 0), ("down7b", 11008, 4096, 0), ("gate", 4096, 14336, 0)]
     if os.environ.get("SHAPES"):
         shapes = [s for s in shapes if s[0] in os.environ["SHAPES"].split(",")]
     cfgs = [(0, 0, 0)] + [(w, 1, d) for w in (4, 8, 16) for d in (1, 2, 4, 8)] + [(0, 0, 0)]  # (want = 1: the ring depth is the forced one unless ONE block exceeds the LDS)
